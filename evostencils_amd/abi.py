@@ -1,0 +1,263 @@
+"""ctypes mirror of include/evomg.h and a thin object wrapper over a loaded C-ABI library.
+
+The same wrapper drives the HIP backend (symbol prefix ``evomg_``, csrc/libevomg.so) and — from
+tests/bench only — the CPU oracle (prefix ``oracle_``), because both consume the same op program.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+ABI_VERSION = 1
+MAX_LEVELS = 24
+MAX_DIM = 3
+STENCIL_ENTRIES = 7
+MAX_BLOCK_CELLS = 8
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3
+SOLVE_CONVERGED, SOLVE_MAXITER, SOLVE_DIVERGED, SOLVE_WALL_LIMIT = 0, 1, 2, 3
+REAL_F64, COMPLEX_F64 = 0, 1
+BC_DIRICHLET, BC_HELMHOLTZ_ROBIN = 0, 1
+OUTER_MG_ITERATION, OUTER_PBICGSTAB = 0, 1
+CGS_CG, CGS_BICGSTAB = 0, 1
+F_SOL, F_RHS, F_RES, F_CORR, F_CGS_RHS, F_COUNT = 0, 1, 2, 3, 4, 5
+(OP_SMOOTH, OP_RESIDUAL, OP_RESTRICT, OP_PROLONG_ADD, OP_PROLONG_SET, OP_SET_ZERO, OP_COPY,
+ OP_COARSE_SOLVE, OP_RICHARDSON) = range(1, 10)
+PART_SINGLE, PART_RED_BLACK = 0, 1
+
+OP_NAMES = {OP_SMOOTH: "SMOOTH", OP_RESIDUAL: "RESIDUAL", OP_RESTRICT: "RESTRICT",
+            OP_PROLONG_ADD: "PROLONG_ADD", OP_PROLONG_SET: "PROLONG_SET", OP_SET_ZERO: "SET_ZERO",
+            OP_COPY: "COPY", OP_COARSE_SOLVE: "COARSE_SOLVE", OP_RICHARDSON: "RICHARDSON"}
+
+
+class C64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("dimension", C.c_int32), ("min_level", C.c_int32),
+        ("max_level", C.c_int32), ("scalar_kind", C.c_int32), ("bc_kind", C.c_int32),
+        ("outer_kind", C.c_int32), ("cgs_kind", C.c_int32), ("max_iterations", C.c_int32),
+        ("cgs_max_iterations", C.c_int32), ("target_res_reduction", C.c_double),
+        ("cgs_target_res_reduction", C.c_double),
+        ("mg_stencil", (C64 * STENCIL_ENTRIES) * MAX_LEVELS),
+        ("outer_stencil", C64 * STENCIL_ENTRIES),
+        ("wavenumber", C.c_double),
+    ]
+
+
+class Op(C.Structure):
+    _fields_ = [
+        ("opcode", C.c_int32), ("level", C.c_int32), ("dst", C.c_int32), ("src0", C.c_int32),
+        ("src1", C.c_int32), ("partitioning", C.c_int32), ("block", C.c_int32 * MAX_DIM),
+        ("reserved", C.c_int32), ("omega", C.c_double),
+    ]
+
+    def key(self):
+        return (self.opcode, self.level, self.dst, self.src0, self.src1, self.partitioning,
+                tuple(self.block), self.omega)
+
+    def __repr__(self):
+        return (f"Op({OP_NAMES.get(self.opcode, self.opcode)}, L={self.level}, dst={self.dst}, "
+                f"src0={self.src0}, src1={self.src1}, part={self.partitioning}, "
+                f"block={tuple(self.block)}, omega={self.omega})")
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("time_ms", C.c_double), ("conv_factor", C.c_double), ("n_iterations", C.c_double),
+        ("init_res_norm", C.c_double), ("final_res_norm", C.c_double),
+        ("status", C.c_int32), ("n_history", C.c_int32),
+    ]
+
+
+class Bench(C.Structure):
+    _fields_ = [("ms", C.c_double), ("bytes", C.c_double), ("gbps", C.c_double),
+                ("launches", C.c_int32), ("reserved", C.c_int32)]
+
+
+def make_op(opcode, level, dst=0, src0=0, src1=0, partitioning=PART_SINGLE, block=(1, 1, 1), omega=1.0) -> Op:
+    op = Op()
+    op.opcode, op.level, op.dst, op.src0, op.src1 = opcode, level, dst, src0, src1
+    op.partitioning = partitioning
+    blk = tuple(block) + (1,) * (MAX_DIM - len(block))
+    for i in range(MAX_DIM):
+        op.block[i] = int(blk[i])
+    op.omega = float(omega)
+    return op
+
+
+def ops_array(ops: Sequence[Op]):
+    arr = (Op * max(len(ops), 1))()
+    for i, op in enumerate(ops):
+        arr[i] = op
+    return arr
+
+
+# every symbol include/evomg.h declares, without prefix
+EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
+            "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name"]
+# the oracle implements the numerical subset
+ORACLE_EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
+                   "set_field", "set_operators", "evaluate", "run_ops", "norm"]
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded C-ABI library; `prefix` selects evomg_* (HIP) or oracle_* (CPU oracle)."""
+
+    def __init__(self, path: str, prefix: str, symbols: Sequence[str]):
+        self.path, self.prefix = path, prefix
+        self.lib = C.CDLL(path)
+        self.fn = {}
+        for s in symbols:
+            self.fn[s] = getattr(self.lib, f"{prefix}_{s}")  # AttributeError if a symbol is missing
+        dp = C.POINTER(C.c_double)
+        f = self.fn
+        f["create"].argtypes = [C.POINTER(Problem), C.c_int, C.POINTER(C.c_void_p)]
+        f["create"].restype = C.c_int
+        f["destroy"].argtypes = [C.c_void_p]
+        f["destroy"].restype = None
+        f["last_error"].argtypes = [C.c_void_p]
+        f["last_error"].restype = C.c_char_p
+        f["abi_version"].argtypes = []
+        f["abi_version"].restype = C.c_int
+        for name in ("set_initial_field", "get_field", "set_field"):
+            f[name].argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+            f[name].restype = C.c_int
+        f["set_operators"].argtypes = [C.c_void_p, C.POINTER(Problem)]
+        f["set_operators"].restype = C.c_int
+        f["evaluate"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.c_double,
+                                  C.POINTER(Result), dp, C.c_int]
+        f["evaluate"].restype = C.c_int
+        f["run_ops"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int]
+        f["run_ops"].restype = C.c_int
+        f["norm"].argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+        f["norm"].restype = C.c_int
+        if "bench_op" in f:
+            f["bench_op"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.POINTER(Bench)]
+            f["bench_op"].restype = C.c_int
+        if "kernel_name" in f:
+            f["kernel_name"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_char_p, C.c_int]
+            f["kernel_name"].restype = C.c_int
+
+
+@dataclass
+class SolveOutcome:
+    time_ms: float
+    conv_factor: float
+    n_iterations: float
+    init_res_norm: float
+    final_res_norm: float
+    status: int
+    history: Optional[np.ndarray] = None
+
+
+class Handle:
+    """One solver instance (all level fields allocated once) on one device."""
+
+    def __init__(self, library: Library, problem: Problem, device_id: int = 0):
+        self.L = library
+        self.problem = problem
+        self._h = C.c_void_p()
+        rc = library.fn["create"](C.byref(problem), device_id, C.byref(self._h))
+        if rc != OK:
+            msg = library.fn["last_error"](None)
+            raise BackendError(f"{library.prefix}_create failed with status {rc}: "
+                               f"{msg.decode() if msg else ''}")
+        self.dimension = problem.dimension
+        self.is_complex = problem.scalar_kind == COMPLEX_F64
+
+    def close(self):
+        if self._h:
+            self.L.fn["destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            msg = self.L.fn["last_error"](self._h)
+            raise BackendError(f"{self.L.prefix}_{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+    def nodes(self, level: int) -> int:
+        return (1 << level) + 1
+
+    def field_shape(self, level: int):
+        # numpy index order [i2][i1][i0]: x (i0) is the fastest dimension
+        return (self.nodes(level),) * self.dimension
+
+    def _host(self, level, array):
+        dt = np.complex128 if self.is_complex else np.float64
+        a = np.ascontiguousarray(array, dtype=dt)
+        if a.shape != self.field_shape(level):
+            raise ValueError(f"field shape {a.shape} != {self.field_shape(level)}")
+        return a
+
+    def set_initial_field(self, level, field, array):
+        a = self._host(level, array)
+        self._check(self.L.fn["set_initial_field"](self._h, level, field,
+                                                   a.ctypes.data_as(C.POINTER(C.c_double))), "set_initial_field")
+
+    def set_field(self, level, field, array):
+        a = self._host(level, array)
+        self._check(self.L.fn["set_field"](self._h, level, field,
+                                           a.ctypes.data_as(C.POINTER(C.c_double))), "set_field")
+
+    def get_field(self, level, field) -> np.ndarray:
+        dt = np.complex128 if self.is_complex else np.float64
+        out = np.empty(self.field_shape(level), dtype=dt)
+        self._check(self.L.fn["get_field"](self._h, level, field,
+                                           out.ctypes.data_as(C.POINTER(C.c_double))), "get_field")
+        return out
+
+    def set_operators(self, problem: Problem):
+        self._check(self.L.fn["set_operators"](self._h, C.byref(problem)), "set_operators")
+        self.problem = problem
+
+    def run_ops(self, ops: Sequence[Op]):
+        arr = ops_array(ops)
+        self._check(self.L.fn["run_ops"](self._h, arr, len(ops)), "run_ops")
+
+    def try_evaluate(self, ops: Sequence[Op], evaluation_samples=1, wall_limit_ms=0.0, history_capacity=0):
+        """Returns (status_code, SolveOutcome|None) without raising for rejected programs."""
+        arr = ops_array(ops)
+        res = Result()
+        hist = np.zeros(max(history_capacity, 1), dtype=np.float64)
+        rc = self.L.fn["evaluate"](self._h, arr, len(ops), evaluation_samples, float(wall_limit_ms),
+                                   C.byref(res), hist.ctypes.data_as(C.POINTER(C.c_double)) if history_capacity else None,
+                                   history_capacity)
+        if rc != OK:
+            return rc, None
+        h = hist[:res.n_history].copy() if history_capacity else None
+        return rc, SolveOutcome(res.time_ms, res.conv_factor, res.n_iterations, res.init_res_norm,
+                                res.final_res_norm, res.status, h)
+
+    def evaluate(self, ops, evaluation_samples=1, wall_limit_ms=0.0, history_capacity=0) -> SolveOutcome:
+        rc, out = self.try_evaluate(ops, evaluation_samples, wall_limit_ms, history_capacity)
+        self._check(rc, "evaluate")
+        return out
+
+    def norm(self, level, field) -> float:
+        v = C.c_double()
+        self._check(self.L.fn["norm"](self._h, level, field, C.byref(v)), "norm")
+        return v.value
+
+    def bench_op(self, op: Op, warmup=10, reps=100) -> Bench:
+        b = Bench()
+        self._check(self.L.fn["bench_op"](self._h, C.byref(op), warmup, reps, C.byref(b)), "bench_op")
+        return b
+
+    def kernel_name(self, op: Op) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self.L.fn["kernel_name"](self._h, C.byref(op), buf, 256), "kernel_name")
+        return buf.value.decode()

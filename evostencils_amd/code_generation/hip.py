@@ -1,0 +1,331 @@
+"""``ProgramGenerator`` — drop-in replacement for the reference's backend class
+``evostencils.code_generation.exastencils.ProgramGenerator`` (exastencils.py:39-1147) behind the
+duck-typed interface the optimizer uses (callers: optimization/program.py:115-141,
+407,439,805,853,891-895,909-926; scripts/optimize.py:55-68).
+
+Where the reference writes ExaSlang, starts the ExaStencils JVM twice, runs `make` and executes the
+generated binary (exastencils.py:485-537), this class lowers the candidate to an op program and
+calls ``evomg_evaluate`` (include/evomg.h) on one MI355X. There is no CPU fallback: without the HIP
+library / a GPU the constructor raises.
+"""
+import math
+import os
+from typing import List, Optional
+
+from evostencils_amd import abi, problems
+from evostencils_amd.code_generation import exaslang, lowering, opprogram
+from evostencils_amd.ir import base, system
+
+
+class Field:
+    """exastencils.py:29-36"""
+
+    def __init__(self, name=None, level=None, cycle_storage=None):
+        self.name, self.level, self.cycle_storage = name, level, cycle_storage
+
+    def to_exa(self):
+        return f"{self.name}@{self.level}"
+
+
+class CycleStorage:
+    """Names of the arrays of one level (exastencils.py:14-26). Opaque to the optimizer."""
+
+    def __init__(self, equations, fields, grids):
+        self.grid = grids
+        self.solution = [Field(f"{s.name}", g.level, self) for g, s in zip(grids, fields)]
+        self.rhs = []
+        for f, g in zip(fields, grids):
+            for eq in equations:
+                if eq.level == g.level and eq.associated_field == f:
+                    self.rhs.append(Field(f"{eq.rhs_name}", g.level, self))
+                    break
+        self.residual = [Field(f"gen_residual_{s.name}", g.level, self) for g, s in zip(grids, fields)]
+        self.correction = [Field(f"gen_error_{s.name}", g.level, self) for g, s in zip(grids, fields)]
+
+
+def _read_key_values(path):
+    out = {}
+    with open(path, "r") as fh:
+        for line in fh:
+            if "=" in line and not line.lstrip().startswith("//"):
+                k, v = line.split("=", 1)
+                out[k.strip(" \t")] = v.strip(' \t\n"')
+    return out
+
+
+class ProgramGenerator:
+    """Same constructor arguments as the reference (exastencils.py:40-43); the ExaStencils-specific
+    ones (compiler path, platform file, compiler timeouts) are accepted and ignored. Either pass the
+    reference-style `base_path` + `settings_path` + `knowledge_path` of one of the known example
+    problems, or pass `problem=` (a problems.ProblemDescription) directly.
+
+    Extra keyword-only arguments: `device_id` (default: LOCAL_RANK or mpi_rank), `library` (an
+    abi.Library; default: the in-tree HIP library, loaded on first use)."""
+
+    def __init__(self, absolute_compiler_path: Optional[str] = None, base_path: Optional[str] = None,
+                 settings_path: Optional[str] = None, knowledge_path: Optional[str] = None,
+                 platform_path: Optional[str] = None, mpi_rank=0, solution_equations=None,
+                 cycle_name="gen_mgCycle", model_based_estimation=False, evaluation_timeout=300,
+                 code_generation_timeout=300, c_compiler_timeout=120, solver_iteration_limit=None, *,
+                 problem: Optional[problems.ProblemDescription] = None, device_id: Optional[int] = None,
+                 library: Optional[abi.Library] = None):
+        if isinstance(solution_equations, str):
+            solution_equations = [solution_equations]
+        self._average_generation_time = 0
+        self._counter = 0
+        self.timeout_evaluate = evaluation_timeout
+        self.timeout_exastencils_compiler = code_generation_timeout
+        self.timeout_c_compiler = c_compiler_timeout
+        self._solver_iteration_limit = solver_iteration_limit
+        self._absolute_compiler_path = absolute_compiler_path
+        self._base_path = base_path
+        self._platform_path = platform_path
+        self._settings_path = settings_path
+        self._knowledge_path = knowledge_path
+        self._mpi_rank = mpi_rank
+        self._cycle_name = cycle_name
+        # exastencils.py:64-70: no `with jacobi` prefix under model-based estimation
+        self._use_jacobi_prefix = not model_based_estimation
+        self._solution_equations = solution_equations
+        if problem is None:
+            if base_path is None or settings_path is None or knowledge_path is None:
+                raise ValueError("either `problem` or base_path/settings_path/knowledge_path is required")
+            knowledge = _read_key_values(os.path.join(base_path, knowledge_path))
+            settings = _read_key_values(os.path.join(base_path, settings_path))
+            config = settings.get("configName")
+            if config not in problems.BY_NAME:
+                raise RuntimeError(f"unknown problem {config!r}; known: {sorted(problems.BY_NAME)}")
+            problem = problems.BY_NAME[config](int(knowledge["minLevel"]), int(knowledge["maxLevel"]))
+            if int(knowledge["dimensionality"]) != problem.dimension:
+                raise RuntimeError("dimensionality mismatch between knowledge file and problem")
+        self._problem = problem
+        self._original_min_level = problem.min_level
+        self._original_max_level = problem.max_level
+        self._device_id = device_id if device_id is not None else int(os.environ.get("LOCAL_RANK", mpi_rank))
+        self._library = library
+        self._handle = None
+        self._handle_levels = None
+        self._handle_params = None
+        self._solver_cache = {}
+        self._set_problem(problem)
+
+    # ---- read-only attributes the optimizer reads (scripts/optimize.py:60-68) ------------------
+    uses_FAS = property(lambda self: False)
+    absolute_compiler_path = property(lambda self: self._absolute_compiler_path)
+    knowledge_path = property(lambda self: self._knowledge_path)
+    settings_path = property(lambda self: self._settings_path)
+    platform_path = property(lambda self: self._platform_path)
+    base_path = property(lambda self: self._base_path)
+    problem_name = property(lambda self: self._problem.name)
+    compiler_available = property(lambda self: True)
+    dimension = property(lambda self: self._problem.dimension)
+    finest_grid = property(lambda self: self._finest_grid)
+    equations = property(lambda self: self._equations)
+    operators = property(lambda self: self._operators)
+    fields = property(lambda self: self._fields)
+    coarsening_factor = property(lambda self: self._coarsening_factor)
+    min_level = property(lambda self: self._problem.min_level)
+    max_level = property(lambda self: self._problem.max_level)
+    solution_equations = property(lambda self: self._solution_equations)
+    mpi_rank = property(lambda self: self._mpi_rank)
+    solver_iteration_limit = property(lambda self: self._solver_iteration_limit)
+    problem = property(lambda self: self._problem)
+
+    def _set_problem(self, problem):
+        self._problem = problem
+        self._equations, self._operators, self._fields = problem.l2_information()
+        d, L = problem.dimension, problem.max_level
+        self._coarsening_factor = [(2,) * d for _ in self._fields]
+        self._finest_grid = [base.Grid((2 ** L,) * d, (1 / (2 ** L),) * d, L) for _ in self._fields]
+
+    # ---- storage handles (exastencils.py:586-592) -------------------------------------------------
+    def generate_storage(self, min_level: int, max_level: int, finest_grids: List[base.Grid]):
+        storage, grid = [], finest_grids
+        for _ in range(min_level, max_level + 1):
+            storage.append(CycleStorage(self.equations, self.fields, grid))
+            grid = system.get_coarse_grid(grid, self.coarsening_factor)
+        return storage
+
+    # ---- native handle ------------------------------------------------------------------------------
+    def _lib(self) -> abi.Library:
+        if self._library is None:
+            from evostencils_amd import native
+            self._library = native.library()     # raises if the HIP library is missing
+        return self._library
+
+    def _ensure_handle(self, min_level, max_level, parameters=None):
+        """One native solver instance per (level window, problem); operators are re-targeted in place
+        when only PDE parameters (k) change."""
+        key = (self._problem.name, min_level, max_level)
+        params = dict(self._problem.parameters)
+        if parameters:
+            params.update(parameters)
+        frozen = tuple(sorted(params.items()))
+        if self._handle is None or self._handle_levels != key:
+            if self._handle is not None:
+                self._handle.close()
+            window = self._problem.with_levels(min_level, max_level)
+            self._handle = abi.Handle(self._lib(), window.to_c(params), self._device_id)
+            self._handle.set_initial_field(max_level, abi.F_SOL, window.initial_solution(max_level))
+            self._handle.set_initial_field(max_level, abi.F_RHS, window.right_hand_side(max_level))
+            self._handle_levels, self._handle_params, self._window = key, frozen, window
+        elif self._handle_params != frozen:
+            self._handle.set_operators(self._window.to_c(params))
+            self._handle_params = frozen
+        return self._handle
+
+    def initialize_code_generation(self, min_level: int, max_level: int):
+        """exastencils.py:445-466: one-time setup for a level range. Here: allocate the device fields."""
+        self._ensure_handle(min_level, max_level)
+        self._counter += 1
+        return None
+
+    def reinitialize(self, min_level, max_level, global_expressions):
+        """exastencils.py:196-215: problem-size bump ("generalisation"); `global_expressions` replaces
+        PDE parameters (e.g. {'k': 160.0})."""
+        new = self._problem.with_levels(min_level, max_level)
+        for name, value in (global_expressions or {}).items():
+            new.parameters[name] = value
+        self._set_problem(new)
+
+    # ---- lowering -----------------------------------------------------------------------------------
+    def _names(self):
+        return exaslang.FieldNames([f.name for f in self.fields],
+                                   [next(eq.rhs_name for eq in self.equations if eq.associated_field == f)
+                                    for f in self.fields])
+
+    def lower(self, expression, min_level, max_level, use_global_weights=False):
+        return lowering.lower(expression, self.fields, min_level, max_level, self._cycle_name, use_global_weights)
+
+    def generate_multigrid(self, expression, storages, min_level: int, max_level: int, use_global_weights=False):
+        """Statement text only (exastencils.py:684-925). `storages` is accepted for signature parity."""
+        stmts = self.lower(expression, min_level, max_level, use_global_weights)
+        return exaslang.render(stmts, self._names(), max_level, self.dimension, self._use_jacobi_prefix)
+
+    def generate_cycle_function(self, expression, storages, min_level: int, level, max_level: int,
+                                use_global_weights=False):
+        """exastencils.py:318-336: `Function <cycle_name>@<level> { ... }`."""
+        program = f"Function {self._cycle_name}@{level} {{\n"
+        program += self.generate_multigrid(expression, storages, min_level, max_level, use_global_weights)
+        program += "}\n\n"
+        return program
+
+    def generate_op_program(self, expression, min_level, max_level) -> List[abi.Op]:
+        stmts = self.lower(expression, min_level, max_level)
+        self._verify_operators(stmts)
+        return opprogram.encode(stmts)
+
+    def _verify_operators(self, stmts):
+        """The op program carries no coefficients: make sure the DAG's operator IS the problem's."""
+        for st in stmts:
+            if st.kind not in ("smooth", "residual", "richardson"):
+                continue
+            stencil = st.operator_stencil
+            if stencil is None and st.operator_entry is not None and hasattr(st.operator_entry, "generate_stencil"):
+                stencil = st.operator_entry.generate_stencil()
+            if stencil is None or hasattr(stencil, "constant_stencils"):
+                raise lowering.UnsupportedExpression("system operator must be a constant stencil")
+            expected = self._problem.mg_stencil(st.level, self._problem.parameters)
+            offsets = problems._star_offsets(self.dimension)
+            got = {tuple(o): complex(v) for o, v in stencil.entries}
+            if set(got) - set(offsets):
+                raise lowering.UnsupportedExpression("only 5-/7-point star stencils are supported")
+            for o, v in zip(offsets, expected):
+                if got.get(o, 0j) != complex(v):
+                    raise lowering.UnsupportedExpression(
+                        f"operator {st.operator_name}@{st.level} differs from the problem's operator")
+
+    # ---- THE call (exastencils.py:485-537) -----------------------------------------------------------
+    def generate_and_evaluate(self, expression, storages, min_level: int, max_level: int, solver_program: str,
+                              infinity=1e100, evaluation_samples=3, global_variable_values=None):
+        if global_variable_values is None:
+            global_variable_values = {}
+        if solver_program and "Function" in solver_program:
+            # multi-run optimisation (levels_per_run < max-min) splices earlier evolved cycles in as text;
+            # this backend evaluates whole level windows only.
+            raise NotImplementedError("solver_program with pre-evolved cycle functions is not supported")
+        try:
+            ops = self.generate_op_program(expression, min_level, max_level)
+        except lowering.UnsupportedExpression:
+            return infinity, infinity, infinity
+        self._counter += 1
+        mapping = dict(global_variable_values)
+        n = 3 if "k" in mapping else 1          # Helmholtz: k, 2k, 4k (exastencils.py:518-532)
+        total_t = total_rho = total_it = 0
+        for _ in range(n):
+            runtime, rho, iterations = self.compile_and_run(ops, min_level, max_level, mapping=mapping,
+                                                            infinity=infinity,
+                                                            evaluation_samples=evaluation_samples)
+            total_t += runtime
+            total_rho += rho
+            total_it += iterations
+            if iterations >= infinity or rho > 1:
+                return total_t, total_rho, total_it
+            if n > 1:
+                mapping["k"] *= 2
+        return total_t / n, total_rho / n, total_it / n
+
+    def compile_and_run(self, ops, min_level, max_level, mapping=None, infinity=1e100, evaluation_samples=3):
+        """exastencils.py:468-483 + evaluate :417-443; nothing is compiled here."""
+        try:
+            handle = self._ensure_handle(min_level, max_level, mapping)
+            cap = self._problem.max_iterations + 2
+            rc, out = handle.try_evaluate(ops, evaluation_samples, 1e3 * float(self.timeout_evaluate), cap)
+        except abi.BackendError:
+            return infinity, infinity, infinity
+        if rc != abi.OK or out.status == abi.SOLVE_WALL_LIMIT:
+            return infinity, infinity, infinity
+        return self.interpret_outcome(out, infinity, self._solver_iteration_limit,
+                                      self._problem.outer_kind == abi.OUTER_PBICGSTAB)
+
+    @staticmethod
+    def interpret_outcome(out: abi.SolveOutcome, infinity, solver_iteration_limit=None, krylov_outer=False):
+        """What `parse_output` + `evaluate` derive from the executable's stdout (exastencils.py:417-443,
+        539-584), computed from the residual history instead of printed text."""
+        rho_inf = math.sqrt(infinity)
+        hist = out.history
+        factors = []
+        count = 0
+        if krylov_outer:
+            # the Helmholtz solver prints ONE line with |res|/|initRes| (Helmholtz exa3:193,198)
+            pairs = [(hist[0], hist[-1])] if hist is not None and len(hist) >= 2 else []
+        else:
+            pairs = list(zip(hist[:-1], hist[1:])) if hist is not None else []
+        for prev, cur in pairs:
+            rho = cur / prev if prev != 0 else float("nan")
+            if math.isinf(rho) or math.isnan(rho):
+                factors.append(rho_inf)
+            else:
+                factors.append(rho)
+                count += 1
+        if count > 0:
+            convergence_factor = 1
+            exponent = 1.0 / len(factors)
+            for rho in factors:
+                convergence_factor *= math.pow(rho, exponent)
+        else:
+            convergence_factor = infinity
+        iterations = out.n_iterations
+        if krylov_outer:
+            iterations -= 1      # `repeat ... count curStep` prints the 0-based step (exa3:160,193)
+        if out.status != abi.SOLVE_CONVERGED:
+            iterations = infinity   # "Maximum number of solver iterations" (exastencils.py:555-557)
+        if iterations == 0:
+            iterations = infinity
+        if solver_iteration_limit is not None and iterations >= solver_iteration_limit:
+            iterations = infinity
+        time_to_solution = out.time_ms
+        if iterations >= infinity or convergence_factor > 1:
+            return time_to_solution, convergence_factor, iterations
+        if math.isinf(convergence_factor) or math.isnan(convergence_factor):
+            return infinity, infinity, infinity
+        return time_to_solution, convergence_factor, iterations
+
+    # ---- pieces of the reference interface that have no work left to do ---------------------------------
+    def invalidate_solver_cache(self):
+        self._solver_cache = {}
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None

@@ -1,0 +1,274 @@
+"""IR DAG -> ordered statement list: the backend's restatement of the reference's lowering
+``ProgramGenerator.generate_multigrid`` (evostencils/code_generation/exastencils.py:684-925).
+
+The reference emits ExaSlang text directly; here the walk produces neutral ``Statement`` records,
+one per ExaSlang statement the reference would emit and in the same order, which are then rendered
+either as ExaSlang text (exaslang.py, pinned by golden strings captured from the reference) or as an
+op program for the C-ABI (opprogram.py). One walker, two renderers: text and numerics cannot drift.
+
+Dispatch is on (module-tail, class-name) pairs taken from the MRO, so DAGs built from the
+reference's own ``evostencils.ir`` classes are accepted as well as ``evostencils_amd.ir`` ones.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+from evostencils_amd.ir import partitioning as part
+from evostencils_amd.stencils import multiple
+
+
+class UnsupportedExpression(RuntimeError):
+    """The DAG is well-formed for the reference but outside what this backend implements."""
+
+
+def _tags(obj):
+    return {(c.__module__.rsplit(".", 1)[-1], c.__name__) for c in type(obj).__mro__}
+
+
+def isa(obj, module_tail: str, name: str) -> bool:
+    return (module_tail, name) in _tags(obj)
+
+
+# field roles (exastencils.py:295-316)
+SOLUTION, RHS, RESIDUAL, CORRECTION, CGS_RHS = "solution", "rhs", "residual", "correction", "cgs_rhs"
+
+
+@dataclass
+class FieldRef:
+    role: str
+    level: int
+    index: int = 0          # field index inside the system (always 0 for scalar PDEs)
+
+
+@dataclass
+class Statement:
+    kind: str               # zero | smooth | residual | richardson | restrict | prolong_add | prolong_set
+    #                         | copy | coarse_solve
+    level: int
+    dst: Optional[FieldRef] = None
+    src: Optional[FieldRef] = None
+    rhs: Optional[FieldRef] = None
+    weight: object = 1.0    # float, or 'omega_<id>' / '1' strings when use_global_weights
+    partitioning: str = "single"
+    block: Tuple[int, ...] = ()
+    operator_name: str = ""
+    operator_level: int = 0
+    operator_entry: object = None   # IR operator expression (row entry) for text rendering
+    operator_stencil: object = None  # constant stencil of the system operator (smoother equations)
+    group: str = ""          # smoother: 'independent' | 'dependent' (exastencils.py:774-822)
+    cycle_name: str = ""
+
+
+class Lowering:
+    """One pass over one expression DAG. `fields` = list of sympy symbols / names of the unknowns."""
+
+    def __init__(self, fields, min_level: int, max_level: int, cycle_name: str = "gen_mgCycle",
+                 use_global_weights: bool = False):
+        self.fields = fields
+        self.min_level = min_level
+        self.max_level = max_level
+        self.cycle_name = cycle_name
+        self.use_global_weights = use_global_weights
+        self.out: List[Statement] = []
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _sol(self, level, i=0):
+        # u@max on the finest level, gen_error_u below (exastencils.py:296-301)
+        return FieldRef(CORRECTION if level < self.max_level else SOLUTION, level, i)
+
+    def _source_field(self, expression, level, i=0):
+        """exastencils.py:594-604 — note system.RightHandSide is a system.Approximation subclass, so the
+        reference's first test already catches it (its RightHandSide branch is unreachable)."""
+        if isa(expression, "system", "Approximation") or isa(expression, "base", "Cycle"):
+            return self._sol(level, i)
+        if isa(expression, "base", "Residual"):
+            return FieldRef(RESIDUAL, level, i)
+        if isa(expression, "system", "RightHandSide"):
+            return FieldRef(RHS, level, i)
+        return FieldRef(CORRECTION, level, i)
+
+    def _weight(self, cycle):
+        if self.use_global_weights and hasattr(cycle, "global_id"):
+            return "1" if cycle.global_id is None else f"omega_{cycle.global_id}"
+        return cycle.relaxation_factor
+
+    def _single_field(self, grids):
+        if len(grids) != 1:
+            raise UnsupportedExpression("systems of PDEs (more than one unknown) are not supported yet")
+
+    def _zero_if_needed(self, approximation, grids):
+        if isa(approximation, "system", "ZeroApproximation"):
+            for i, g in enumerate(grids):
+                self.out.append(Statement("zero", g.level, dst=self._sol(g.level, i)))
+
+    def _preamble(self, rhs_tested, rhs_emitted, approximation_tested, approximation_emitted):
+        """Emit a not-yet-emitted right-hand side and a nested approximation first. The reference tests
+        one object and descends into another (identical in every DAG the grammar builds); both are
+        kept apart here (exastencils.py:699-705,746-752,828-832)."""
+        if not isa(rhs_tested, "system", "RightHandSide") and not rhs_emitted.valid:
+            self.visit(rhs_emitted)
+            rhs_emitted.valid = True
+        if not isa(approximation_tested, "system", "Approximation"):
+            self.visit(approximation_emitted)
+
+    # -- the walk --------------------------------------------------------------------------------
+    def visit(self, e):
+        if isa(e, "base", "Cycle"):
+            return self._cycle(e)
+        if isa(e, "base", "Residual"):
+            return self._residual(e)
+        if isa(e, "base", "Multiplication"):
+            return self._multiplication(e)
+        if isa(e, "base", "Addition") or isa(e, "base", "Subtraction"):
+            raise UnsupportedExpression("Addition/Subtraction nodes only occur in the FAS backend")
+        raise UnsupportedExpression(f"Not implemented: {type(e).__name__}")
+
+    def _cycle(self, e):
+        weight = self._weight(e)
+        corr = e.correction
+        grids = e.grid
+        self._single_field(grids)
+        if isa(corr, "base", "Residual"):
+            # x += w * (b - A x)
+            self._preamble(corr.rhs, e.rhs, corr.approximation, e.approximation)
+            self._zero_if_needed(e.approximation, grids)
+            for i, g in enumerate(grids):
+                entry = corr.operator.entries[i][i]
+                self.out.append(Statement("richardson", g.level, dst=self._sol(g.level, i),
+                                          rhs=FieldRef(RHS, g.level, i), weight=weight,
+                                          operator_entry=entry, operator_name=getattr(entry, "name", ""),
+                                          operator_level=g.level))
+        elif isa(corr, "base", "Multiplication"):
+            op1 = corr.operand1
+            if isa(op1, "system", "InterGridOperator"):
+                self.visit(corr.operand2)
+                for i, g in enumerate(grids):
+                    entry = op1.entries[i][i]
+                    if isa(entry, "base", "Prolongation"):
+                        op_level = entry.coarse_grid.level
+                    elif isa(entry, "base", "Restriction"):
+                        op_level = entry.fine_grid.level
+                    else:
+                        raise UnsupportedExpression("Unexpected entry")
+                    src = self._source_field(corr.operand2, op_level, i)
+                    kind = "prolong_add" if isa(entry, "base", "Prolongation") else "restrict_add"
+                    self.out.append(Statement(kind, g.level, dst=self._sol(g.level, i), src=src, weight=weight,
+                                              operator_name=entry.name, operator_level=op_level))
+            elif isa(op1, "base", "Inverse"):
+                residual = corr.operand2
+                if not isa(residual, "base", "Residual"):
+                    raise UnsupportedExpression("smoother must be applied to a residual")
+                self._preamble(residual.rhs, residual.rhs, residual.approximation, residual.approximation)
+                self._zero_if_needed(e.approximation, grids)
+                self._smoother(e, op1.operand, residual.operator, weight)
+            else:
+                raise UnsupportedExpression("Unsupported operator")
+        else:
+            raise UnsupportedExpression("Expected multiplication")
+
+    def _smoother(self, cycle, smoothing_operator, system_operator, weight):
+        grids = cycle.grid
+        g = grids[0]
+        dim = g.dimension
+        sys_entry = system_operator.entries[0][0]
+        sys_stencil = sys_entry.generate_stencil() if hasattr(sys_entry, "generate_stencil") else None
+        if sys_stencil is None or hasattr(sys_stencil, "constant_stencils"):
+            raise UnsupportedExpression("system operator must be a constant-coefficient stencil")
+        elementwise = False
+        if isa(smoothing_operator, "system", "Diagonal"):
+            block = (1,) * dim
+        elif isa(smoothing_operator, "system", "ElementwiseDiagonal"):
+            block = (1,) * dim
+            elementwise = True
+        elif isa(smoothing_operator, "system", "Operator"):
+            sm_stencil = smoothing_operator.entries[0][0].generate_stencil()
+            block = tuple(multiple.period_shape(sm_stencil))
+            if not multiple.is_block_diagonal_of(sm_stencil, sys_stencil, block):
+                raise UnsupportedExpression("custom smoothing operator is not the block diagonal of the system operator")
+        else:
+            raise UnsupportedExpression("Can not extract equations from smoothing operator")
+        cells = 1
+        for b in block:
+            cells *= b
+        # one unknown => an independent equation; the reference moves it to the dependent list for
+        # ElementwiseDiagonal (exastencils.py:775-777) — same text either way. Blocks with >1 cell are
+        # coupled through the 5-/7-point stencil => all dependent, one `solve locally` block.
+        group = "independent" if (cells == 1 and not elementwise) else "dependent"
+        self.out.append(Statement("smooth", g.level, dst=self._sol(g.level, 0), rhs=FieldRef(RHS, g.level, 0),
+                                  weight=weight, partitioning=part.kind_of(cycle.partitioning), block=block,
+                                  operator_name=getattr(sys_entry, "name", ""), operator_level=g.level,
+                                  operator_entry=sys_entry, operator_stencil=sys_stencil, group=group))
+
+    def _residual(self, e):
+        self._preamble(e.rhs, e.rhs, e.approximation, e.approximation)
+        grids = e.grid
+        self._single_field(grids)
+        self._zero_if_needed(e.approximation, grids)
+        for i, g in enumerate(grids):
+            entry = e.operator.entries[i][i]
+            self.out.append(Statement("residual", g.level, dst=FieldRef(RESIDUAL, g.level, i),
+                                      src=self._sol(g.level, i), rhs=FieldRef(RHS, g.level, i),
+                                      operator_entry=entry, operator_name=getattr(entry, "name", ""),
+                                      operator_level=g.level))
+
+    def _multiplication(self, e):
+        op1 = e.operand1
+        if isa(op1, "system", "InterGridOperator"):
+            self.visit(e.operand2)
+            grids = e.grid
+            self._single_field(grids)
+            for i, g in enumerate(grids):
+                entry = op1.entries[i][i]
+                if isa(entry, "base", "Prolongation"):
+                    op_level = entry.coarse_grid.level
+                elif isa(entry, "base", "Restriction"):
+                    op_level = entry.fine_grid.level
+                else:
+                    raise UnsupportedExpression("Unexpected entry")
+                src = self._source_field(e.operand2, op_level, i)
+                if isa(op1, "system", "Restriction"):
+                    self.out.append(Statement("restrict", g.level, dst=FieldRef(RHS, g.level, i), src=src,
+                                              operator_name=entry.name, operator_level=op_level))
+                else:
+                    self.out.append(Statement("prolong_set", g.level, dst=FieldRef(CORRECTION, g.level, i), src=src,
+                                              operator_name=entry.name, operator_level=op_level))
+        elif isa(op1, "base", "CoarseGridSolver"):
+            self.visit(e.operand2)
+            level = self.max_level
+            grids2 = e.operand2.grid
+            self._single_field(grids2)
+            for i, g in enumerate(grids2):
+                level = min(level, g.level)
+                if g.level == self.min_level:
+                    self.out.append(Statement("copy", g.level, dst=FieldRef(CGS_RHS, g.level, i),
+                                              src=FieldRef(RHS, g.level, i)))
+                    self.out.append(Statement("zero", g.level, dst=FieldRef(CORRECTION, g.level, i)))
+                else:
+                    self.out.append(Statement("zero", g.level, dst=self._sol(g.level, i)))
+            self.out.append(Statement("coarse_solve", level, cycle_name=self.cycle_name))
+            for i, g in enumerate(e.grid):
+                self.out.append(Statement("copy", g.level, dst=FieldRef(CORRECTION, g.level, i),
+                                          src=self._sol(g.level, i)))
+                if g.level != self.min_level:
+                    self.out.append(Statement("copy", g.level, dst=FieldRef(CORRECTION, g.level, i),
+                                              src=self._sol(g.level, i)))
+        else:
+            raise UnsupportedExpression("Not implemented")
+
+
+def reset_valid_flags(expression):
+    """exastencils.py:330-334: clear the `valid` marks the pass left on shared sub-expressions."""
+    def rec(e):
+        if e is not None:
+            e.valid = False
+            e.mutate(rec)
+    rec(expression)
+
+
+def lower(expression, fields, min_level, max_level, cycle_name="gen_mgCycle", use_global_weights=False):
+    """Statement list for one candidate; always leaves the DAG's `valid` flags cleared."""
+    walker = Lowering(fields, min_level, max_level, cycle_name, use_global_weights)
+    try:
+        walker.visit(expression)
+    finally:
+        reset_valid_flags(expression)
+    return walker.out

@@ -1,0 +1,61 @@
+"""Statement list -> op program (array of evomg_op_t, include/evomg.h): the numerical twin of
+exaslang.py. No sympy on this path."""
+from typing import List
+
+from evostencils_amd import abi
+from evostencils_amd.code_generation import lowering as low
+
+_ROLE = {low.SOLUTION: abi.F_SOL, low.RHS: abi.F_RHS, low.RESIDUAL: abi.F_RES,
+         low.CORRECTION: abi.F_CORR, low.CGS_RHS: abi.F_CGS_RHS}
+
+
+def _f(ref: low.FieldRef) -> int:
+    if ref.index != 0:
+        raise low.UnsupportedExpression("systems of PDEs are not supported yet")
+    return _ROLE[ref.role]
+
+
+def _w(weight) -> float:
+    if isinstance(weight, str):
+        raise low.UnsupportedExpression("symbolic (global) weights cannot be evaluated numerically")
+    return float(weight)
+
+
+def encode(statements) -> List[abi.Op]:
+    ops = []
+    for st in statements:
+        k = st.kind
+        if k == "zero":
+            ops.append(abi.make_op(abi.OP_SET_ZERO, st.level, _f(st.dst)))
+        elif k == "copy":
+            ops.append(abi.make_op(abi.OP_COPY, st.level, _f(st.dst), _f(st.src)))
+        elif k == "coarse_solve":
+            ops.append(abi.make_op(abi.OP_COARSE_SOLVE, st.level, abi.F_CORR, abi.F_CGS_RHS))
+        elif k == "residual":
+            _require_plain_operator(st)
+            ops.append(abi.make_op(abi.OP_RESIDUAL, st.level, _f(st.dst), _f(st.src), _f(st.rhs)))
+        elif k == "richardson":
+            _require_plain_operator(st)
+            ops.append(abi.make_op(abi.OP_RICHARDSON, st.level, _f(st.dst), _f(st.dst), _f(st.rhs),
+                                   omega=_w(st.weight)))
+        elif k == "prolong_add":
+            ops.append(abi.make_op(abi.OP_PROLONG_ADD, st.level, _f(st.dst), _f(st.src), omega=_w(st.weight)))
+        elif k == "prolong_set":
+            ops.append(abi.make_op(abi.OP_PROLONG_SET, st.level, _f(st.dst), _f(st.src)))
+        elif k == "restrict":
+            ops.append(abi.make_op(abi.OP_RESTRICT, st.level, _f(st.dst), _f(st.src)))
+        elif k == "smooth":
+            _require_plain_operator(st)
+            partitioning = abi.PART_RED_BLACK if st.partitioning == "red_black" else abi.PART_SINGLE
+            ops.append(abi.make_op(abi.OP_SMOOTH, st.level, _f(st.dst), 0, _f(st.rhs), partitioning,
+                                   st.block, _w(st.weight)))
+        else:
+            raise low.UnsupportedExpression(f"statement kind {k!r} has no kernel")
+    return ops
+
+
+def _require_plain_operator(st):
+    e = st.operator_entry
+    if e is None or not low.isa(e, "base", "Operator") or low.isa(e, "base", "Identity") \
+            or low.isa(e, "base", "ZeroOperator"):
+        raise low.UnsupportedExpression("only plain stencil operators are supported as system operator")

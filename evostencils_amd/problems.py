@@ -1,0 +1,249 @@
+"""Problem descriptors: the numerical test problems of the reference's example_problems/ directory
+as plain data (replaces the .exa2/.exa3/.knowledge/.settings files + ExaStencils' debug L3 that
+code_generation/parser.py:25-143 reads).
+
+  poisson_2d   example_problems/Poisson/2D_FD_Poisson_fromL2.{exa2,exa3,knowledge}
+  poisson_3d   example_problems/Poisson/3D_FD_Poisson_fromL2.{exa2,exa3,knowledge}
+  helmholtz_2d example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.{exa3,exa4,knowledge}
+
+Field arrays are numpy arrays indexed [i2][i1][i0] (x fastest), (2^L+1)^d nodes including the
+boundary ("Field ... on Node", 2D_FD_Poisson_fromL2.exa2:4).
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from evostencils_amd import abi
+from evostencils_amd.ir import base
+from evostencils_amd.stencils import constant
+
+
+def _star_offsets(dim):
+    offs = [(0,) * dim]
+    for d in range(dim):
+        for s in (-1, 1):
+            o = [0] * dim
+            o[d] = s
+            offs.append(tuple(o))
+    return offs
+
+
+def _fw_restriction_stencil(dim):
+    """[1/4 1/2 1/4]^(x)d on fine-grid offsets."""
+    import itertools
+    w1 = {-1: 0.25, 0: 0.5, 1: 0.25}
+    return constant.Stencil([(o, float(np.prod([w1[c] for c in o])))
+                             for o in itertools.product((-1, 0, 1), repeat=dim)], dim)
+
+
+def _linear_prolongation_stencil(dim):
+    """[1/2 1 1/2]^(x)d (the transpose of full weighting times 2^d)."""
+    import itertools
+    w1 = {-1: 0.5, 0: 1.0, 1: 0.5}
+    return constant.Stencil([(o, float(np.prod([w1[c] for c in o])))
+                             for o in itertools.product((-1, 0, 1), repeat=dim)], dim)
+
+
+@dataclass
+class ProblemDescription:
+    name: str
+    dimension: int
+    min_level: int
+    max_level: int
+    scalar_kind: int = abi.REAL_F64
+    bc_kind: int = abi.BC_DIRICHLET
+    outer_kind: int = abi.OUTER_MG_ITERATION
+    cgs_kind: int = abi.CGS_CG
+    max_iterations: int = 100
+    cgs_max_iterations: int = 1000
+    target_res_reduction: float = 1e-12
+    cgs_target_res_reduction: float = 1e-12
+    field_name: str = "u"
+    rhs_name: str = "RHS_u"
+    operator_name: str = "Laplace"
+    equation_name: str = "solEq"
+    restriction_name: str = "gen_restrictionForRes_u"
+    prolongation_name: str = "gen_prolongationForSol_u"
+    # level -> 7 star-stencil coefficients (centre, -x, +x, -y, +y, -z, +z) of the MG operator
+    mg_stencil: Callable[[int, Dict[str, complex]], List[complex]] = None
+    outer_stencil: Optional[Callable[[int, Dict[str, complex]], List[complex]]] = None
+    # finest-level initial solution (with boundary values) and right-hand side
+    initial_solution: Callable[[int], np.ndarray] = None
+    right_hand_side: Callable[[int], np.ndarray] = None
+    parameters: Dict[str, complex] = field(default_factory=dict)
+
+    def nodes(self, level):
+        return (1 << level) + 1
+
+    def with_levels(self, min_level, max_level):
+        import dataclasses
+        return dataclasses.replace(self, min_level=min_level, max_level=max_level,
+                                   parameters=dict(self.parameters))
+
+    # ---- C-ABI descriptor -------------------------------------------------------------------
+    def to_c(self, parameters: Optional[Dict[str, complex]] = None) -> abi.Problem:
+        params = dict(self.parameters)
+        if parameters:
+            params.update(parameters)
+        p = abi.Problem()
+        p.abi_version = abi.ABI_VERSION
+        p.dimension, p.min_level, p.max_level = self.dimension, self.min_level, self.max_level
+        p.scalar_kind, p.bc_kind = self.scalar_kind, self.bc_kind
+        p.outer_kind, p.cgs_kind = self.outer_kind, self.cgs_kind
+        p.max_iterations, p.cgs_max_iterations = self.max_iterations, self.cgs_max_iterations
+        p.target_res_reduction = self.target_res_reduction
+        p.cgs_target_res_reduction = self.cgs_target_res_reduction
+        for level in range(self.min_level, self.max_level + 1):
+            for e, v in enumerate(self.mg_stencil(level, params)):
+                v = complex(v)
+                p.mg_stencil[level][e].re, p.mg_stencil[level][e].im = v.real, v.imag
+        if self.outer_stencil is not None:
+            for e, v in enumerate(self.outer_stencil(self.max_level, params)):
+                v = complex(v)
+                p.outer_stencil[e].re, p.outer_stencil[e].im = v.real, v.imag
+        p.wavenumber = float(np.real(params.get("k", 0.0)))
+        return p
+
+    # ---- what the reference's parser would extract (parser.py:25-111) -------------------------
+    def l2_information(self, parameters=None):
+        """(equations, operators, fields) as EquationInfo / OperatorInfo / sympy.Symbol lists."""
+        import sympy
+        from evostencils_amd.grammar import multigrid as mg
+        params = dict(self.parameters)
+        if parameters:
+            params.update(parameters)
+        fields = [sympy.Symbol(self.field_name)]
+        equations, operators = [], []
+        offs = _star_offsets(self.dimension)
+        for level in range(self.min_level, self.max_level + 1):
+            eq = mg.EquationInfo(self.equation_name, level,
+                                 f"( {self.operator_name}@{level} * {self.field_name}@{level} ) == {self.rhs_name}@{level}")
+            eq._associated_field = fields[0]
+            equations.append(eq)
+            coeffs = self.mg_stencil(level, params)[:1 + 2 * self.dimension]
+            vals = [float(np.real(c)) if self.scalar_kind == abi.REAL_F64 else complex(c) for c in coeffs]
+            op = mg.OperatorInfo(self.operator_name, level, constant.Stencil(list(zip(offs, vals)), self.dimension))
+            operators.append(op)
+            # the default inter-grid operators exist on every level (grammar/multigrid.py:156-157 asserts it)
+            r = mg.OperatorInfo(self.restriction_name, level, _fw_restriction_stencil(self.dimension), base.Restriction)
+            r._associated_field = fields[0]
+            operators.append(r)
+            pr = mg.OperatorInfo(self.prolongation_name, level, _linear_prolongation_stencil(self.dimension), base.Prolongation)
+            pr._associated_field = fields[0]
+            operators.append(pr)
+        return equations, operators, fields
+
+
+# ---------------------------------------------------------------------------------------------
+def _coords(level, dim):
+    n = (1 << level) + 1
+    x = np.arange(n, dtype=np.float64) * (1.0 / (n - 1))   # node i at i*h
+    return n, x
+
+
+def _boundary_mask(n, dim):
+    m = np.zeros((n,) * dim, dtype=bool)
+    for d in range(dim):
+        sl = [slice(None)] * dim
+        sl[d] = 0
+        m[tuple(sl)] = True
+        sl[d] = n - 1
+        m[tuple(sl)] = True
+    return m
+
+
+def poisson_2d(min_level=5, max_level=9) -> ProblemDescription:
+    """-Laplace u = pi^2 cos(pi x) - 4 pi^2 sin(2 pi y) on (0,1)^2, u = cos(pi x) - sin(2 pi y) on the
+    boundary, u0 = 0 (Poisson/2D_FD_Poisson_fromL2.exa2:1-19); generated solver: 1e-12 / 100 its,
+    CG coarse solver 1e-12 / 1000 its (exa3:2-14); default levels 5..9 (knowledge:3-4)."""
+    def st(level, _params):
+        h = 1.0 / (1 << level)
+        c = 2.0 / (h ** 2) + 2.0 / (h ** 2)
+        o = -1.0 / (h ** 2)
+        return [c, o, o, o, o, 0.0, 0.0]
+
+    def u0(level):
+        n, x = _coords(level, 2)
+        X, Y = x[None, :], x[:, None]               # [i1][i0]
+        bc = np.cos(np.pi * X) - np.sin(2.0 * np.pi * Y)
+        return np.where(_boundary_mask(n, 2), bc, 0.0)
+
+    def rhs(level):
+        n, x = _coords(level, 2)
+        X, Y = x[None, :], x[:, None]
+        return (np.pi ** 2 * np.cos(np.pi * X) - 4.0 * np.pi ** 2 * np.sin(2.0 * np.pi * Y)) + 0.0 * X * Y
+
+    return ProblemDescription("2D_FD_Poisson_fromL2", 2, min_level, max_level, mg_stencil=st,
+                              initial_solution=u0, right_hand_side=rhs)
+
+
+def poisson_3d(min_level=2, max_level=6) -> ProblemDescription:
+    """-Laplace u = 0 on (0,1)^3, u = x^2 - y^2/2 - z^2/2 on the boundary of the finest level, u0 = 0
+    (Poisson/3D_FD_Poisson_fromL2.exa2:2-19); solver as 2D; default levels 2..6 (knowledge:3-4)."""
+    def st(level, _params):
+        h = 1.0 / (1 << level)
+        c = 2.0 / (h ** 2) + 2.0 / (h ** 2) + 2.0 / (h ** 2)
+        o = -1.0 / (h ** 2)
+        return [c, o, o, o, o, o, o]
+
+    def u0(level):
+        n, x = _coords(level, 3)
+        X, Y, Z = x[None, None, :], x[None, :, None], x[:, None, None]   # [i2][i1][i0]
+        bc = X * X - 0.5 * Y * Y - 0.5 * Z * Z
+        return np.where(_boundary_mask(n, 3), bc, 0.0)
+
+    def rhs(level):
+        n = (1 << level) + 1
+        return np.zeros((n, n, n))
+
+    return ProblemDescription("3D_FD_Poisson_fromL2", 3, min_level, max_level, mg_stencil=st,
+                              initial_solution=u0, right_hand_side=rhs)
+
+
+def helmholtz_2d(min_level=3, max_level=7, k=80.0) -> ProblemDescription:
+    """(-Laplace - k^2) u = f, f = B-spline approximation of a Dirac pulse at (1/2,1/2); multigrid acts on
+    the shifted operator M = -Laplace - k^2 (1 + 0.5i) as preconditioner of BiCGStab on A
+    (Helmholtz/2D_FD_Helmholtz_fromL3.exa3:24,55-84,144-200); coarsest level: BiCGStab <= 1000 its, 1e-6
+    (exa3:396-433); Dirichlet 0 top/bottom, first-order Robin left/right (exa4:43-59)."""
+    shift = 1.0 + 0.5j
+
+    def st_m(level, params):
+        h = 1.0 / (1 << level)
+        kk = params["k"]
+        c = 2.0 / (h ** 2) + 2.0 / (h ** 2) - kk ** 2 * shift
+        o = -1.0 / (h ** 2)
+        return [c, o, o, o, o, 0.0, 0.0]
+
+    def st_a(level, params):
+        h = 1.0 / (1 << level)
+        kk = params["k"]
+        c = 2.0 / (h ** 2) + 2.0 / (h ** 2) - kk ** 2
+        o = -1.0 / (h ** 2)
+        return [c, o, o, o, o, 0.0, 0.0]
+
+    def u0(level):
+        n = (1 << level) + 1
+        return np.zeros((n, n), dtype=np.complex128)
+
+    def rhs(level):
+        n, x = _coords(level, 2)
+        h = 1.0 / (n - 1)
+        X, Y = x[None, :], x[:, None]
+        bx = np.maximum(0.0, -(np.abs(X - 0.5) - h) / h ** 2)
+        by = np.maximum(0.0, -(np.abs(Y - 0.5) - h) / h ** 2)
+        return (bx * by).astype(np.complex128)
+
+    return ProblemDescription("2D_FD_Helmholtz_fromL3", 2, min_level, max_level,
+                              scalar_kind=abi.COMPLEX_F64, bc_kind=abi.BC_HELMHOLTZ_ROBIN,
+                              outer_kind=abi.OUTER_PBICGSTAB, cgs_kind=abi.CGS_BICGSTAB,
+                              max_iterations=10000, cgs_max_iterations=1000,
+                              target_res_reduction=1e-7, cgs_target_res_reduction=1e-6,
+                              field_name="u", rhs_name="f", operator_name="M", equation_name="PrecEq",
+                              restriction_name="Restriction_u", prolongation_name="Prolongation_u",
+                              mg_stencil=st_m, outer_stencil=st_a, initial_solution=u0,
+                              right_hand_side=rhs, parameters={"k": float(k)})
+
+
+BY_NAME = {"2D_FD_Poisson_fromL2": poisson_2d, "3D_FD_Poisson_fromL2": poisson_3d,
+           "2D_FD_Helmholtz_fromL3": helmholtz_2d}

@@ -1,0 +1,200 @@
+/*
+ * evomg.h — C-ABI of the MI355X-native multigrid fitness-evaluation backend.
+ *
+ * This header is the drop-in boundary for ONE path of jonas-schmitt/evostencils:
+ * the generate -> compile -> run -> parse fitness evaluation of
+ *   evostencils/code_generation/exastencils.py:485-537  ProgramGenerator.generate_and_evaluate
+ * Instead of emitting ExaSlang text, starting two JVMs, running `make` and a
+ * generated OpenMP executable, the Python side lowers the same IR DAG to a flat
+ * *op program* (one evomg_op_t per ExaSlang statement the reference would emit,
+ * exastencils.py:684-925) and hands it to evomg_evaluate(), which interprets it
+ * with hand-written HIP kernels on one MI355X.
+ *
+ * Plain C, no torch types, no C++ in the signatures: bindable from ctypes/cffi.
+ * Every function returns an int status (EVOMG_OK == 0) and never aborts; a bad
+ * candidate is reported through evomg_result_t.status, mirroring the reference's
+ * "sentinels, not exceptions" convention (exastencils.py:430-439,476-483).
+ * A handle is not thread-safe; use one handle per GPU / per process.
+ */
+#ifndef EVOMG_H
+#define EVOMG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVOMG_ABI_VERSION 1
+#define EVOMG_MAX_LEVELS 24       /* levels are absolute: grid level L has 2^L+1 nodes per dimension */
+#define EVOMG_MAX_DIM 3
+#define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
+#define EVOMG_MAX_BLOCK_CELLS 8   /* maximum_local_system_size default, optimization/program.py:107 */
+
+/* status codes (function return values) */
+enum {
+  EVOMG_OK = 0,
+  EVOMG_ERR_INVALID = 1,      /* bad argument / malformed op program */
+  EVOMG_ERR_DEVICE = 2,       /* HIP runtime error (no device, OOM, launch failure) */
+  EVOMG_ERR_UNSUPPORTED = 3   /* well-formed but not implemented (e.g. 3D complex) */
+};
+
+/* outcome of one candidate evaluation (evomg_result_t.status) */
+enum {
+  EVOMG_SOLVE_CONVERGED = 0,  /* res <= target_res_reduction * init_res */
+  EVOMG_SOLVE_MAXITER = 1,    /* "maximum number of solver iterations" (exastencils.py:555-557) */
+  EVOMG_SOLVE_DIVERGED = 2,   /* NaN/Inf residual norm */
+  EVOMG_SOLVE_WALL_LIMIT = 3  /* wall_limit_ms exceeded: counterpart of the subprocess timeout (exastencils.py:430-431) */
+};
+
+/* scalar kind of all fields of a problem */
+enum { EVOMG_REAL_F64 = 0, EVOMG_COMPLEX_F64 = 1 };
+
+/* boundary handling applied after every field write */
+enum {
+  EVOMG_BC_DIRICHLET = 0,       /* boundary nodes are never written by field loops (Poisson 2D/3D) */
+  EVOMG_BC_HELMHOLTZ_ROBIN = 1  /* Dirichlet 0 at y=0,1; x_b = x_in / (1 - i k h) at x=0,1
+                                   (example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa4:43-59) */
+};
+
+/* outer solver loop */
+enum {
+  EVOMG_OUTER_MG_ITERATION = 0, /* "generate solver for u in solEq": repeat cycle until reduction / maxNumIts
+                                   (example_problems/Poisson/2D_FD_Poisson_fromL2.exa3:2-4) */
+  EVOMG_OUTER_PBICGSTAB = 1     /* MG-preconditioned BiCGStab, 2 cycles per iteration
+                                   (example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3:144-200) */
+};
+
+/* coarse-grid solver = gen_mgCycle@minLevel */
+enum {
+  EVOMG_CGS_CG = 0,       /* solver_cgs = "CG" (Poisson/2D_FD_Poisson_fromL2.exa3:12-14) */
+  EVOMG_CGS_BICGSTAB = 1  /* explicit BiCGStab text, Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 */
+};
+
+typedef struct { double re, im; } evomg_c64;
+
+/*
+ * Problem descriptor: replaces the .knowledge/.settings/.exa2/.exa3 file zoo the
+ * reference parses (code_generation/parser.py:25-143). Pure data.
+ */
+typedef struct {
+  int32_t abi_version;          /* must be EVOMG_ABI_VERSION */
+  int32_t dimension;            /* 2 or 3 (knowledge: dimensionality) */
+  int32_t min_level;            /* coarsest level (knowledge: minLevel) */
+  int32_t max_level;            /* finest level   (knowledge: maxLevel) */
+  int32_t scalar_kind;          /* EVOMG_REAL_F64 | EVOMG_COMPLEX_F64 */
+  int32_t bc_kind;              /* EVOMG_BC_* */
+  int32_t outer_kind;           /* EVOMG_OUTER_* */
+  int32_t cgs_kind;             /* EVOMG_CGS_* */
+  int32_t max_iterations;       /* solver_maxNumIts */
+  int32_t cgs_max_iterations;   /* solver_cgs_maxNumIts */
+  double  target_res_reduction;     /* solver_targetResReduction */
+  double  cgs_target_res_reduction; /* solver_cgs_targetResReduction */
+  /* System operator per absolute level (index = level), rediscretised per level
+   * (SURVEY App. B.4). Star stencil, entry order: centre, -x, +x, -y, +y, -z, +z.
+   * For real problems .im == 0. This is the operator the multigrid cycle acts on
+   * (Laplace for Poisson, the shifted preconditioner M for Helmholtz). */
+  evomg_c64 mg_stencil[EVOMG_MAX_LEVELS][EVOMG_STENCIL_ENTRIES];
+  /* Operator of the outer Krylov solver on the finest level only (Helmholtz A);
+   * ignored for EVOMG_OUTER_MG_ITERATION. */
+  evomg_c64 outer_stencil[EVOMG_STENCIL_ENTRIES];
+  /* Robin factor numerator data: wavenumber k (Helmholtz). */
+  double wavenumber;
+} evomg_problem_t;
+
+/* field slots of one level (exastencils.py:14-26,295-316) */
+enum {
+  EVOMG_F_SOL = 0,      /* u@max on the finest level, gen_error_u@L below it (exastencils.py:296-301) */
+  EVOMG_F_RHS = 1,      /* RHS_u@L */
+  EVOMG_F_RES = 2,      /* gen_residual_u@L */
+  EVOMG_F_CORR = 3,     /* gen_error_u@L; the same array as SOL below the finest level */
+  EVOMG_F_CGS_RHS = 4,  /* gen_rhs_u@min (exastencils.py:890-892) */
+  EVOMG_F_COUNT = 5
+};
+
+/* opcodes: one per ExaSlang statement kind the reference emits */
+enum {
+  EVOMG_OP_SMOOTH = 1,       /* solve locally at dst@L [with jacobi] relax w {...}        exastencils.py:778-822 */
+  EVOMG_OP_RESIDUAL = 2,     /* dst@L = src1@L - (A@L * src0@L)                           exastencils.py:837-853 */
+  EVOMG_OP_RESTRICT = 3,     /* dst@L = R@(L+1) * src0@(L+1)                              exastencils.py:868-873 */
+  EVOMG_OP_PROLONG_ADD = 4,  /* dst@L += w * (P@(L-1) * src0@(L-1))                       exastencils.py:742-743 */
+  EVOMG_OP_PROLONG_SET = 5,  /* dst@L  = P@(L-1) * src0@(L-1)                             exastencils.py:870-873 */
+  EVOMG_OP_SET_ZERO = 6,     /* dst@L = 0                                                 exastencils.py:709,756,836,892,895 */
+  EVOMG_OP_COPY = 7,         /* dst@L = src0@L                                            exastencils.py:891,901 */
+  EVOMG_OP_COARSE_SOLVE = 8, /* gen_mgCycle@min(): Krylov solve on gen_error/gen_rhs@min  exastencils.py:896 */
+  EVOMG_OP_RICHARDSON = 9    /* dst@L += w * (src1@L - A@L*dst@L)                         exastencils.py:710-726 */
+};
+
+enum { EVOMG_PART_SINGLE = 0, EVOMG_PART_RED_BLACK = 1 };  /* ir/partitioning.py:18,34 */
+
+typedef struct {
+  int32_t opcode;        /* EVOMG_OP_* */
+  int32_t level;         /* level of dst */
+  int32_t dst;           /* EVOMG_F_* */
+  int32_t src0;          /* EVOMG_F_* (operand field; for SMOOTH unused) */
+  int32_t src1;          /* EVOMG_F_* (right-hand side for SMOOTH/RESIDUAL/RICHARDSON) */
+  int32_t partitioning;  /* EVOMG_PART_*; RED_BLACK => "color with {((i0+i1[+i2])%2), ...}" and in place */
+  int32_t block[EVOMG_MAX_DIM]; /* block shape of the local solve, (1,1,1) = point smoother */
+  int32_t reserved;
+  double  omega;         /* relaxation factor */
+} evomg_op_t;
+
+typedef struct {
+  double  time_ms;         /* mean wall time of the solve loop over evaluation_samples runs */
+  double  conv_factor;     /* (final/init)^(1/n): geometric mean of the per-iteration residual ratios */
+  double  n_iterations;    /* iterations performed */
+  double  init_res_norm;
+  double  final_res_norm;
+  int32_t status;          /* EVOMG_SOLVE_* */
+  int32_t n_history;       /* number of residual norms written to res_history (init + one per iteration) */
+} evomg_result_t;
+
+typedef struct {
+  double ms;               /* mean duration of one launch (HIP events on the handle's stream) */
+  double bytes;            /* algorithmic bytes of one launch (SURVEY 8d table x points of the level) */
+  double gbps;             /* bytes / ms */
+  int32_t launches;
+  int32_t reserved;
+} evomg_bench_t;
+
+typedef struct evomg_handle evomg_handle_t;
+
+/* -- lifetime ------------------------------------------------------------ */
+/* Allocates every level's fields on device `device_id` once; fields are reused across candidates. */
+int  evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t** out);
+void evomg_destroy(evomg_handle_t* h);
+const char* evomg_last_error(const evomg_handle_t* h);  /* h may be NULL: error of the last failed create */
+int  evomg_abi_version(void);
+
+/* -- problem data (K10): dense host arrays, x fastest, (2^L+1)^d scalars; complex = interleaved re,im -- */
+/* Sets the *initial* content of a field (restored at the start of every solve). Only SOL and RHS of the
+ * finest level are meaningful inputs (u with its boundary values, RHS_u). */
+int  evomg_set_initial_field(evomg_handle_t* h, int level, int field, const double* host);
+/* Reads back the current content of a field after an evaluate/run_ops call. */
+int  evomg_get_field(evomg_handle_t* h, int level, int field, double* host);
+/* Overwrites the current content of a field (test hook for per-kernel parity). */
+int  evomg_set_field(evomg_handle_t* h, int level, int field, const double* host);
+/* Re-targets the operators, e.g. Helmholtz wavenumber sweep k, 2k, 4k (exastencils.py:518-532). */
+int  evomg_set_operators(evomg_handle_t* h, const evomg_problem_t* problem);
+
+/* -- the call -------------------------------------------------------------- */
+/* One candidate: validates the op program, runs the solver loop `evaluation_samples` times.
+ * res_history may be NULL; otherwise receives the residual norms of the last sample. */
+int  evomg_evaluate(evomg_handle_t* h, const evomg_op_t* ops, int n_ops,
+                    int evaluation_samples, double wall_limit_ms,
+                    evomg_result_t* out, double* res_history, int history_capacity);
+/* Executes the op program once on the current field contents (no solver loop). Test hook. */
+int  evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops);
+/* L2 norm of the current content of a field over the inner nodes (the solver loop's norm). */
+int  evomg_norm(evomg_handle_t* h, int level, int field, double* out);
+
+/* -- measurement ------------------------------------------------------------ */
+/* Times `reps` back-to-back launches of one op on the handle's stream with HIP events. */
+int  evomg_bench_op(evomg_handle_t* h, const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out);
+/* Name of the device kernel an op dispatches to (for matching rocprofv3 kernel-trace rows). */
+int  evomg_kernel_name(evomg_handle_t* h, const evomg_op_t* op, char* buf, int buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVOMG_H */

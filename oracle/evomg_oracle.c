@@ -1,0 +1,270 @@
+/*
+ * evomg_oracle.c — CPU ORACLE. TEST INFRASTRUCTURE ONLY: never imported, linked or called by the
+ * product path (evostencils_amd/); used by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the checker / reported baseline.
+ *
+ * What it restates: the numerics of one fitness evaluation of the reference, i.e. what the
+ * ExaStencils-generated executable computes when run by
+ *   evostencils/code_generation/exastencils.py:417-443 (evaluate) for the statement list emitted by
+ *   evostencils/code_generation/exastencils.py:684-925 (generate_multigrid),
+ * on the problems example_problems/Poisson/{2D,3D}_FD_Poisson_fromL2.* and
+ * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.*.
+ *
+ * PARITY UNPINNED: the arithmetic lives in ExaStencils v1.1 (github.com/lssfau/ExaStencils, tag v1.1,
+ * README.md:19-21), a JVM code generator that is not under /root/reference and cannot run in this
+ * pipeline (no java). The reference holds no numerical golden vectors for this path (no tests at all).
+ * This oracle is therefore pinned only by (i) known-answer tests derived from the reference's problem
+ * files (tests/test_oracle_known_answers.py) and (ii) the explicit algorithms spelled out in ExaSlang in
+ * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3 (BiCGStab, V-cycle, norms).
+ *
+ * It consumes the same op program (include/evomg.h) as the HIP backend and exposes the same entry points
+ * with the prefix `oracle_` instead of `evomg_`.
+ */
+#define _POSIX_C_SOURCE 199309L
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/evomg.h"
+
+static double now_ms(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+/* ===================== real instantiation ===================== */
+#define SC double
+#define FN(x) x##_r
+#define SC_IS_COMPLEX 0
+static inline double sc_add(double a, double b) { return a + b; }
+static inline double sc_sub(double a, double b) { return a - b; }
+static inline double sc_mul(double a, double b) { return a * b; }
+static inline double sc_div(double a, double b) { return a / b; }
+static inline double sc_rmul(double r, double a) { return r * a; }
+static inline double sc_neg(double a) { return -a; }
+static inline double sc_zero(void) { return 0.0; }
+static inline double sc_from_real(double r) { return r; }
+static inline double sc_from_c64(evomg_c64 z) { return z.re; }
+static inline int sc_iszero(double a) { return a == 0.0; }
+static inline double sc_norm_from_dot(double d) { return sqrt(d); }
+#include "evomg_oracle_impl.h"
+#undef SC
+#undef FN
+#undef SC_IS_COMPLEX
+#define sc_add csc_add
+#define sc_sub csc_sub
+#define sc_mul csc_mul
+#define sc_div csc_div
+#define sc_rmul csc_rmul
+#define sc_neg csc_neg
+#define sc_zero csc_zero
+#define sc_from_real csc_from_real
+#define sc_from_c64 csc_from_c64
+#define sc_iszero csc_iszero
+#define sc_norm_from_dot csc_norm_from_dot
+
+/* ===================== complex instantiation ===================== */
+typedef struct { double re, im; } cplx;
+#define SC cplx
+#define FN(x) x##_c
+#define SC_IS_COMPLEX 1
+static inline cplx csc_add(cplx a, cplx b) { cplx r = {a.re + b.re, a.im + b.im}; return r; }
+static inline cplx csc_sub(cplx a, cplx b) { cplx r = {a.re - b.re, a.im - b.im}; return r; }
+static inline cplx csc_mul(cplx a, cplx b) {
+  cplx r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+  return r;
+}
+/* textbook division (a * conj(b)) / |b|^2, fixed order */
+static inline cplx csc_div(cplx a, cplx b) {
+  const double d = b.re * b.re + b.im * b.im;
+  cplx r = {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+  return r;
+}
+static inline cplx csc_rmul(double s, cplx a) { cplx r = {s * a.re, s * a.im}; return r; }
+static inline cplx csc_neg(cplx a) { cplx r = {-a.re, -a.im}; return r; }
+static inline cplx csc_zero(void) { cplx r = {0.0, 0.0}; return r; }
+static inline cplx csc_from_real(double s) { cplx r = {s, 0.0}; return r; }
+static inline cplx csc_from_c64(evomg_c64 z) { cplx r = {z.re, z.im}; return r; }
+static inline int csc_iszero(cplx a) { return a.re == 0.0 && a.im == 0.0; }
+/* |sqrt(z)| = sqrt(|z|): `fabs(curRes)` of a Complex<Real> sqrt(dot(r,r)) (Helmholtz exa3:86-88,191) */
+static inline double csc_norm_from_dot(cplx d) { return sqrt(sqrt(d.re * d.re + d.im * d.im)); }
+#include "evomg_oracle_impl.h"
+#undef SC
+#undef FN
+
+/* ===================== C entry points (same shapes as evomg_*) ===================== */
+typedef struct {
+  int is_complex;
+  ctx_t_r* r;
+  ctx_t_c* c;
+} oracle_handle_t;
+
+static char g_err[256];
+
+const char* oracle_last_error(const oracle_handle_t* h) {
+  if (!h) return g_err;
+  return h->is_complex ? h->c->err : h->r->err;
+}
+
+static int check_problem(const evomg_problem_t* p) {
+  if (!p || p->abi_version != EVOMG_ABI_VERSION) { snprintf(g_err, sizeof g_err, "abi mismatch"); return EVOMG_ERR_INVALID; }
+  if (p->dimension != 2 && p->dimension != 3) { snprintf(g_err, sizeof g_err, "dimension"); return EVOMG_ERR_INVALID; }
+  if (p->min_level < 1 || p->max_level >= EVOMG_MAX_LEVELS || p->min_level > p->max_level) {
+    snprintf(g_err, sizeof g_err, "levels"); return EVOMG_ERR_INVALID;
+  }
+  if (p->scalar_kind == EVOMG_COMPLEX_F64 && p->dimension != 2) { snprintf(g_err, sizeof g_err, "complex 3D"); return EVOMG_ERR_UNSUPPORTED; }
+  if (p->bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && p->scalar_kind != EVOMG_COMPLEX_F64) return EVOMG_ERR_INVALID;
+  if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) return EVOMG_ERR_UNSUPPORTED;
+  return EVOMG_OK;
+}
+
+int oracle_create(const evomg_problem_t* p, int device_id, oracle_handle_t** out) {
+  (void)device_id;
+  int rc = check_problem(p);
+  if (rc != EVOMG_OK) return rc;
+  oracle_handle_t* h = (oracle_handle_t*)calloc(1, sizeof *h);
+  h->is_complex = (p->scalar_kind == EVOMG_COMPLEX_F64);
+  rc = h->is_complex ? create_c(p, &h->c) : create_r(p, &h->r);
+  if (rc != EVOMG_OK) { free(h); return rc; }
+  *out = h;
+  return EVOMG_OK;
+}
+
+void oracle_destroy(oracle_handle_t* h) {
+  if (!h) return;
+  if (h->is_complex) destroy_c(h->c); else destroy_r(h->r);
+  free(h);
+}
+
+int oracle_abi_version(void) { return EVOMG_ABI_VERSION; }
+
+#define LEVEL_OK(P, L) ((L) >= (P).min_level && (L) <= (P).max_level)
+
+int oracle_set_initial_field(oracle_handle_t* h, int level, int field, const double* host) {
+  if (!h || !host || field < 0 || field >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+  if (h->is_complex) {
+    if (!LEVEL_OK(h->c->prob, level)) return EVOMG_ERR_INVALID;
+    if (field == EVOMG_F_CORR && level < h->c->prob.max_level) field = EVOMG_F_SOL;
+    level_t_c* lv = &h->c->lv[level];
+    if (!lv->f[field]) return EVOMG_ERR_INVALID;
+    if (!lv->init[field]) lv->init[field] = zalloc_c(lv->count);
+    memcpy(lv->init[field], host, lv->count * sizeof(cplx));
+    memcpy(lv->f[field], host, lv->count * sizeof(cplx));
+  } else {
+    if (!LEVEL_OK(h->r->prob, level)) return EVOMG_ERR_INVALID;
+    if (field == EVOMG_F_CORR && level < h->r->prob.max_level) field = EVOMG_F_SOL;
+    level_t_r* lv = &h->r->lv[level];
+    if (!lv->f[field]) return EVOMG_ERR_INVALID;
+    if (!lv->init[field]) lv->init[field] = zalloc_r(lv->count);
+    memcpy(lv->init[field], host, lv->count * sizeof(double));
+    memcpy(lv->f[field], host, lv->count * sizeof(double));
+  }
+  return EVOMG_OK;
+}
+
+int oracle_set_field(oracle_handle_t* h, int level, int field, const double* host) {
+  if (!h || !host || field < 0 || field >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+  if (h->is_complex) {
+    if (!LEVEL_OK(h->c->prob, level)) return EVOMG_ERR_INVALID;
+    cplx* p = field_c(h->c, level, field);
+    if (!p) return EVOMG_ERR_INVALID;
+    memcpy(p, host, h->c->lv[level].count * sizeof(cplx));
+  } else {
+    if (!LEVEL_OK(h->r->prob, level)) return EVOMG_ERR_INVALID;
+    double* p = field_r(h->r, level, field);
+    if (!p) return EVOMG_ERR_INVALID;
+    memcpy(p, host, h->r->lv[level].count * sizeof(double));
+  }
+  return EVOMG_OK;
+}
+
+int oracle_get_field(oracle_handle_t* h, int level, int field, double* host) {
+  if (!h || !host || field < 0 || field >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+  if (h->is_complex) {
+    if (!LEVEL_OK(h->c->prob, level)) return EVOMG_ERR_INVALID;
+    const cplx* p = field_c(h->c, level, field);
+    if (!p) return EVOMG_ERR_INVALID;
+    memcpy(host, p, h->c->lv[level].count * sizeof(cplx));
+  } else {
+    if (!LEVEL_OK(h->r->prob, level)) return EVOMG_ERR_INVALID;
+    const double* p = field_r(h->r, level, field);
+    if (!p) return EVOMG_ERR_INVALID;
+    memcpy(host, p, h->r->lv[level].count * sizeof(double));
+  }
+  return EVOMG_OK;
+}
+
+int oracle_set_operators(oracle_handle_t* h, const evomg_problem_t* p) {
+  if (!h || !p) return EVOMG_ERR_INVALID;
+  if (h->is_complex) {
+    ctx_t_c* c = h->c;
+    if (p->min_level != c->prob.min_level || p->max_level != c->prob.max_level) return EVOMG_ERR_INVALID;
+    for (int L = p->min_level; L <= p->max_level; ++L)
+      for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e) c->lv[L].st[e] = csc_from_c64(p->mg_stencil[L][e]);
+    for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e) c->outer_st[e] = csc_from_c64(p->outer_stencil[e]);
+    memcpy(c->prob.mg_stencil, p->mg_stencil, sizeof p->mg_stencil);
+    memcpy(c->prob.outer_stencil, p->outer_stencil, sizeof p->outer_stencil);
+    c->prob.wavenumber = p->wavenumber;
+  } else {
+    ctx_t_r* c = h->r;
+    if (p->min_level != c->prob.min_level || p->max_level != c->prob.max_level) return EVOMG_ERR_INVALID;
+    for (int L = p->min_level; L <= p->max_level; ++L)
+      for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e) c->lv[L].st[e] = p->mg_stencil[L][e].re;
+    memcpy(c->prob.mg_stencil, p->mg_stencil, sizeof p->mg_stencil);
+  }
+  return EVOMG_OK;
+}
+
+int oracle_run_ops(oracle_handle_t* h, const evomg_op_t* ops, int n_ops) {
+  if (!h || (!ops && n_ops > 0) || n_ops < 0) return EVOMG_ERR_INVALID;
+  return h->is_complex ? run_ops_c(h->c, ops, n_ops) : run_ops_r(h->r, ops, n_ops);
+}
+
+int oracle_norm(oracle_handle_t* h, int level, int field, double* out) {
+  if (!h || !out || field < 0 || field >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+  if (h->is_complex) {
+    if (!LEVEL_OK(h->c->prob, level)) return EVOMG_ERR_INVALID;
+    const cplx* p = field_c(h->c, level, field);
+    if (!p) return EVOMG_ERR_INVALID;
+    *out = norm_c(h->c, level, p);
+  } else {
+    if (!LEVEL_OK(h->r->prob, level)) return EVOMG_ERR_INVALID;
+    const double* p = field_r(h->r, level, field);
+    if (!p) return EVOMG_ERR_INVALID;
+    *out = norm_r(h->r, level, p);
+  }
+  return EVOMG_OK;
+}
+
+int oracle_evaluate(oracle_handle_t* h, const evomg_op_t* ops, int n_ops, int evaluation_samples,
+                    double wall_limit_ms, evomg_result_t* out, double* res_history, int history_capacity) {
+  if (!h || !out || (!ops && n_ops > 0) || n_ops < 0 || evaluation_samples < 1) return EVOMG_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  /* validate once */
+  for (int i = 0; i < n_ops; ++i) {
+    int rc = h->is_complex ? check_op_c(h->c, &ops[i]) : check_op_r(h->r, &ops[i]);
+    if (rc != EVOMG_OK) return rc;
+  }
+  double tsum = 0.0;
+  evomg_result_t r;
+  for (int s = 0; s < evaluation_samples; ++s) {
+    memset(&r, 0, sizeof r);
+    if (h->is_complex) {
+      reset_fields_c(h->c);
+      if (h->c->prob.outer_kind == EVOMG_OUTER_PBICGSTAB) solve_pbicgstab_c(h->c, ops, n_ops, wall_limit_ms, &r, res_history, history_capacity);
+      else solve_mg_c(h->c, ops, n_ops, wall_limit_ms, &r, res_history, history_capacity);
+    } else {
+      reset_fields_r(h->r);
+      if (h->r->prob.outer_kind == EVOMG_OUTER_PBICGSTAB) return EVOMG_ERR_UNSUPPORTED;
+      solve_mg_r(h->r, ops, n_ops, wall_limit_ms, &r, res_history, history_capacity);
+    }
+    tsum += r.time_ms;
+    if (r.status != EVOMG_SOLVE_CONVERGED) { evaluation_samples = s + 1; break; }
+  }
+  *out = r;
+  out->time_ms = tsum / (double)evaluation_samples;
+  return EVOMG_OK;
+}

@@ -1,0 +1,788 @@
+/*
+ * evomg_oracle_impl.h — scalar-generic body of the CPU oracle. TEST INFRASTRUCTURE ONLY.
+ *
+ * Included twice by evomg_oracle.c with
+ *   SC   = scalar type (double | cplx)
+ *   FN(x) = name mangler (x##_r | x##_c)
+ * and the scalar primitives sc_* defined by the includer.
+ *
+ * Every function is a restatement of what ExaStencils' generated C++ computes for
+ * one ExaSlang statement kind that the reference's lowering emits
+ * (evostencils/code_generation/exastencils.py:684-925). ExaStencils itself is not
+ * in /root/reference (third-party, tag v1.1); semantics marked [EXTERNAL] follow
+ * SURVEY.md Appendix B. PARITY WITH A REAL EXASTENCILS RUN IS UNPINNED.
+ *
+ * Arithmetic is written as explicit, fixed-order two-operand operations and is
+ * compiled with -ffp-contract=off, so that the HIP kernels (same order, same flag)
+ * reproduce every pointwise result bit for bit.
+ */
+
+typedef struct {
+  int L;            /* absolute level */
+  int n;            /* nodes per dimension = 2^L + 1 */
+  size_t count;     /* n^d */
+  SC* f[EVOMG_F_COUNT];
+  SC* init[EVOMG_F_COUNT];   /* initial contents (NULL = zero) */
+  SC* alt;          /* ping-pong twin for out-of-place smoothers */
+  SC* tmp[6];       /* Krylov work vectors (allocated on demand) */
+  SC  st[EVOMG_STENCIL_ENTRIES];
+} FN(level_t);
+
+typedef struct {
+  evomg_problem_t prob;
+  int dim;
+  FN(level_t) lv[EVOMG_MAX_LEVELS];
+  SC outer_st[EVOMG_STENCIL_ENTRIES];
+  SC robin;         /* 1 / (1 - i k h) per level is computed on the fly */
+  char err[256];
+} FN(ctx_t);
+
+#define IDX2(n, i, j) ((size_t)(i) + (size_t)(n) * (size_t)(j))
+#define IDX3(n, i, j, k) ((size_t)(i) + (size_t)(n) * ((size_t)(j) + (size_t)(n) * (size_t)(k)))
+#ifndef OMP_WORTH
+/* small levels run serially: a parallel region costs more than the loop */
+#define OMP_WORTH(n) ((c->dim == 3) ? ((n) >= 33) : ((n) >= 257))
+#endif
+
+static SC* FN(zalloc)(size_t count) {
+  SC* p = (SC*)calloc(count, sizeof(SC));
+  return p;
+}
+
+static SC* FN(field)(FN(ctx_t)* c, int level, int field) {
+  /* gen_error_u@L and the solution of level L < max are the same array (exastencils.py:296-301). */
+  if (field == EVOMG_F_CORR && level < c->prob.max_level) field = EVOMG_F_SOL;
+  return c->lv[level].f[field];
+}
+static void FN(set_fieldptr)(FN(ctx_t)* c, int level, int field, SC* p) {
+  if (field == EVOMG_F_CORR && level < c->prob.max_level) field = EVOMG_F_SOL;
+  c->lv[level].f[field] = p;
+}
+
+/* ---- boundary handling (K8) [EXTERNAL: SURVEY App. B.2] ------------------------------------ */
+/* Dirichlet: boundary nodes are simply never written. Helmholtz: Robin at x = 0, 1:
+ * x_b = x_in / (1 - i k h)   (example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa4:43-59),
+ * Dirichlet 0 at y = 0, 1 (already zero and never written). */
+static void FN(apply_bc)(FN(ctx_t)* c, int level, SC* x) {
+#if SC_IS_COMPLEX
+  if (c->prob.bc_kind != EVOMG_BC_HELMHOLTZ_ROBIN) return;
+  const int n = c->lv[level].n;
+  const double h = 1.0 / (double)(n - 1);
+  cplx den; den.re = 1.0; den.im = -(c->prob.wavenumber * h);
+  /* rows j = 1 .. n-2 only: the corner/top/bottom nodes are Dirichlet 0 */
+  for (int j = 1; j < n - 1; ++j) {
+    x[IDX2(n, 0, j)] = sc_div(x[IDX2(n, 1, j)], den);
+    x[IDX2(n, n - 1, j)] = sc_div(x[IDX2(n, n - 2, j)], den);
+  }
+#else
+  (void)c; (void)level; (void)x;
+#endif
+}
+
+/* ---- stencil application at one inner node ------------------------------------------------- */
+static inline SC FN(apply_st2)(const SC* st, const SC* x, int n, int i, int j) {
+  SC a = sc_mul(st[0], x[IDX2(n, i, j)]);
+  a = sc_add(a, sc_mul(st[1], x[IDX2(n, i - 1, j)]));
+  a = sc_add(a, sc_mul(st[2], x[IDX2(n, i + 1, j)]));
+  a = sc_add(a, sc_mul(st[3], x[IDX2(n, i, j - 1)]));
+  a = sc_add(a, sc_mul(st[4], x[IDX2(n, i, j + 1)]));
+  return a;
+}
+static inline SC FN(apply_st3)(const SC* st, const SC* x, int n, int i, int j, int k) {
+  SC a = sc_mul(st[0], x[IDX3(n, i, j, k)]);
+  a = sc_add(a, sc_mul(st[1], x[IDX3(n, i - 1, j, k)]));
+  a = sc_add(a, sc_mul(st[2], x[IDX3(n, i + 1, j, k)]));
+  a = sc_add(a, sc_mul(st[3], x[IDX3(n, i, j - 1, k)]));
+  a = sc_add(a, sc_mul(st[4], x[IDX3(n, i, j + 1, k)]));
+  a = sc_add(a, sc_mul(st[5], x[IDX3(n, i, j, k - 1)]));
+  a = sc_add(a, sc_mul(st[6], x[IDX3(n, i, j, k + 1)]));
+  return a;
+}
+/* point relaxation: x* = (f - sum_{o != 0} a_o x_o) / a_0 ; x <- (1-w) x + w x*
+ * ("solve locally ... relax w" with one unknown, exastencils.py:608-633) [EXTERNAL: App. B.5] */
+static inline SC FN(relax2)(const SC* st, const SC* x, const SC* f, int n, int i, int j, double om, double omm) {
+  SC s = f[IDX2(n, i, j)];
+  s = sc_sub(s, sc_mul(st[1], x[IDX2(n, i - 1, j)]));
+  s = sc_sub(s, sc_mul(st[2], x[IDX2(n, i + 1, j)]));
+  s = sc_sub(s, sc_mul(st[3], x[IDX2(n, i, j - 1)]));
+  s = sc_sub(s, sc_mul(st[4], x[IDX2(n, i, j + 1)]));
+  SC xs = sc_div(s, st[0]);
+  return sc_add(sc_rmul(omm, x[IDX2(n, i, j)]), sc_rmul(om, xs));
+}
+static inline SC FN(relax3)(const SC* st, const SC* x, const SC* f, int n, int i, int j, int k, double om, double omm) {
+  SC s = f[IDX3(n, i, j, k)];
+  s = sc_sub(s, sc_mul(st[1], x[IDX3(n, i - 1, j, k)]));
+  s = sc_sub(s, sc_mul(st[2], x[IDX3(n, i + 1, j, k)]));
+  s = sc_sub(s, sc_mul(st[3], x[IDX3(n, i, j - 1, k)]));
+  s = sc_sub(s, sc_mul(st[4], x[IDX3(n, i, j + 1, k)]));
+  s = sc_sub(s, sc_mul(st[5], x[IDX3(n, i, j, k - 1)]));
+  s = sc_sub(s, sc_mul(st[6], x[IDX3(n, i, j, k + 1)]));
+  SC xs = sc_div(s, st[0]);
+  return sc_add(sc_rmul(omm, x[IDX3(n, i, j, k)]), sc_rmul(om, xs));
+}
+
+/* ---- K1: damped Jacobi ("with jacobi": writes the next slot, then advance; exastencils.py:338-359) */
+static void FN(smooth_jacobi)(FN(ctx_t)* c, int level, int dstf, int rhsf, double om) {
+  FN(level_t)* lv = &c->lv[level];
+  const int n = lv->n;
+  const SC* x = FN(field)(c, level, dstf);
+  const SC* f = FN(field)(c, level, rhsf);
+  SC* y = lv->alt;
+  const double omm = 1.0 - om;
+  if (c->dim == 2) {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        if (i == 0 || j == 0 || i == n - 1 || j == n - 1) y[IDX2(n, i, j)] = x[IDX2(n, i, j)];
+        else y[IDX2(n, i, j)] = FN(relax2)(lv->st, x, f, n, i, j, om, omm);
+      }
+  } else {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int k = 0; k < n; ++k)
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+          if (i == 0 || j == 0 || k == 0 || i == n - 1 || j == n - 1 || k == n - 1)
+            y[IDX3(n, i, j, k)] = x[IDX3(n, i, j, k)];
+          else y[IDX3(n, i, j, k)] = FN(relax3)(lv->st, x, f, n, i, j, k, om, omm);
+        }
+  }
+  FN(apply_bc)(c, level, y);
+  lv->alt = (SC*)x;
+  FN(set_fieldptr)(c, level, dstf, y);
+}
+
+/* ---- K2: red-black Gauss-Seidel: colour 0 = even index sum first, then colour 1, in place,
+ * boundary handling in between (exastencils.py:659-667,785-798) [EXTERNAL: App. B.7] */
+static void FN(smooth_rbgs)(FN(ctx_t)* c, int level, int dstf, int rhsf, double om) {
+  FN(level_t)* lv = &c->lv[level];
+  const int n = lv->n;
+  SC* x = FN(field)(c, level, dstf);
+  const SC* f = FN(field)(c, level, rhsf);
+  const double omm = 1.0 - om;
+  for (int colour = 0; colour < 2; ++colour) {
+    if (c->dim == 2) {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+      for (int j = 1; j < n - 1; ++j)
+        for (int i = 1; i < n - 1; ++i)
+          if (((i + j) & 1) == colour) x[IDX2(n, i, j)] = FN(relax2)(lv->st, x, f, n, i, j, om, omm);
+    } else {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+      for (int k = 1; k < n - 1; ++k)
+        for (int j = 1; j < n - 1; ++j)
+          for (int i = 1; i < n - 1; ++i)
+            if (((i + j + k) & 1) == colour)
+              x[IDX3(n, i, j, k)] = FN(relax3)(lv->st, x, f, n, i, j, k, om, omm);
+    }
+    FN(apply_bc)(c, level, x);
+  }
+}
+
+/* ---- K3: collective block-Jacobi. Non-overlapping tiles of shape `b` anchored at the first inner
+ * node; tiles cut by the far boundary solve the smaller system (IR meaning:
+ * evostencils/stencils/multiple.py:204-217; SURVEY App. B.6 decision). Unknown order inside a tile:
+ * i0 outermost, as the reference lists them (notebooks/tutorial.ipynb:3432-3447). Dense solve =
+ * Gaussian elimination without pivoting in that order. */
+static void FN(smooth_block)(FN(ctx_t)* c, int level, int dstf, int rhsf, double om, const int* b) {
+  FN(level_t)* lv = &c->lv[level];
+  const int n = lv->n, dim = c->dim;
+  const SC* x = FN(field)(c, level, dstf);
+  const SC* f = FN(field)(c, level, rhsf);
+  SC* y = lv->alt;
+  const SC* st = lv->st;
+  const double omm = 1.0 - om;
+  const int bx = b[0], by = b[1], bz = (dim == 3) ? b[2] : 1;
+  const int inner = n - 2;
+  const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by, tz = (dim == 3) ? (inner + bz - 1) / bz : 1;
+  memcpy(y, x, lv->count * sizeof(SC));
+  static const int off[7][3] = {{0,0,0},{-1,0,0},{1,0,0},{0,-1,0},{0,1,0},{0,0,-1},{0,0,1}};
+  const int nnb = 1 + 2 * dim;
+#pragma omp parallel for schedule(static) collapse(2) if (OMP_WORTH(n))
+  for (int tk = 0; tk < tz; ++tk)
+    for (int tj = 0; tj < ty; ++tj)
+      for (int ti = 0; ti < tx; ++ti) {
+        const int i0 = 1 + ti * bx, j0 = 1 + tj * by, k0 = (dim == 3) ? 1 + tk * bz : 0;
+        const int mx = (i0 + bx <= n - 1) ? bx : (n - 1 - i0);
+        const int my = (j0 + by <= n - 1) ? by : (n - 1 - j0);
+        const int mz = (dim == 3) ? ((k0 + bz <= n - 1) ? bz : (n - 1 - k0)) : 1;
+        const int m = mx * my * mz;
+        SC A[EVOMG_MAX_BLOCK_CELLS][EVOMG_MAX_BLOCK_CELLS];
+        SC r[EVOMG_MAX_BLOCK_CELLS];
+        for (int p = 0; p < m; ++p)
+          for (int q = 0; q < m; ++q) A[p][q] = sc_zero();
+        /* assemble: unknown index p = (ci*my + cj)*mz + ck  (i0 outermost) */
+        for (int ci = 0; ci < mx; ++ci)
+          for (int cj = 0; cj < my; ++cj)
+            for (int ck = 0; ck < mz; ++ck) {
+              const int p = (ci * my + cj) * mz + ck;
+              const int gi = i0 + ci, gj = j0 + cj, gk = k0 + ck;
+              const size_t gc = (dim == 3) ? IDX3(n, gi, gj, gk) : IDX2(n, gi, gj);
+              SC s = f[gc];
+              A[p][p] = st[0];
+              for (int e = 1; e < nnb; ++e) {
+                const int di = ci + off[e][0], dj = cj + off[e][1], dk = ck + off[e][2];
+                if (di >= 0 && di < mx && dj >= 0 && dj < my && dk >= 0 && dk < mz) {
+                  A[p][(di * my + dj) * mz + dk] = st[e];
+                } else {
+                  const size_t gn = (dim == 3) ? IDX3(n, gi + off[e][0], gj + off[e][1], gk + off[e][2])
+                                               : IDX2(n, gi + off[e][0], gj + off[e][1]);
+                  s = sc_sub(s, sc_mul(st[e], x[gn]));
+                }
+              }
+              r[p] = s;
+            }
+        /* forward elimination */
+        for (int p = 0; p < m; ++p) {
+          for (int q = p + 1; q < m; ++q) {
+            if (sc_iszero(A[q][p])) continue;
+            const SC fac = sc_div(A[q][p], A[p][p]);
+            for (int t = p + 1; t < m; ++t) A[q][t] = sc_sub(A[q][t], sc_mul(fac, A[p][t]));
+            r[q] = sc_sub(r[q], sc_mul(fac, r[p]));
+          }
+        }
+        /* back substitution */
+        for (int p = m - 1; p >= 0; --p) {
+          SC s = r[p];
+          for (int t = p + 1; t < m; ++t) s = sc_sub(s, sc_mul(A[p][t], r[t]));
+          r[p] = sc_div(s, A[p][p]);
+        }
+        for (int ci = 0; ci < mx; ++ci)
+          for (int cj = 0; cj < my; ++cj)
+            for (int ck = 0; ck < mz; ++ck) {
+              const int p = (ci * my + cj) * mz + ck;
+              const size_t gc = (dim == 3) ? IDX3(n, i0 + ci, j0 + cj, k0 + ck) : IDX2(n, i0 + ci, j0 + cj);
+              y[gc] = sc_add(sc_rmul(omm, x[gc]), sc_rmul(om, r[p]));
+            }
+      }
+  FN(apply_bc)(c, level, y);
+  lv->alt = (SC*)x;
+  FN(set_fieldptr)(c, level, dstf, y);
+}
+
+/* ---- generic y = A x on inner nodes (boundary of y untouched) -------------------------------- */
+static void FN(apply_op)(FN(ctx_t)* c, int level, const SC* st, const SC* x, SC* y) {
+  const int n = c->lv[level].n;
+  if (c->dim == 2) {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int j = 1; j < n - 1; ++j)
+      for (int i = 1; i < n - 1; ++i) y[IDX2(n, i, j)] = FN(apply_st2)(st, x, n, i, j);
+  } else {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int k = 1; k < n - 1; ++k)
+      for (int j = 1; j < n - 1; ++j)
+        for (int i = 1; i < n - 1; ++i) y[IDX3(n, i, j, k)] = FN(apply_st3)(st, x, n, i, j, k);
+  }
+}
+
+/* ---- K4: residual  r = f - (A x)   (exastencils.py:837-853) ------------------------------------ */
+static void FN(residual_st)(FN(ctx_t)* c, int level, const SC* st, const SC* x, const SC* f, SC* r) {
+  const int n = c->lv[level].n;
+  if (c->dim == 2) {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int j = 1; j < n - 1; ++j)
+      for (int i = 1; i < n - 1; ++i)
+        r[IDX2(n, i, j)] = sc_sub(f[IDX2(n, i, j)], FN(apply_st2)(st, x, n, i, j));
+  } else {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int k = 1; k < n - 1; ++k)
+      for (int j = 1; j < n - 1; ++j)
+        for (int i = 1; i < n - 1; ++i)
+          r[IDX3(n, i, j, k)] = sc_sub(f[IDX3(n, i, j, k)], FN(apply_st3)(st, x, n, i, j, k));
+  }
+  FN(apply_bc)(c, level, r);
+}
+
+/* ---- K5: full-weighting restriction, coarse-point driven [EXTERNAL: App. B.3]
+ * weights [1/4 1/2 1/4]^(x)d (consistent with stencils/gallery.py:188-219) --------------------- */
+static void FN(restrict_fw)(FN(ctx_t)* c, int coarse_level, const SC* fine, SC* coarse) {
+  const int nc = c->lv[coarse_level].n, nf = c->lv[coarse_level + 1].n;
+  if (c->dim == 2) {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(nf))
+    for (int J = 1; J < nc - 1; ++J)
+      for (int I = 1; I < nc - 1; ++I) {
+        const int i = 2 * I, j = 2 * J;
+        SC e = sc_add(sc_add(fine[IDX2(nf, i - 1, j)], fine[IDX2(nf, i + 1, j)]),
+                      sc_add(fine[IDX2(nf, i, j - 1)], fine[IDX2(nf, i, j + 1)]));
+        SC k = sc_add(sc_add(fine[IDX2(nf, i - 1, j - 1)], fine[IDX2(nf, i + 1, j - 1)]),
+                      sc_add(fine[IDX2(nf, i - 1, j + 1)], fine[IDX2(nf, i + 1, j + 1)]));
+        SC v = sc_rmul(0.25, fine[IDX2(nf, i, j)]);
+        v = sc_add(v, sc_rmul(0.125, e));
+        v = sc_add(v, sc_rmul(0.0625, k));
+        coarse[IDX2(nc, I, J)] = v;
+      }
+  } else {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(nf))
+    for (int K = 1; K < nc - 1; ++K)
+      for (int J = 1; J < nc - 1; ++J)
+        for (int I = 1; I < nc - 1; ++I) {
+          const int i = 2 * I, j = 2 * J, k = 2 * K;
+          SC face = sc_zero(), edge = sc_zero(), corner = sc_zero();
+          /* fixed order: dz outermost, then dy, then dx */
+          for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+              for (int dx = -1; dx <= 1; ++dx) {
+                const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+                const SC v = fine[IDX3(nf, i + dx, j + dy, k + dz)];
+                if (nz == 1) face = sc_add(face, v);
+                else if (nz == 2) edge = sc_add(edge, v);
+                else if (nz == 3) corner = sc_add(corner, v);
+              }
+          SC v = sc_rmul(0.125, fine[IDX3(nf, i, j, k)]);
+          v = sc_add(v, sc_rmul(0.0625, face));
+          v = sc_add(v, sc_rmul(0.03125, edge));
+          v = sc_add(v, sc_rmul(0.015625, corner));
+          coarse[IDX3(nc, I, J, K)] = v;
+        }
+  }
+  FN(apply_bc)(c, coarse_level, coarse);
+}
+
+/* ---- K6/K6': bi-/tri-linear prolongation of the coarse field to fine inner node (i,j[,k]) ------- */
+static inline SC FN(interp2)(const SC* cz, int nc, int i, int j) {
+  const int I = i >> 1, J = j >> 1;
+  if (!(i & 1) && !(j & 1)) return cz[IDX2(nc, I, J)];
+  if ((i & 1) && !(j & 1)) return sc_rmul(0.5, sc_add(cz[IDX2(nc, I, J)], cz[IDX2(nc, I + 1, J)]));
+  if (!(i & 1) && (j & 1)) return sc_rmul(0.5, sc_add(cz[IDX2(nc, I, J)], cz[IDX2(nc, I, J + 1)]));
+  return sc_rmul(0.25, sc_add(sc_add(cz[IDX2(nc, I, J)], cz[IDX2(nc, I + 1, J)]),
+                              sc_add(cz[IDX2(nc, I, J + 1)], cz[IDX2(nc, I + 1, J + 1)])));
+}
+static inline SC FN(interp3)(const SC* cz, int nc, int i, int j, int k) {
+  const int I = i >> 1, J = j >> 1, K = k >> 1;
+  const int ox = i & 1, oy = j & 1, oz = k & 1;
+  /* sum over the 2^(#odd) coarse parents, fixed order dz, dy, dx; weight 1/2^(#odd) */
+  SC s = sc_zero();
+  for (int dz = 0; dz <= oz; ++dz)
+    for (int dy = 0; dy <= oy; ++dy)
+      for (int dx = 0; dx <= ox; ++dx) s = sc_add(s, cz[IDX3(nc, I + dx, J + dy, K + dz)]);
+  const int nodd = ox + oy + oz;
+  const double w = (nodd == 0) ? 1.0 : (nodd == 1) ? 0.5 : (nodd == 2) ? 0.25 : 0.125;
+  return sc_rmul(w, s);
+}
+static void FN(prolong)(FN(ctx_t)* c, int fine_level, const SC* coarse, SC* fine, int accumulate, double om) {
+  const int nf = c->lv[fine_level].n, nc = c->lv[fine_level - 1].n;
+  if (c->dim == 2) {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(nf))
+    for (int j = 1; j < nf - 1; ++j)
+      for (int i = 1; i < nf - 1; ++i) {
+        const SC v = FN(interp2)(coarse, nc, i, j);
+        if (accumulate) fine[IDX2(nf, i, j)] = sc_add(fine[IDX2(nf, i, j)], sc_rmul(om, v));
+        else fine[IDX2(nf, i, j)] = v;
+      }
+  } else {
+#pragma omp parallel for schedule(static) if (OMP_WORTH(nf))
+    for (int k = 1; k < nf - 1; ++k)
+      for (int j = 1; j < nf - 1; ++j)
+        for (int i = 1; i < nf - 1; ++i) {
+          const SC v = FN(interp3)(coarse, nc, i, j, k);
+          if (accumulate) fine[IDX3(nf, i, j, k)] = sc_add(fine[IDX3(nf, i, j, k)], sc_rmul(om, v));
+          else fine[IDX3(nf, i, j, k)] = v;
+        }
+  }
+  FN(apply_bc)(c, fine_level, fine);
+}
+
+/* ---- reductions over inner nodes: per-row partial sums, rows summed in order -> independent of
+ * the thread count. dot(a,b) = sum a_i * b_i WITHOUT conjugation: literal reading of the DSL's
+ * `dot ( resHat, Residual )` typed Complex<Real> (Helmholtz/2D_FD_Helmholtz_fromL3.exa3:86-88,158) [EXTERNAL] */
+static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
+  const int n = c->lv[level].n;
+  const int rows = (c->dim == 2) ? n : n * n;
+  SC* part = (SC*)malloc((size_t)rows * sizeof(SC));
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+  for (int r = 0; r < rows; ++r) {
+    SC s = sc_zero();
+    const int j = (c->dim == 2) ? r : r % n, k = (c->dim == 2) ? 1 : r / n;
+    if (j >= 1 && j < n - 1 && k >= 1 && (c->dim == 2 || k < n - 1)) {
+      const size_t base = (size_t)r * (size_t)n;
+      for (int i = 1; i < n - 1; ++i) s = sc_add(s, sc_mul(a[base + i], b[base + i]));
+    }
+    part[r] = s;
+  }
+  SC s = sc_zero();
+  for (int r = 0; r < rows; ++r) s = sc_add(s, part[r]);
+  free(part);
+  return s;
+}
+/* residual norm of the solver loop: |sqrt(dot(r,r))|  (for real fields: sqrt(sum r^2)) [EXTERNAL: App. B.8] */
+static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_from_dot(FN(dot)(c, level, a, a)); }
+
+static void FN(zero_inner)(FN(ctx_t)* c, int level, SC* x) {
+  const int n = c->lv[level].n;
+  if (c->dim == 2) {
+    for (int j = 1; j < n - 1; ++j)
+      for (int i = 1; i < n - 1; ++i) x[IDX2(n, i, j)] = sc_zero();
+  } else {
+    for (int k = 1; k < n - 1; ++k)
+      for (int j = 1; j < n - 1; ++j)
+        for (int i = 1; i < n - 1; ++i) x[IDX3(n, i, j, k)] = sc_zero();
+  }
+  FN(apply_bc)(c, level, x);
+}
+
+static SC* FN(tmpvec)(FN(ctx_t)* c, int level, int which) {
+  FN(level_t)* lv = &c->lv[level];
+  if (!lv->tmp[which]) lv->tmp[which] = FN(zalloc)(lv->count);
+  return lv->tmp[which];
+}
+
+/* z = x + a*y on inner nodes (a scalar) */
+static void FN(axpy_to)(FN(ctx_t)* c, int level, SC* z, const SC* x, SC a, const SC* y) {
+  const int n = c->lv[level].n;
+  const int rows = (c->dim == 2) ? n : n * n;
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+  for (int r = 0; r < rows; ++r) {
+    const int j = (c->dim == 2) ? r : r % n, k = (c->dim == 2) ? 1 : r / n;
+    if (j >= 1 && j < n - 1 && k >= 1 && (c->dim == 2 || k < n - 1)) {
+      const size_t base = (size_t)r * (size_t)n;
+      for (int i = 1; i < n - 1; ++i) z[base + i] = sc_add(x[base + i], sc_mul(a, y[base + i]));
+    }
+  }
+}
+
+/* ---- K9a: CG coarse-grid solver = gen_mgCycle@minLevel for Poisson
+ * (solver_cgs = "CG", 1000 its, 1e-12: Poisson/2D_FD_Poisson_fromL2.exa3:12-14) [EXTERNAL: App. B.9] */
+static int FN(coarse_cg)(FN(ctx_t)* c) {
+  const int L = c->prob.min_level;
+  FN(level_t)* lv = &c->lv[L];
+  SC* x = FN(field)(c, L, EVOMG_F_CORR);
+  const SC* b = FN(field)(c, L, EVOMG_F_CGS_RHS);
+  SC* r = FN(field)(c, L, EVOMG_F_RES);
+  SC* p = FN(tmpvec)(c, L, 0);
+  SC* ap = FN(tmpvec)(c, L, 1);
+  FN(residual_st)(c, L, lv->st, x, b, r);
+  SC rr = FN(dot)(c, L, r, r);
+  const double res0 = sc_norm_from_dot(rr);
+  if (res0 == 0.0) return 0;
+  memcpy(p, r, lv->count * sizeof(SC));
+  int it = 0;
+  for (; it < c->prob.cgs_max_iterations; ++it) {
+    FN(apply_op)(c, L, lv->st, p, ap);
+    const SC pap = FN(dot)(c, L, p, ap);
+    const SC alpha = sc_div(rr, pap);
+    FN(axpy_to)(c, L, x, x, alpha, p);
+    FN(axpy_to)(c, L, r, r, sc_neg(alpha), ap);
+    const SC rr_new = FN(dot)(c, L, r, r);
+    const double res = sc_norm_from_dot(rr_new);
+    if (!(res > c->prob.cgs_target_res_reduction * res0)) { ++it; break; }
+    const SC beta = sc_div(rr_new, rr);
+    FN(axpy_to)(c, L, p, r, beta, p);
+    rr = rr_new;
+  }
+  FN(apply_bc)(c, L, x);
+  return it;
+}
+
+/* ---- K9b: BiCGStab coarse-grid solver: literal restatement of
+ * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 (the DSL text IS the spec). */
+static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
+  const int L = c->prob.min_level;
+  FN(level_t)* lv = &c->lv[L];
+  SC* x = FN(field)(c, L, EVOMG_F_CORR);        /* gen_error_u */
+  const SC* f = FN(field)(c, L, EVOMG_F_CGS_RHS); /* f@coarsest == gen_rhs_u */
+  SC* r = FN(field)(c, L, EVOMG_F_RES);         /* gen_residual_u */
+  SC* p = FN(tmpvec)(c, L, 0);
+  SC* nu = FN(tmpvec)(c, L, 1);
+  SC* hh = FN(tmpvec)(c, L, 2);
+  SC* s = FN(tmpvec)(c, L, 3);
+  SC* t = FN(tmpvec)(c, L, 4);
+  SC* rhat = FN(tmpvec)(c, L, 5);
+  const SC* st = lv->st;
+  FN(residual_st)(c, L, st, x, f, r);
+  const double res0 = FN(norm)(c, L, r);
+  if (res0 == 0.0) return 0;
+  SC alpha = sc_from_real(1.0), beta, rho, rho_new = sc_from_real(1.0), omega = sc_from_real(1.0);
+  memcpy(rhat, r, lv->count * sizeof(SC));
+  memset(nu, 0, lv->count * sizeof(SC));
+  memset(p, 0, lv->count * sizeof(SC));
+  int it = 0;
+  for (; it < c->prob.cgs_max_iterations; ++it) {
+    rho = rho_new;
+    rho_new = FN(dot)(c, L, rhat, r);
+    beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
+    /* p = r + beta * (p - omega * nu) ; boundary of p handled by applyBC_p@coarsest */
+    FN(axpy_to)(c, L, p, p, sc_neg(omega), nu);
+    FN(axpy_to)(c, L, p, r, beta, p);
+    FN(apply_bc)(c, L, p);
+    FN(apply_op)(c, L, st, p, nu);
+    alpha = sc_div(rho_new, FN(dot)(c, L, rhat, nu));
+    FN(axpy_to)(c, L, hh, x, alpha, p);
+    FN(axpy_to)(c, L, s, r, sc_neg(alpha), nu);
+    FN(apply_bc)(c, L, s);
+    FN(apply_op)(c, L, st, s, t);
+    omega = sc_div(FN(dot)(c, L, t, s), FN(dot)(c, L, t, t));
+    FN(axpy_to)(c, L, x, hh, omega, s);
+    FN(apply_bc)(c, L, x);
+    FN(axpy_to)(c, L, r, s, sc_neg(omega), t);
+    FN(apply_bc)(c, L, r);
+    const double res = FN(norm)(c, L, r);
+    if (res < c->prob.cgs_target_res_reduction * res0) { ++it; break; }
+    if (!(res == res)) { ++it; break; }  /* NaN guard: the DSL would spin to the iteration cap */
+  }
+  return it;
+}
+
+/* ---- op interpreter ----------------------------------------------------------------------------- */
+static int FN(check_op)(FN(ctx_t)* c, const evomg_op_t* op) {
+  const int lo = c->prob.min_level, hi = c->prob.max_level;
+  if (op->level < lo || op->level > hi) return EVOMG_ERR_INVALID;
+  if (op->dst < 0 || op->dst >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+  switch (op->opcode) {
+    case EVOMG_OP_SMOOTH: {
+      if (op->src1 < 0 || op->src1 >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+      int cells = 1;
+      for (int d = 0; d < c->dim; ++d) { if (op->block[d] < 1) return EVOMG_ERR_INVALID; cells *= op->block[d]; }
+      if (cells > EVOMG_MAX_BLOCK_CELLS) return EVOMG_ERR_INVALID;
+      if (cells > 1 && op->partitioning != EVOMG_PART_SINGLE) return EVOMG_ERR_UNSUPPORTED;
+      return EVOMG_OK;
+    }
+    case EVOMG_OP_RESIDUAL: case EVOMG_OP_RICHARDSON:
+      if (op->src1 < 0 || op->src1 >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+      if (op->opcode == EVOMG_OP_RESIDUAL && (op->src0 < 0 || op->src0 >= EVOMG_F_COUNT)) return EVOMG_ERR_INVALID;
+      return EVOMG_OK;
+    case EVOMG_OP_RESTRICT:
+      if (op->level >= hi || op->src0 < 0 || op->src0 >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+      return EVOMG_OK;
+    case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET:
+      if (op->level <= lo || op->src0 < 0 || op->src0 >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+      return EVOMG_OK;
+    case EVOMG_OP_SET_ZERO: return EVOMG_OK;
+    case EVOMG_OP_COPY:
+      if (op->src0 < 0 || op->src0 >= EVOMG_F_COUNT) return EVOMG_ERR_INVALID;
+      return EVOMG_OK;
+    case EVOMG_OP_COARSE_SOLVE:
+      if (op->level != lo) return EVOMG_ERR_INVALID;
+      return EVOMG_OK;
+    default: return EVOMG_ERR_INVALID;
+  }
+}
+
+static int FN(exec_op)(FN(ctx_t)* c, const evomg_op_t* op) {
+  const int L = op->level;
+  switch (op->opcode) {
+    case EVOMG_OP_SMOOTH: {
+      const int cells = op->block[0] * op->block[1] * ((c->dim == 3) ? op->block[2] : 1);
+      if (cells > 1) FN(smooth_block)(c, L, op->dst, op->src1, op->omega, op->block);
+      else if (op->partitioning == EVOMG_PART_RED_BLACK) FN(smooth_rbgs)(c, L, op->dst, op->src1, op->omega);
+      else FN(smooth_jacobi)(c, L, op->dst, op->src1, op->omega);
+      return EVOMG_OK;
+    }
+    case EVOMG_OP_RESIDUAL:
+      FN(residual_st)(c, L, c->lv[L].st, FN(field)(c, L, op->src0), FN(field)(c, L, op->src1), FN(field)(c, L, op->dst));
+      return EVOMG_OK;
+    case EVOMG_OP_RICHARDSON: {
+      /* x += w * (f - A x): evaluated Jacobi-style from the old x */
+      FN(level_t)* lv = &c->lv[L];
+      SC* x = FN(field)(c, L, op->dst);
+      SC* y = lv->alt;
+      memcpy(y, x, lv->count * sizeof(SC));
+      FN(residual_st)(c, L, lv->st, x, FN(field)(c, L, op->src1), y);   /* y(inner) = f - A x */
+      FN(axpy_to)(c, L, y, x, sc_from_real(op->omega), y);
+      FN(apply_bc)(c, L, y);
+      lv->alt = x;
+      FN(set_fieldptr)(c, L, op->dst, y);
+      return EVOMG_OK;
+    }
+    case EVOMG_OP_RESTRICT:
+      FN(restrict_fw)(c, L, FN(field)(c, L + 1, op->src0), FN(field)(c, L, op->dst));
+      return EVOMG_OK;
+    case EVOMG_OP_PROLONG_ADD:
+      FN(prolong)(c, L, FN(field)(c, L - 1, op->src0), FN(field)(c, L, op->dst), 1, op->omega);
+      return EVOMG_OK;
+    case EVOMG_OP_PROLONG_SET:
+      FN(prolong)(c, L, FN(field)(c, L - 1, op->src0), FN(field)(c, L, op->dst), 0, 1.0);
+      return EVOMG_OK;
+    case EVOMG_OP_SET_ZERO:
+      FN(zero_inner)(c, L, FN(field)(c, L, op->dst));
+      return EVOMG_OK;
+    case EVOMG_OP_COPY: {
+      SC* d = FN(field)(c, L, op->dst);
+      const SC* s = FN(field)(c, L, op->src0);
+      if (d != s) memcpy(d, s, c->lv[L].count * sizeof(SC));
+      return EVOMG_OK;
+    }
+    case EVOMG_OP_COARSE_SOLVE:
+      if (c->prob.cgs_kind == EVOMG_CGS_BICGSTAB) FN(coarse_bicgstab)(c);
+      else FN(coarse_cg)(c);
+      return EVOMG_OK;
+  }
+  return EVOMG_ERR_INVALID;
+}
+
+static int FN(run_ops)(FN(ctx_t)* c, const evomg_op_t* ops, int n_ops) {
+  for (int i = 0; i < n_ops; ++i) {
+    int rc = FN(check_op)(c, &ops[i]);
+    if (rc != EVOMG_OK) { snprintf(c->err, sizeof c->err, "op %d (opcode %d) rejected: %d", i, ops[i].opcode, rc); return rc; }
+  }
+  for (int i = 0; i < n_ops; ++i) {
+    int rc = FN(exec_op)(c, &ops[i]);
+    if (rc != EVOMG_OK) return rc;
+  }
+  return EVOMG_OK;
+}
+
+static void FN(reset_fields)(FN(ctx_t)* c) {
+  for (int L = c->prob.min_level; L <= c->prob.max_level; ++L) {
+    FN(level_t)* lv = &c->lv[L];
+    for (int f = 0; f < EVOMG_F_COUNT; ++f) {
+      if (!lv->f[f]) continue;
+      if (lv->init[f]) memcpy(lv->f[f], lv->init[f], lv->count * sizeof(SC));
+      else memset(lv->f[f], 0, lv->count * sizeof(SC));
+    }
+  }
+}
+
+/* ---- outer loop A: "generate solver for u in solEq" [EXTERNAL: App. B.8]
+ * residual -> initRes; repeat { cycle; residual; norm } until res <= target*initRes or maxNumIts. */
+static void FN(solve_mg)(FN(ctx_t)* c, const evomg_op_t* ops, int n_ops, double wall_limit_ms,
+                         evomg_result_t* out, double* hist, int cap) {
+  const int L = c->prob.max_level;
+  FN(level_t)* lv = &c->lv[L];
+  int nh = 0;
+  const double t0 = now_ms();
+  FN(residual_st)(c, L, lv->st, FN(field)(c, L, EVOMG_F_SOL), FN(field)(c, L, EVOMG_F_RHS), FN(field)(c, L, EVOMG_F_RES));
+  const double res0 = FN(norm)(c, L, FN(field)(c, L, EVOMG_F_RES));
+  if (hist && nh < cap) hist[nh] = res0;
+  ++nh;
+  double res = res0;
+  int it = 0, status = EVOMG_SOLVE_MAXITER;
+  if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+  else
+    for (it = 1; it <= c->prob.max_iterations; ++it) {
+      for (int i = 0; i < n_ops; ++i) FN(exec_op)(c, &ops[i]);
+      FN(residual_st)(c, L, lv->st, FN(field)(c, L, EVOMG_F_SOL), FN(field)(c, L, EVOMG_F_RHS), FN(field)(c, L, EVOMG_F_RES));
+      res = FN(norm)(c, L, FN(field)(c, L, EVOMG_F_RES));
+      if (hist && nh < cap) hist[nh] = res;
+      ++nh;
+      if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+      if (res <= c->prob.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+      if (wall_limit_ms > 0 && now_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+    }
+  if (it > c->prob.max_iterations) it = c->prob.max_iterations;
+  out->time_ms = now_ms() - t0;
+  out->n_iterations = (double)it;
+  out->init_res_norm = res0;
+  out->final_res_norm = res;
+  out->status = status;
+  out->n_history = nh < cap || !hist ? nh : cap;
+  out->conv_factor = (it > 0 && res0 > 0) ? pow(res / res0, 1.0 / (double)it) : 0.0;
+}
+
+/* ---- outer loop B: MG-preconditioned BiCGStab, literal restatement of
+ * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3:144-200. Field roles:
+ * Solution -> tmp[0]@max, Residual -> RES@max, p/ap/s/t/h/resHat -> tmp[..]@max... the MG cycle
+ * works on u (= SOL@max) and f (= RHS@max). RHS (the PDE right-hand side) is init[RHS]. */
+static void FN(solve_pbicgstab)(FN(ctx_t)* c, const evomg_op_t* ops, int n_ops, double wall_limit_ms,
+                                evomg_result_t* out, double* hist, int cap) {
+  const int L = c->prob.max_level;
+  FN(level_t)* lv = &c->lv[L];
+  const SC* A = c->outer_st;
+  const size_t bytes = lv->count * sizeof(SC);
+  SC* Sol = FN(zalloc)(lv->count);
+  SC* Res = FN(zalloc)(lv->count);
+  SC* p = FN(zalloc)(lv->count);
+  SC* ap = FN(zalloc)(lv->count);
+  SC* s = FN(zalloc)(lv->count);
+  SC* t = FN(zalloc)(lv->count);
+  SC* hh = FN(zalloc)(lv->count);
+  SC* rhat = FN(zalloc)(lv->count);
+  SC* RHS = lv->init[EVOMG_F_RHS];
+  int nh = 0;
+  const double t0 = now_ms();
+  if (lv->init[EVOMG_F_SOL]) memcpy(Sol, lv->init[EVOMG_F_SOL], bytes);
+  FN(apply_bc)(c, L, Sol);
+  /* Residual = RHS - A * Solution   (no BC declared on Residual@finest: exa3:26) */
+  {
+    const int n = lv->n;
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+    for (int j = 1; j < n - 1; ++j)
+      for (int i = 1; i < n - 1; ++i)
+        Res[IDX2(n, i, j)] = sc_sub(RHS[IDX2(n, i, j)], FN(apply_st2)(A, Sol, n, i, j));
+  }
+  const double res0 = FN(norm)(c, L, Res);
+  if (hist && nh < cap) hist[nh] = res0;
+  ++nh;
+  double res = res0;
+  int it = 0, status = EVOMG_SOLVE_MAXITER;
+  SC alpha = sc_from_real(1.0), beta, rho, rho_new = sc_from_real(1.0), omega = sc_from_real(1.0);
+  memcpy(rhat, Res, bytes);
+  if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+  else
+    for (it = 1; it <= c->prob.max_iterations; ++it) {
+      rho = rho_new;
+      rho_new = FN(dot)(c, L, rhat, Res);
+      beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
+      FN(axpy_to)(c, L, p, p, sc_neg(omega), ap);
+      FN(axpy_to)(c, L, p, Res, beta, p);
+      /* u = 0 ; f = p ; gen_mgCycle() */
+      SC* u = FN(field)(c, L, EVOMG_F_SOL);
+      memset(u, 0, bytes);
+      memcpy(FN(field)(c, L, EVOMG_F_RHS), p, bytes);
+      for (int i = 0; i < n_ops; ++i) FN(exec_op)(c, &ops[i]);
+      u = FN(field)(c, L, EVOMG_F_SOL);
+      FN(apply_op)(c, L, A, u, ap);
+      alpha = sc_div(rho_new, FN(dot)(c, L, rhat, ap));
+      FN(axpy_to)(c, L, hh, Sol, alpha, u);
+      FN(axpy_to)(c, L, s, Res, sc_neg(alpha), ap);
+      /* u = 0 ; f = s ; gen_mgCycle() */
+      memset(u, 0, bytes);
+      memcpy(FN(field)(c, L, EVOMG_F_RHS), s, bytes);
+      for (int i = 0; i < n_ops; ++i) FN(exec_op)(c, &ops[i]);
+      u = FN(field)(c, L, EVOMG_F_SOL);
+      FN(apply_op)(c, L, A, u, t);
+      omega = sc_div(FN(dot)(c, L, t, s), FN(dot)(c, L, t, t));
+      FN(axpy_to)(c, L, Sol, hh, omega, u);
+      FN(apply_bc)(c, L, Sol);
+      FN(axpy_to)(c, L, Res, s, sc_neg(omega), t);
+      res = FN(norm)(c, L, Res);
+      if (hist && nh < cap) hist[nh] = res;
+      ++nh;
+      if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+      if (res < c->prob.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+      if (wall_limit_ms > 0 && now_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+    }
+  if (it > c->prob.max_iterations) it = c->prob.max_iterations;
+  out->time_ms = now_ms() - t0;
+  /* keep the solution readable through CORR@max (otherwise unused on the finest level) */
+  memcpy(lv->f[EVOMG_F_CORR], Sol, bytes);
+  memcpy(lv->f[EVOMG_F_RES], Res, bytes);
+  out->n_iterations = (double)it;
+  out->init_res_norm = res0;
+  out->final_res_norm = res;
+  out->status = status;
+  out->n_history = nh < cap || !hist ? nh : cap;
+  /* the DSL prints ONE line: convergence factor = |res| / |initRes|  (exa3:193) */
+  out->conv_factor = (res0 > 0) ? res / res0 : 0.0;
+  free(Sol); free(Res); free(p); free(ap); free(s); free(t); free(hh); free(rhat);
+}
+
+static int FN(create)(const evomg_problem_t* pr, FN(ctx_t)** outc) {
+  FN(ctx_t)* c = (FN(ctx_t)*)calloc(1, sizeof(FN(ctx_t)));
+  if (!c) return EVOMG_ERR_DEVICE;
+  c->prob = *pr;
+  c->dim = pr->dimension;
+  for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e) c->outer_st[e] = sc_from_c64(pr->outer_stencil[e]);
+  for (int L = pr->min_level; L <= pr->max_level; ++L) {
+    FN(level_t)* lv = &c->lv[L];
+    lv->L = L;
+    lv->n = (1 << L) + 1;
+    lv->count = (size_t)lv->n * (size_t)lv->n * (size_t)(c->dim == 3 ? lv->n : 1);
+    for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e) lv->st[e] = sc_from_c64(pr->mg_stencil[L][e]);
+    lv->f[EVOMG_F_SOL] = FN(zalloc)(lv->count);
+    lv->f[EVOMG_F_RHS] = FN(zalloc)(lv->count);
+    lv->f[EVOMG_F_RES] = FN(zalloc)(lv->count);
+    if (L == pr->max_level) lv->f[EVOMG_F_CORR] = FN(zalloc)(lv->count);
+    if (L == pr->min_level) lv->f[EVOMG_F_CGS_RHS] = FN(zalloc)(lv->count);
+    lv->alt = FN(zalloc)(lv->count);
+  }
+  *outc = c;
+  return EVOMG_OK;
+}
+
+static void FN(destroy)(FN(ctx_t)* c) {
+  for (int L = c->prob.min_level; L <= c->prob.max_level; ++L) {
+    FN(level_t)* lv = &c->lv[L];
+    for (int f = 0; f < EVOMG_F_COUNT; ++f) { free(lv->f[f]); free(lv->init[f]); }
+    free(lv->alt);
+    for (int t = 0; t < 6; ++t) free(lv->tmp[t]);
+  }
+  free(c);
+}

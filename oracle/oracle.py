@@ -1,0 +1,41 @@
+"""ctypes wrapper of the CPU oracle (oracle/libevomg_oracle.so). TEST INFRASTRUCTURE ONLY.
+
+Reuses the product's ctypes struct definitions (evostencils_amd.abi) because the oracle consumes the
+same op program; the product never imports this module.
+"""
+import os
+import subprocess
+
+from evostencils_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevomg_oracle.so")
+
+
+def build(force=False):
+    """Compile oracle/evomg_oracle.c with gcc (recipe: oracle/Makefile)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def library() -> abi.Library:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = abi.Library(LIB_PATH, "oracle", abi.ORACLE_EXPORTED)
+    return _lib
+
+
+def create(problem_description, parameters=None) -> abi.Handle:
+    """Oracle solver instance with the problem's initial fields loaded."""
+    h = abi.Handle(library(), problem_description.to_c(parameters), 0)
+    L = problem_description.max_level
+    h.set_initial_field(L, abi.F_SOL, problem_description.initial_solution(L))
+    h.set_initial_field(L, abi.F_RHS, problem_description.right_hand_side(L))
+    return h

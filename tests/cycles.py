@@ -1,0 +1,92 @@
+"""Candidate cycles used by the tests, written against a *context* (name -> production/terminal
+dictionary). The same functions run against evostencils_amd.grammar.productions.generate_context
+(our IR) and, in tests/golden/generate_golden.py, against the reference's own productions captured
+from evostencils.grammar.multigrid.add_level — so both sides build the identical DAG shape.
+
+Relaxation factors are indices into np.linspace(0.1, 1.9, 37) (grammar/multigrid.py:428):
+index i -> 0.1 + 0.05 i, e.g. 14 -> 0.8, 18 -> 0.9999999999999999, 21 -> 1.15.
+"""
+
+
+def smooth(P, depth, cycle, spec):
+    """spec: ('jacobi', idx) | ('rbgs', idx) | ('block', idx, shape)"""
+    kind = spec[0]
+    if kind == "jacobi":
+        return P[f"collective_jacobi_{depth}"](spec[1], P["single"], cycle)
+    if kind == "rbgs":
+        return P[f"collective_jacobi_{depth}"](spec[1], P["red_black"], cycle)
+    if kind == "block":
+        return P[f"collective_block_jacobi_{depth}"](spec[1], (tuple(spec[2]),), cycle)
+    raise ValueError(kind)
+
+
+def v_cycle(P, depth, pre, post, cgc_index=18):
+    """`depth`+1 levels; pre/post: per level (finest first) list of smoother specs. Returns the state
+    (cycle expression, rhs)."""
+    state = P["u_and_f"]
+    cycle = P["residual_0"](state)
+    for d in range(depth):
+        for spec in pre[d]:
+            state = smooth(P, d, cycle, spec)
+            cycle = P[f"residual_{d}"](state)
+        if d < depth - 1:
+            cycle = P[f"coarsening_{d}"](P[f"A_{d + 1}"], P[f"zero_{d + 1}"], P[f"R_{d}"], cycle)
+        else:
+            state = P[f"correct_with_coarse_grid_solver_{d}"](cgc_index, P[f"P_{d + 1}"], P[f"CGS_{d + 1}"],
+                                                              P[f"R_{d}"], cycle)
+    for d in range(depth - 1, -1, -1):
+        if d < depth - 1:
+            state = P[f"update_with_coarse_grid_correction_{d}"](cgc_index, P[f"P_{d + 1}"], state)
+        for spec in post[d]:
+            cycle = P[f"residual_{d}"](state)
+            state = smooth(P, d, cycle, spec)
+    return state
+
+
+def tutorial_cycle(P):
+    """The evolved 5-level cycle recorded in the reference's tutorial notebook
+    (notebooks/tutorial.ipynb:3422-3470): levels 9..5, depth 4."""
+    c = P["residual_0"](P["u_and_f"])
+    c = P["coarsening_0"](P["A_1"], P["zero_1"], P["R_0"], c)
+    c = P["coarsening_1"](P["A_2"], P["zero_2"], P["R_1"], c)
+    c = P["coarsening_2"](P["A_3"], P["zero_3"], P["R_2"], c)
+    s = P["collective_block_jacobi_3"](5, ((3, 2),), c)            # 0.35
+    s = P["collective_block_jacobi_3"](0, ((1, 6),), P["residual_3"](s))   # 0.1
+    s = P["correct_with_coarse_grid_solver_3"](0, P["P_4"], P["CGS_4"], P["R_3"], P["residual_3"](s))  # 0.1
+    s = P["update_with_coarse_grid_correction_2"](31, P["P_3"], s)  # 1.65
+    s = P["update_with_coarse_grid_correction_1"](33, P["P_2"], s)  # 1.75
+    s = P["collective_jacobi_1"](13, P["single"], P["residual_1"](s))   # 0.7499999999999999
+    s = P["update_with_coarse_grid_correction_0"](18, P["P_1"], s)  # 0.9999999999999999
+    s = P["collective_jacobi_0"](31, P["single"], P["residual_0"](s))   # 1.65
+    s = P["collective_jacobi_0"](28, P["red_black"], P["residual_0"](s))  # 1.5
+    return s
+
+
+# name -> (problem, min_level, max_level, builder(P))
+def _jac(i): return ("jacobi", i)
+def _rb(i): return ("rbgs", i)
+def _blk(i, shape): return ("block", i, shape)
+
+
+CASES = {
+    # C1: 3-level V(1,1) Jacobi w=0.8 on 2D Poisson level 8
+    "poisson2d_L8_v11_jacobi": ("2D_FD_Poisson_fromL2", 6, 8,
+                                lambda P: v_cycle(P, 2, [[_jac(14)], [_jac(14)]], [[_jac(14)], [_jac(14)]])),
+    # fine Jacobi, coarse RB-GS (SURVEY App. E probe)
+    "poisson2d_L8_v11_mixed": ("2D_FD_Poisson_fromL2", 6, 8,
+                               lambda P: v_cycle(P, 2, [[_jac(14)], [_rb(18)]], [[_jac(14)], [_rb(18)]])),
+    # 4-level V(2,1) RB-GS w=1.15 (the reference's default smoother setting, Poisson exa3:6-10)
+    "poisson2d_L7_v21_rbgs": ("2D_FD_Poisson_fromL2", 4, 7,
+                              lambda P: v_cycle(P, 3, [[_rb(21)] * 2] * 3, [[_rb(21)]] * 3)),
+    # block smoothers of several shapes, irregular sweep counts
+    "poisson2d_L7_blocks": ("2D_FD_Poisson_fromL2", 4, 7,
+                            lambda P: v_cycle(P, 3, [[_blk(10, (2, 1))], [_blk(12, (2, 2)), _jac(9)], []],
+                                              [[_blk(16, (1, 2)), _rb(20)], [], [_blk(5, (3, 2))]], cgc_index=17)),
+    "poisson2d_tutorial": ("2D_FD_Poisson_fromL2", 5, 9, tutorial_cycle),
+    # 3D: block-Jacobi V(2,2) (C4 shape) and RB-GS
+    "poisson3d_L4_v22_block": ("3D_FD_Poisson_fromL2", 2, 4,
+                               lambda P: v_cycle(P, 2, [[_blk(10, (2, 1, 1))] * 2] * 2, [[_blk(10, (2, 1, 1))] * 2] * 2)),
+    "poisson3d_L4_mixed": ("3D_FD_Poisson_fromL2", 2, 4,
+                           lambda P: v_cycle(P, 2, [[_rb(23)], [_blk(8, (2, 2, 1)), _jac(12)]],
+                                             [[_jac(12), _rb(23)], [_blk(8, (1, 2, 2))]], cgc_index=19)),
+}

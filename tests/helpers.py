@@ -1,0 +1,44 @@
+"""Shared test plumbing: contexts, generators and op programs for the cases in tests/cycles.py."""
+import os
+
+from evostencils_amd import abi, problems
+from evostencils_amd.code_generation.hip import ProgramGenerator
+from evostencils_amd.grammar import productions
+from evostencils_amd.ir import base, system
+
+import cycles
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class _NoLibrary:
+    """Stands in for the native library where a test only lowers (no GPU needed)."""
+
+
+def generator_for(problem_name, min_level, max_level, library=None, **kw):
+    pd = problems.BY_NAME[problem_name](min_level, max_level)
+    return ProgramGenerator(problem=pd, library=library or _NoLibrary(), **kw)
+
+
+def context_for(gen: ProgramGenerator, min_level, max_level):
+    fields, equations = gen.fields, gen.equations
+    finest = gen.finest_grid
+    approximation = system.Approximation("x", [base.Approximation(f.name, g) for f, g in zip(fields, finest)])
+    top = [eq for eq in equations if eq.level == max_level]
+    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, g) for eq, g in zip(top, finest)])
+    return productions.generate_context(approximation, rhs, gen.dimension, gen.coarsening_factor, max_level,
+                                        equations, gen.operators, fields, depth=max_level - min_level)
+
+
+def build_case(name, library=None):
+    """(generator, expression, min_level, max_level) for a named case of cycles.CASES."""
+    problem, min_level, max_level, builder = cycles.CASES[name]
+    gen = generator_for(problem, min_level, max_level, library)
+    ctx = context_for(gen, min_level, max_level)
+    expression, _ = builder(ctx)
+    return gen, expression, min_level, max_level
+
+
+def ops_for_case(name):
+    gen, expression, lo, hi = build_case(name)
+    return gen, gen.generate_op_program(expression, lo, hi)
