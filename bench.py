@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py — candidate multigrid solves per second on the BASELINE.json headline config.
+
+Workload (config.workload, BASELINE.json configs[1]): 2D Poisson 5-point, 4096^2 cells (level 12, 4097^2
+nodes), 6-level V(1,1) cycle (levels 12..7) with red-black Gauss-Seidel w=1, CG on the coarsest level,
+solved to 1e-12 residual reduction — the reference's problem example_problems/Poisson/2D_FD_Poisson_fromL2.*
+at maxLevel=12 evaluated through the drop-in ProgramGenerator.generate_and_evaluate path.
+
+One "step" = one complete candidate evaluation (lower DAG -> op program -> solve on the GPU) with all fields
+resident in HBM. With --gpus N each rank evaluates its own candidates (weak scaling, no data-path collective);
+the two fitness scalars (convergence factor, time) of every rank are gathered to rank 0 with one tiny RCCL
+gather per step, as the optimizer's per-generation allgather does (optimization/program.py:582).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def build_candidate(gen, lo, hi):
+    """6-level V(1,1) RB-GS, w = linspace(0.1,1.9,37)[18] (= 1.0 up to round-off, the grammar's value)."""
+    import cycles
+    from helpers import context_for
+    ctx = context_for(gen, lo, hi)
+    depth = hi - lo
+    rb = [("rbgs", 18)]
+    expression, _ = cycles.v_cycle(ctx, depth, [rb] * depth, [rb] * depth, cgc_index=18)
+    return expression
+
+
+def cpu_baseline(ops, lo, hi, threads):
+    """The oracle (CPU restatement, kind 'port') on ONE full solve of the same workload."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    from evostencils_amd import problems
+    from oracle import oracle
+    h = oracle.create(problems.poisson_2d(lo, hi))
+    t0 = time.time()
+    out = h.evaluate(ops, 1, 0, 128)
+    wall = time.time() - t0
+    h.close()
+    return {"value": 1.0 / wall, "unit": "solves/s", "cores": threads, "kind": "port",
+            "sample": f"1 full solve of the same workload ({int(out.n_iterations)} V-cycles, {wall:.1f} s wall, "
+                      f"gcc -O3 -fopenmp -ffp-contract=off)",
+            "iterations": out.n_iterations, "final_res_norm": out.final_res_norm}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--max-level", type=int, default=12)
+    ap.add_argument("--min-level", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from evostencils_amd import abi, native, problems
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    from evostencils_amd import population
+
+    lo, hi = args.min_level, args.max_level
+    gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank,
+                           library=native.library())
+    gen.initialize_code_generation(lo, hi)
+    storages = gen.generate_storage(lo, hi, gen.finest_grid)
+    expression = build_candidate(gen, lo, hi)
+
+    def step():
+        t, rho, its = gen.generate_and_evaluate(expression, storages, lo, hi, "", evaluation_samples=1)
+        return population.gather_fitness([(rho, t, its)], world, local_rank)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel: finest-level RB-GS smoother (24 B/node algorithmic) ----
+    ops = gen.generate_op_program(expression, lo, hi)
+    smooth = next(o for o in ops if o.opcode == abi.OP_SMOOTH and o.level == hi)
+    handle = gen._handle
+    b = handle.bench_op(smooth, warmup=10, reps=100)
+    kname = handle.kernel_name(smooth)
+    n_nodes = ((1 << hi) + 1) ** 2
+    roofline = {"bound": "hbm", "achieved": b.gbps, "peak": 8000.0, "unit": "GB/s", "frac": b.gbps / 8000.0,
+                "traffic": None, "kernel": kname,
+                "bytes_per_launch": b.bytes, "ms_per_launch": b.ms,
+                "note": f"24 B/node x {n_nodes} nodes per full red+black sweep; time = HIP events around 100 sweeps"}
+
+    if rank == 0:
+        rho, t_ms, its = last[0]
+        line = {
+            "metric": "candidate MG solves/sec", "value": world * args.steps / elapsed, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"2D Poisson 5-pt, {1 << hi}^2 grid (level {hi}), {hi - lo + 1}-level V(1,1) "
+                                   f"RB-Gauss-Seidel cycle, CG coarse solve, 1e-12 reduction",
+                       "iterations_per_solve": its, "convergence_factor": rho, "solve_time_ms": t_ms,
+                       "parallelism": f"candidates sharded 1/GPU x {world}, RCCL fitness gather"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(ops, lo, hi, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,795 @@
+// evomg.hip — runtime of the MI355X multigrid fitness-evaluation backend: device field storage, the op-program
+// interpreter, the solver loops and the C-ABI of include/evomg.h.
+//
+// Replaces, for one candidate, everything the reference does between lowering and parsed result
+// (evostencils/code_generation/exastencils.py:485-537): no JVM, no g++, no subprocess — the op program is
+// interpreted as a train of pre-compiled HIP kernel launches on one stream of one GPU.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/evomg.h"
+#include "evomg_kernels.h"
+#include "evomg_krylov.h"
+
+namespace {
+
+thread_local char g_create_error[512] = "";
+
+double wall_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct ImplBase {
+  virtual ~ImplBase() {}
+  virtual int init() = 0;
+  virtual int set_initial_field(int level, int field, const double* host) = 0;
+  virtual int get_field(int level, int field, double* host) = 0;
+  virtual int set_field(int level, int field, const double* host) = 0;
+  virtual int set_operators(const evomg_problem_t* p) = 0;
+  virtual int evaluate(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out,
+                       double* hist, int cap) = 0;
+  virtual int run_ops(const evomg_op_t* ops, int n_ops) = 0;
+  virtual int norm(int level, int field, double* out) = 0;
+  virtual int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) = 0;
+  virtual int kernel_name(const evomg_op_t* op, char* buf, int len) = 0;
+  char err[512] = "";
+};
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      snprintf(err, sizeof err, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return EVOMG_ERR_DEVICE;                                                                         \
+    }                                                                                                  \
+  } while (0)
+
+template <typename T> struct type_name;
+template <> struct type_name<double> { static const char* get() { return "double"; } };
+template <> struct type_name<cplx> { static const char* get() { return "cplx"; } };
+
+constexpr int kDotBlocks = 1024;
+constexpr int kTmpVectors = 6;
+
+template <typename T> struct Level {
+  Geo g{};
+  size_t elems = 0;             // allocated elements (pitch * rows)
+  T* f[EVOMG_F_COUNT] = {};
+  T* init[EVOMG_F_COUNT] = {};  // device copies of the initial contents (nullptr = zero)
+  T* alt = nullptr;             // ping-pong twin for out-of-place smoothers
+  T* tmp[kTmpVectors] = {};     // Krylov work vectors, allocated on demand
+  Stencil<T> st{};
+};
+
+template <typename T> class Impl : public ImplBase {
+ public:
+  Impl(const evomg_problem_t& p, int device) : prob_(p), device_(device), dim_(p.dimension) {}
+
+  ~Impl() override {
+    (void)hipSetDevice(device_);
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      Level<T>& lv = lv_[L];
+      for (int f = 0; f < EVOMG_F_COUNT; ++f) {
+        if (lv.f[f]) (void)hipFree(lv.f[f]);
+        if (lv.init[f]) (void)hipFree(lv.init[f]);
+      }
+      if (lv.alt) (void)hipFree(lv.alt);
+      for (auto*& t : lv.tmp)
+        if (t) (void)hipFree(t);
+    }
+    for (auto* v : outer_) if (v) (void)hipFree(v);
+    if (partials_) (void)hipFree(partials_);
+    if (dscalar_) (void)hipFree(dscalar_);
+    if (dinfo_) (void)hipFree(dinfo_);
+    if (hscalar_) (void)hipHostFree(hscalar_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+
+  int init() override {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device_ < 0 || device_ >= count) {
+      snprintf(err, sizeof err, "device %d not available (%d devices)", device_, count);
+      return EVOMG_ERR_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ev0_));
+    HIP_TRY(hipEventCreate(&ev1_));
+    HIP_TRY(hipMalloc(&partials_, sizeof(T) * kDotBlocks));
+    HIP_TRY(hipMalloc(&dscalar_, sizeof(T) * 8));
+    HIP_TRY(hipMalloc(&dinfo_, sizeof(int) * 4));
+    HIP_TRY(hipHostMalloc(&hscalar_, sizeof(T) * 8));
+    const int align = 128 / (int)sizeof(T);
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      Level<T>& lv = lv_[L];
+      const int n = (1 << L) + 1;
+      lv.g.n = n;
+      lv.g.pitch = ((n + align - 1) / align) * align;
+      lv.g.plane = (dim_ == 3) ? (long)lv.g.pitch * n : 0;
+      lv.elems = (size_t)lv.g.pitch * n * (dim_ == 3 ? n : 1);
+      for (int f : {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES}) HIP_TRY(alloc_zero(&lv.f[f], lv.elems));
+      if (L == prob_.max_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_F_CORR], lv.elems));
+      if (L == prob_.min_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_F_CGS_RHS], lv.elems));
+      HIP_TRY(alloc_zero(&lv.alt, lv.elems));
+    }
+    load_stencils(prob_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+
+  int set_initial_field(int level, int field, const double* host) override {
+    if (!level_ok(level) || !host) return invalid("set_initial_field: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    field = canon(level, field);
+    Level<T>& lv = lv_[level];
+    if (field < 0 || !lv.f[field]) return invalid("set_initial_field: no such field on this level");
+    if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
+    HIP_TRY(upload(lv, lv.init[field], host));
+    HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+
+  int set_field(int level, int field, const double* host) override {
+    if (!level_ok(level) || !host) return invalid("set_field: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    T* d = fieldptr(level, field);
+    if (!d) return invalid("set_field: no such field on this level");
+    HIP_TRY(upload(lv_[level], d, host));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+
+  int get_field(int level, int field, double* host) override {
+    if (!level_ok(level) || !host) return invalid("get_field: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    const T* d = fieldptr(level, field);
+    if (!d) return invalid("get_field: no such field on this level");
+    const Level<T>& lv = lv_[level];
+    const size_t rows = (size_t)lv.g.n * (dim_ == 3 ? lv.g.n : 1);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(T), d, lv.g.pitch * sizeof(T), lv.g.n * sizeof(T), rows,
+                        hipMemcpyDeviceToHost));
+    return EVOMG_OK;
+  }
+
+  int set_operators(const evomg_problem_t* p) override {
+    if (!p || p->min_level != prob_.min_level || p->max_level != prob_.max_level ||
+        p->dimension != prob_.dimension || p->scalar_kind != prob_.scalar_kind)
+      return invalid("set_operators: descriptor does not match the handle");
+    memcpy(prob_.mg_stencil, p->mg_stencil, sizeof p->mg_stencil);
+    memcpy(prob_.outer_stencil, p->outer_stencil, sizeof p->outer_stencil);
+    prob_.wavenumber = p->wavenumber;
+    load_stencils(prob_);
+    return EVOMG_OK;
+  }
+
+  int run_ops(const evomg_op_t* ops, int n_ops) override {
+    HIP_TRY(hipSetDevice(device_));
+    int rc = validate(ops, n_ops);
+    if (rc != EVOMG_OK) return rc;
+    for (int i = 0; i < n_ops; ++i) {
+      rc = exec(ops[i]);
+      if (rc != EVOMG_OK) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+
+  int norm(int level, int field, double* out) override {
+    if (!level_ok(level) || !out) return invalid("norm: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    const T* d = fieldptr(level, field);
+    if (!d) return invalid("norm: no such field on this level");
+    T v;
+    int rc = dot_to_host(level, d, d, &v);
+    if (rc != EVOMG_OK) return rc;
+    *out = sc_norm_from_dot(v);
+    return EVOMG_OK;
+  }
+
+  int evaluate(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out,
+               double* hist, int cap) override {
+    HIP_TRY(hipSetDevice(device_));
+    if (!out || samples < 1 || n_ops < 0 || (!ops && n_ops > 0)) return invalid("evaluate: bad arguments");
+    memset(out, 0, sizeof *out);
+    int rc = validate(ops, n_ops);
+    if (rc != EVOMG_OK) return rc;
+    double tsum = 0.0;
+    evomg_result_t r;
+    int done = 0;
+    for (int s = 0; s < samples; ++s) {
+      memset(&r, 0, sizeof r);
+      rc = reset_fields();
+      if (rc != EVOMG_OK) return rc;
+      if (prob_.outer_kind == EVOMG_OUTER_PBICGSTAB) rc = solve_pbicgstab(ops, n_ops, wall_limit_ms, &r, hist, cap);
+      else rc = solve_mg(ops, n_ops, wall_limit_ms, &r, hist, cap);
+      if (rc != EVOMG_OK) return rc;
+      tsum += r.time_ms;
+      ++done;
+      if (r.status != EVOMG_SOLVE_CONVERGED) break;
+    }
+    *out = r;
+    out->time_ms = tsum / (double)done;
+    return EVOMG_OK;
+  }
+
+  int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) override {
+    HIP_TRY(hipSetDevice(device_));
+    if (!op || !out || reps < 1 || warmup < 0) return invalid("bench_op: bad arguments");
+    int rc = validate(op, 1);
+    if (rc != EVOMG_OK) return rc;
+    for (int i = 0; i < warmup; ++i) {
+      rc = exec(*op);
+      if (rc != EVOMG_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev0_, stream_));
+    for (int i = 0; i < reps; ++i) {
+      rc = exec(*op);
+      if (rc != EVOMG_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev1_, stream_));
+    HIP_TRY(hipEventSynchronize(ev1_));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0_, ev1_));
+    out->ms = (double)ms / reps;
+    out->bytes = algorithmic_bytes(*op);
+    out->gbps = out->bytes / (out->ms * 1e-3) * 1e-9;
+    out->launches = reps;
+    return EVOMG_OK;
+  }
+
+  int kernel_name(const evomg_op_t* op, char* buf, int len) override {
+    if (!op || !buf || len < 8) return invalid("kernel_name: bad arguments");
+    const char* base = "?";
+    switch (op->opcode) {
+      case EVOMG_OP_SMOOTH: {
+        const int cells = op->block[0] * op->block[1] * (dim_ == 3 ? op->block[2] : 1);
+        base = cells > 1 ? "evomg_block_jacobi" : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
+        break;
+      }
+      case EVOMG_OP_RESIDUAL: base = "evomg_apply"; break;
+      case EVOMG_OP_RICHARDSON: base = "evomg_richardson"; break;
+      case EVOMG_OP_RESTRICT: base = "evomg_restrict"; break;
+      case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: base = "evomg_prolong"; break;
+      case EVOMG_OP_SET_ZERO: base = "evomg_zero_inner"; break;
+      case EVOMG_OP_COPY: base = "hipMemcpyAsync"; break;
+      case EVOMG_OP_COARSE_SOLVE: base = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? "evomg_bicgstab_single_wg" : "evomg_cg_single_wg"; break;
+    }
+    snprintf(buf, len, "%s<%s, %d", base, type_name<T>::get(), dim_);
+    return EVOMG_OK;
+  }
+
+ private:
+  // ---- storage ---------------------------------------------------------------------------------------------------
+  hipError_t alloc_zero(T** p, size_t elems) {
+    hipError_t e = hipMalloc(p, elems * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(*p, 0, elems * sizeof(T), stream_);
+  }
+  hipError_t upload(const Level<T>& lv, T* dst, const double* host) {
+    const size_t rows = (size_t)lv.g.n * (dim_ == 3 ? lv.g.n : 1);
+    hipError_t e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess) return e;
+    return hipMemcpy2D(dst, lv.g.pitch * sizeof(T), host, lv.g.n * sizeof(T), lv.g.n * sizeof(T), rows,
+                       hipMemcpyHostToDevice);
+  }
+  bool level_ok(int L) const { return L >= prob_.min_level && L <= prob_.max_level; }
+  int canon(int level, int field) const {
+    if (field < 0 || field >= EVOMG_F_COUNT) return -1;
+    // gen_error_u@L and the solution of level L < max are the same array (exastencils.py:296-301)
+    if (field == EVOMG_F_CORR && level < prob_.max_level) return EVOMG_F_SOL;
+    return field;
+  }
+  T* fieldptr(int level, int field) {
+    field = canon(level, field);
+    return field < 0 ? nullptr : lv_[level].f[field];
+  }
+  void set_fieldptr(int level, int field, T* p) { lv_[level].f[canon(level, field)] = p; }
+  int invalid(const char* msg) {
+    snprintf(err, sizeof err, "%s", msg);
+    return EVOMG_ERR_INVALID;
+  }
+  void load_stencils(const evomg_problem_t& p) {
+    for (int L = p.min_level; L <= p.max_level; ++L)
+      for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e)
+        lv_[L].st.c[e] = scalar_traits<T>::from_c64(p.mg_stencil[L][e].re, p.mg_stencil[L][e].im);
+    for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e)
+      outer_st_.c[e] = scalar_traits<T>::from_c64(p.outer_stencil[e].re, p.outer_stencil[e].im);
+  }
+  int tmpvec(int level, int which, T** out) {
+    Level<T>& lv = lv_[level];
+    if (!lv.tmp[which]) HIP_TRY(alloc_zero(&lv.tmp[which], lv.elems));
+    *out = lv.tmp[which];
+    return EVOMG_OK;
+  }
+
+  // ---- launch geometry -------------------------------------------------------------------------------------------
+  static dim3 node_block() { return dim3(64, 4, 1); }
+  dim3 node_grid(const Geo& g) const { return dim3((g.n + 63) / 64, (g.n + 3) / 4, dim_ == 3 ? g.n : 1); }
+  double kh(int level) const { return prob_.wavenumber / (double)(lv_[level].g.n - 1); }
+
+  int apply_bc(int level, T* x) {
+    if constexpr (scalar_traits<T>::is_complex) {
+      if (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN) {
+        const Geo& g = lv_[level].g;
+        hipLaunchKernelGGL(evomg_robin_bc, dim3((g.n + 255) / 256), dim3(256), 0, stream_, g, x, kh(level));
+      }
+    }
+    return EVOMG_OK;
+  }
+
+  // ---- validation (mirrors oracle FN(check_op)) ---------------------------------------------------------------------
+  int validate(const evomg_op_t* ops, int n_ops) {
+    for (int i = 0; i < n_ops; ++i) {
+      const evomg_op_t& op = ops[i];
+      const int lo = prob_.min_level, hi = prob_.max_level;
+      bool ok = op.level >= lo && op.level <= hi && op.dst >= 0 && op.dst < EVOMG_F_COUNT;
+      auto fld = [&](int f, int level) { return f >= 0 && f < EVOMG_F_COUNT && level >= lo && level <= hi && fieldptr(level, f) != nullptr; };
+      int rc = EVOMG_ERR_INVALID;
+      if (ok) {
+        ok = fld(op.dst, op.level);
+        switch (op.opcode) {
+          case EVOMG_OP_SMOOTH: {
+            ok = ok && fld(op.src1, op.level);
+            int cells = 1;
+            for (int d = 0; d < dim_; ++d) {
+              if (op.block[d] < 1) ok = false;
+              cells *= op.block[d] > 0 ? op.block[d] : 1;
+            }
+            if (cells > EVOMG_MAX_BLOCK_CELLS) ok = false;
+            if (ok && cells > 1 && op.partitioning != EVOMG_PART_SINGLE) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
+            if (op.partitioning != EVOMG_PART_SINGLE && op.partitioning != EVOMG_PART_RED_BLACK) ok = false;
+            break;
+          }
+          case EVOMG_OP_RESIDUAL: ok = ok && fld(op.src0, op.level) && fld(op.src1, op.level); break;
+          case EVOMG_OP_RICHARDSON: ok = ok && fld(op.src1, op.level); break;
+          case EVOMG_OP_RESTRICT: ok = ok && op.level < hi && fld(op.src0, op.level + 1); break;
+          case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: ok = ok && op.level > lo && fld(op.src0, op.level - 1); break;
+          case EVOMG_OP_SET_ZERO: break;
+          case EVOMG_OP_COPY: ok = ok && fld(op.src0, op.level); break;
+          case EVOMG_OP_COARSE_SOLVE: ok = ok && op.level == lo; break;
+          default: ok = false;
+        }
+      }
+      if (!ok) {
+        snprintf(err, sizeof err, "op %d (opcode %d, level %d) rejected", i, op.opcode, op.level);
+        return rc;
+      }
+    }
+    return EVOMG_OK;
+  }
+
+  // ---- op interpreter ----------------------------------------------------------------------------------------------
+  int exec(const evomg_op_t& op) {
+    const int L = op.level;
+    Level<T>& lv = lv_[L];
+    const Geo& g = lv.g;
+    const dim3 blk = node_block(), grd = node_grid(g);
+    switch (op.opcode) {
+      case EVOMG_OP_SMOOTH: {
+        const double om = op.omega, omm = 1.0 - op.omega;
+        T* x = fieldptr(L, op.dst);
+        const T* f = fieldptr(L, op.src1);
+        const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
+        if (cells > 1) {
+          T* y = lv.alt;
+          const int bx = op.block[0], by = op.block[1], bz = dim_ == 3 ? op.block[2] : 1;
+          const int inner = g.n - 2;
+          const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by, tz = dim_ == 3 ? (inner + bz - 1) / bz : 1;
+          if (dim_ == 2) {
+            hipLaunchKernelGGL((evomg_copy_boundary<T, 2>), grd, blk, 0, stream_, g, x, y);
+            hipLaunchKernelGGL((evomg_block_jacobi<T, 2>), dim3((tx + 63) / 64, (ty + 3) / 4, 1), blk, 0, stream_, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
+          } else {
+            hipLaunchKernelGGL((evomg_copy_boundary<T, 3>), grd, blk, 0, stream_, g, x, y);
+            hipLaunchKernelGGL((evomg_block_jacobi<T, 3>), dim3((tx + 63) / 64, (ty + 3) / 4, tz), blk, 0, stream_, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
+          }
+          apply_bc(L, y);
+          lv.alt = x;
+          set_fieldptr(L, op.dst, y);
+        } else if (op.partitioning == EVOMG_PART_RED_BLACK) {
+          const dim3 hgrd((g.n / 2 + 1 + 63) / 64, grd.y, grd.z);
+          for (int colour = 0; colour < 2; ++colour) {
+            if (dim_ == 2) hipLaunchKernelGGL((evomg_rbgs_colour<T, 2>), hgrd, blk, 0, stream_, g, lv.st, x, f, om, omm, colour);
+            else hipLaunchKernelGGL((evomg_rbgs_colour<T, 3>), hgrd, blk, 0, stream_, g, lv.st, x, f, om, omm, colour);
+            apply_bc(L, x);
+          }
+        } else {
+          T* y = lv.alt;
+          if (dim_ == 2) hipLaunchKernelGGL((evomg_jacobi<T, 2>), grd, blk, 0, stream_, g, lv.st, x, f, y, om, omm);
+          else hipLaunchKernelGGL((evomg_jacobi<T, 3>), grd, blk, 0, stream_, g, lv.st, x, f, y, om, omm);
+          apply_bc(L, y);
+          lv.alt = x;
+          set_fieldptr(L, op.dst, y);
+        }
+        break;
+      }
+      case EVOMG_OP_RESIDUAL:
+        residual(L, lv.st, fieldptr(L, op.src0), fieldptr(L, op.src1), fieldptr(L, op.dst));
+        apply_bc(L, fieldptr(L, op.dst));
+        break;
+      case EVOMG_OP_RICHARDSON: {
+        T* x = fieldptr(L, op.dst);
+        T* y = lv.alt;
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_richardson<T, 2>), grd, blk, 0, stream_, g, lv.st, x, fieldptr(L, op.src1), y, op.omega);
+        else hipLaunchKernelGGL((evomg_richardson<T, 3>), grd, blk, 0, stream_, g, lv.st, x, fieldptr(L, op.src1), y, op.omega);
+        apply_bc(L, y);
+        lv.alt = x;
+        set_fieldptr(L, op.dst, y);
+        break;
+      }
+      case EVOMG_OP_RESTRICT: {
+        const Geo& gf = lv_[L + 1].g;
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_restrict<T, 2>), grd, blk, 0, stream_, g, gf, fieldptr(L + 1, op.src0), fieldptr(L, op.dst));
+        else hipLaunchKernelGGL((evomg_restrict<T, 3>), grd, blk, 0, stream_, g, gf, fieldptr(L + 1, op.src0), fieldptr(L, op.dst));
+        apply_bc(L, fieldptr(L, op.dst));
+        break;
+      }
+      case EVOMG_OP_PROLONG_ADD:
+      case EVOMG_OP_PROLONG_SET: {
+        const Geo& gc = lv_[L - 1].g;
+        const T* cz = fieldptr(L - 1, op.src0);
+        T* fz = fieldptr(L, op.dst);
+        if (op.opcode == EVOMG_OP_PROLONG_ADD) {
+          if (dim_ == 2) hipLaunchKernelGGL((evomg_prolong<T, 2, true>), grd, blk, 0, stream_, g, gc, cz, fz, op.omega);
+          else hipLaunchKernelGGL((evomg_prolong<T, 3, true>), grd, blk, 0, stream_, g, gc, cz, fz, op.omega);
+        } else {
+          if (dim_ == 2) hipLaunchKernelGGL((evomg_prolong<T, 2, false>), grd, blk, 0, stream_, g, gc, cz, fz, 1.0);
+          else hipLaunchKernelGGL((evomg_prolong<T, 3, false>), grd, blk, 0, stream_, g, gc, cz, fz, 1.0);
+        }
+        apply_bc(L, fz);
+        break;
+      }
+      case EVOMG_OP_SET_ZERO: {
+        T* x = fieldptr(L, op.dst);
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_zero_inner<T, 2>), grd, blk, 0, stream_, g, x);
+        else hipLaunchKernelGGL((evomg_zero_inner<T, 3>), grd, blk, 0, stream_, g, x);
+        apply_bc(L, x);
+        break;
+      }
+      case EVOMG_OP_COPY: {
+        T* d = fieldptr(L, op.dst);
+        const T* s = fieldptr(L, op.src0);
+        if (d != s) HIP_TRY(hipMemcpyAsync(d, s, lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        break;
+      }
+      case EVOMG_OP_COARSE_SOLVE: return coarse_solve();
+      default: return invalid("exec: unknown opcode");
+    }
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }
+
+  void residual(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
+    const Geo& g = lv_[L].g;
+    if (dim_ == 2) hipLaunchKernelGGL((evomg_apply<T, 2, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
+    else hipLaunchKernelGGL((evomg_apply<T, 3, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
+  }
+  void apply_operator(int L, const Stencil<T>& st, const T* x, T* y) {
+    const Geo& g = lv_[L].g;
+    if (dim_ == 2) hipLaunchKernelGGL((evomg_apply<T, 2, false>), node_grid(g), node_block(), 0, stream_, g, st, x, (const T*)nullptr, y);
+    else hipLaunchKernelGGL((evomg_apply<T, 3, false>), node_grid(g), node_block(), 0, stream_, g, st, x, (const T*)nullptr, y);
+  }
+  void axpy(int L, T* z, const T* x, T a, const T* y) {
+    const Geo& g = lv_[L].g;
+    if (dim_ == 2) hipLaunchKernelGGL((evomg_axpy<T, 2>), node_grid(g), node_block(), 0, stream_, g, z, x, a, y);
+    else hipLaunchKernelGGL((evomg_axpy<T, 3>), node_grid(g), node_block(), 0, stream_, g, z, x, a, y);
+  }
+
+  int coarse_solve() {
+    const int L = prob_.min_level;
+    Level<T>& lv = lv_[L];
+    T* x = fieldptr(L, EVOMG_F_CORR);
+    const T* b = fieldptr(L, EVOMG_F_CGS_RHS);
+    T* r = fieldptr(L, EVOMG_F_RES);
+    T* w[kTmpVectors];
+    const int need = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? 6 : 2;
+    for (int i = 0; i < need; ++i) {
+      int rc = tmpvec(L, i, &w[i]);
+      if (rc != EVOMG_OK) return rc;
+    }
+    const dim3 one(1), thr(EVOMG_KRYLOV_THREADS);
+    if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
+      const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
+      if constexpr (scalar_traits<T>::is_complex) {
+        if (dim_ != 2) return invalid("complex problems are 2D only");
+        if (robin) hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 2, true>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, kh(L), dinfo_);
+        else hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 2, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
+      } else {
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 2, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
+        else hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 3, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
+      }
+    } else {
+      if (dim_ == 2) hipLaunchKernelGGL((evomg_cg_single_wg<T, 2>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      else hipLaunchKernelGGL((evomg_cg_single_wg<T, 3>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      apply_bc(L, x);
+    }
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }
+
+  // ---- reductions ----------------------------------------------------------------------------------------------------
+  void dot_async(int L, const T* a, const T* b, T* dev_out) {
+    const Geo& g = lv_[L].g;
+    const int m = g.n - 2;
+    const long rows = dim_ == 2 ? m : (long)m * m;
+    const int blocks = (int)(rows < kDotBlocks ? rows : kDotBlocks);
+    if (dim_ == 2) hipLaunchKernelGGL((evomg_dot_partial<T, 2>), dim3(blocks), dim3(256), 0, stream_, g, a, b, partials_);
+    else hipLaunchKernelGGL((evomg_dot_partial<T, 3>), dim3(blocks), dim3(256), 0, stream_, g, a, b, partials_);
+    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dev_out);
+  }
+  int dot_to_host(int L, const T* a, const T* b, T* out) {
+    dot_async(L, a, b, dscalar_);
+    HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = hscalar_[0];
+    return EVOMG_OK;
+  }
+
+  int reset_fields() {
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      Level<T>& lv = lv_[L];
+      for (int f = 0; f < EVOMG_F_COUNT; ++f) {
+        if (!lv.f[f]) continue;
+        if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        else HIP_TRY(hipMemsetAsync(lv.f[f], 0, lv.elems * sizeof(T), stream_));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+
+  // ---- outer loop A: generated MG iteration (oracle FN(solve_mg)) ----------------------------------------------------------
+  int solve_mg(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
+    const int L = prob_.max_level;
+    Level<T>& lv = lv_[L];
+    int nh = 0;
+    const double t0 = wall_ms();
+    residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+    T d;
+    int rc = dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
+    if (rc != EVOMG_OK) return rc;
+    const double res0 = sc_norm_from_dot(d);
+    if (hist && nh < cap) hist[nh] = res0;
+    ++nh;
+    double res = res0;
+    int it = 0, status = EVOMG_SOLVE_MAXITER;
+    if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+    else
+      for (it = 1; it <= prob_.max_iterations; ++it) {
+        for (int i = 0; i < n_ops; ++i) {
+          rc = exec(ops[i]);
+          if (rc != EVOMG_OK) return rc;
+        }
+        residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+        rc = dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
+        if (rc != EVOMG_OK) return rc;
+        res = sc_norm_from_dot(d);
+        if (hist && nh < cap) hist[nh] = res;
+        ++nh;
+        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+        if (res <= prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+        if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+      }
+    if (it > prob_.max_iterations) it = prob_.max_iterations;
+    out->time_ms = wall_ms() - t0;
+    out->n_iterations = (double)it;
+    out->init_res_norm = res0;
+    out->final_res_norm = res;
+    out->status = status;
+    out->n_history = (nh < cap || !hist) ? nh : cap;
+    out->conv_factor = (it > 0 && res0 > 0) ? pow(res / res0, 1.0 / (double)it) : 0.0;
+    return EVOMG_OK;
+  }
+
+  // ---- outer loop B: MG-preconditioned BiCGStab (oracle FN(solve_pbicgstab); Helmholtz exa3:144-200) ------------------------
+  int solve_pbicgstab(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
+    if (dim_ != 2) return invalid("preconditioned BiCGStab outer solver is 2D only");
+    const int L = prob_.max_level;
+    Level<T>& lv = lv_[L];
+    const size_t bytes = lv.elems * sizeof(T);
+    for (auto*& v : outer_)
+      if (!v) HIP_TRY(alloc_zero(&v, lv.elems));
+    T *Sol = outer_[0], *Res = outer_[1], *p = outer_[2], *ap = outer_[3], *s = outer_[4], *t = outer_[5],
+      *hh = outer_[6], *rhat = outer_[7];
+    for (auto* v : outer_) HIP_TRY(hipMemsetAsync(v, 0, bytes, stream_));
+    const T* RHS = lv.init[EVOMG_F_RHS];
+    if (!RHS) return invalid("no right-hand side set");
+    int nh = 0;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const double t0 = wall_ms();
+    if (lv.init[EVOMG_F_SOL]) HIP_TRY(hipMemcpyAsync(Sol, lv.init[EVOMG_F_SOL], bytes, hipMemcpyDeviceToDevice, stream_));
+    apply_bc(L, Sol);
+    residual(L, outer_st_, Sol, RHS, Res);
+    T d;
+    int rc = dot_to_host(L, Res, Res, &d);
+    if (rc != EVOMG_OK) return rc;
+    const double res0 = sc_norm_from_dot(d);
+    if (hist && nh < cap) hist[nh] = res0;
+    ++nh;
+    double res = res0;
+    int it = 0, status = EVOMG_SOLVE_MAXITER;
+    const T one = scalar_traits<T>::from_real(1.0);
+    T alpha = one, beta, rho, rho_new = one, omega = one;
+    HIP_TRY(hipMemcpyAsync(rhat, Res, bytes, hipMemcpyDeviceToDevice, stream_));
+    auto precondition = [&](const T* rhs_src) -> int {   // u = 0 ; f = rhs ; gen_mgCycle()
+      HIP_TRY(hipMemsetAsync(fieldptr(L, EVOMG_F_SOL), 0, bytes, stream_));
+      HIP_TRY(hipMemcpyAsync(fieldptr(L, EVOMG_F_RHS), rhs_src, bytes, hipMemcpyDeviceToDevice, stream_));
+      for (int i = 0; i < n_ops; ++i) {
+        int r2 = exec(ops[i]);
+        if (r2 != EVOMG_OK) return r2;
+      }
+      return EVOMG_OK;
+    };
+    if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+    else
+      for (it = 1; it <= prob_.max_iterations; ++it) {
+        rho = rho_new;
+        if ((rc = dot_to_host(L, rhat, Res, &rho_new)) != EVOMG_OK) return rc;
+        beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
+        axpy(L, p, p, sc_neg(omega), ap);
+        axpy(L, p, Res, beta, p);
+        if ((rc = precondition(p)) != EVOMG_OK) return rc;
+        T* u = fieldptr(L, EVOMG_F_SOL);
+        apply_operator(L, outer_st_, u, ap);
+        T ra;
+        if ((rc = dot_to_host(L, rhat, ap, &ra)) != EVOMG_OK) return rc;
+        alpha = sc_div(rho_new, ra);
+        axpy(L, hh, Sol, alpha, u);
+        axpy(L, s, Res, sc_neg(alpha), ap);
+        if ((rc = precondition(s)) != EVOMG_OK) return rc;
+        u = fieldptr(L, EVOMG_F_SOL);
+        apply_operator(L, outer_st_, u, t);
+        T ts, tt;
+        if ((rc = dot_to_host(L, t, s, &ts)) != EVOMG_OK) return rc;
+        if ((rc = dot_to_host(L, t, t, &tt)) != EVOMG_OK) return rc;
+        omega = sc_div(ts, tt);
+        axpy(L, Sol, hh, omega, u);
+        apply_bc(L, Sol);
+        axpy(L, Res, s, sc_neg(omega), t);
+        if ((rc = dot_to_host(L, Res, Res, &d)) != EVOMG_OK) return rc;
+        res = sc_norm_from_dot(d);
+        if (hist && nh < cap) hist[nh] = res;
+        ++nh;
+        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+        if (res < prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+        if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+      }
+    if (it > prob_.max_iterations) it = prob_.max_iterations;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    out->time_ms = wall_ms() - t0;
+    HIP_TRY(hipMemcpyAsync(lv.f[EVOMG_F_CORR], Sol, bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(lv.f[EVOMG_F_RES], Res, bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    out->n_iterations = (double)it;
+    out->init_res_norm = res0;
+    out->final_res_norm = res;
+    out->status = status;
+    out->n_history = (nh < cap || !hist) ? nh : cap;
+    out->conv_factor = res0 > 0 ? res / res0 : 0.0;
+    return EVOMG_OK;
+  }
+
+  // algorithmic bytes of one op launch: SURVEY.md 8(d) table x node count of the op's level
+  double algorithmic_bytes(const evomg_op_t& op) const {
+    const Geo& g = lv_[op.level].g;
+    const double N = pow((double)g.n, dim_);
+    const double w = (double)sizeof(T);
+    const double frac = 1.0 / (double)(1 << dim_);
+    switch (op.opcode) {
+      case EVOMG_OP_SMOOTH: case EVOMG_OP_RESIDUAL: case EVOMG_OP_RICHARDSON: return 3 * w * N;
+      case EVOMG_OP_RESTRICT: { const double Nf = pow((double)lv_[op.level + 1].g.n, dim_); return (w + w * frac) * Nf; }
+      case EVOMG_OP_PROLONG_ADD: return (2 * w + w * frac) * N;
+      case EVOMG_OP_PROLONG_SET: return (w + w * frac) * N;
+      case EVOMG_OP_SET_ZERO: return w * N;
+      case EVOMG_OP_COPY: return 2 * w * N;
+      default: return 0.0;
+    }
+  }
+
+  evomg_problem_t prob_;
+  int device_;
+  int dim_;
+  Level<T> lv_[EVOMG_MAX_LEVELS];
+  Stencil<T> outer_st_{};
+  T* outer_[8] = {};
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  T* partials_ = nullptr;
+  T* dscalar_ = nullptr;
+  T* hscalar_ = nullptr;
+  int* dinfo_ = nullptr;
+};
+
+int check_problem(const evomg_problem_t* p, char* err, size_t len) {
+  if (!p) { snprintf(err, len, "null problem"); return EVOMG_ERR_INVALID; }
+  if (p->abi_version != EVOMG_ABI_VERSION) { snprintf(err, len, "abi version %d != %d", p->abi_version, EVOMG_ABI_VERSION); return EVOMG_ERR_INVALID; }
+  if (p->dimension != 2 && p->dimension != 3) { snprintf(err, len, "dimension must be 2 or 3"); return EVOMG_ERR_INVALID; }
+  if (p->min_level < 1 || p->max_level >= EVOMG_MAX_LEVELS || p->min_level > p->max_level) { snprintf(err, len, "bad level range"); return EVOMG_ERR_INVALID; }
+  if (p->scalar_kind != EVOMG_REAL_F64 && p->scalar_kind != EVOMG_COMPLEX_F64) { snprintf(err, len, "bad scalar kind"); return EVOMG_ERR_INVALID; }
+  if (p->scalar_kind == EVOMG_COMPLEX_F64 && p->dimension != 2) { snprintf(err, len, "complex problems are 2D only"); return EVOMG_ERR_UNSUPPORTED; }
+  if (p->bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && p->scalar_kind != EVOMG_COMPLEX_F64) { snprintf(err, len, "Robin BC needs complex fields"); return EVOMG_ERR_INVALID; }
+  if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) { snprintf(err, len, "PBiCGStab outer solver is 2D only"); return EVOMG_ERR_UNSUPPORTED; }
+  if (p->max_iterations < 1 || p->cgs_max_iterations < 1) { snprintf(err, len, "iteration limits must be positive"); return EVOMG_ERR_INVALID; }
+  return EVOMG_OK;
+}
+
+}  // namespace
+
+struct evomg_handle {
+  ImplBase* impl;
+};
+
+extern "C" {
+
+int evomg_abi_version(void) { return EVOMG_ABI_VERSION; }
+
+int evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t** out) {
+  if (!out) return EVOMG_ERR_INVALID;
+  *out = nullptr;
+  int rc = check_problem(problem, g_create_error, sizeof g_create_error);
+  if (rc != EVOMG_OK) return rc;
+  ImplBase* impl = nullptr;
+  if (problem->scalar_kind == EVOMG_COMPLEX_F64) impl = new Impl<cplx>(*problem, device_id);
+  else impl = new Impl<double>(*problem, device_id);
+  rc = impl->init();
+  if (rc != EVOMG_OK) {
+    snprintf(g_create_error, sizeof g_create_error, "%s", impl->err);
+    delete impl;
+    return rc;
+  }
+  *out = new evomg_handle{impl};
+  return EVOMG_OK;
+}
+
+void evomg_destroy(evomg_handle_t* h) {
+  if (!h) return;
+  delete h->impl;
+  delete h;
+}
+
+const char* evomg_last_error(const evomg_handle_t* h) { return h ? h->impl->err : g_create_error; }
+
+int evomg_set_initial_field(evomg_handle_t* h, int level, int field, const double* host) {
+  return h ? h->impl->set_initial_field(level, field, host) : EVOMG_ERR_INVALID;
+}
+int evomg_get_field(evomg_handle_t* h, int level, int field, double* host) {
+  return h ? h->impl->get_field(level, field, host) : EVOMG_ERR_INVALID;
+}
+int evomg_set_field(evomg_handle_t* h, int level, int field, const double* host) {
+  return h ? h->impl->set_field(level, field, host) : EVOMG_ERR_INVALID;
+}
+int evomg_set_operators(evomg_handle_t* h, const evomg_problem_t* problem) {
+  return h ? h->impl->set_operators(problem) : EVOMG_ERR_INVALID;
+}
+int evomg_evaluate(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int evaluation_samples, double wall_limit_ms,
+                   evomg_result_t* out, double* res_history, int history_capacity) {
+  return h ? h->impl->evaluate(ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity)
+           : EVOMG_ERR_INVALID;
+}
+int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {
+  if (!h || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
+  return h->impl->run_ops(ops, n_ops);
+}
+int evomg_norm(evomg_handle_t* h, int level, int field, double* out) {
+  return h ? h->impl->norm(level, field, out) : EVOMG_ERR_INVALID;
+}
+int evomg_bench_op(evomg_handle_t* h, const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) {
+  return h ? h->impl->bench_op(op, warmup, reps, out) : EVOMG_ERR_INVALID;
+}
+int evomg_kernel_name(evomg_handle_t* h, const evomg_op_t* op, char* buf, int buf_len) {
+  return h ? h->impl->kernel_name(op, buf, buf_len) : EVOMG_ERR_INVALID;
+}
+
+}  // extern "C"

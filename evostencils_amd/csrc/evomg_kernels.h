@@ -1,0 +1,340 @@
+// evomg_kernels.h — HIP kernels for gfx950 (wave64), one family per ExaSlang statement kind
+// (SURVEY.md 2.3, K1..K9). FP64 / complex-FP64 5- and 7-point stencils: bandwidth-bound, no MFMA.
+//
+// Data layout in HBM: one array per (field, level); node (i0,i1,i2) at i0 + pitch*i1 + plane*i2 with
+// pitch = n rounded up to a 128-byte multiple (rows start cache-line aligned), plane = pitch*n.
+// Boundary nodes are part of the array (index 0 and n-1 per dimension).
+#pragma once
+#include "evomg_scalar.h"
+
+struct Geo {
+  int n;          // nodes per dimension
+  int pitch;      // elements per row
+  long plane;     // elements per z-plane (pitch * n), 0 for 2D
+};
+
+template <int DIM> __device__ __forceinline__ long gidx(const Geo& g, int i, int j, int k) {
+  if (DIM == 2) return (long)i + (long)g.pitch * j;
+  return (long)i + (long)g.pitch * j + g.plane * k;
+}
+
+// thread -> node mapping of the generic kernels: block (64,4,1); grid (ceil(n/64), ceil(n/4), DIM==3 ? n : 1)
+template <int DIM> __device__ __forceinline__ bool node_of_thread(const Geo& g, int& i, int& j, int& k) {
+  i = blockIdx.x * blockDim.x + threadIdx.x;
+  j = blockIdx.y * blockDim.y + threadIdx.y;
+  k = (DIM == 3) ? (int)blockIdx.z : 0;
+  return i < g.n && j < g.n && (DIM == 2 || k < g.n);
+}
+template <int DIM> __device__ __forceinline__ bool is_inner(const Geo& g, int i, int j, int k) {
+  const int m = g.n - 1;
+  return i > 0 && i < m && j > 0 && j < m && (DIM == 2 || (k > 0 && k < m));
+}
+
+// ---- pointwise formulas: identical operation order to oracle FN(apply_st2/3), FN(relax2/3) ---------------
+template <typename T, int DIM>
+__device__ __forceinline__ T apply_stencil(const Stencil<T>& st, const T* __restrict__ x, const Geo& g, long c) {
+  T a = sc_mul(st.c[0], x[c]);
+  a = sc_add(a, sc_mul(st.c[1], x[c - 1]));
+  a = sc_add(a, sc_mul(st.c[2], x[c + 1]));
+  a = sc_add(a, sc_mul(st.c[3], x[c - g.pitch]));
+  a = sc_add(a, sc_mul(st.c[4], x[c + g.pitch]));
+  if (DIM == 3) {
+    a = sc_add(a, sc_mul(st.c[5], x[c - g.plane]));
+    a = sc_add(a, sc_mul(st.c[6], x[c + g.plane]));
+  }
+  return a;
+}
+template <typename T, int DIM>
+__device__ __forceinline__ T relax_point(const Stencil<T>& st, const T* __restrict__ x, const T* __restrict__ f,
+                                         const Geo& g, long c, double om, double omm) {
+  T s = f[c];
+  s = sc_sub(s, sc_mul(st.c[1], x[c - 1]));
+  s = sc_sub(s, sc_mul(st.c[2], x[c + 1]));
+  s = sc_sub(s, sc_mul(st.c[3], x[c - g.pitch]));
+  s = sc_sub(s, sc_mul(st.c[4], x[c + g.pitch]));
+  if (DIM == 3) {
+    s = sc_sub(s, sc_mul(st.c[5], x[c - g.plane]));
+    s = sc_sub(s, sc_mul(st.c[6], x[c + g.plane]));
+  }
+  const T xs = sc_div(s, st.c[0]);
+  return sc_add(sc_rmul(omm, x[c]), sc_rmul(om, xs));
+}
+
+// ---- K1: damped Jacobi, out of place (reads x, f; writes y incl. a copy of the boundary) -------------------
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_jacobi(Geo g, Stencil<T> st, const T* __restrict__ x,
+                                                    const T* __restrict__ f, T* __restrict__ y, double om, double omm) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(g, i, j, k)) return;
+  const long c = gidx<DIM>(g, i, j, k);
+  y[c] = is_inner<DIM>(g, i, j, k) ? relax_point<T, DIM>(st, x, f, g, c, om, omm) : x[c];
+}
+
+// ---- K2 (two-pass form): one colour of red-black Gauss-Seidel, in place ------------------------------------
+// thread tx handles node i = 2*tx + offset so that all threads of the launch work on the requested colour.
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_rbgs_colour(Geo g, Stencil<T> st, T* __restrict__ x,
+                                                         const T* __restrict__ f, double om, double omm, int colour) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = (DIM == 3) ? (int)blockIdx.z : 0;
+  const int i = 2 * t + ((j + k + colour) & 1);
+  if (!is_inner<DIM>(g, i, j, k)) return;
+  const long c = gidx<DIM>(g, i, j, k);
+  x[c] = relax_point<T, DIM>(st, x, f, g, c, om, omm);
+}
+
+// ---- K3: collective block-Jacobi, one thread per tile (tiles anchored at the first inner node) -----------
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_block_jacobi(Geo g, Stencil<T> st, const T* __restrict__ x,
+                                                          const T* __restrict__ f, T* __restrict__ y, double om,
+                                                          double omm, int bx, int by, int bz, int tx, int ty, int tz) {
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tj = blockIdx.y * blockDim.y + threadIdx.y;
+  const int tk = (DIM == 3) ? (int)blockIdx.z : 0;
+  if (ti >= tx || tj >= ty || tk >= tz) return;
+  const int n = g.n;
+  const int i0 = 1 + ti * bx, j0 = 1 + tj * by, k0 = (DIM == 3) ? 1 + tk * bz : 0;
+  const int mx = (i0 + bx <= n - 1) ? bx : (n - 1 - i0);
+  const int my = (j0 + by <= n - 1) ? by : (n - 1 - j0);
+  const int mz = (DIM == 3) ? ((k0 + bz <= n - 1) ? bz : (n - 1 - k0)) : 1;
+  const int m = mx * my * mz;
+  T A[8][8];
+  T r[8];
+  for (int p = 0; p < m; ++p)
+    for (int q = 0; q < m; ++q) A[p][q] = scalar_traits<T>::zero();
+  const int nnb = 1 + 2 * DIM;
+  for (int ci = 0; ci < mx; ++ci)
+    for (int cj = 0; cj < my; ++cj)
+      for (int ck = 0; ck < mz; ++ck) {
+        const int p = (ci * my + cj) * mz + ck;
+        const long gc = gidx<DIM>(g, i0 + ci, j0 + cj, k0 + ck);
+        T s = f[gc];
+        A[p][p] = st.c[0];
+        for (int e = 1; e < nnb; ++e) {
+          const int ox = (e == 1) ? -1 : (e == 2) ? 1 : 0;
+          const int oy = (e == 3) ? -1 : (e == 4) ? 1 : 0;
+          const int oz = (e == 5) ? -1 : (e == 6) ? 1 : 0;
+          const int di = ci + ox, dj = cj + oy, dk = ck + oz;
+          if (di >= 0 && di < mx && dj >= 0 && dj < my && dk >= 0 && dk < mz) {
+            A[p][(di * my + dj) * mz + dk] = st.c[e];
+          } else {
+            const long gn = gc + ox + (long)g.pitch * oy + g.plane * oz;
+            s = sc_sub(s, sc_mul(st.c[e], x[gn]));
+          }
+        }
+        r[p] = s;
+      }
+  for (int p = 0; p < m; ++p)
+    for (int q = p + 1; q < m; ++q) {
+      if (sc_iszero(A[q][p])) continue;
+      const T fac = sc_div(A[q][p], A[p][p]);
+      for (int t = p + 1; t < m; ++t) A[q][t] = sc_sub(A[q][t], sc_mul(fac, A[p][t]));
+      r[q] = sc_sub(r[q], sc_mul(fac, r[p]));
+    }
+  for (int p = m - 1; p >= 0; --p) {
+    T s = r[p];
+    for (int t = p + 1; t < m; ++t) s = sc_sub(s, sc_mul(A[p][t], r[t]));
+    r[p] = sc_div(s, A[p][p]);
+  }
+  for (int ci = 0; ci < mx; ++ci)
+    for (int cj = 0; cj < my; ++cj)
+      for (int ck = 0; ck < mz; ++ck) {
+        const int p = (ci * my + cj) * mz + ck;
+        const long gc = gidx<DIM>(g, i0 + ci, j0 + cj, k0 + ck);
+        y[gc] = sc_add(sc_rmul(omm, x[gc]), sc_rmul(om, r[p]));
+      }
+}
+
+// copies the boundary shell x -> y (block smoother writes only inner tiles)
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_copy_boundary(Geo g, const T* __restrict__ x, T* __restrict__ y) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(g, i, j, k)) return;
+  if (is_inner<DIM>(g, i, j, k)) return;
+  const long c = gidx<DIM>(g, i, j, k);
+  y[c] = x[c];
+}
+
+// ---- K4: residual r = f - A x on inner nodes; y = A x variant for the Krylov solvers ------------------------
+template <typename T, int DIM, bool RESIDUAL>
+__global__ void __launch_bounds__(256) evomg_apply(Geo g, Stencil<T> st, const T* __restrict__ x,
+                                                   const T* __restrict__ f, T* __restrict__ r) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(g, i, j, k)) return;
+  if (!is_inner<DIM>(g, i, j, k)) return;
+  const long c = gidx<DIM>(g, i, j, k);
+  const T ax = apply_stencil<T, DIM>(st, x, g, c);
+  r[c] = RESIDUAL ? sc_sub(f[c], ax) : ax;
+}
+
+// Richardson step y = x + w * (f - A x) on inner nodes (y pre-filled with x on the boundary by the caller)
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_richardson(Geo g, Stencil<T> st, const T* __restrict__ x,
+                                                        const T* __restrict__ f, T* __restrict__ y, double om) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(g, i, j, k)) return;
+  const long c = gidx<DIM>(g, i, j, k);
+  if (!is_inner<DIM>(g, i, j, k)) { y[c] = x[c]; return; }
+  const T res = sc_sub(f[c], apply_stencil<T, DIM>(st, x, g, c));
+  y[c] = sc_add(x[c], sc_mul(scalar_traits<T>::from_real(om), res));
+}
+
+// ---- K5: full-weighting restriction, coarse-node driven ----------------------------------------------------
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_restrict(Geo gc, Geo gf, const T* __restrict__ fine, T* __restrict__ coarse) {
+  int I, J, K;
+  if (!node_of_thread<DIM>(gc, I, J, K)) return;
+  if (!is_inner<DIM>(gc, I, J, K)) return;
+  const int i = 2 * I, j = 2 * J, k = 2 * K;
+  if (DIM == 2) {
+    const long c = gidx<2>(gf, i, j, 0);
+    const long p = gf.pitch;
+    const T e = sc_add(sc_add(fine[c - 1], fine[c + 1]), sc_add(fine[c - p], fine[c + p]));
+    const T q = sc_add(sc_add(fine[c - p - 1], fine[c - p + 1]), sc_add(fine[c + p - 1], fine[c + p + 1]));
+    T v = sc_rmul(0.25, fine[c]);
+    v = sc_add(v, sc_rmul(0.125, e));
+    v = sc_add(v, sc_rmul(0.0625, q));
+    coarse[gidx<2>(gc, I, J, 0)] = v;
+  } else {
+    T face = scalar_traits<T>::zero(), edge = scalar_traits<T>::zero(), corner = scalar_traits<T>::zero();
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+          if (nz == 0) continue;
+          const T v = fine[gidx<3>(gf, i + dx, j + dy, k + dz)];
+          if (nz == 1) face = sc_add(face, v);
+          else if (nz == 2) edge = sc_add(edge, v);
+          else corner = sc_add(corner, v);
+        }
+    T v = sc_rmul(0.125, fine[gidx<3>(gf, i, j, k)]);
+    v = sc_add(v, sc_rmul(0.0625, face));
+    v = sc_add(v, sc_rmul(0.03125, edge));
+    v = sc_add(v, sc_rmul(0.015625, corner));
+    coarse[gidx<3>(gc, I, J, K)] = v;
+  }
+}
+
+// ---- K6 / K6': bi-/tri-linear prolongation, fine-node driven; ACC: fine += w * P coarse ---------------------
+template <typename T, int DIM>
+__device__ __forceinline__ T interpolate(const Geo& gc, const T* __restrict__ cz, int i, int j, int k) {
+  const int I = i >> 1, J = j >> 1, K = k >> 1;
+  const int ox = i & 1, oy = j & 1, oz = (DIM == 3) ? (k & 1) : 0;
+  if (DIM == 2) {
+    const long c = gidx<2>(gc, I, J, 0);
+    const long p = gc.pitch;
+    if (!ox && !oy) return cz[c];
+    if (ox && !oy) return sc_rmul(0.5, sc_add(cz[c], cz[c + 1]));
+    if (!ox && oy) return sc_rmul(0.5, sc_add(cz[c], cz[c + p]));
+    return sc_rmul(0.25, sc_add(sc_add(cz[c], cz[c + 1]), sc_add(cz[c + p], cz[c + p + 1])));
+  }
+  T s = scalar_traits<T>::zero();
+  for (int dz = 0; dz <= oz; ++dz)
+    for (int dy = 0; dy <= oy; ++dy)
+      for (int dx = 0; dx <= ox; ++dx) s = sc_add(s, cz[gidx<3>(gc, I + dx, J + dy, K + dz)]);
+  const int nodd = ox + oy + oz;
+  const double w = (nodd == 0) ? 1.0 : (nodd == 1) ? 0.5 : (nodd == 2) ? 0.25 : 0.125;
+  return sc_rmul(w, s);
+}
+template <typename T, int DIM, bool ACC>
+__global__ void __launch_bounds__(256) evomg_prolong(Geo gf, Geo gc, const T* __restrict__ coarse, T* __restrict__ fine, double om) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(gf, i, j, k)) return;
+  if (!is_inner<DIM>(gf, i, j, k)) return;
+  const long c = gidx<DIM>(gf, i, j, k);
+  const T v = interpolate<T, DIM>(gc, coarse, i, j, k);
+  fine[c] = ACC ? sc_add(fine[c], sc_rmul(om, v)) : v;
+}
+
+// ---- K7: zero the inner nodes ---------------------------------------------------------------------------------
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_zero_inner(Geo g, T* __restrict__ x) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(g, i, j, k)) return;
+  if (!is_inner<DIM>(g, i, j, k)) return;
+  x[gidx<DIM>(g, i, j, k)] = scalar_traits<T>::zero();
+}
+
+// ---- K8: Helmholtz Robin boundary at x = 0, 1:  x_b = x_in / (1 - i k h)  (2D complex only) ----------------
+__global__ void __launch_bounds__(256) evomg_robin_bc(Geo g, cplx* __restrict__ x, double kh) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < 1 || j >= g.n - 1) return;
+  const cplx den{1.0, -kh};
+  const long row = (long)g.pitch * j;
+  x[row] = sc_div(x[row + 1], den);
+  x[row + g.n - 1] = sc_div(x[row + g.n - 2], den);
+}
+
+// ---- reductions ---------------------------------------------------------------------------------------------------
+// wave64 shuffle reduction followed by an LDS reduction across the block's waves; fixed order => deterministic.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ cplx wave_sum(cplx v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v.re += __shfl_down(v.re, off, 64);
+    v.im += __shfl_down(v.im, off, 64);
+  }
+  return v;
+}
+// all threads of the block receive the sum; `red` = LDS scratch of >= 17 elements; blockDim multiple of 64
+template <typename T> __device__ __forceinline__ T block_sum(T v, T* red) {
+  const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  const int nthreads = blockDim.x * blockDim.y * blockDim.z;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  v = wave_sum(v);
+  __syncthreads();            // protects `red` against the previous use
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    T t = (lane < nwaves) ? red[lane] : scalar_traits<T>::zero();
+    t = wave_sum(t);
+    if (lane == 0) red[16] = t;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+// dot over inner nodes, pass 1: grid-stride over rows, one partial per block (fixed grid => deterministic)
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_dot_partial(Geo g, const T* __restrict__ a, const T* __restrict__ b,
+                                                         T* __restrict__ partial) {
+  __shared__ T red[17];
+  const int m = g.n - 2;
+  const long rows = (DIM == 2) ? m : (long)m * m;
+  T s = scalar_traits<T>::zero();
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int j = 1 + (int)(r % m), k = (DIM == 3) ? 1 + (int)(r / m) : 0;
+    const long base = gidx<DIM>(g, 0, j, k);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) s = sc_add(s, sc_mul(a[base + i], b[base + i]));
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// pass 2: one block sums the partials in a fixed order
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_dot_final(const T* __restrict__ partial, int count, T* __restrict__ out) {
+  __shared__ T red[17];
+  T s = scalar_traits<T>::zero();
+  for (int i = threadIdx.x; i < count; i += blockDim.x) s = sc_add(s, partial[i]);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// z = x + a*y on inner nodes
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_axpy(Geo g, T* __restrict__ z, const T* __restrict__ x, T a,
+                                                  const T* __restrict__ y) {
+  int i, j, k;
+  if (!node_of_thread<DIM>(g, i, j, k)) return;
+  if (!is_inner<DIM>(g, i, j, k)) return;
+  const long c = gidx<DIM>(g, i, j, k);
+  z[c] = sc_add(x[c], sc_mul(a, y[c]));
+}

@@ -1,0 +1,32 @@
+"""Loader of the in-tree HIP library. There is NO fallback: if csrc/libevomg.so is missing or does
+not load, importing code gets a RuntimeError telling how to build it."""
+import os
+
+from evostencils_amd import abi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libevomg.so")
+_library = None
+
+
+def library() -> abi.Library:
+    global _library
+    if _library is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"HIP backend not built: {LIB_PATH} is missing. "
+                               f"Run `python -m evostencils_amd.build` (needs hipcc).")
+        try:
+            _library = abi.Library(LIB_PATH, "evomg", abi.EXPORTED)
+        except OSError as exc:
+            raise RuntimeError(f"HIP backend failed to load ({LIB_PATH}): {exc}") from exc
+        if _library.fn["abi_version"]() != abi.ABI_VERSION:
+            raise RuntimeError("HIP backend ABI version mismatch; rebuild with `python -m evostencils_amd.build`")
+    return _library
+
+
+def create(problem_description, device_id=0, parameters=None) -> abi.Handle:
+    """Native solver instance with the problem's initial fields uploaded."""
+    h = abi.Handle(library(), problem_description.to_c(parameters), device_id)
+    L = problem_description.max_level
+    h.set_initial_field(L, abi.F_SOL, problem_description.initial_solution(L))
+    h.set_initial_field(L, abi.F_RHS, problem_description.right_hand_side(L))
+    return h

@@ -1,0 +1,85 @@
+"""Population-level evaluation: candidates shard embarrassingly across the GPUs of one node, one
+process per GPU; the only exchange is one small collective per generation carrying the fitness
+scalars — the RCCL-over-xGMI counterpart of the reference's mpi4py object collectives
+(optimization/program.py:285-310: allgather/gather helpers; :534-536 round-robin re-evaluation
+`i % nprocs == rank`; :582 per-generation `allgather(offspring)`).
+
+Payload: [n_local x (index, convergence factor, time ms, iterations)] float64 — a few KiB, latency
+bound; no intra-solve communication ever happens (one solve lives on one GPU).
+torch.distributed is used as plumbing only: backend "nccl" is RCCL on ROCm, "gloo" serves the CPU tests.
+"""
+from typing import Callable, List, Sequence, Tuple
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world_info():
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n_candidates: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment, as the reference's `i % nprocs == rank` (program.py:534-535)."""
+    return [i for i in range(n_candidates) if i % world == rank]
+
+
+def _device(local_rank):
+    import torch
+    dist = _dist()
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", local_rank)
+    return torch.device("cpu")
+
+
+def gather_fitness(local: Sequence[Tuple[float, float, float]], world: int, local_rank: int = 0,
+                   dst: int = 0):
+    """Gather per-rank lists of (rho, time_ms, iterations) to `dst` (north_star: "tiny RCCL gather of the
+    fitness scalars back to rank 0"). Every rank must pass the same number of entries. Returns the
+    concatenated list on `dst` (rank order), the local list elsewhere. No-op for a single process."""
+    if world <= 1:
+        return list(local)
+    import torch
+    dist = _dist()
+    t = torch.tensor(list(local), dtype=torch.float64, device=_device(local_rank)).reshape(-1, 3)
+    if dist.get_rank() == dst:
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.gather(t, out, dst=dst)
+        return [tuple(row) for chunk in out for row in chunk.cpu().tolist()]
+    dist.gather(t, None, dst=dst)
+    return list(local)
+
+
+def allgather_fitness(indexed: Sequence[Tuple[int, float, float, float]], n_total: int, world: int,
+                      local_rank: int = 0):
+    """All ranks obtain the fitness of all candidates: rows (index, rho, time_ms, iterations), padded to
+    the largest shard. Counterpart of `allgather([(i, fitness)])` (program.py:536)."""
+    if world <= 1:
+        return sorted(indexed)
+    import torch
+    dist = _dist()
+    per = (n_total + world - 1) // world
+    t = torch.full((per, 4), -1.0, dtype=torch.float64, device=_device(local_rank))
+    if indexed:
+        t[:len(indexed)] = torch.tensor(list(indexed), dtype=torch.float64)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    rows = [tuple(r) for chunk in out for r in chunk.cpu().tolist() if r[0] >= 0]
+    return sorted((int(r[0]), r[1], r[2], r[3]) for r in rows)
+
+
+def evaluate_population(evaluate: Callable[[int], Tuple[float, float, float]], n_candidates: int,
+                        local_rank: int = 0):
+    """Evaluates candidates `i % world == rank` with `evaluate(i) -> (time_ms, rho, iterations)` (the triple
+    ProgramGenerator.generate_and_evaluate returns) and returns, on every rank, the list
+    [(i, rho, time_ms, iterations)] for ALL candidates."""
+    rank, world = world_info()
+    mine = []
+    for i in shard_indices(n_candidates, rank, world):
+        t_ms, rho, its = evaluate(i)
+        mine.append((i, float(rho), float(t_ms), float(its)))
+    return allgather_fitness(mine, n_candidates, world, local_rank)

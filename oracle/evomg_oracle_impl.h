@@ -380,30 +380,79 @@ static void FN(prolong)(FN(ctx_t)* c, int fine_level, const SC* coarse, SC* fine
   FN(apply_bc)(c, fine_level, fine);
 }
 
-/* ---- reductions over inner nodes: per-row partial sums, rows summed in order -> independent of
- * the thread count. dot(a,b) = sum a_i * b_i WITHOUT conjugation: literal reading of the DSL's
- * `dot ( resHat, Residual )` typed Complex<Real> (Helmholtz/2D_FD_Helmholtz_fromL3.exa3:86-88,158) [EXTERNAL] */
+/* ---- reductions over inner nodes. dot(a,b) = sum a_i * b_i WITHOUT conjugation: literal reading of the DSL's
+ * `dot ( resHat, Residual )` typed Complex<Real> (Helmholtz/2D_FD_Helmholtz_fromL3.exa3:86-88,158) [EXTERNAL].
+ *
+ * Summation order = the device's two-pass reduction (csrc/evomg_kernels.h evomg_dot_partial / evomg_dot_final),
+ * restated so that Krylov recurrences fed by these sums (preconditioned BiCGStab on the finest level) follow the
+ * same trajectory on both sides: pass 1 — B = min(rows, 1024) blocks of 256 threads, block b takes the inner rows
+ * b, b+B, ..., thread t the nodes i = 1+t, 1+t+256, ... of each row, then a wave64 shuffle tree per wave and the
+ * same tree over the 4 wave sums; pass 2 — 256 threads take the partials t, t+256, ..., same trees. */
+#define DOT_BLOCKS 1024
+#define DOT_THREADS 256
+static SC FN(tree64)(SC* v);
+static SC FN(block_tree)(SC* th) {
+  SC waves[64];
+  for (int w = 0; w < 64; ++w) waves[w] = sc_zero();
+  for (int w = 0; w < DOT_THREADS / 64; ++w) waves[w] = FN(tree64)(&th[64 * w]);
+  return FN(tree64)(waves);
+}
 static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
-  const int n = c->lv[level].n;
-  const int rows = (c->dim == 2) ? n : n * n;
-  SC* part = (SC*)malloc((size_t)rows * sizeof(SC));
+  const int n = c->lv[level].n, m = n - 2;
+  const long rows = (c->dim == 2) ? m : (long)m * m;
+  const int B = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
+  SC partial[DOT_BLOCKS];
 #pragma omp parallel for schedule(static) if (OMP_WORTH(n))
-  for (int r = 0; r < rows; ++r) {
-    SC s = sc_zero();
-    const int j = (c->dim == 2) ? r : r % n, k = (c->dim == 2) ? 1 : r / n;
-    if (j >= 1 && j < n - 1 && k >= 1 && (c->dim == 2 || k < n - 1)) {
-      const size_t base = (size_t)r * (size_t)n;
-      for (int i = 1; i < n - 1; ++i) s = sc_add(s, sc_mul(a[base + i], b[base + i]));
+  for (int blk = 0; blk < B; ++blk) {
+    SC th[DOT_THREADS];
+    for (int t = 0; t < DOT_THREADS; ++t) th[t] = sc_zero();
+    for (long r = blk; r < rows; r += B) {
+      const int j = 1 + (int)(r % m), k = (c->dim == 3) ? 1 + (int)(r / m) : 0;
+      const size_t base = (c->dim == 3) ? IDX3(n, 0, j, k) : IDX2(n, 0, j);
+      for (int i = 1; i <= m; ++i) {
+        const int t = (i - 1) % DOT_THREADS;
+        th[t] = sc_add(th[t], sc_mul(a[base + i], b[base + i]));
+      }
     }
-    part[r] = s;
+    partial[blk] = FN(block_tree)(th);
   }
-  SC s = sc_zero();
-  for (int r = 0; r < rows; ++r) s = sc_add(s, part[r]);
-  free(part);
-  return s;
+  SC th[DOT_THREADS];
+  for (int t = 0; t < DOT_THREADS; ++t) th[t] = sc_zero();
+  for (int i = 0; i < B; ++i) th[i % DOT_THREADS] = sc_add(th[i % DOT_THREADS], partial[i]);
+  return FN(block_tree)(th);
 }
 /* residual norm of the solver loop: |sqrt(dot(r,r))|  (for real fields: sqrt(sum r^2)) [EXTERNAL: App. B.8] */
 static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_from_dot(FN(dot)(c, level, a, a)); }
+
+/* Canonical reduction order of the coarse-grid Krylov solvers. The HIP solvers run as ONE 1024-thread
+ * workgroup (csrc/evomg_krylov.h): thread t accumulates the inner nodes q = t, t+1024, ... (q runs x-fastest
+ * over the inner nodes) in increasing q, each wave64 folds its 64 partials with the shuffle tree
+ * (offsets 32,16,..,1), then the 16 wave sums are folded by the same tree (padded with zeros). Restating that
+ * order here makes CG / BiCGStab on the oracle bit-identical to the device solvers; without it the two differ
+ * by summation round-off, which a Krylov recurrence amplifies up to the attainable-accuracy floor. */
+#define KRYLOV_LANES 1024
+static SC FN(tree64)(SC* v) {
+  for (int off = 32; off > 0; off >>= 1)
+    for (int l = 0; l < off; ++l) v[l] = sc_add(v[l], v[l + off]);
+  return v[0];
+}
+static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
+  const int n = c->lv[level].n, m = n - 2;
+  const long total = (c->dim == 2) ? (long)m * m : (long)m * m * m;
+  SC part[KRYLOV_LANES];
+  for (int t = 0; t < KRYLOV_LANES; ++t) part[t] = sc_zero();
+  for (long q = 0; q < total; ++q) {
+    const int i = 1 + (int)(q % m);
+    const long r = q / m;
+    const size_t idx = (c->dim == 2) ? IDX2(n, i, 1 + (int)r) : IDX3(n, i, 1 + (int)(r % m), 1 + (int)(r / m));
+    const int t = (int)(q % KRYLOV_LANES);
+    part[t] = sc_add(part[t], sc_mul(a[idx], b[idx]));
+  }
+  SC waves[64];
+  for (int w = 0; w < 64; ++w) waves[w] = sc_zero();
+  for (int w = 0; w < KRYLOV_LANES / 64; ++w) waves[w] = FN(tree64)(&part[64 * w]);
+  return FN(tree64)(waves);
+}
 
 static void FN(zero_inner)(FN(ctx_t)* c, int level, SC* x) {
   const int n = c->lv[level].n;
@@ -449,18 +498,19 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   SC* p = FN(tmpvec)(c, L, 0);
   SC* ap = FN(tmpvec)(c, L, 1);
   FN(residual_st)(c, L, lv->st, x, b, r);
-  SC rr = FN(dot)(c, L, r, r);
+  SC rr = FN(dot_canon)(c, L, r, r);
   const double res0 = sc_norm_from_dot(rr);
   if (res0 == 0.0) return 0;
-  memcpy(p, r, lv->count * sizeof(SC));
+  /* p = r on the inner nodes; p keeps its homogeneous boundary (an error-type field) */
+  FN(axpy_to)(c, L, p, r, sc_zero(), r);
   int it = 0;
   for (; it < c->prob.cgs_max_iterations; ++it) {
     FN(apply_op)(c, L, lv->st, p, ap);
-    const SC pap = FN(dot)(c, L, p, ap);
+    const SC pap = FN(dot_canon)(c, L, p, ap);
     const SC alpha = sc_div(rr, pap);
     FN(axpy_to)(c, L, x, x, alpha, p);
     FN(axpy_to)(c, L, r, r, sc_neg(alpha), ap);
-    const SC rr_new = FN(dot)(c, L, r, r);
+    const SC rr_new = FN(dot_canon)(c, L, r, r);
     const double res = sc_norm_from_dot(rr_new);
     if (!(res > c->prob.cgs_target_res_reduction * res0)) { ++it; break; }
     const SC beta = sc_div(rr_new, rr);
@@ -487,7 +537,7 @@ static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
   SC* rhat = FN(tmpvec)(c, L, 5);
   const SC* st = lv->st;
   FN(residual_st)(c, L, st, x, f, r);
-  const double res0 = FN(norm)(c, L, r);
+  const double res0 = sc_norm_from_dot(FN(dot_canon)(c, L, r, r));
   if (res0 == 0.0) return 0;
   SC alpha = sc_from_real(1.0), beta, rho, rho_new = sc_from_real(1.0), omega = sc_from_real(1.0);
   memcpy(rhat, r, lv->count * sizeof(SC));
@@ -496,24 +546,24 @@ static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
   int it = 0;
   for (; it < c->prob.cgs_max_iterations; ++it) {
     rho = rho_new;
-    rho_new = FN(dot)(c, L, rhat, r);
+    rho_new = FN(dot_canon)(c, L, rhat, r);
     beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
     /* p = r + beta * (p - omega * nu) ; boundary of p handled by applyBC_p@coarsest */
     FN(axpy_to)(c, L, p, p, sc_neg(omega), nu);
     FN(axpy_to)(c, L, p, r, beta, p);
     FN(apply_bc)(c, L, p);
     FN(apply_op)(c, L, st, p, nu);
-    alpha = sc_div(rho_new, FN(dot)(c, L, rhat, nu));
+    alpha = sc_div(rho_new, FN(dot_canon)(c, L, rhat, nu));
     FN(axpy_to)(c, L, hh, x, alpha, p);
     FN(axpy_to)(c, L, s, r, sc_neg(alpha), nu);
     FN(apply_bc)(c, L, s);
     FN(apply_op)(c, L, st, s, t);
-    omega = sc_div(FN(dot)(c, L, t, s), FN(dot)(c, L, t, t));
+    omega = sc_div(FN(dot_canon)(c, L, t, s), FN(dot_canon)(c, L, t, t));
     FN(axpy_to)(c, L, x, hh, omega, s);
     FN(apply_bc)(c, L, x);
     FN(axpy_to)(c, L, r, s, sc_neg(omega), t);
     FN(apply_bc)(c, L, r);
-    const double res = FN(norm)(c, L, r);
+    const double res = sc_norm_from_dot(FN(dot_canon)(c, L, r, r));
     if (res < c->prob.cgs_target_res_reduction * res0) { ++it; break; }
     if (!(res == res)) { ++it; break; }  /* NaN guard: the DSL would spin to the iteration cap */
   }

@@ -1,0 +1,70 @@
+"""CPU-side checks of the boundary: the HIP library loads without a GPU and exports every symbol
+include/evomg.h declares; the ctypes mirror has the same struct sizes as the C header."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from evostencils_amd import abi, build
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "evomg.h")
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return build.build()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(evomg_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_wrapper_binds():
+    assert declared_functions() == sorted(f"evomg_{s}" for s in abi.EXPORTED)
+
+
+def test_library_loads_and_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    lib.evomg_abi_version.restype = ctypes.c_int
+    assert lib.evomg_abi_version() == abi.ABI_VERSION
+
+
+def test_wrapper_binds_library(libpath):
+    lib = abi.Library(libpath, "evomg", abi.EXPORTED)
+    assert lib.fn["abi_version"]() == abi.ABI_VERSION
+
+
+def test_struct_sizes_match_c_header():
+    src = r'''
+    #include <stdio.h>
+    #include "evomg.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu\n", sizeof(evomg_problem_t), sizeof(evomg_op_t), sizeof(evomg_result_t), sizeof(evomg_bench_t));
+      return 0;
+    }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(abi.Problem), ctypes.sizeof(abi.Op), ctypes.sizeof(abi.Result), ctypes.sizeof(abi.Bench)]
+
+
+def test_create_rejects_bad_descriptors_without_touching_the_gpu(libpath):
+    lib = abi.Library(libpath, "evomg", abi.EXPORTED)
+    p = abi.Problem()
+    p.abi_version = 999
+    with pytest.raises(abi.BackendError):
+        abi.Handle(lib, p, 0)
+    p.abi_version, p.dimension = abi.ABI_VERSION, 4
+    with pytest.raises(abi.BackendError):
+        abi.Handle(lib, p, 0)

@@ -1,0 +1,253 @@
+"""GPU parity tests proper: the HIP backend (through the C-ABI, csrc/libevomg.so) against the CPU oracle
+on the same seeded inputs.
+
+Bars
+ * pointwise kernels (smoothers, residual, restriction, prolongation, zero, copy, Robin BC): BIT-EXACT
+   (identical operation order, both sides built with -ffp-contract=off);
+ * reductions / Krylov coarse solves / whole solves: floating-point order of the sums differs between the
+   wave-shuffle tree and the oracle's row-wise sum -> relative tolerance 1e-10 on residual norms (the
+   tolerance north_star states), identical iteration counts.
+"""
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, problems
+import cycles
+from helpers import ops_for_case
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def native():
+    from evostencils_amd import native as nat
+    nat.library()  # raises if the HIP library is missing: no fallback
+    return nat
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def make_pair(native, oracle, pd, parameters=None):
+    return native.create(pd, 0, parameters), oracle.create(pd, parameters)
+
+
+def random_field(rng, shape, is_complex):
+    a = rng.standard_normal(shape)
+    if is_complex:
+        a = a + 1j * rng.standard_normal(shape)
+    return a
+
+
+def zero_boundary(a):
+    a = a.copy()
+    for d in range(a.ndim):
+        sl = [slice(None)] * a.ndim
+        sl[d] = 0
+        a[tuple(sl)] = 0
+        sl[d] = -1
+        a[tuple(sl)] = 0
+    return a
+
+
+PROBLEMS = {
+    "poisson2d": lambda: problems.poisson_2d(3, 6),
+    "poisson3d": lambda: problems.poisson_3d(2, 4),
+    "helmholtz2d": lambda: problems.helmholtz_2d(3, 6, k=20.0),
+}
+
+
+def load_random_state(hg, ho, pd, rng):
+    """Same random contents in every field of every level on both sides."""
+    for L in range(pd.min_level, pd.max_level + 1):
+        shape = hg.field_shape(L)
+        fields = [abi.F_SOL, abi.F_RHS, abi.F_RES]
+        if L == pd.max_level:
+            fields.append(abi.F_CORR)
+        if L == pd.min_level:
+            fields.append(abi.F_CGS_RHS)
+        for f in fields:
+            a = random_field(rng, shape, hg.is_complex)
+            if pd.bc_kind == abi.BC_HELMHOLTZ_ROBIN:
+                a = zero_boundary(a)
+            hg.set_field(L, f, a)
+            ho.set_field(L, f, a)
+
+
+def pointwise_ops(pd):
+    d = pd.dimension
+    lo, hi = pd.min_level, pd.max_level
+    mid = hi - 1
+    one = (1, 1, 1)
+    ops = [
+        ("jacobi", abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.8), (hi, abi.F_SOL)),
+        ("jacobi_coarse", abi.make_op(abi.OP_SMOOTH, mid, abi.F_CORR, 0, abi.F_RHS, abi.PART_SINGLE, one, 1.3), (mid, abi.F_SOL)),
+        ("rbgs", abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.15), (hi, abi.F_SOL)),
+        ("rbgs_coarse", abi.make_op(abi.OP_SMOOTH, lo, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 0.6), (lo, abi.F_SOL)),
+        ("residual", abi.make_op(abi.OP_RESIDUAL, hi, abi.F_RES, abi.F_SOL, abi.F_RHS), (hi, abi.F_RES)),
+        ("richardson", abi.make_op(abi.OP_RICHARDSON, hi, abi.F_SOL, abi.F_SOL, abi.F_RHS, omega=0.3 / abs(complex(pd.mg_stencil(hi, pd.parameters)[0]))), (hi, abi.F_SOL)),
+        ("restrict", abi.make_op(abi.OP_RESTRICT, mid, abi.F_RHS, abi.F_RES), (mid, abi.F_RHS)),
+        ("prolong_add", abi.make_op(abi.OP_PROLONG_ADD, hi, abi.F_SOL, abi.F_CORR, omega=0.95), (hi, abi.F_SOL)),
+        ("prolong_set", abi.make_op(abi.OP_PROLONG_SET, hi, abi.F_CORR, abi.F_CORR), (hi, abi.F_CORR)),
+        ("zero", abi.make_op(abi.OP_SET_ZERO, mid, abi.F_SOL), (mid, abi.F_SOL)),
+        ("copy", abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS), (lo, abi.F_CGS_RHS)),
+    ]
+    shapes2 = [(2, 1), (1, 2), (2, 2), (3, 2), (1, 6), (4, 2), (8, 1), (1, 3)]
+    shapes3 = [(2, 1, 1), (1, 2, 1), (1, 1, 2), (2, 2, 1), (2, 2, 2), (1, 2, 3), (4, 1, 2)]
+    for b in (shapes2 if d == 2 else shapes3):
+        blk = tuple(b) + (1,) * (3 - len(b))
+        ops.append((f"block{b}", abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, blk, 0.7), (hi, abi.F_SOL)))
+    return ops
+
+
+@pytest.mark.parametrize("pname", sorted(PROBLEMS))
+def test_pointwise_kernels_are_bit_exact(native, oracle, pname):
+    pd = PROBLEMS[pname]()
+    hg, ho = make_pair(native, oracle, pd)
+    rng = np.random.default_rng(1234)
+    for name, op, (lvl, fld) in pointwise_ops(pd):
+        load_random_state(hg, ho, pd, rng)
+        hg.run_ops([op])
+        ho.run_ops([op])
+        got, want = hg.get_field(lvl, fld), ho.get_field(lvl, fld)
+        assert np.array_equal(got, want), f"{pname}:{name}: max diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("pname", sorted(PROBLEMS))
+def test_smoother_sequences_stay_bit_exact(native, oracle, pname):
+    """Ping-pong buffers, colour order and boundary handling over several consecutive sweeps."""
+    pd = PROBLEMS[pname]()
+    hg, ho = make_pair(native, oracle, pd)
+    rng = np.random.default_rng(99)
+    load_random_state(hg, ho, pd, rng)
+    hi = pd.max_level
+    one = (1, 1, 1)
+    blk = (2, 1, 1) if pd.dimension == 2 else (2, 2, 1)
+    seq = [abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.8),
+           abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.1),
+           abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, blk, 0.9),
+           abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.5),
+           abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.0),
+           abi.make_op(abi.OP_RESIDUAL, hi, abi.F_RES, abi.F_SOL, abi.F_RHS)]
+    hg.run_ops(seq)
+    ho.run_ops(seq)
+    assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+    assert np.array_equal(hg.get_field(hi, abi.F_RES), ho.get_field(hi, abi.F_RES))
+
+
+@pytest.mark.parametrize("pname", sorted(PROBLEMS))
+def test_norm_and_coarse_solver_within_tolerance(native, oracle, pname):
+    pd = PROBLEMS[pname]()
+    hg, ho = make_pair(native, oracle, pd)
+    rng = np.random.default_rng(7)
+    load_random_state(hg, ho, pd, rng)
+    for L in range(pd.min_level, pd.max_level + 1):
+        a, b = hg.norm(L, abi.F_RHS), ho.norm(L, abi.F_RHS)
+        assert abs(a - b) <= 1e-13 * b
+    lo = pd.min_level
+    zero = abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR)
+    solve = abi.make_op(abi.OP_COARSE_SOLVE, lo)
+    res = abi.make_op(abi.OP_RESIDUAL, lo, abi.F_RES, abi.F_CORR, abi.F_CGS_RHS)
+    hg.run_ops([zero, solve, res])
+    ho.run_ops([zero, solve, res])
+    # canonical reduction order on both sides (oracle FN(dot_canon)): the Krylov solve is bit-identical
+    assert np.array_equal(hg.get_field(lo, abi.F_CORR), ho.get_field(lo, abi.F_CORR))
+    # both must actually have solved the system to the configured reduction
+    tol = pd.cgs_target_res_reduction
+    assert hg.norm(lo, abi.F_RES) <= 50 * tol * ho.norm(lo, abi.F_CGS_RHS)
+
+
+def compare_solves(og, oo, same_iterations=True):
+    assert og.status == oo.status
+    if same_iterations:
+        assert og.n_iterations == oo.n_iterations
+        assert len(og.history) == len(oo.history)
+        rel = np.abs(og.history - oo.history) / oo.history
+        assert rel.max() <= REL_TOL, f"residual history differs: max rel {rel.max():.3e}"
+    assert abs(og.final_res_norm - oo.final_res_norm) <= REL_TOL * oo.final_res_norm + 1e-300 or not same_iterations
+
+
+@pytest.mark.parametrize("name", sorted(cycles.CASES))
+def test_whole_solves_match_the_oracle(native, oracle, name):
+    """Every golden-string candidate: lowering -> op program -> solve on both sides."""
+    problem, lo, hi, _ = cycles.CASES[name]
+    gen, ops = ops_for_case(name)
+    pd = problems.BY_NAME[problem](lo, hi)
+    hg, ho = make_pair(native, oracle, pd)
+    og = hg.evaluate(ops, 1, 0, 128)
+    oo = ho.evaluate(ops, 1, 0, 128)
+    compare_solves(og, oo)
+    # every field-updating kernel incl. the Krylov coarse solver follows the oracle's operation order
+    # => the converged solution is bit-identical; only the (non-feedback) outer norm differs in sum order
+    assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+
+
+def test_helmholtz_pbicgstab_matches_the_oracle(native, oracle):
+    """Reference V(2,1) RB-GS w=0.6 cycle of Helmholtz exa3:202-272 as preconditioner, k*h = 0.625."""
+    from test_helmholtz_oracle import reference_vcycle_ops
+    lo, hi = 3, 6
+    pd = problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
+    hg, ho = make_pair(native, oracle, pd)
+    ops = reference_vcycle_ops(lo, hi)
+    og = hg.evaluate(ops, 1, 0, 256)
+    oo = ho.evaluate(ops, 1, 0, 256)
+    assert og.status == oo.status == abi.SOLVE_CONVERGED
+    assert og.n_iterations == oo.n_iterations
+    rel = np.abs(og.history - oo.history) / oo.history
+    assert rel.max() <= 1e-8     # Krylov recurrences amplify the reduction-order round-off
+    sg, so = hg.get_field(hi, abi.F_CORR), ho.get_field(hi, abi.F_CORR)
+    assert np.abs(sg - so).max() <= 1e-7 * np.abs(so).max()
+
+
+def test_evaluation_samples_and_reset(native):
+    """Fields are restored before every sample: repeated evaluations give identical numbers."""
+    pd = problems.poisson_2d(3, 7)
+    h = native.create(pd)
+    gen, ops = ops_for_case("poisson2d_L7_v21_rbgs")
+    pd = problems.poisson_2d(4, 7)
+    h = native.create(pd)
+    a = h.evaluate(ops, 3, 0, 128)
+    b = h.evaluate(ops, 1, 0, 128)
+    assert a.n_iterations == b.n_iterations and np.array_equal(a.history, b.history)
+    assert a.time_ms > 0
+
+
+def test_large_grid_properties(native):
+    """Sizes the oracle would not finish quickly: size-independent properties on the GPU alone —
+    textbook V(1,1) RB-GS convergence, O(h^2) error against the analytic solution, and residual
+    reduction to 1e-12 (2D level 10: 1025^2; 3D level 6: 65^3)."""
+    from test_oracle_known_answers import simple_vcycle, exact_2d
+    errs = {}
+    for hi in (9, 10):
+        pd = problems.poisson_2d(4, hi)
+        h = native.create(pd)
+        out = h.evaluate(simple_vcycle(4, hi), 1, 0, 128)
+        assert out.status == abi.SOLVE_CONVERGED and out.conv_factor < 0.1
+        errs[hi] = np.abs(h.get_field(hi, abi.F_SOL) - exact_2d(hi)).max()
+        h.close()
+    assert 3.7 < errs[9] / errs[10] < 4.3
+    pd = problems.poisson_3d(2, 6)
+    h = native.create(pd)
+    out = h.evaluate(simple_vcycle(2, 6, pre=2, post=2, om=0.8, part=abi.PART_SINGLE, block=(2, 1, 1)), 1, 0, 128)
+    assert out.status == abi.SOLVE_CONVERGED
+    n = 65
+    x = np.arange(n) / (n - 1)
+    exact = x[None, None, :] ** 2 - 0.5 * x[None, :, None] ** 2 - 0.5 * x[:, None, None] ** 2
+    assert np.abs(h.get_field(6, abi.F_SOL) - exact).max() < 1e-10
+
+
+def test_rejects_malformed_programs(native):
+    h = native.create(problems.poisson_2d(3, 5))
+    rc, _ = h.try_evaluate([abi.make_op(abi.OP_SMOOTH, 9, abi.F_SOL, 0, abi.F_RHS)], 1, 0, 0)
+    assert rc == abi.ERR_INVALID
+    rc, _ = h.try_evaluate([abi.make_op(abi.OP_SMOOTH, 5, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (2, 1, 1))], 1, 0, 0)
+    assert rc == abi.ERR_UNSUPPORTED
+    rc, _ = h.try_evaluate([abi.make_op(abi.OP_COARSE_SOLVE, 4)], 1, 0, 0)
+    assert rc == abi.ERR_INVALID
+    rc, _ = h.try_evaluate([abi.make_op(abi.OP_COPY, 5, abi.F_CGS_RHS, abi.F_RHS)], 1, 0, 0)
+    assert rc == abi.ERR_INVALID   # gen_rhs_u exists on the coarsest level only
