@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -511,12 +512,47 @@ template <typename T> class Impl : public ImplBase {
         else hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 3, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
       }
     } else {
-      if (dim_ == 2) hipLaunchKernelGGL((evomg_cg_single_wg<T, 2>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
-      else hipLaunchKernelGGL((evomg_cg_single_wg<T, 3>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      bool launched = false;
+      int rc = (dim_ == 2) ? launch_cg_lds<2>(lv, x, b, r, &launched) : launch_cg_lds<3>(lv, x, b, r, &launched);
+      if (rc != EVOMG_OK) return rc;
+      if (!launched) {
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_cg_single_wg<T, 2>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+        else hipLaunchKernelGGL((evomg_cg_single_wg<T, 3>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      }
       apply_bc(L, x);
     }
     HIP_TRY(hipGetLastError());
     return EVOMG_OK;
+  }
+
+  // LDS-resident CG when the coarsest grid fits one CU's LDS (cg_lds_elems) with at most 16 nodes per thread
+  template <int DIM, int ITEMS> int launch_cg_lds_items(const Level<T>& lv, T* x, const T* b, T* r, size_t lds_bytes) {
+    auto kern = evomg_cg_lds<T, DIM, ITEMS>;
+    if (!cg_lds_attr_set_[DIM - 2][ITEMS]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      cg_lds_attr_set_[DIM - 2][ITEMS] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(EVOMG_KRYLOV_THREADS), lds_bytes, stream_, lv.g, lv.st, x, b, r,
+                       prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+    return EVOMG_OK;
+  }
+  template <int DIM> int launch_cg_lds(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
+    *launched = false;
+    if (!use_lds_krylov_) return EVOMG_OK;
+    const long m = lv.g.n - 2;
+    const long total = (DIM == 2) ? m * m : m * m * m;
+    const size_t lds_bytes = (size_t)(cg_lds_elems<DIM>(lv.g.n) + 32) * sizeof(T);
+    if (lds_bytes > 160 * 1024) return EVOMG_OK;
+    const long items = (total + EVOMG_KRYLOV_THREADS - 1) / EVOMG_KRYLOV_THREADS;
+    int rc;
+    if (items <= 1) rc = launch_cg_lds_items<DIM, 1>(lv, x, b, r, lds_bytes);
+    else if (items <= 2) rc = launch_cg_lds_items<DIM, 2>(lv, x, b, r, lds_bytes);
+    else if (items <= 4) rc = launch_cg_lds_items<DIM, 4>(lv, x, b, r, lds_bytes);
+    else if (items <= 8) rc = launch_cg_lds_items<DIM, 8>(lv, x, b, r, lds_bytes);
+    else if (items <= 16) rc = launch_cg_lds_items<DIM, 16>(lv, x, b, r, lds_bytes);
+    else return EVOMG_OK;
+    *launched = (rc == EVOMG_OK);
+    return rc;
   }
 
   // ---- reductions ----------------------------------------------------------------------------------------------------
@@ -710,6 +746,8 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  bool cg_lds_attr_set_[2][17] = {};
+  bool use_lds_krylov_ = (getenv("EVOMG_NO_LDS_KRYLOV") == nullptr);
 };
 
 int check_problem(const evomg_problem_t* p, char* err, size_t len) {

@@ -193,3 +193,147 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
   }
   if (threadIdx.x == 0) info[0] = it;
 }
+
+// ---- CG with the search direction resident in LDS -------------------------------------------------------------
+// For coarsest grids whose inner nodes fit the CU's 160 KB LDS (2D up to 129^2, 3D up to 17^3 in FP64) the
+// whole iteration runs out of LDS + registers: p sits in LDS surrounded by a zero halo (the homogeneous boundary
+// of an error-type field), so the 5/7-point SpMV needs no boundary tests; every thread keeps the residual r and
+// the iterate x of its ITEMS nodes in registers; A p is recomputed for the residual update instead of being
+// stored (LDS reads are cheaper than 32 more VGPRs at 1024 threads/CU). Node ownership q = t + 1024 i and the
+// reduction tree are those of evomg_cg_single_wg, i.e. the canonical order the oracle restates: results are
+// bit-identical to the global-memory kernel and to the oracle.
+template <typename T, int DIM>
+__device__ __forceinline__ T lds_apply(const Stencil<T>& st, const T* __restrict__ p, int o, int row, int plane) {
+  T a = sc_mul(st.c[0], p[o]);
+  a = sc_add(a, sc_mul(st.c[1], p[o - 1]));
+  a = sc_add(a, sc_mul(st.c[2], p[o + 1]));
+  a = sc_add(a, sc_mul(st.c[3], p[o - row]));
+  a = sc_add(a, sc_mul(st.c[4], p[o + row]));
+  if (DIM == 3) {
+    a = sc_add(a, sc_mul(st.c[5], p[o - plane]));
+    a = sc_add(a, sc_mul(st.c[6], p[o + plane]));
+  }
+  return a;
+}
+
+template <int DIM> __host__ __device__ inline long cg_lds_elems(int n) {
+  const long m = n - 2, row = m + 1;
+  if (DIM == 2) return (m + 2) * row;
+  return (m + 2) * row * (m + 1) + row;
+}
+
+// Walks the ITEMS nodes q = t, t+1024, ... owned by a thread, yielding each node's offset in the padded LDS image
+// without storing 16 offsets per thread: the (ix, iy) carry arithmetic of "+1024" is replayed in every pass.
+template <int DIM> struct ItemWalk {
+  int m, row, plane;
+  int inc, cx, cy;          // q += 1024  ==>  ix += cx, iy += cy (+ carries), off += inc (+ carries)
+  int ix0, iy0, off0, cnt;
+  __device__ __forceinline__ ItemWalk(const Geo& g, long total) {
+    m = g.n - 2;
+    row = m + 1;
+    plane = row * (m + 1);
+    const int t = threadIdx.x;
+    const int T0 = EVOMG_KRYLOV_THREADS;
+    cx = T0 % m;
+    const int rest = T0 / m;
+    cy = (DIM == 2) ? rest : rest % m;
+    const int cz = (DIM == 2) ? 0 : rest / m;
+    inc = (DIM == 2) ? rest * row + cx : cz * plane + cy * row + cx;
+    ix0 = t % m;
+    const int r0 = t / m;
+    iy0 = (DIM == 2) ? r0 : r0 % m;
+    const int iz0 = (DIM == 2) ? 0 : r0 / m;
+    off0 = (DIM == 2) ? (iy0 + 1) * row + ix0 + 1 : (iz0 + 1) * plane + (iy0 + 1) * row + ix0 + 1;
+    cnt = (t < total) ? (int)((total - t + T0 - 1) / T0) : 0;
+  }
+  template <int ITEMS, typename F> __device__ __forceinline__ void each(F&& f) const {
+    int off = off0, ix = ix0, iy = iy0;
+    // opaque to the optimiser: otherwise LICM hoists all ITEMS offsets out of the CG iteration loop and keeps
+    // them live (that, not the LDS reads, is what spilled at 16 items per thread)
+    asm volatile("" : "+v"(off), "+v"(ix), "+v"(iy));
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (i < cnt) f(i, off, ix, iy);
+      // keep the scheduler from hoisting every item's LDS reads to the top (it would spill at 16 items/thread)
+      if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      off += inc;
+      ix += cx;
+      iy += cy;
+      if (ix >= m) { ix -= m; off += 1; iy += 1; }          // x wraps into the next row: row - m = 1
+      if (DIM == 3 && iy >= m) { iy -= m; off += row; }     // y wraps into the next plane: plane - m*row = row
+    }
+  }
+};
+
+template <typename T, int DIM, int ITEMS>
+__global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
+evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
+             double tol, int* __restrict__ info) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* red = reinterpret_cast<T*>(lds_raw);          // 17 + pad -> 32 elements
+  T* p = red + 32;
+  const int m = g.n - 2;
+  const long total = (DIM == 2) ? (long)m * m : (long)m * m * m;
+  const long lds_elems = cg_lds_elems<DIM>(g.n);
+  const T zero = scalar_traits<T>::zero();
+  for (long i = threadIdx.x; i < lds_elems; i += blockDim.x) p[i] = zero;
+  __syncthreads();
+  const ItemWalk<DIM> walk(g, total);
+  const int row = walk.row, plane = walk.plane;
+  // global index of the node at padded LDS offset `off` (2D: needs ix, iy only)
+  auto gindex = [&](int off, int ix, int iy) -> long {
+    if (DIM == 2) return gidx<2>(g, ix + 1, iy + 1, 0);
+    const int iz = off / plane - 1;
+    return gidx<3>(g, ix + 1, iy + 1, iz + 1);
+  };
+
+  T r[ITEMS], xr[ITEMS];
+  T loc = zero;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) { r[i] = zero; xr[i] = zero; }
+  walk.template each<ITEMS>([&](int i, int off, int ix, int iy) {
+    const long c = gindex(off, ix, iy);
+    const T v = sc_sub(b[c], apply_stencil<T, DIM>(st, x, g, c));
+    r[i] = v;
+    xr[i] = x[c];
+    p[off] = v;
+    loc = sc_add(loc, sc_mul(v, v));
+  });
+  T rr = block_sum(loc, red);
+  const double res0 = sc_norm_from_dot(rr);
+  int it = 0;
+  if (res0 != 0.0) {
+    for (; it < maxit; ++it) {
+      // block_sum / the trailing barrier of the previous iteration made every p entry visible
+      loc = zero;
+      walk.template each<ITEMS>([&](int i, int off, int, int) {
+        loc = sc_add(loc, sc_mul(p[off], lds_apply<T, DIM>(st, p, off, row, plane)));
+      });
+      const T pap = block_sum(loc, red);
+      const T alpha = sc_div(rr, pap);
+      const T nalpha = sc_neg(alpha);
+      loc = zero;
+      walk.template each<ITEMS>([&](int i, int off, int, int) {
+        const T pv = p[off];
+        const T apv = lds_apply<T, DIM>(st, p, off, row, plane);
+        xr[i] = sc_add(xr[i], sc_mul(alpha, pv));
+        const T rv = sc_add(r[i], sc_mul(nalpha, apv));
+        r[i] = rv;
+        loc = sc_add(loc, sc_mul(rv, rv));
+      });
+      const T rrn = block_sum(loc, red);   // contains barriers: all reads of p are done before p is rewritten
+      const double res = sc_norm_from_dot(rrn);
+      if (!(res > tol * res0)) { ++it; break; }
+      const T beta = sc_div(rrn, rr);
+      walk.template each<ITEMS>([&](int i, int off, int, int) { p[off] = sc_add(r[i], sc_mul(beta, p[off])); });
+      rr = rrn;
+      __syncthreads();
+    }
+  }
+  walk.template each<ITEMS>([&](int i, int off, int ix, int iy) {
+    const long c = gindex(off, ix, iy);
+    x[c] = xr[i];
+    r_out[c] = r[i];
+  });
+  if (threadIdx.x == 0) info[0] = it;
+}

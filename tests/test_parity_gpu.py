@@ -251,3 +251,35 @@ def test_rejects_malformed_programs(native):
     assert rc == abi.ERR_INVALID
     rc, _ = h.try_evaluate([abi.make_op(abi.OP_COPY, 5, abi.F_CGS_RHS, abi.F_RHS)], 1, 0, 0)
     assert rc == abi.ERR_INVALID   # gen_rhs_u exists on the coarsest level only
+
+
+@pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4)])
+def test_lds_resident_cg_is_bit_identical(native, oracle, dim, lo, monkeypatch):
+    """The LDS-resident CG (p in LDS with a zero halo, r/x in registers), the global-memory single-workgroup CG
+    and the oracle follow one summation order: all three give the same bits (129^2 = the C2 coarsest grid)."""
+    pd = problems.poisson_2d(lo, lo + 1) if dim == 2 else problems.poisson_3d(lo, lo + 1)
+    rng = np.random.default_rng(lo * 10 + dim)
+    shape = ((1 << lo) + 1,) * dim
+    rhs = rng.standard_normal(shape)
+    x0 = zero_boundary(rng.standard_normal(shape)) * 1e-3
+    ops = [abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+    results = []
+    for no_lds in (False, True):
+        if no_lds:
+            monkeypatch.setenv("EVOMG_NO_LDS_KRYLOV", "1")
+        else:
+            monkeypatch.delenv("EVOMG_NO_LDS_KRYLOV", raising=False)
+        h = native.create(pd)
+        h.set_field(lo, abi.F_CGS_RHS, rhs)
+        h.set_field(lo, abi.F_CORR, x0)
+        h.run_ops(ops)
+        results.append((h.get_field(lo, abi.F_CORR), h.get_field(lo, abi.F_RES)))
+        h.close()
+    ho = oracle.create(pd)
+    ho.set_field(lo, abi.F_CGS_RHS, rhs)
+    ho.set_field(lo, abi.F_CORR, x0)
+    ho.run_ops(ops)
+    want_x, want_r = ho.get_field(lo, abi.F_CORR), ho.get_field(lo, abi.F_RES)
+    for got_x, got_r in results:
+        assert np.array_equal(got_x, want_x)
+        assert np.array_equal(got_r[(slice(1, -1),) * dim], want_r[(slice(1, -1),) * dim])
