@@ -18,6 +18,7 @@
 #include "../../include/evomg.h"
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"
+#include "evomg_strip.h"
 
 namespace {
 
@@ -258,9 +259,16 @@ template <typename T> class Impl : public ImplBase {
       case EVOMG_OP_SMOOTH: {
         const int cells = op->block[0] * op->block[1] * (dim_ == 3 ? op->block[2] : 1);
         base = cells > 1 ? "evomg_block_jacobi" : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
+        if (cells == 1 && use_strip(lv_[op->level].g)) {
+          snprintf(buf, len, "evomg_strip2d<%s, %d", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI);
+          return EVOMG_OK;
+        }
         break;
       }
-      case EVOMG_OP_RESIDUAL: base = "evomg_apply"; break;
+      case EVOMG_OP_RESIDUAL:
+        base = "evomg_apply";
+        if (use_strip(lv_[op->level].g)) { snprintf(buf, len, "evomg_strip2d<%s, %d", type_name<T>::get(), STRIP_RESIDUAL); return EVOMG_OK; }
+        break;
       case EVOMG_OP_RICHARDSON: base = "evomg_richardson"; break;
       case EVOMG_OP_RESTRICT: base = "evomg_restrict"; break;
       case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: base = "evomg_prolong"; break;
@@ -399,6 +407,13 @@ template <typename T> class Impl : public ImplBase {
           apply_bc(L, y);
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
+        } else if (use_strip(g)) {
+          T* y = lv.alt;
+          if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip<STRIP_RBGS>(g, lv.st, x, f, y, om, omm);
+          else launch_strip<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
+          apply_bc(L, y);
+          lv.alt = x;
+          set_fieldptr(L, op.dst, y);
         } else if (op.partitioning == EVOMG_PART_RED_BLACK) {
           const dim3 hgrd((g.n / 2 + 1 + 63) / 64, grd.y, grd.z);
           for (int colour = 0; colour < 2; ++colour) {
@@ -472,8 +487,27 @@ template <typename T> class Impl : public ImplBase {
     return EVOMG_OK;
   }
 
+  // ---- 2D marching-strip kernels (evomg_strip.h) ------------------------------------------------------------------
+  bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
+  template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    // enough waves to fill 256 CUs several times over, but chunks tall enough to amortise the vertical halo
+    // measured on MI355X at 4097^2 (tools/tune_strip.py, interleaved A/B): smoothers are fastest with tall chunks
+    // (vertical halo 4/64), the residual with short ones
+    int rows = strip_rows_ > 0 ? strip_rows_ : (MODE == STRIP_RESIDUAL ? 16 : 64);
+    while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+    rows = (rows + 1) & ~1;   // even chunk heights: the kernel relies on y0 being even (static row parity)
+    const int chunks = (g.n + rows - 1) / rows;
+    const int waves = strips * chunks;
+    const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);   // multiple of 8: XCD remap in the kernel
+    const double robin_kh = (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN) ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
+    if (strip_nt_) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
+  }
+
   void residual(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
     const Geo& g = lv_[L].g;
+    if (use_strip(g)) { launch_strip<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
     if (dim_ == 2) hipLaunchKernelGGL((evomg_apply<T, 2, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
     else hipLaunchKernelGGL((evomg_apply<T, 3, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
   }
@@ -748,6 +782,10 @@ template <typename T> class Impl : public ImplBase {
   int* dinfo_ = nullptr;
   bool cg_lds_attr_set_[2][17] = {};
   bool use_lds_krylov_ = (getenv("EVOMG_NO_LDS_KRYLOV") == nullptr);
+  bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
+  int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
+  int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
+  bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
 };
 
 int check_problem(const evomg_problem_t* p, char* err, size_t len) {

@@ -518,6 +518,7 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
     rr = rr_new;
   }
   FN(apply_bc)(c, L, x);
+  if (getenv("EVOMG_ORACLE_DEBUG")) fprintf(stderr, "[oracle] coarse CG: %d iterations (cap %d)\n", it, c->prob.cgs_max_iterations);
   return it;
 }
 

@@ -283,3 +283,42 @@ def test_lds_resident_cg_is_bit_identical(native, oracle, dim, lo, monkeypatch):
     for got_x, got_r in results:
         assert np.array_equal(got_x, want_x)
         assert np.array_equal(got_r[(slice(1, -1),) * dim], want_r[(slice(1, -1),) * dim])
+
+
+@pytest.mark.parametrize("pname,level", [("poisson2d", 8), ("poisson2d", 9), ("helmholtz2d", 8)])
+@pytest.mark.parametrize("rows,pf", [(32, 0), (8, 1), (64, 0), (13, 1)])
+def test_marching_strip_kernels_match_generic_kernels(native, pname, level, rows, pf, monkeypatch):
+    """The DPP marching-strip kernels (Jacobi, fused two-colour RB-GS, residual) against the plain
+    thread-per-node kernels (themselves bit-exact vs the oracle) on grids with several strips and chunks,
+    for several chunk heights, with and without non-temporal right-hand-side loads."""
+    pd = problems.poisson_2d(level - 1, level) if pname == "poisson2d" else problems.helmholtz_2d(level - 1, level, k=30.0)
+    rng = np.random.default_rng(level * 100 + rows)
+    shape = ((1 << level) + 1,) * 2
+    cx = pname != "poisson2d"
+    x0 = random_field(rng, shape, cx)
+    f0 = random_field(rng, shape, cx)
+    r0 = random_field(rng, shape, cx)
+    if cx:
+        x0, f0, r0 = zero_boundary(x0), zero_boundary(f0), zero_boundary(r0)
+    one = (1, 1, 1)
+    seq = [abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.15),
+           abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.8),
+           abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 0.6),
+           abi.make_op(abi.OP_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)]
+    out = []
+    for strip in (True, False):
+        if strip:
+            monkeypatch.delenv("EVOMG_NO_STRIP", raising=False)
+            monkeypatch.setenv("EVOMG_STRIP_ROWS", str(rows))
+            monkeypatch.setenv("EVOMG_STRIP_NT", str(pf))   # pf: non-temporal rhs loads on/off
+        else:
+            monkeypatch.setenv("EVOMG_NO_STRIP", "1")
+        h = native.create(pd)
+        h.set_field(level, abi.F_SOL, x0)
+        h.set_field(level, abi.F_RHS, f0)
+        h.set_field(level, abi.F_RES, r0)
+        h.run_ops(seq)
+        out.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
+        h.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
