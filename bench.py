@@ -20,6 +20,9 @@ import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
+# HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+# gfx950 correction FETCH_SIZE x2; see profiles/README.md). None until measured for the current kernel build.
+TRAFFIC_BYTES_PER_LAUNCH = 434.17e6   # 2 x FETCH_SIZE (299.5 MB) + WRITE_SIZE (134.7 MB), profiles/r01_pmc_smoother.md
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -98,31 +101,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ops = gen.generate_op_program(expression, lo, hi)
+    smooth = next(o for o in ops if o.opcode == abi.OP_SMOOTH and o.level == hi)
+    handle = gen._handle
+
     for _ in range(args.warmup):
         step()
     fence()
+    # live HIP-event timing of the dominant kernel (finest-level RB-GS sweep) on the backend's own stream,
+    # over exactly the timed region
+    handle.profile_begin(abi.OP_SMOOTH, hi)
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = step()
     fence()
     elapsed = time.perf_counter() - t0
+    live = handle.profile_end()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- roofline of the dominant kernel: finest-level RB-GS smoother (24 B/node algorithmic) ----
-    ops = gen.generate_op_program(expression, lo, hi)
-    smooth = next(o for o in ops if o.opcode == abi.OP_SMOOTH and o.level == hi)
-    handle = gen._handle
-    b = handle.bench_op(smooth, warmup=10, reps=100)
+    # ---- roofline of the dominant kernel: finest-level fused RB-GS sweep, 24 B/node algorithmic ----
     kname = handle.kernel_name(smooth)
     n_nodes = ((1 << hi) + 1) ** 2
-    roofline = {"bound": "hbm", "achieved": b.gbps, "peak": 8000.0, "unit": "GB/s", "frac": b.gbps / 8000.0,
-                "traffic": None, "kernel": kname,
-                "bytes_per_launch": b.bytes, "ms_per_launch": b.ms,
-                "note": f"24 B/node x {n_nodes} nodes per full red+black sweep; time = HIP events around 100 sweeps"}
+    b2b = handle.bench_op(smooth, warmup=10, reps=100)     # SURVEY 8(d) procedure: back-to-back ping-pong sweeps
+    roofline = {"bound": "hbm", "achieved": live.gbps, "peak": 8000.0, "unit": "GB/s", "frac": live.gbps / 8000.0,
+                "traffic": TRAFFIC_BYTES_PER_LAUNCH, "kernel": kname,
+                "bytes_per_launch": live.bytes, "ms_per_launch": live.ms, "launches_timed": live.launches,
+                "back_to_back": {"ms_per_launch": b2b.ms, "achieved": b2b.gbps, "frac": b2b.gbps / 8000.0},
+                "note": f"algorithmic 24 B/node x {n_nodes} nodes per fused red+black sweep; 'achieved' = mean over the "
+                        f"{live.launches} finest-level sweeps inside the timed solves (HIP events on the backend stream); "
+                        f"'back_to_back' = 100 consecutive ping-pong sweeps; 'traffic' = HBM bytes/launch from "
+                        f"rocprofv3 PMC (profiles/), null if not collected for this build"}
 
     if rank == 0:
         rho, t_ms, its = last[0]

@@ -98,7 +98,8 @@ def ops_array(ops: Sequence[Op]):
 
 # every symbol include/evomg.h declares, without prefix
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
-            "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name"]
+            "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
+            "profile_begin", "profile_end"]
 # the oracle implements the numerical subset
 ORACLE_EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
                    "set_field", "set_operators", "evaluate", "run_ops", "norm"]
@@ -142,6 +143,11 @@ class Library:
         if "bench_op" in f:
             f["bench_op"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.POINTER(Bench)]
             f["bench_op"].restype = C.c_int
+        if "profile_begin" in f:
+            f["profile_begin"].argtypes = [C.c_void_p, C.c_int, C.c_int]
+            f["profile_begin"].restype = C.c_int
+            f["profile_end"].argtypes = [C.c_void_p, C.POINTER(Bench)]
+            f["profile_end"].restype = C.c_int
         if "kernel_name" in f:
             f["kernel_name"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_char_p, C.c_int]
             f["kernel_name"].restype = C.c_int
@@ -255,6 +261,14 @@ class Handle:
     def bench_op(self, op: Op, warmup=10, reps=100) -> Bench:
         b = Bench()
         self._check(self.L.fn["bench_op"](self._h, C.byref(op), warmup, reps, C.byref(b)), "bench_op")
+        return b
+
+    def profile_begin(self, opcode: int, level: int):
+        self._check(self.L.fn["profile_begin"](self._h, opcode, level), "profile_begin")
+
+    def profile_end(self) -> Bench:
+        b = Bench()
+        self._check(self.L.fn["profile_end"](self._h, C.byref(b)), "profile_end")
         return b
 
     def kernel_name(self, op: Op) -> str:

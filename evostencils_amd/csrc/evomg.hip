@@ -42,6 +42,8 @@ struct ImplBase {
   virtual int norm(int level, int field, double* out) = 0;
   virtual int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) = 0;
   virtual int kernel_name(const evomg_op_t* op, char* buf, int len) = 0;
+  virtual int profile_begin(int opcode, int level) = 0;
+  virtual int profile_end(evomg_bench_t* out) = 0;
   char err[512] = "";
 };
 
@@ -92,6 +94,7 @@ template <typename T> class Impl : public ImplBase {
     if (dscalar_) (void)hipFree(dscalar_);
     if (dinfo_) (void)hipFree(dinfo_);
     if (hscalar_) (void)hipHostFree(hscalar_);
+    for (auto e : prof_events_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -260,14 +263,14 @@ template <typename T> class Impl : public ImplBase {
         const int cells = op->block[0] * op->block[1] * (dim_ == 3 ? op->block[2] : 1);
         base = cells > 1 ? "evomg_block_jacobi" : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
         if (cells == 1 && use_strip(lv_[op->level].g)) {
-          snprintf(buf, len, "evomg_strip2d<%s, %d", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI);
+          snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
         break;
       }
       case EVOMG_OP_RESIDUAL:
         base = "evomg_apply";
-        if (use_strip(lv_[op->level].g)) { snprintf(buf, len, "evomg_strip2d<%s, %d", type_name<T>::get(), STRIP_RESIDUAL); return EVOMG_OK; }
+        if (use_strip(lv_[op->level].g)) { snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), STRIP_RESIDUAL, strip_streams(lv_[op->level].g) ? "true" : "false"); return EVOMG_OK; }
         break;
       case EVOMG_OP_RICHARDSON: base = "evomg_richardson"; break;
       case EVOMG_OP_RESTRICT: base = "evomg_restrict"; break;
@@ -277,6 +280,34 @@ template <typename T> class Impl : public ImplBase {
       case EVOMG_OP_COARSE_SOLVE: base = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? "evomg_bicgstab_single_wg" : "evomg_cg_single_wg"; break;
     }
     snprintf(buf, len, "%s<%s, %d", base, type_name<T>::get(), dim_);
+    return EVOMG_OK;
+  }
+
+  int profile_begin(int opcode, int level) override {
+    if (!level_ok(level)) return invalid("profile_begin: bad level");
+    prof_opcode_ = opcode;
+    prof_level_ = level;
+    prof_used_ = 0;
+    prof_bytes_ = 0.0;
+    return EVOMG_OK;
+  }
+
+  int profile_end(evomg_bench_t* out) override {
+    if (!out) return invalid("profile_end: null result");
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < prof_used_; i += 2) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, prof_events_[i], prof_events_[i + 1]));
+      total += ms;
+    }
+    const int launches = (int)(prof_used_ / 2);
+    out->launches = launches;
+    out->ms = launches ? total / launches : 0.0;
+    out->bytes = prof_bytes_;
+    out->gbps = (launches && total > 0) ? prof_bytes_ / (out->ms * 1e-3) * 1e-9 : 0.0;
+    prof_opcode_ = -1;
     return EVOMG_OK;
   }
 
@@ -382,6 +413,25 @@ template <typename T> class Impl : public ImplBase {
 
   // ---- op interpreter ----------------------------------------------------------------------------------------------
   int exec(const evomg_op_t& op) {
+    const bool timed = op.opcode == prof_opcode_ && op.level == prof_level_;
+    if (timed) {
+      while (prof_events_.size() < prof_used_ + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        prof_events_.push_back(e);
+      }
+      HIP_TRY(hipEventRecord(prof_events_[prof_used_], stream_));
+    }
+    const int rc = exec_impl(op);
+    if (timed) {
+      HIP_TRY(hipEventRecord(prof_events_[prof_used_ + 1], stream_));
+      prof_used_ += 2;
+      prof_bytes_ = algorithmic_bytes(op);
+    }
+    return rc;
+  }
+
+  int exec_impl(const evomg_op_t& op) {
     const int L = op.level;
     Level<T>& lv = lv_[L];
     const Geo& g = lv.g;
@@ -489,6 +539,7 @@ template <typename T> class Impl : public ImplBase {
 
   // ---- 2D marching-strip kernels (evomg_strip.h) ------------------------------------------------------------------
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
+  bool strip_streams(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.pitch * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
     // enough waves to fill 256 CUs several times over, but chunks tall enough to amortise the vertical halo
@@ -501,7 +552,10 @@ template <typename T> class Impl : public ImplBase {
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);   // multiple of 8: XCD remap in the kernel
     const double robin_kh = (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN) ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
-    if (strip_nt_) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
+    // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
+    // smaller levels all three stay cache-resident and a streaming hint would only evict f
+    const bool nt = strip_streams(g);
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
   }
 
@@ -781,6 +835,10 @@ template <typename T> class Impl : public ImplBase {
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
   bool cg_lds_attr_set_[2][17] = {};
+  int prof_opcode_ = -1, prof_level_ = -1;
+  size_t prof_used_ = 0;
+  double prof_bytes_ = 0.0;
+  std::vector<hipEvent_t> prof_events_;
   bool use_lds_krylov_ = (getenv("EVOMG_NO_LDS_KRYLOV") == nullptr);
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
@@ -863,6 +921,12 @@ int evomg_norm(evomg_handle_t* h, int level, int field, double* out) {
 }
 int evomg_bench_op(evomg_handle_t* h, const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) {
   return h ? h->impl->bench_op(op, warmup, reps, out) : EVOMG_ERR_INVALID;
+}
+int evomg_profile_begin(evomg_handle_t* h, int opcode, int level) {
+  return h ? h->impl->profile_begin(opcode, level) : EVOMG_ERR_INVALID;
+}
+int evomg_profile_end(evomg_handle_t* h, evomg_bench_t* out) {
+  return h ? h->impl->profile_end(out) : EVOMG_ERR_INVALID;
 }
 int evomg_kernel_name(evomg_handle_t* h, const evomg_op_t* op, char* buf, int buf_len) {
   return h ? h->impl->kernel_name(op, buf, buf_len) : EVOMG_ERR_INVALID;

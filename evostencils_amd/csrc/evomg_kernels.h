@@ -302,6 +302,67 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* red) {
   return red[16];
 }
 
+// ---- fast variants of the same reduction trees (used by the LDS-resident Krylov kernels) ---------------------------
+// Same summation order as wave_sum / block_sum (v[l] += v[l+off], off = 32,16,8,4,2,1; then the same tree over the
+// wave sums padded with zeros) but without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) bring
+// lane l+32 / l+16, DPP row_shl:n brings lane l+n inside a 16-lane row. Only lane 0's value is meaningful.
+__device__ __forceinline__ double lanes_plus32(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double lanes_plus16(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[1], (int)a[1]);
+}
+template <int N> __device__ __forceinline__ double row_plus(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_tree(double v) {   // offsets 8,4,2,1 inside row 0
+  v += row_plus<8>(v);
+  v += row_plus<4>(v);
+  v += row_plus<2>(v);
+  v += row_plus<1>(v);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_fast(double v) {
+  v += lanes_plus32(v);
+  v += lanes_plus16(v);
+  return row_tree(v);
+}
+__device__ __forceinline__ cplx wave_sum_fast(cplx v) { return cplx{wave_sum_fast(v.re), wave_sum_fast(v.im)}; }
+// tree over <= 16 wave sums held by lanes 0..15 (other lanes hold +0.0): the two cross-row steps add zeros
+__device__ __forceinline__ double wave16_tree(double t) {
+  t += 0.0;
+  t += 0.0;
+  return row_tree(t);
+}
+__device__ __forceinline__ cplx wave16_tree(cplx t) { return cplx{wave16_tree(t.re), wave16_tree(t.im)}; }
+__device__ __forceinline__ double first_lane(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ cplx first_lane(cplx v) { return cplx{first_lane(v.re), first_lane(v.im)}; }
+// ONE barrier per reduction: wave sums go to a double-buffered LDS slot array (`red` holds 2 x 16 elements, `phase`
+// alternates), then EVERY wave folds the 16 sums itself. Reuse of a buffer is two reductions later, i.e. behind the
+// barrier of the reduction in between, which all waves only reach after their reads of this one.
+template <typename T> __device__ __forceinline__ T block_sum_fast(T v, T* red, int& phase) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  v = wave_sum_fast(v);
+  T* buf = red + 16 * (phase & 1);
+  ++phase;
+  if (lane == 0) buf[wave] = v;
+  __syncthreads();
+  T t = (lane < nwaves) ? buf[lane] : scalar_traits<T>::zero();
+  return first_lane(wave16_tree(t));
+}
+
 // dot over inner nodes, pass 1: grid-stride over rows, one partial per block (fixed grid => deterministic)
 template <typename T, int DIM>
 __global__ void __launch_bounds__(256) evomg_dot_partial(Geo g, const T* __restrict__ a, const T* __restrict__ b,

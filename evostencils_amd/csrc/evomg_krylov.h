@@ -255,7 +255,7 @@ template <int DIM> struct ItemWalk {
     for (int i = 0; i < ITEMS; ++i) {
       if (i < cnt) f(i, off, ix, iy);
       // keep the scheduler from hoisting every item's LDS reads to the top (it would spill at 16 items/thread)
-      if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       off += inc;
       ix += cx;
       iy += cy;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
              double tol, int* __restrict__ info) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  T* red = reinterpret_cast<T*>(lds_raw);          // 17 + pad -> 32 elements
+  T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
   T* p = red + 32;
   const int m = g.n - 2;
   const long total = (DIM == 2) ? (long)m * m : (long)m * m * m;
@@ -299,7 +299,8 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
     p[off] = v;
     loc = sc_add(loc, sc_mul(v, v));
   });
-  T rr = block_sum(loc, red);
+  int red_phase = 0;
+  T rr = block_sum_fast(loc, red, red_phase);
   const double res0 = sc_norm_from_dot(rr);
   int it = 0;
   if (res0 != 0.0) {
@@ -309,7 +310,7 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
       walk.template each<ITEMS>([&](int i, int off, int, int) {
         loc = sc_add(loc, sc_mul(p[off], lds_apply<T, DIM>(st, p, off, row, plane)));
       });
-      const T pap = block_sum(loc, red);
+      const T pap = block_sum_fast(loc, red, red_phase);
       const T alpha = sc_div(rr, pap);
       const T nalpha = sc_neg(alpha);
       loc = zero;
@@ -321,7 +322,7 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
         r[i] = rv;
         loc = sc_add(loc, sc_mul(rv, rv));
       });
-      const T rrn = block_sum(loc, red);   // contains barriers: all reads of p are done before p is rewritten
+      const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);

@@ -191,6 +191,11 @@ int  evomg_norm(evomg_handle_t* h, int level, int field, double* out);
 /* -- measurement ------------------------------------------------------------ */
 /* Times `reps` back-to-back launches of one op on the handle's stream with HIP events. */
 int  evomg_bench_op(evomg_handle_t* h, const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out);
+/* Live measurement inside a solve: between profile_begin and profile_end every launch of an op with this opcode
+ * on this level is bracketed by HIP events on the handle's stream; profile_end reports the mean duration per
+ * launch, the launch count and the algorithmic bytes of one launch. */
+int  evomg_profile_begin(evomg_handle_t* h, int opcode, int level);
+int  evomg_profile_end(evomg_handle_t* h, evomg_bench_t* out);
 /* Name of the device kernel an op dispatches to (for matching rocprofv3 kernel-trace rows). */
 int  evomg_kernel_name(evomg_handle_t* h, const evomg_op_t* op, char* buf, int buf_len);
 

@@ -1,0 +1,79 @@
+"""N>1 path on CPU: world_size-2 `gloo` process groups exercise the sharding and the fitness collectives that run
+over RCCL (`nccl` backend) on the GPU node. The evaluate callback is a stand-in (no GPU here); what is tested is
+the partitioning, padding and ordering of the exchange."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from evostencils_amd import population
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_fitness(i):
+    return (10.0 + i, 0.1 + 0.001 * i, float(5 + i % 3))      # (time_ms, rho, iterations)
+
+
+def _worker(rank, world, port, n_candidates, queue):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        evaluated = []
+
+        def evaluate(i):
+            evaluated.append(i)
+            return _fake_fitness(i)
+
+        rows = population.evaluate_population(evaluate, n_candidates)
+        gathered = population.gather_fitness([(0.5 + rank, 1.0 + rank, 7.0)], world)
+        queue.put((rank, evaluated, rows, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_candidates", [8, 7, 1])
+def test_population_is_sharded_round_robin_and_gathered(n_candidates):
+    world = 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_candidates, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, evaluated, rows, gathered = queue.get(timeout=120)
+        results[rank] = (evaluated, rows, gathered)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [(i, 0.1 + 0.001 * i, 10.0 + i, float(5 + i % 3)) for i in range(n_candidates)]
+    for rank in range(world):
+        evaluated, rows, gathered = results[rank]
+        assert evaluated == [i for i in range(n_candidates) if i % world == rank]      # program.py:534-535
+        assert [r[0] for r in rows] == list(range(n_candidates))
+        for got, want in zip(rows, expected):
+            assert got[0] == want[0] and all(abs(a - b) < 1e-15 for a, b in zip(got[1:], want[1:]))
+    # gather to rank 0 in rank order; other ranks keep their local list
+    assert results[0][2] == [(0.5, 1.0, 7.0), (1.5, 2.0, 7.0)]
+    assert results[1][2] == [(1.5, 2.0, 7.0)]
+
+
+def test_single_process_is_identity():
+    assert population.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert population.gather_fitness([(0.1, 2.0, 3.0)], 1) == [(0.1, 2.0, 3.0)]
+    rows = population.evaluate_population(_fake_fitness, 3)
+    assert [r[0] for r in rows] == [0, 1, 2]
