@@ -216,10 +216,12 @@ __device__ __forceinline__ T lds_apply(const Stencil<T>& st, const T* __restrict
   return a;
 }
 
+// padded LDS image of p: two spare zero rows in front (the dummy cell of ItemWalk::each_all sits in the second one,
+// so that its own south neighbour is still inside the image), then the halo'ed grid
 template <int DIM> __host__ __device__ inline long cg_lds_elems(int n) {
   const long m = n - 2, row = m + 1;
-  if (DIM == 2) return (m + 2) * row;
-  return (m + 2) * row * (m + 1) + row;
+  if (DIM == 2) return (m + 2) * row + 2 * row;
+  return (m + 2) * row * (m + 1) + 3 * row;
 }
 
 // Walks the ITEMS nodes q = t, t+1024, ... owned by a thread, yielding each node's offset in the padded LDS image
@@ -243,8 +245,26 @@ template <int DIM> struct ItemWalk {
     const int r0 = t / m;
     iy0 = (DIM == 2) ? r0 : r0 % m;
     const int iz0 = (DIM == 2) ? 0 : r0 / m;
-    off0 = (DIM == 2) ? (iy0 + 1) * row + ix0 + 1 : (iz0 + 1) * plane + (iy0 + 1) * row + ix0 + 1;
+    off0 = 2 * row + ((DIM == 2) ? (iy0 + 1) * row + ix0 + 1 : (iz0 + 1) * plane + (iy0 + 1) * row + ix0 + 1);
     cnt = (t < total) ? (int)((total - t + T0 - 1) / T0) : 0;
+  }
+  // Branch-free pass over all ITEMS slots: slots beyond this thread's node count are pointed at a dummy LDS cell
+  // (second spare front row, column 1) whose value and neighbours are zero and which no real node ever reads, so they
+  // contribute exact zeros. Without per-slot branches the 5 LDS reads of several nodes are in flight together.
+  template <int ITEMS, int GROUP, typename F> __device__ __forceinline__ void each_all(F&& f) const {
+    int off = off0;
+    int ix = ix0, iy = iy0;
+    asm volatile("" : "+v"(off), "+v"(ix), "+v"(iy));
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      f(i, (i < cnt) ? off : row + 1);
+      if ((i & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead
+      off += inc;
+      ix += cx;
+      iy += cy;
+      if (ix >= m) { ix -= m; off += 1; iy += 1; }
+      if (DIM == 3 && iy >= m) { iy -= m; off += row; }
+    }
   }
   template <int ITEMS, typename F> __device__ __forceinline__ void each(F&& f) const {
     int off = off0, ix = ix0, iy = iy0;
@@ -283,7 +303,7 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
   // global index of the node at padded LDS offset `off` (2D: needs ix, iy only)
   auto gindex = [&](int off, int ix, int iy) -> long {
     if (DIM == 2) return gidx<2>(g, ix + 1, iy + 1, 0);
-    const int iz = off / plane - 1;
+    const int iz = (off - 2 * row) / plane - 1;
     return gidx<3>(g, ix + 1, iy + 1, iz + 1);
   };
 
@@ -307,14 +327,14 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
     for (; it < maxit; ++it) {
       // block_sum / the trailing barrier of the previous iteration made every p entry visible
       loc = zero;
-      walk.template each<ITEMS>([&](int i, int off, int, int) {
+      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) {
         loc = sc_add(loc, sc_mul(p[off], lds_apply<T, DIM>(st, p, off, row, plane)));
       });
       const T pap = block_sum_fast(loc, red, red_phase);
       const T alpha = sc_div(rr, pap);
       const T nalpha = sc_neg(alpha);
       loc = zero;
-      walk.template each<ITEMS>([&](int i, int off, int, int) {
+      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) {
         const T pv = p[off];
         const T apv = lds_apply<T, DIM>(st, p, off, row, plane);
         xr[i] = sc_add(xr[i], sc_mul(alpha, pv));
@@ -326,7 +346,7 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);
-      walk.template each<ITEMS>([&](int i, int off, int, int) { p[off] = sc_add(r[i], sc_mul(beta, p[off])); });
+      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) { p[off] = sc_add(r[i], sc_mul(beta, p[off])); });
       rr = rrn;
       __syncthreads();
     }
