@@ -613,13 +613,31 @@ template <typename T> class Impl : public ImplBase {
     return EVOMG_OK;
   }
 
-  // LDS-resident CG when the coarsest grid fits one CU's LDS (cg_lds_elems) with at most 16 nodes per thread
-  template <int DIM, int ITEMS> int launch_cg_lds_items(const Level<T>& lv, T* x, const T* b, T* r, size_t lds_bytes) {
-    auto kern = evomg_cg_lds<T, DIM, ITEMS>;
-    if (!cg_lds_attr_set_[DIM - 2][ITEMS]) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      cg_lds_attr_set_[DIM - 2][ITEMS] = true;
+  // LDS-resident CG when the coarsest grid fits one CU's LDS: 2D tile kernel (<= 16 rows per thread), else the
+  // strided kernel (3D, <= 16 nodes per thread); otherwise the caller falls back to the global-memory kernel
+  template <typename K> int set_lds_limit(K kern, int slot, size_t lds_bytes) {
+    if (!cg_lds_attr_set_[slot]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+      cg_lds_attr_set_[slot] = true;
     }
+    (void)lds_bytes;
+    return EVOMG_OK;
+  }
+  template <int RT, int CB> int launch_cg_lds2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
+    const size_t lds_bytes = (size_t)(cg_lds2d_elems(own, RT) + 32) * sizeof(T);
+    if (lds_bytes > 160 * 1024 || own.cb != CB) return EVOMG_OK;
+    auto kern = evomg_cg_lds2d<T, RT, CB>;
+    int rc = set_lds_limit(kern, slot, lds_bytes);
+    if (rc != EVOMG_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(EVOMG_KRYLOV_THREADS), lds_bytes, stream_, lv.g, lv.st, x, b, r,
+                       prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+    *launched = true;
+    return EVOMG_OK;
+  }
+  template <int DIM, int ITEMS> int launch_cg_lds_items(const Level<T>& lv, T* x, const T* b, T* r, size_t lds_bytes, int slot) {
+    auto kern = evomg_cg_lds<T, DIM, ITEMS>;
+    int rc = set_lds_limit(kern, slot, lds_bytes);
+    if (rc != EVOMG_OK) return rc;
     hipLaunchKernelGGL(kern, dim3(1), dim3(EVOMG_KRYLOV_THREADS), lds_bytes, stream_, lv.g, lv.st, x, b, r,
                        prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
     return EVOMG_OK;
@@ -627,17 +645,30 @@ template <typename T> class Impl : public ImplBase {
   template <int DIM> int launch_cg_lds(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
     *launched = false;
     if (!use_lds_krylov_) return EVOMG_OK;
-    const long m = lv.g.n - 2;
-    const long total = (DIM == 2) ? m * m : m * m * m;
+    const KrylovOwn own = krylov_own<DIM>(lv.g.n);
+    if (DIM == 2) {
+      if (!own.tile || own.R > 16) return EVOMG_OK;
+      // one column block (m <= 64): 16 bands; two column blocks (m <= 128): 8 bands of up to 16 rows
+      if (own.cb == 1) {
+        if (own.R <= 1) return launch_cg_lds2d<1, 1>(lv, x, b, r, own, 0, launched);
+        if (own.R <= 2) return launch_cg_lds2d<2, 1>(lv, x, b, r, own, 1, launched);
+        if (own.R <= 4) return launch_cg_lds2d<4, 1>(lv, x, b, r, own, 2, launched);
+        return EVOMG_OK;
+      }
+      if (own.cb == 2) {
+        if (own.R <= 8) return launch_cg_lds2d<8, 2>(lv, x, b, r, own, 3, launched);
+        return launch_cg_lds2d<16, 2>(lv, x, b, r, own, 4, launched);
+      }
+      return EVOMG_OK;
+    }
     const size_t lds_bytes = (size_t)(cg_lds_elems<DIM>(lv.g.n) + 32) * sizeof(T);
     if (lds_bytes > 160 * 1024) return EVOMG_OK;
-    const long items = (total + EVOMG_KRYLOV_THREADS - 1) / EVOMG_KRYLOV_THREADS;
+    const long items = (own.total + EVOMG_KRYLOV_THREADS - 1) / EVOMG_KRYLOV_THREADS;
     int rc;
-    if (items <= 1) rc = launch_cg_lds_items<DIM, 1>(lv, x, b, r, lds_bytes);
-    else if (items <= 2) rc = launch_cg_lds_items<DIM, 2>(lv, x, b, r, lds_bytes);
-    else if (items <= 4) rc = launch_cg_lds_items<DIM, 4>(lv, x, b, r, lds_bytes);
-    else if (items <= 8) rc = launch_cg_lds_items<DIM, 8>(lv, x, b, r, lds_bytes);
-    else if (items <= 16) rc = launch_cg_lds_items<DIM, 16>(lv, x, b, r, lds_bytes);
+    if (items <= 1) rc = launch_cg_lds_items<DIM, 1>(lv, x, b, r, lds_bytes, 5);
+    else if (items <= 2) rc = launch_cg_lds_items<DIM, 2>(lv, x, b, r, lds_bytes, 6);
+    else if (items <= 4) rc = launch_cg_lds_items<DIM, 4>(lv, x, b, r, lds_bytes, 7);
+    else if (items <= 8) rc = launch_cg_lds_items<DIM, 8>(lv, x, b, r, lds_bytes, 8);
     else return EVOMG_OK;
     *launched = (rc == EVOMG_OK);
     return rc;
@@ -834,7 +865,7 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
-  bool cg_lds_attr_set_[2][17] = {};
+  bool cg_lds_attr_set_[16] = {};
   int prof_opcode_ = -1, prof_level_ = -1;
   size_t prof_used_ = 0;
   double prof_bytes_ = 0.0;

@@ -1,13 +1,15 @@
 // evomg_krylov.h — coarse-grid solvers (K9) as ONE persistent workgroup per solve.
 //
 // gen_mgCycle@minLevel is a Krylov iteration on a small grid (129^2 for the 4096^2 / 6-level config): hundreds of
-// iterations of SpMV + 2..5 dot products on ~1e4 points. Run as separate launches every dot product would be a
-// kernel boundary (~1.5 us) plus a host round trip for the stopping test; instead the whole solve is one launch of
-// one 1024-thread workgroup (16 wave64s on one CU): vectors live in global memory but stay in that CU's L1/L2,
-// dot products are wave-shuffle + LDS reductions, the stopping test never leaves the device.
+// iterations of SpMV + 2..5 dot products on ~1e4 nodes. As separate launches every dot product would be a kernel
+// boundary (~1.5 us) plus a host round trip for the stopping test; instead the whole solve is one launch of one
+// 1024-thread workgroup (16 wave64s on one CU), dot products are wave-level trees + one LDS hop, and the stopping
+// test never leaves the device.
 //
 // Algorithms: CG as configured in Poisson/2D_FD_Poisson_fromL2.exa3:12-14; BiCGStab literally as written in
-// Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 (same statement order as oracle FN(coarse_cg)/FN(coarse_bicgstab)).
+// Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433. Node ownership, reduction order and the fused-multiply-add
+// arithmetic are the ones the oracle restates (oracle/evomg_oracle_impl.h, "Krylov solvers on the coarsest grid"),
+// so every variant below (global-memory, LDS-resident) produces the same bits as the oracle.
 #pragma once
 #include "evomg_kernels.h"
 
@@ -18,6 +20,52 @@ template <int DIM> __device__ __forceinline__ long inner_index(const Geo& g, lon
   const long t = q / m;
   if (DIM == 2) return gidx<2>(g, i, 1 + (int)t, 0);
   return gidx<3>(g, i, 1 + (int)(t % m), 1 + (int)(t / m));
+}
+
+// ---- canonical node ownership ------------------------------------------------------------------------------------
+// 2D "tile": wave w covers the 64 columns of column block w % cb and the R rows of band w / cb; lane = column,
+// rows ascending. Otherwise "strided": thread t owns q = t, t+1024, ... (q x-fastest over the inner nodes).
+struct KrylovOwn {
+  int tile, m, cb, bands, R;
+  long total;
+};
+template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
+  KrylovOwn o;
+  o.m = n - 2;
+  o.total = (DIM == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
+  o.cb = (o.m + 63) / 64;
+  o.tile = (DIM == 2 && o.cb <= 16) ? 1 : 0;
+  o.bands = o.tile ? 16 / o.cb : 0;
+  o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
+  return o;
+}
+// visits the global indices of this thread's nodes in canonical order
+template <int DIM, typename F> __device__ __forceinline__ void own_each(const Geo& g, const KrylovOwn& o, F&& f) {
+  if (DIM == 2 && o.tile) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int band = w / o.cb, ix = 64 * (w % o.cb) + l;
+    if (band >= o.bands || ix >= o.m) return;
+    const int iy0 = band * o.R;
+    const int rows = min(o.R, o.m - iy0);
+    long c = gidx<2>(g, ix + 1, iy0 + 1, 0);
+    for (int i = 0; i < rows; ++i, c += g.pitch) f(c);
+  } else {
+    for (long q = threadIdx.x; q < o.total; q += EVOMG_KRYLOV_THREADS) f(inner_index<DIM>(g, q, o.m));
+  }
+}
+
+template <typename T, int DIM>
+__device__ __forceinline__ T apply_stencil_fma(const Stencil<T>& st, const T* __restrict__ x, const Geo& g, long c) {
+  T a = sc_mul(st.c[0], x[c]);
+  a = sc_fma(st.c[1], x[c - 1], a);
+  a = sc_fma(st.c[2], x[c + 1], a);
+  a = sc_fma(st.c[3], x[c - g.pitch], a);
+  a = sc_fma(st.c[4], x[c + g.pitch], a);
+  if (DIM == 3) {
+    a = sc_fma(st.c[5], x[c - g.plane], a);
+    a = sc_fma(st.c[6], x[c + g.plane], a);
+  }
+  return a;
 }
 
 template <typename T, bool ROBIN>
@@ -34,23 +82,22 @@ __device__ __forceinline__ void wg_apply_bc(const Geo& g, T* __restrict__ v, dou
   __syncthreads();
 }
 
+// ---- CG, vectors in global memory (L2-resident): any grid size ----------------------------------------------------
 // info[0] = iterations performed
 template <typename T, int DIM>
 __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r,
                    T* __restrict__ p, T* __restrict__ ap, int maxit, double tol, int* __restrict__ info) {
   __shared__ T red[17];
-  const int m = g.n - 2;
-  const long total = (DIM == 2) ? (long)m * m : (long)m * m * m;
+  const KrylovOwn own = krylov_own<DIM>(g.n);
   const T zero = scalar_traits<T>::zero();
   T loc = zero;
-  for (long q = threadIdx.x; q < total; q += blockDim.x) {
-    const long c = inner_index<DIM>(g, q, m);
-    const T v = sc_sub(b[c], apply_stencil<T, DIM>(st, x, g, c));
+  own_each<DIM>(g, own, [&](long c) {
+    const T v = sc_sub(b[c], apply_stencil_fma<T, DIM>(st, x, g, c));
     r[c] = v;
     p[c] = v;
-    loc = sc_add(loc, sc_mul(v, v));
-  }
+    loc = sc_fma(v, v, loc);
+  });
   T rr = block_sum(loc, red);
   const double res0 = sc_norm_from_dot(rr);
   if (res0 == 0.0) {
@@ -61,31 +108,26 @@ evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict_
   int it = 0;
   for (; it < maxit; ++it) {
     loc = zero;
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      const T v = apply_stencil<T, DIM>(st, p, g, c);
+    own_each<DIM>(g, own, [&](long c) {
+      const T v = apply_stencil_fma<T, DIM>(st, p, g, c);
       ap[c] = v;
-      loc = sc_add(loc, sc_mul(p[c], v));
-    }
+      loc = sc_fma(p[c], v, loc);
+    });
     const T pap = block_sum(loc, red);
     const T alpha = sc_div(rr, pap);
     const T nalpha = sc_neg(alpha);
     loc = zero;
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      x[c] = sc_add(x[c], sc_mul(alpha, p[c]));
-      const T rv = sc_add(r[c], sc_mul(nalpha, ap[c]));
+    own_each<DIM>(g, own, [&](long c) {
+      x[c] = sc_fma(alpha, p[c], x[c]);
+      const T rv = sc_fma(nalpha, ap[c], r[c]);
       r[c] = rv;
-      loc = sc_add(loc, sc_mul(rv, rv));
-    }
+      loc = sc_fma(rv, rv, loc);
+    });
     const T rrn = block_sum(loc, red);
     const double res = sc_norm_from_dot(rrn);
     if (!(res > tol * res0)) { ++it; break; }
     const T beta = sc_div(rrn, rr);
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      p[c] = sc_add(r[c], sc_mul(beta, p[c]));
-    }
+    own_each<DIM>(g, own, [&](long c) { p[c] = sc_fma(beta, p[c], r[c]); });
     rr = rrn;
     __syncthreads();
   }
@@ -93,17 +135,14 @@ evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict_
 }
 
 template <typename T, int DIM>
-__device__ __forceinline__ T wg_dot(const Geo& g, const T* __restrict__ a, const T* __restrict__ b, T* red) {
-  const int m = g.n - 2;
-  const long total = (DIM == 2) ? (long)m * m : (long)m * m * m;
+__device__ __forceinline__ T wg_dot(const Geo& g, const KrylovOwn& own, const T* __restrict__ a,
+                                    const T* __restrict__ b, T* red) {
   T loc = scalar_traits<T>::zero();
-  for (long q = threadIdx.x; q < total; q += blockDim.x) {
-    const long c = inner_index<DIM>(g, q, m);
-    loc = sc_add(loc, sc_mul(a[c], b[c]));
-  }
+  own_each<DIM>(g, own, [&](long c) { loc = sc_fma(a[c], b[c], loc); });
   return block_sum(loc, red);
 }
 
+// ---- BiCGStab, vectors in global memory; ROBIN: Helmholtz boundary handling of p, s, x, r ---------------------------
 template <typename T, int DIM, bool ROBIN>
 __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r,
@@ -111,21 +150,19 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
                          T* __restrict__ t, T* __restrict__ rhat, int maxit, double tol, double kh,
                          int* __restrict__ info) {
   __shared__ T red[17];
-  const int m = g.n - 2;
-  const long total = (DIM == 2) ? (long)m * m : (long)m * m * m;
+  const KrylovOwn own = krylov_own<DIM>(g.n);
   const T zero = scalar_traits<T>::zero();
   T loc = zero;
-  for (long q = threadIdx.x; q < total; q += blockDim.x) {
-    const long c = inner_index<DIM>(g, q, m);
-    const T v = sc_sub(f[c], apply_stencil<T, DIM>(st, x, g, c));
+  own_each<DIM>(g, own, [&](long c) {
+    const T v = sc_sub(f[c], apply_stencil_fma<T, DIM>(st, x, g, c));
     r[c] = v;
     rhat[c] = v;
     nu[c] = zero;
     p[c] = zero;
-    loc = sc_add(loc, sc_mul(v, v));
-  }
+    loc = sc_fma(v, v, loc);
+  });
   const double res0 = sc_norm_from_dot(block_sum(loc, red));
-  wg_apply_bc<T, ROBIN>(g, r, kh);   // residual_st applies the field's BC
+  wg_apply_bc<T, ROBIN>(g, r, kh);
   // rhat is a plain copy of r including its boundary values; p and nu start as zero everywhere
   if constexpr (ROBIN) {
     for (int j = 1 + threadIdx.x; j < g.n - 1; j += blockDim.x) {
@@ -146,45 +183,36 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
   int it = 0;
   for (; it < maxit; ++it) {
     rho = rho_new;
-    rho_new = wg_dot<T, DIM>(g, rhat, r, red);
+    rho_new = wg_dot<T, DIM>(g, own, rhat, r, red);
     beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
     const T nomega = sc_neg(omega);
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      const T pv = sc_add(p[c], sc_mul(nomega, nu[c]));
-      p[c] = sc_add(r[c], sc_mul(beta, pv));
-    }
+    own_each<DIM>(g, own, [&](long c) {
+      const T pv = sc_fma(nomega, nu[c], p[c]);
+      p[c] = sc_fma(beta, pv, r[c]);
+    });
     wg_apply_bc<T, ROBIN>(g, p, kh);
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      nu[c] = apply_stencil<T, DIM>(st, p, g, c);
-    }
+    own_each<DIM>(g, own, [&](long c) { nu[c] = apply_stencil_fma<T, DIM>(st, p, g, c); });
     __syncthreads();
-    alpha = sc_div(rho_new, wg_dot<T, DIM>(g, rhat, nu, red));
+    alpha = sc_div(rho_new, wg_dot<T, DIM>(g, own, rhat, nu, red));
     const T nalpha = sc_neg(alpha);
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      hh[c] = sc_add(x[c], sc_mul(alpha, p[c]));
-      s[c] = sc_add(r[c], sc_mul(nalpha, nu[c]));
-    }
+    own_each<DIM>(g, own, [&](long c) {
+      hh[c] = sc_fma(alpha, p[c], x[c]);
+      s[c] = sc_fma(nalpha, nu[c], r[c]);
+    });
     wg_apply_bc<T, ROBIN>(g, s, kh);
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      t[c] = apply_stencil<T, DIM>(st, s, g, c);
-    }
+    own_each<DIM>(g, own, [&](long c) { t[c] = apply_stencil_fma<T, DIM>(st, s, g, c); });
     __syncthreads();
-    const T ts = wg_dot<T, DIM>(g, t, s, red);
-    const T tt = wg_dot<T, DIM>(g, t, t, red);
+    const T ts = wg_dot<T, DIM>(g, own, t, s, red);
+    const T tt = wg_dot<T, DIM>(g, own, t, t, red);
     omega = sc_div(ts, tt);
     const T nomega2 = sc_neg(omega);
     loc = zero;
-    for (long q = threadIdx.x; q < total; q += blockDim.x) {
-      const long c = inner_index<DIM>(g, q, m);
-      x[c] = sc_add(hh[c], sc_mul(omega, s[c]));
-      const T rv = sc_add(s[c], sc_mul(nomega2, t[c]));
+    own_each<DIM>(g, own, [&](long c) {
+      x[c] = sc_fma(omega, s[c], hh[c]);
+      const T rv = sc_fma(nomega2, t[c], s[c]);
       r[c] = rv;
-      loc = sc_add(loc, sc_mul(rv, rv));
-    }
+      loc = sc_fma(rv, rv, loc);
+    });
     const double res = sc_norm_from_dot(block_sum(loc, red));
     wg_apply_bc<T, ROBIN>(g, x, kh);
     wg_apply_bc<T, ROBIN>(g, r, kh);
@@ -194,24 +222,144 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
   if (threadIdx.x == 0) info[0] = it;
 }
 
-// ---- CG with the search direction resident in LDS -------------------------------------------------------------
-// For coarsest grids whose inner nodes fit the CU's 160 KB LDS (2D up to 129^2, 3D up to 17^3 in FP64) the
-// whole iteration runs out of LDS + registers: p sits in LDS surrounded by a zero halo (the homogeneous boundary
-// of an error-type field), so the 5/7-point SpMV needs no boundary tests; every thread keeps the residual r and
-// the iterate x of its ITEMS nodes in registers; A p is recomputed for the residual update instead of being
-// stored (LDS reads are cheaper than 32 more VGPRs at 1024 threads/CU). Node ownership q = t + 1024 i and the
-// reduction tree are those of evomg_cg_single_wg, i.e. the canonical order the oracle restates: results are
-// bit-identical to the global-memory kernel and to the oracle.
+// ---- CG with the search direction resident in LDS (2D tile ownership) ----------------------------------------------
+// For coarsest grids up to 129^2 (real) the whole iteration runs out of LDS + registers:
+//   * p lives in LDS as an image of (bands*R + 2) rows x (64*cb + 2) columns with a zero halo (the homogeneous boundary
+//     of an error-type field plus the slack of incomplete tiles), so the SpMV needs no boundary tests;
+//   * a thread owns R consecutive rows of one column: the LDS addresses of all its nodes are base + constant, i.e.
+//     immediate offsets (no per-node address arithmetic), consecutive lanes hit consecutive banks, and the south /
+//     north neighbours are the thread's own previous / next node, kept in a three-value register window: 3 LDS reads
+//     per node and SpMV (centre of the next row, west, east) instead of 5;
+//   * the residual r and the iterate x of the thread's nodes stay in registers; A p is recomputed for the residual
+//     update instead of being stored (at 1024 threads per CU there are 128 VGPRs per thread);
+//   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
+// `rt` = unrolled rows per thread (template R >= own.R); slack rows below the last band stay inside the image
+__host__ __device__ inline long cg_lds2d_elems(const KrylovOwn& o, int rt) {
+  return (long)(o.bands * o.R + (rt - o.R) + 2) * (64 * o.cb + 2);
+}
+
+template <typename T, int R, int CB>
+__global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
+evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
+               double tol, int* __restrict__ info) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
+  T* p = red + 32;
+  const KrylovOwn own = krylov_own<2>(g.n);
+  constexpr int W = 64 * CB + 2;                   // row stride of the LDS image: compile-time, so that every node's
+                                                   // LDS address is base + immediate offset (own.cb == CB, host-checked)
+  const long lds_elems = cg_lds2d_elems(own, R);
+  const T zero = scalar_traits<T>::zero();
+  for (long i = threadIdx.x; i < lds_elems; i += blockDim.x) p[i] = zero;
+  __syncthreads();
+
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int band = w / own.cb, ix = 64 * (w % own.cb) + l;
+  const bool active = band < own.bands;            // wave-uniform: waves beyond cb*bands own nothing
+  const int iy0 = active ? band * own.R : 0;
+  const int rows = active ? max(0, min(own.R, own.m - iy0)) : 0;   // wave-uniform
+  const bool col_ok = ix < own.m;
+  // image offset of the thread's first node: image row iy0+1, image column ix+1 (always inside the image)
+  T* const pc0 = p + (iy0 + 1) * W + ix + 1;
+  const long c0 = gidx<2>(g, min(ix, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
+
+  T r[R], xr[R];
+  T loc = zero;
+  // branch-free: slots that are not nodes of this thread read a clamped (valid) address and are masked to zero
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const bool ok = col_ok && i < rows;
+    const long c = c0 + (long)g.pitch * (i < rows ? i : 0);
+    const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
+    r[i] = v;
+    xr[i] = x[c];
+    if (ok) pc0[i * W] = v;
+    loc = sc_fma(v, v, loc);
+  }
+  int red_phase = 0;
+  T rr = block_sum_fast(loc, red, red_phase);
+  const double res0 = sc_norm_from_dot(rr);
+  int it = 0;
+  if (res0 != 0.0) {
+    for (; it < maxit; ++it) {
+      // ---- pass 1: p . A p ----
+      loc = zero;
+      {
+        T ps = pc0[-W], pc = pc0[0];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const T pn = pc0[(i + 1) * W], pw = pc0[i * W - 1], pe = pc0[i * W + 1];
+          T a = sc_mul(st.c[0], pc);
+          a = sc_fma(st.c[1], pw, a);
+          a = sc_fma(st.c[2], pe, a);
+          a = sc_fma(st.c[3], ps, a);
+          a = sc_fma(st.c[4], pn, a);
+          // slots that are not nodes of this thread (slack column / rows past the band) contribute an exact zero
+          const bool ok = col_ok && i < rows;
+          loc = sc_fma(ok ? pc : zero, ok ? a : zero, loc);
+          ps = pc;
+          pc = pn;
+          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (VGPR budget)
+        }
+      }
+      const T pap = block_sum_fast(loc, red, red_phase);
+      const T alpha = sc_div(rr, pap);
+      const T nalpha = sc_neg(alpha);
+      // ---- pass 2: x += alpha p ; r -= alpha A p ; r . r ----
+      loc = zero;
+      {
+        T ps = pc0[-W], pc = pc0[0];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const T pn = pc0[(i + 1) * W], pw = pc0[i * W - 1], pe = pc0[i * W + 1];
+          T a = sc_mul(st.c[0], pc);
+          a = sc_fma(st.c[1], pw, a);
+          a = sc_fma(st.c[2], pe, a);
+          a = sc_fma(st.c[3], ps, a);
+          a = sc_fma(st.c[4], pn, a);
+          const bool ok = col_ok && i < rows;
+          xr[i] = sc_fma(alpha, pc, xr[i]);            // only written back for real nodes
+          const T rv = ok ? sc_fma(nalpha, a, r[i]) : zero;
+          r[i] = rv;
+          loc = sc_fma(rv, rv, loc);
+          ps = pc;
+          pc = pn;
+          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (VGPR budget)
+        }
+      }
+      const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
+      const double res = sc_norm_from_dot(rrn);
+      if (!(res > tol * res0)) { ++it; break; }
+      const T beta = sc_div(rrn, rr);
+      // ---- pass 3: p = r + beta p on the thread's own nodes ----
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        if (col_ok && i < rows) pc0[i * W] = sc_fma(beta, pc0[i * W], r[i]);
+      rr = rrn;
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (col_ok && i < rows) {
+      const long c = c0 + (long)g.pitch * i;
+      x[c] = xr[i];
+      r_out[c] = r[i];
+    }
+  if (threadIdx.x == 0) info[0] = it;
+}
+
+// ---- CG with the search direction resident in LDS (strided ownership: 3D grids up to 17^3) -------------------------
 template <typename T, int DIM>
-__device__ __forceinline__ T lds_apply(const Stencil<T>& st, const T* __restrict__ p, int o, int row, int plane) {
+__device__ __forceinline__ T lds_apply_fma(const Stencil<T>& st, const T* __restrict__ p, int o, int row, int plane) {
   T a = sc_mul(st.c[0], p[o]);
-  a = sc_add(a, sc_mul(st.c[1], p[o - 1]));
-  a = sc_add(a, sc_mul(st.c[2], p[o + 1]));
-  a = sc_add(a, sc_mul(st.c[3], p[o - row]));
-  a = sc_add(a, sc_mul(st.c[4], p[o + row]));
+  a = sc_fma(st.c[1], p[o - 1], a);
+  a = sc_fma(st.c[2], p[o + 1], a);
+  a = sc_fma(st.c[3], p[o - row], a);
+  a = sc_fma(st.c[4], p[o + row], a);
   if (DIM == 3) {
-    a = sc_add(a, sc_mul(st.c[5], p[o - plane]));
-    a = sc_add(a, sc_mul(st.c[6], p[o + plane]));
+    a = sc_fma(st.c[5], p[o - plane], a);
+    a = sc_fma(st.c[6], p[o + plane], a);
   }
   return a;
 }
@@ -225,7 +373,7 @@ template <int DIM> __host__ __device__ inline long cg_lds_elems(int n) {
 }
 
 // Walks the ITEMS nodes q = t, t+1024, ... owned by a thread, yielding each node's offset in the padded LDS image
-// without storing 16 offsets per thread: the (ix, iy) carry arithmetic of "+1024" is replayed in every pass.
+// without storing one offset per node: the (ix, iy) carry arithmetic of "+1024" is replayed in every pass.
 template <int DIM> struct ItemWalk {
   int m, row, plane;
   int inc, cx, cy;          // q += 1024  ==>  ix += cx, iy += cy (+ carries), off += inc (+ carries)
@@ -250,10 +398,11 @@ template <int DIM> struct ItemWalk {
   }
   // Branch-free pass over all ITEMS slots: slots beyond this thread's node count are pointed at a dummy LDS cell
   // (second spare front row, column 1) whose value and neighbours are zero and which no real node ever reads, so they
-  // contribute exact zeros. Without per-slot branches the 5 LDS reads of several nodes are in flight together.
+  // contribute exact zeros. Without per-slot branches the LDS reads of several nodes are in flight together.
   template <int ITEMS, int GROUP, typename F> __device__ __forceinline__ void each_all(F&& f) const {
     int off = off0;
     int ix = ix0, iy = iy0;
+    // opaque to the optimiser: otherwise LICM hoists all ITEMS offsets out of the CG iteration loop and keeps them live
     asm volatile("" : "+v"(off), "+v"(ix), "+v"(iy));
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -262,25 +411,21 @@ template <int DIM> struct ItemWalk {
       off += inc;
       ix += cx;
       iy += cy;
-      if (ix >= m) { ix -= m; off += 1; iy += 1; }
-      if (DIM == 3 && iy >= m) { iy -= m; off += row; }
+      if (ix >= m) { ix -= m; off += 1; iy += 1; }          // x wraps into the next row: row - m = 1
+      if (DIM == 3 && iy >= m) { iy -= m; off += row; }     // y wraps into the next plane: plane - m*row = row
     }
   }
   template <int ITEMS, typename F> __device__ __forceinline__ void each(F&& f) const {
     int off = off0, ix = ix0, iy = iy0;
-    // opaque to the optimiser: otherwise LICM hoists all ITEMS offsets out of the CG iteration loop and keeps
-    // them live (that, not the LDS reads, is what spilled at 16 items per thread)
     asm volatile("" : "+v"(off), "+v"(ix), "+v"(iy));
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       if (i < cnt) f(i, off, ix, iy);
-      // keep the scheduler from hoisting every item's LDS reads to the top (it would spill at 16 items/thread)
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       off += inc;
       ix += cx;
       iy += cy;
-      if (ix >= m) { ix -= m; off += 1; iy += 1; }          // x wraps into the next row: row - m = 1
-      if (DIM == 3 && iy >= m) { iy -= m; off += row; }     // y wraps into the next plane: plane - m*row = row
+      if (ix >= m) { ix -= m; off += 1; iy += 1; }
+      if (DIM == 3 && iy >= m) { iy -= m; off += row; }
     }
   }
 };
@@ -300,7 +445,6 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
   __syncthreads();
   const ItemWalk<DIM> walk(g, total);
   const int row = walk.row, plane = walk.plane;
-  // global index of the node at padded LDS offset `off` (2D: needs ix, iy only)
   auto gindex = [&](int off, int ix, int iy) -> long {
     if (DIM == 2) return gidx<2>(g, ix + 1, iy + 1, 0);
     const int iz = (off - 2 * row) / plane - 1;
@@ -313,11 +457,11 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
   for (int i = 0; i < ITEMS; ++i) { r[i] = zero; xr[i] = zero; }
   walk.template each<ITEMS>([&](int i, int off, int ix, int iy) {
     const long c = gindex(off, ix, iy);
-    const T v = sc_sub(b[c], apply_stencil<T, DIM>(st, x, g, c));
+    const T v = sc_sub(b[c], apply_stencil_fma<T, DIM>(st, x, g, c));
     r[i] = v;
     xr[i] = x[c];
     p[off] = v;
-    loc = sc_add(loc, sc_mul(v, v));
+    loc = sc_fma(v, v, loc);
   });
   int red_phase = 0;
   T rr = block_sum_fast(loc, red, red_phase);
@@ -325,10 +469,9 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
   int it = 0;
   if (res0 != 0.0) {
     for (; it < maxit; ++it) {
-      // block_sum / the trailing barrier of the previous iteration made every p entry visible
       loc = zero;
       walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) {
-        loc = sc_add(loc, sc_mul(p[off], lds_apply<T, DIM>(st, p, off, row, plane)));
+        loc = sc_fma(p[off], lds_apply_fma<T, DIM>(st, p, off, row, plane), loc);
       });
       const T pap = block_sum_fast(loc, red, red_phase);
       const T alpha = sc_div(rr, pap);
@@ -336,17 +479,17 @@ evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T
       loc = zero;
       walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) {
         const T pv = p[off];
-        const T apv = lds_apply<T, DIM>(st, p, off, row, plane);
-        xr[i] = sc_add(xr[i], sc_mul(alpha, pv));
-        const T rv = sc_add(r[i], sc_mul(nalpha, apv));
+        const T apv = lds_apply_fma<T, DIM>(st, p, off, row, plane);
+        xr[i] = sc_fma(alpha, pv, xr[i]);
+        const T rv = sc_fma(nalpha, apv, r[i]);
         r[i] = rv;
-        loc = sc_add(loc, sc_mul(rv, rv));
+        loc = sc_fma(rv, rv, loc);
       });
       const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);
-      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) { p[off] = sc_add(r[i], sc_mul(beta, p[off])); });
+      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) { p[off] = sc_fma(beta, p[off], r[i]); });
       rr = rrn;
       __syncthreads();
     }

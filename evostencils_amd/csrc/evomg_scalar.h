@@ -20,12 +20,20 @@ EVOMG_HD double sc_neg(double a) { return -a; }
 EVOMG_HD bool sc_iszero(double a) { return a == 0.0; }
 EVOMG_HD double sc_norm_from_dot(double d) { return sqrt(d); }
 
+// fused multiply-add a*b + c (one rounding per real product-accumulate) — used inside the Krylov solvers only;
+// same formulas as the oracle's sc_fma / csc_fma
+EVOMG_HD double sc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 EVOMG_HD cplx sc_add(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
 EVOMG_HD cplx sc_sub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
 EVOMG_HD cplx sc_mul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 EVOMG_HD cplx sc_div(cplx a, cplx b) {
   const double d = b.re * b.re + b.im * b.im;
   return cplx{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+EVOMG_HD cplx sc_fma(cplx a, cplx b, cplx c) {
+  return cplx{__builtin_fma(-a.im, b.im, __builtin_fma(a.re, b.re, c.re)),
+              __builtin_fma(a.im, b.re, __builtin_fma(a.re, b.im, c.im))};
 }
 EVOMG_HD cplx sc_rmul(double s, cplx a) { return cplx{s * a.re, s * a.im}; }
 EVOMG_HD cplx sc_neg(cplx a) { return cplx{-a.re, -a.im}; }

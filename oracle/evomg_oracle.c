@@ -50,6 +50,7 @@ static inline double sc_from_real(double r) { return r; }
 static inline double sc_from_c64(evomg_c64 z) { return z.re; }
 static inline int sc_iszero(double a) { return a == 0.0; }
 static inline double sc_norm_from_dot(double d) { return sqrt(d); }
+static inline double sc_fma(double a, double b, double c) { return fma(a, b, c); }
 #include "evomg_oracle_impl.h"
 #undef SC
 #undef FN
@@ -65,6 +66,7 @@ static inline double sc_norm_from_dot(double d) { return sqrt(d); }
 #define sc_from_c64 csc_from_c64
 #define sc_iszero csc_iszero
 #define sc_norm_from_dot csc_norm_from_dot
+#define sc_fma csc_fma
 
 /* ===================== complex instantiation ===================== */
 typedef struct { double re, im; } cplx;
@@ -90,6 +92,11 @@ static inline cplx csc_from_real(double s) { cplx r = {s, 0.0}; return r; }
 static inline cplx csc_from_c64(evomg_c64 z) { cplx r = {z.re, z.im}; return r; }
 static inline int csc_iszero(cplx a) { return a.re == 0.0 && a.im == 0.0; }
 /* |sqrt(z)| = sqrt(|z|): `fabs(curRes)` of a Complex<Real> sqrt(dot(r,r)) (Helmholtz exa3:86-88,191) */
+/* a*b + c with one rounding per real product-accumulate, fixed order (device: evomg_scalar.h sc_fma) */
+static inline cplx csc_fma(cplx a, cplx b, cplx c) {
+  cplx r = {fma(-a.im, b.im, fma(a.re, b.re, c.re)), fma(a.im, b.re, fma(a.re, b.im, c.im))};
+  return r;
+}
 static inline double csc_norm_from_dot(cplx d) { return sqrt(sqrt(d.re * d.re + d.im * d.im)); }
 #include "evomg_oracle_impl.h"
 #undef SC

@@ -424,34 +424,119 @@ static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
 /* residual norm of the solver loop: |sqrt(dot(r,r))|  (for real fields: sqrt(sum r^2)) [EXTERNAL: App. B.8] */
 static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_from_dot(FN(dot)(c, level, a, a)); }
 
-/* Canonical reduction order of the coarse-grid Krylov solvers. The HIP solvers run as ONE 1024-thread
- * workgroup (csrc/evomg_krylov.h): thread t accumulates the inner nodes q = t, t+1024, ... (q runs x-fastest
- * over the inner nodes) in increasing q, each wave64 folds its 64 partials with the shuffle tree
- * (offsets 32,16,..,1), then the 16 wave sums are folded by the same tree (padded with zeros). Restating that
- * order here makes CG / BiCGStab on the oracle bit-identical to the device solvers; without it the two differ
- * by summation round-off, which a Krylov recurrence amplifies up to the attainable-accuracy floor. */
+/* ---- Krylov solvers on the coarsest grid: node ownership, reduction order and arithmetic ----------------------
+ * The HIP solvers run as ONE workgroup of KRYLOV_LANES = 1024 threads = 16 wave64s (csrc/evomg_krylov.h). To make
+ * the oracle bit-identical to them (a Krylov recurrence amplifies any difference in summation order up to the
+ * attainable-accuracy floor) this block restates
+ *   (i) which inner nodes a thread owns and in which order it accumulates them:
+ *       2D "tile" ownership (when cb = ceil(m/64) <= 16): wave w covers the 64 columns of column block w % cb and the
+ *       R = ceil(m / bands) rows of band w / cb (bands = 16 / cb); lane l owns column 64*(w % cb) + l, rows ascending;
+ *       otherwise (3D, or very wide 2D grids) "strided" ownership: thread t owns q = t, t+1024, ... with q running
+ *       x-fastest over the inner nodes;
+ *  (ii) the reduction tree: wave64 tree with offsets 32,16,8,4,2,1, then the same tree over the 16 wave sums;
+ * (iii) fused multiply-add arithmetic inside the solvers (SpMV, dots, vector updates), written out explicitly — what
+ *       a C++ compiler does to the generated solver at -O3 with contraction on, and what halves the FP64 issue
+ *       slots of the device kernels. Pointwise multigrid kernels elsewhere stay unfused. */
 #define KRYLOV_LANES 1024
+typedef struct {
+  int tile, m, cb, bands, R, slots;
+  long total;
+} FN(own_t);
+static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
+  FN(own_t) o;
+  o.m = c->lv[level].n - 2;
+  o.total = (c->dim == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
+  o.cb = (o.m + 63) / 64;
+  o.tile = (c->dim == 2 && o.cb <= 16);
+  o.bands = o.tile ? 16 / o.cb : 0;
+  o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
+  o.slots = o.tile ? o.R : (int)((o.total + KRYLOV_LANES - 1) / KRYLOV_LANES);
+  return o;
+}
+/* dense index of slot i of thread t, or (size_t)-1 if the slot is empty */
+static size_t FN(own_node)(FN(ctx_t)* c, int level, const FN(own_t)* o, int t, int i) {
+  const int n = c->lv[level].n, m = o->m;
+  if (o->tile) {
+    const int w = t >> 6, l = t & 63;
+    const int band = w / o->cb, ix = 64 * (w % o->cb) + l, iy = band * o->R + i;
+    if (band >= o->bands || ix >= m || iy >= m) return (size_t)-1;
+    return IDX2(n, ix + 1, iy + 1);
+  }
+  const long q = t + (long)KRYLOV_LANES * i;
+  if (q >= o->total) return (size_t)-1;
+  const int ix = (int)(q % m);
+  const long r = q / m;
+  return (c->dim == 2) ? IDX2(n, ix + 1, 1 + (int)r) : IDX3(n, ix + 1, 1 + (int)(r % m), 1 + (int)(r / m));
+}
 static SC FN(tree64)(SC* v) {
   for (int off = 32; off > 0; off >>= 1)
     for (int l = 0; l < off; ++l) v[l] = sc_add(v[l], v[l + off]);
   return v[0];
 }
 static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
-  const int n = c->lv[level].n, m = n - 2;
-  const long total = (c->dim == 2) ? (long)m * m : (long)m * m * m;
+  const FN(own_t) o = FN(own_make)(c, level);
   SC part[KRYLOV_LANES];
-  for (int t = 0; t < KRYLOV_LANES; ++t) part[t] = sc_zero();
-  for (long q = 0; q < total; ++q) {
-    const int i = 1 + (int)(q % m);
-    const long r = q / m;
-    const size_t idx = (c->dim == 2) ? IDX2(n, i, 1 + (int)r) : IDX3(n, i, 1 + (int)(r % m), 1 + (int)(r / m));
-    const int t = (int)(q % KRYLOV_LANES);
-    part[t] = sc_add(part[t], sc_mul(a[idx], b[idx]));
+  for (int t = 0; t < KRYLOV_LANES; ++t) {
+    SC s = sc_zero();
+    for (int i = 0; i < o.slots; ++i) {
+      const size_t idx = FN(own_node)(c, level, &o, t, i);
+      if (idx != (size_t)-1) s = sc_fma(a[idx], b[idx], s);
+    }
+    part[t] = s;
   }
   SC waves[64];
   for (int w = 0; w < 64; ++w) waves[w] = sc_zero();
   for (int w = 0; w < KRYLOV_LANES / 64; ++w) waves[w] = FN(tree64)(&part[64 * w]);
   return FN(tree64)(waves);
+}
+/* fused-multiply-add forms used inside the Krylov solvers */
+static inline SC FN(apply_fma2)(const SC* st, const SC* x, int n, int i, int j) {
+  SC a = sc_mul(st[0], x[IDX2(n, i, j)]);
+  a = sc_fma(st[1], x[IDX2(n, i - 1, j)], a);
+  a = sc_fma(st[2], x[IDX2(n, i + 1, j)], a);
+  a = sc_fma(st[3], x[IDX2(n, i, j - 1)], a);
+  a = sc_fma(st[4], x[IDX2(n, i, j + 1)], a);
+  return a;
+}
+static inline SC FN(apply_fma3)(const SC* st, const SC* x, int n, int i, int j, int k) {
+  SC a = sc_mul(st[0], x[IDX3(n, i, j, k)]);
+  a = sc_fma(st[1], x[IDX3(n, i - 1, j, k)], a);
+  a = sc_fma(st[2], x[IDX3(n, i + 1, j, k)], a);
+  a = sc_fma(st[3], x[IDX3(n, i, j - 1, k)], a);
+  a = sc_fma(st[4], x[IDX3(n, i, j + 1, k)], a);
+  a = sc_fma(st[5], x[IDX3(n, i, j, k - 1)], a);
+  a = sc_fma(st[6], x[IDX3(n, i, j, k + 1)], a);
+  return a;
+}
+/* y = A x (RES == 0) or y = f - A x (RES == 1) on inner nodes, fma form */
+static void FN(krylov_apply)(FN(ctx_t)* c, int level, const SC* st, const SC* x, const SC* f, SC* y, int res) {
+  const int n = c->lv[level].n;
+  if (c->dim == 2) {
+    for (int j = 1; j < n - 1; ++j)
+      for (int i = 1; i < n - 1; ++i) {
+        const SC a = FN(apply_fma2)(st, x, n, i, j);
+        y[IDX2(n, i, j)] = res ? sc_sub(f[IDX2(n, i, j)], a) : a;
+      }
+  } else {
+    for (int k = 1; k < n - 1; ++k)
+      for (int j = 1; j < n - 1; ++j)
+        for (int i = 1; i < n - 1; ++i) {
+          const SC a = FN(apply_fma3)(st, x, n, i, j, k);
+          y[IDX3(n, i, j, k)] = res ? sc_sub(f[IDX3(n, i, j, k)], a) : a;
+        }
+  }
+}
+/* z = a*y + x on inner nodes (one fma per real product) */
+static void FN(krylov_axpy)(FN(ctx_t)* c, int level, SC* z, SC a, const SC* y, const SC* x) {
+  const int n = c->lv[level].n;
+  const int rows = (c->dim == 2) ? n : n * n;
+  for (int r = 0; r < rows; ++r) {
+    const int j = (c->dim == 2) ? r : r % n, k = (c->dim == 2) ? 1 : r / n;
+    if (j >= 1 && j < n - 1 && k >= 1 && (c->dim == 2 || k < n - 1)) {
+      const size_t base = (size_t)r * (size_t)n;
+      for (int i = 1; i < n - 1; ++i) z[base + i] = sc_fma(a, y[base + i], x[base + i]);
+    }
+  }
 }
 
 static void FN(zero_inner)(FN(ctx_t)* c, int level, SC* x) {
@@ -497,24 +582,24 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   SC* r = FN(field)(c, L, EVOMG_F_RES);
   SC* p = FN(tmpvec)(c, L, 0);
   SC* ap = FN(tmpvec)(c, L, 1);
-  FN(residual_st)(c, L, lv->st, x, b, r);
+  FN(krylov_apply)(c, L, lv->st, x, b, r, 1);
   SC rr = FN(dot_canon)(c, L, r, r);
   const double res0 = sc_norm_from_dot(rr);
   if (res0 == 0.0) return 0;
   /* p = r on the inner nodes; p keeps its homogeneous boundary (an error-type field) */
-  FN(axpy_to)(c, L, p, r, sc_zero(), r);
+  FN(krylov_axpy)(c, L, p, sc_zero(), r, r);
   int it = 0;
   for (; it < c->prob.cgs_max_iterations; ++it) {
-    FN(apply_op)(c, L, lv->st, p, ap);
+    FN(krylov_apply)(c, L, lv->st, p, NULL, ap, 0);
     const SC pap = FN(dot_canon)(c, L, p, ap);
     const SC alpha = sc_div(rr, pap);
-    FN(axpy_to)(c, L, x, x, alpha, p);
-    FN(axpy_to)(c, L, r, r, sc_neg(alpha), ap);
+    FN(krylov_axpy)(c, L, x, alpha, p, x);
+    FN(krylov_axpy)(c, L, r, sc_neg(alpha), ap, r);
     const SC rr_new = FN(dot_canon)(c, L, r, r);
     const double res = sc_norm_from_dot(rr_new);
     if (!(res > c->prob.cgs_target_res_reduction * res0)) { ++it; break; }
     const SC beta = sc_div(rr_new, rr);
-    FN(axpy_to)(c, L, p, r, beta, p);
+    FN(krylov_axpy)(c, L, p, beta, p, r);
     rr = rr_new;
   }
   FN(apply_bc)(c, L, x);
@@ -537,34 +622,35 @@ static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
   SC* t = FN(tmpvec)(c, L, 4);
   SC* rhat = FN(tmpvec)(c, L, 5);
   const SC* st = lv->st;
-  FN(residual_st)(c, L, st, x, f, r);
+  FN(krylov_apply)(c, L, st, x, f, r, 1);
   const double res0 = sc_norm_from_dot(FN(dot_canon)(c, L, r, r));
-  if (res0 == 0.0) return 0;
-  SC alpha = sc_from_real(1.0), beta, rho, rho_new = sc_from_real(1.0), omega = sc_from_real(1.0);
+  FN(apply_bc)(c, L, r);
   memcpy(rhat, r, lv->count * sizeof(SC));
   memset(nu, 0, lv->count * sizeof(SC));
   memset(p, 0, lv->count * sizeof(SC));
+  if (res0 == 0.0) return 0;
+  SC alpha = sc_from_real(1.0), beta, rho, rho_new = sc_from_real(1.0), omega = sc_from_real(1.0);
   int it = 0;
   for (; it < c->prob.cgs_max_iterations; ++it) {
     rho = rho_new;
     rho_new = FN(dot_canon)(c, L, rhat, r);
     beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
     /* p = r + beta * (p - omega * nu) ; boundary of p handled by applyBC_p@coarsest */
-    FN(axpy_to)(c, L, p, p, sc_neg(omega), nu);
-    FN(axpy_to)(c, L, p, r, beta, p);
+    FN(krylov_axpy)(c, L, p, sc_neg(omega), nu, p);
+    FN(krylov_axpy)(c, L, p, beta, p, r);
     FN(apply_bc)(c, L, p);
-    FN(apply_op)(c, L, st, p, nu);
+    FN(krylov_apply)(c, L, st, p, NULL, nu, 0);
     alpha = sc_div(rho_new, FN(dot_canon)(c, L, rhat, nu));
-    FN(axpy_to)(c, L, hh, x, alpha, p);
-    FN(axpy_to)(c, L, s, r, sc_neg(alpha), nu);
+    FN(krylov_axpy)(c, L, hh, alpha, p, x);
+    FN(krylov_axpy)(c, L, s, sc_neg(alpha), nu, r);
     FN(apply_bc)(c, L, s);
-    FN(apply_op)(c, L, st, s, t);
+    FN(krylov_apply)(c, L, st, s, NULL, t, 0);
     omega = sc_div(FN(dot_canon)(c, L, t, s), FN(dot_canon)(c, L, t, t));
-    FN(axpy_to)(c, L, x, hh, omega, s);
+    FN(krylov_axpy)(c, L, x, omega, s, hh);
     FN(apply_bc)(c, L, x);
-    FN(axpy_to)(c, L, r, s, sc_neg(omega), t);
-    FN(apply_bc)(c, L, r);
+    FN(krylov_axpy)(c, L, r, sc_neg(omega), t, s);
     const double res = sc_norm_from_dot(FN(dot_canon)(c, L, r, r));
+    FN(apply_bc)(c, L, r);
     if (res < c->prob.cgs_target_res_reduction * res0) { ++it; break; }
     if (!(res == res)) { ++it; break; }  /* NaN guard: the DSL would spin to the iteration cap */
   }
