@@ -261,7 +261,7 @@ template <typename T> class Impl : public ImplBase {
     switch (op->opcode) {
       case EVOMG_OP_SMOOTH: {
         const int cells = op->block[0] * op->block[1] * (dim_ == 3 ? op->block[2] : 1);
-        base = cells > 1 ? "evomg_block_jacobi" : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
+        base = cells > 1 ? (block_fast_ ? "evomg_block_jacobi_fast" : "evomg_block_jacobi") : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
         if (cells == 1 && use_strip(lv_[op->level].g)) {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
@@ -447,13 +447,9 @@ template <typename T> class Impl : public ImplBase {
           const int bx = op.block[0], by = op.block[1], bz = dim_ == 3 ? op.block[2] : 1;
           const int inner = g.n - 2;
           const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by, tz = dim_ == 3 ? (inner + bz - 1) / bz : 1;
-          if (dim_ == 2) {
-            hipLaunchKernelGGL((evomg_copy_boundary<T, 2>), grd, blk, 0, stream_, g, x, y);
-            hipLaunchKernelGGL((evomg_block_jacobi<T, 2>), dim3((tx + 63) / 64, (ty + 3) / 4, 1), blk, 0, stream_, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
-          } else {
-            hipLaunchKernelGGL((evomg_copy_boundary<T, 3>), grd, blk, 0, stream_, g, x, y);
-            hipLaunchKernelGGL((evomg_block_jacobi<T, 3>), dim3((tx + 63) / 64, (ty + 3) / 4, tz), blk, 0, stream_, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
-          }
+          const dim3 tgrid((tx + 63) / 64, (ty + 3) / 4, dim_ == 3 ? tz : 1);
+          if (dim_ == 2) block_smooth<2>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
+          else block_smooth<3>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
           apply_bc(L, y);
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
@@ -535,6 +531,49 @@ template <typename T> class Impl : public ImplBase {
     }
     HIP_TRY(hipGetLastError());
     return EVOMG_OK;
+  }
+
+  // block-Jacobi sweep = boundary faces copied to y + full tiles (fast kernel) + the layers of tiles cut by the far
+  // boundary (generic kernel, pinned to the last tile layer of each truncated dimension)
+  template <int DIM> void block_smooth(int cells, dim3 tgrid, const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y,
+                                       double om, double omm, int bx, int by, int bz, int tx, int ty, int tz) {
+    const dim3 blk = node_block();
+    const dim3 fgrid((g.n + 63) / 64, DIM == 3 ? (g.n + 3) / 4 : 1, 2);
+    for (int face = 0; face < DIM; ++face)
+      hipLaunchKernelGGL((evomg_copy_faces<T, DIM>), fgrid, blk, 0, stream_, g, x, y, face);
+    if (!block_fast_) {
+      hipLaunchKernelGGL((evomg_block_jacobi<T, DIM>), tgrid, blk, 0, stream_, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, 0, -1);
+      return;
+    }
+    launch_block_fast<DIM>(cells, tgrid, blk, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
+    const int inner = g.n - 2;
+    const int b[3] = {bx, by, bz};
+    const int t[3] = {tx, ty, tz};
+    for (int d = 0; d < DIM; ++d) {
+      if (inner % b[d] == 0) continue;                 // no tile is cut in this dimension
+      const int ta = (d == 0) ? t[1] : t[0];            // the two free tile coordinates
+      const int tb = (DIM == 3) ? ((d == 2) ? t[1] : t[2]) : 1;
+      if (d == 2) {
+        hipLaunchKernelGGL((evomg_block_jacobi<T, DIM>), dim3((tx + 63) / 64, (ty + 3) / 4, 1), blk, 0, stream_, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, 1, 2);
+      } else {
+        hipLaunchKernelGGL((evomg_block_jacobi<T, DIM>), dim3((ta + 63) / 64, (tb + 3) / 4, 1), blk, 0, stream_, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, 1, d);
+      }
+    }
+  }
+
+  // full tiles: replay of the host-side tile factorisation, one instantiation per number of cells
+  template <int DIM> void launch_block_fast(int cells, dim3 grid, dim3 block, const Geo& g, const Stencil<T>& st, const T* x,
+                                            const T* f, T* y, double om, double omm, int bx, int by, int bz, int tx, int ty, int tz) {
+    const BlockPlan<T> pl = make_block_plan<T, DIM>(st, bx, by, bz);
+    switch (cells) {
+      case 2: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 2>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+      case 3: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 3>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+      case 4: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 4>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+      case 5: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 5>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+      case 6: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 6>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+      case 7: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 7>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+      default: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 8>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
+    }
   }
 
   // ---- 2D marching-strip kernels (evomg_strip.h) ------------------------------------------------------------------
@@ -871,6 +910,7 @@ template <typename T> class Impl : public ImplBase {
   double prof_bytes_ = 0.0;
   std::vector<hipEvent_t> prof_events_;
   bool use_lds_krylov_ = (getenv("EVOMG_NO_LDS_KRYLOV") == nullptr);
+  bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
