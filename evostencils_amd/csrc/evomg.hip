@@ -665,11 +665,22 @@ template <typename T> class Impl : public ImplBase {
   template <int RT, int CB> int launch_cg_lds2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
     const size_t lds_bytes = (size_t)(cg_lds2d_elems(own, RT) + 32) * sizeof(T);
     if (lds_bytes > 160 * 1024 || own.cb != CB) return EVOMG_OK;
-    auto kern = evomg_cg_lds2d<T, RT, CB>;
-    int rc = set_lds_limit(kern, slot, lds_bytes);
-    if (rc != EVOMG_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(EVOMG_KRYLOV_THREADS), lds_bytes, stream_, lv.g, lv.st, x, b, r,
-                       prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+    // rows every active wave is guaranteed to own: all of own.R except in the last band
+    const int last_rows = own.m - (own.bands - 1) * own.R;
+    constexpr int kMaskLast = RT > 1 ? RT - 1 : 0;
+    const bool nearly_full = (own.R == RT) && last_rows >= kMaskLast && own.cb * own.bands == 16;
+    const dim3 one(1), thr(EVOMG_KRYLOV_THREADS);
+    if (nearly_full) {
+      auto kern = evomg_cg_lds2d<T, RT, CB, kMaskLast>;
+      int rc = set_lds_limit(kern, 2 * slot, lds_bytes);
+      if (rc != EVOMG_OK) return rc;
+      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+    } else {
+      auto kern = evomg_cg_lds2d<T, RT, CB, 0>;
+      int rc = set_lds_limit(kern, 2 * slot + 1, lds_bytes);
+      if (rc != EVOMG_OK) return rc;
+      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+    }
     *launched = true;
     return EVOMG_OK;
   }
@@ -704,10 +715,10 @@ template <typename T> class Impl : public ImplBase {
     if (lds_bytes > 160 * 1024) return EVOMG_OK;
     const long items = (own.total + EVOMG_KRYLOV_THREADS - 1) / EVOMG_KRYLOV_THREADS;
     int rc;
-    if (items <= 1) rc = launch_cg_lds_items<DIM, 1>(lv, x, b, r, lds_bytes, 5);
-    else if (items <= 2) rc = launch_cg_lds_items<DIM, 2>(lv, x, b, r, lds_bytes, 6);
-    else if (items <= 4) rc = launch_cg_lds_items<DIM, 4>(lv, x, b, r, lds_bytes, 7);
-    else if (items <= 8) rc = launch_cg_lds_items<DIM, 8>(lv, x, b, r, lds_bytes, 8);
+    if (items <= 1) rc = launch_cg_lds_items<DIM, 1>(lv, x, b, r, lds_bytes, 12);
+    else if (items <= 2) rc = launch_cg_lds_items<DIM, 2>(lv, x, b, r, lds_bytes, 13);
+    else if (items <= 4) rc = launch_cg_lds_items<DIM, 4>(lv, x, b, r, lds_bytes, 14);
+    else if (items <= 8) rc = launch_cg_lds_items<DIM, 8>(lv, x, b, r, lds_bytes, 15);
     else return EVOMG_OK;
     *launched = (rc == EVOMG_OK);
     return rc;
@@ -904,7 +915,7 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
-  bool cg_lds_attr_set_[16] = {};
+  bool cg_lds_attr_set_[24] = {};
   int prof_opcode_ = -1, prof_level_ = -1;
   size_t prof_used_ = 0;
   double prof_bytes_ = 0.0;

@@ -233,12 +233,17 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
 //   * the residual r and the iterate x of the thread's nodes stay in registers; A p is recomputed for the residual
 //     update instead of being stored (at 1024 threads per CU there are 128 VGPRs per thread);
 //   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
-// `rt` = unrolled rows per thread (template R >= own.R); slack rows below the last band stay inside the image
+// LDS image rows: [0] top halo, [1 .. bands*R] node rows (rows >= m+1 are slack = zero), then the bottom halo row(s)
+// reached by the unrolled template rows `rt` >= own.R, then a ZERO REGION of rt+2 rows: lanes whose column does not
+// exist (ix >= m) run on it, so that every value they see is zero and they need no masking at all.
+__host__ __device__ inline long cg_lds2d_rows(const KrylovOwn& o, int rt) { return o.bands * o.R + (rt - o.R) + 2; }
 __host__ __device__ inline long cg_lds2d_elems(const KrylovOwn& o, int rt) {
-  return (long)(o.bands * o.R + (rt - o.R) + 2) * (64 * o.cb + 2);
+  return (cg_lds2d_rows(o, rt) + rt + 2) * (long)(64 * o.cb + 2);
 }
 
-template <typename T, int R, int CB>
+// MASK_FROM: first unrolled row that may lie outside the thread's band (needs masking); rows below it are always
+// nodes of the grid for every active wave (host-checked: the last band keeps at least MASK_FROM rows).
+template <typename T, int R, int CB, int MASK_FROM>
 __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
                double tol, int* __restrict__ info) {
@@ -258,9 +263,18 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   const bool active = band < own.bands;            // wave-uniform: waves beyond cb*bands own nothing
   const int iy0 = active ? band * own.R : 0;
   const int rows = active ? max(0, min(own.R, own.m - iy0)) : 0;   // wave-uniform
-  const bool col_ok = ix < own.m;
-  // image offset of the thread's first node: image row iy0+1, image column ix+1 (always inside the image)
-  T* const pc0 = p + (iy0 + 1) * W + ix + 1;
+  const bool col_ok = active && ix < own.m;
+  // image offset of the thread's first node: image row iy0+1, image column ix+1; threads without a column work on
+  // the zero region below the image instead
+  // separate, mutually opaque OFFSETS (not pointers: the accesses must stay in the LDS address space) for the centre,
+  // west and east neighbours: keeps the compiler from fusing the reads into ds_read2_b64, which moves bytes at half
+  // the rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table)
+  int oc = col_ok ? (iy0 + 1) * W + ix + 1 : (int)(cg_lds2d_rows(own, R) + 1) * W + l + 1;
+  int ow = oc - 1, oe = oc + 1;
+  asm volatile("" : "+v"(oc), "+v"(ow), "+v"(oe));
+  T* const pc0 = p + oc;
+  const T* const pw0 = p + ow;
+  const T* const pe0 = p + oe;
   const long c0 = gidx<2>(g, min(ix, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
 
   T r[R], xr[R];
@@ -288,15 +302,19 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
         T ps = pc0[-W], pc = pc0[0];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const T pn = pc0[(i + 1) * W], pw = pc0[i * W - 1], pe = pc0[i * W + 1];
+          const T pn = pc0[(i + 1) * W], pw = pw0[i * W], pe = pe0[i * W];
           T a = sc_mul(st.c[0], pc);
           a = sc_fma(st.c[1], pw, a);
           a = sc_fma(st.c[2], pe, a);
           a = sc_fma(st.c[3], ps, a);
           a = sc_fma(st.c[4], pn, a);
-          // slots that are not nodes of this thread (slack column / rows past the band) contribute an exact zero
-          const bool ok = col_ok && i < rows;
-          loc = sc_fma(ok ? pc : zero, ok ? a : zero, loc);
+          if (i >= MASK_FROM) {
+            // possibly a slack row below the band: p is zero there but A p is not
+            const bool ok = i < rows;
+            loc = sc_fma(ok ? pc : zero, ok ? a : zero, loc);
+          } else {
+            loc = sc_fma(pc, a, loc);
+          }
           ps = pc;
           pc = pn;
           if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (VGPR budget)
@@ -311,30 +329,33 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
         T ps = pc0[-W], pc = pc0[0];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const T pn = pc0[(i + 1) * W], pw = pc0[i * W - 1], pe = pc0[i * W + 1];
+          const T pn = pc0[(i + 1) * W], pw = pw0[i * W], pe = pe0[i * W];
           T a = sc_mul(st.c[0], pc);
           a = sc_fma(st.c[1], pw, a);
           a = sc_fma(st.c[2], pe, a);
           a = sc_fma(st.c[3], ps, a);
           a = sc_fma(st.c[4], pn, a);
-          const bool ok = col_ok && i < rows;
           xr[i] = sc_fma(alpha, pc, xr[i]);            // only written back for real nodes
-          const T rv = ok ? sc_fma(nalpha, a, r[i]) : zero;
+          T rv = sc_fma(nalpha, a, r[i]);
+          if (i >= MASK_FROM) rv = (i < rows) ? rv : zero;
           r[i] = rv;
           loc = sc_fma(rv, rv, loc);
           ps = pc;
           pc = pn;
-          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (VGPR budget)
+          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
       const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);
-      // ---- pass 3: p = r + beta p on the thread's own nodes ----
+      // ---- pass 3: p = r + beta p on the thread's own nodes (column-less threads rewrite zeros in the zero region) ----
 #pragma unroll
-      for (int i = 0; i < R; ++i)
-        if (col_ok && i < rows) pc0[i * W] = sc_fma(beta, pc0[i * W], r[i]);
+      for (int i = 0; i < R; ++i) {
+        const T pv = sc_fma(beta, pc0[i * W], r[i]);
+        if (i >= MASK_FROM) { if (i < rows) pc0[i * W] = pv; }
+        else pc0[i * W] = pv;
+      }
       rr = rrn;
       __syncthreads();
     }
