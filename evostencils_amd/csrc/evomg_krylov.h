@@ -270,11 +270,20 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   // west and east neighbours: keeps the compiler from fusing the reads into ds_read2_b64, which moves bytes at half
   // the rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table)
   int oc = col_ok ? (iy0 + 1) * W + ix + 1 : (int)(cg_lds2d_rows(own, R) + 1) * W + l + 1;
-  int ow = oc - 1, oe = oc + 1;
-  asm volatile("" : "+v"(oc), "+v"(ow), "+v"(oe));
-  T* const pc0 = p + oc;
-  const T* const pw0 = p + ow;
-  const T* const pe0 = p + oe;
+  // even and odd rows go through different (opaque) base registers: reads of vertically adjacent rows then cannot be
+  // fused either, and rows two apart are 2*W*8 > 2040 bytes apart, beyond ds_read2's offset range
+  int oc2 = oc, ow = oc - 1, ow2 = oc - 1, oe = oc + 1, oe2 = oc + 1;
+  asm volatile("" : "+v"(oc), "+v"(oc2), "+v"(ow), "+v"(ow2), "+v"(oe), "+v"(oe2));
+  T* const pcA = p + oc;
+  T* const pcB = p + oc2;
+  const T* const pwA = p + ow;
+  const T* const pwB = p + ow2;
+  const T* const peA = p + oe;
+  const T* const peB = p + oe2;
+#define PC(i) (((i) & 1) ? pcB : pcA)[(i) * W]
+#define PW(i) (((i) & 1) ? pwB : pwA)[(i) * W]
+#define PE(i) (((i) & 1) ? peB : peA)[(i) * W]
+  T* const pc0 = pcA;
   const long c0 = gidx<2>(g, min(ix, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
 
   T r[R], xr[R];
@@ -299,10 +308,10 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       // ---- pass 1: p . A p ----
       loc = zero;
       {
-        T ps = pc0[-W], pc = pc0[0];
+        T ps = PC(-1), pc = PC(0);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const T pn = pc0[(i + 1) * W], pw = pw0[i * W], pe = pe0[i * W];
+          const T pn = PC(i + 1), pw = PW(i), pe = PE(i);
           T a = sc_mul(st.c[0], pc);
           a = sc_fma(st.c[1], pw, a);
           a = sc_fma(st.c[2], pe, a);
@@ -317,7 +326,7 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
           }
           ps = pc;
           pc = pn;
-          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (VGPR budget)
+          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler look-ahead (VGPR budget)
         }
       }
       const T pap = block_sum_fast(loc, red, red_phase);
@@ -326,10 +335,10 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       // ---- pass 2: x += alpha p ; r -= alpha A p ; r . r ----
       loc = zero;
       {
-        T ps = pc0[-W], pc = pc0[0];
+        T ps = PC(-1), pc = PC(0);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const T pn = pc0[(i + 1) * W], pw = pw0[i * W], pe = pe0[i * W];
+          const T pn = PC(i + 1), pw = PW(i), pe = PE(i);
           T a = sc_mul(st.c[0], pc);
           a = sc_fma(st.c[1], pw, a);
           a = sc_fma(st.c[2], pe, a);
@@ -342,7 +351,7 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
           loc = sc_fma(rv, rv, loc);
           ps = pc;
           pc = pn;
-          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
       const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
@@ -352,9 +361,9 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       // ---- pass 3: p = r + beta p on the thread's own nodes (column-less threads rewrite zeros in the zero region) ----
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const T pv = sc_fma(beta, pc0[i * W], r[i]);
-        if (i >= MASK_FROM) { if (i < rows) pc0[i * W] = pv; }
-        else pc0[i * W] = pv;
+        const T pv = sc_fma(beta, PC(i), r[i]);
+        if (i >= MASK_FROM) { if (i < rows) PC(i) = pv; }
+        else PC(i) = pv;
       }
       rr = rrn;
       __syncthreads();
@@ -367,6 +376,9 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       x[c] = xr[i];
       r_out[c] = r[i];
     }
+#undef PC
+#undef PW
+#undef PE
   if (threadIdx.x == 0) info[0] = it;
 }
 
