@@ -184,10 +184,8 @@ template <typename T> class Impl : public ImplBase {
     HIP_TRY(hipSetDevice(device_));
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
-    for (int i = 0; i < n_ops; ++i) {
-      rc = exec(ops[i]);
-      if (rc != EVOMG_OK) return rc;
-    }
+    rc = exec_program(ops, n_ops, /*cyclic=*/false);
+    if (rc != EVOMG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream_));
     return EVOMG_OK;
   }
@@ -412,6 +410,106 @@ template <typename T> class Impl : public ImplBase {
   }
 
   // ---- op interpreter ----------------------------------------------------------------------------------------------
+  // ---- op program execution with peephole fusion -------------------------------------------------------------------
+  // RESIDUAL@L immediately followed by RESTRICT@(L-1) of that residual runs as ONE kernel (evomg_strip_residual_restrict).
+  // `cyclic`: the program is the body of a solver loop, so "never read again before it is overwritten" can be decided
+  // by scanning around the loop; then the residual field is not even written.
+  bool touches(const evomg_op_t& op, int level, int field, bool* reads) const {
+    auto same = [&](int f, int l) { return l == level && canon(l, f) == canon(level, field); };
+    bool r = false, w = false;
+    switch (op.opcode) {
+      case EVOMG_OP_SMOOTH: r = same(op.dst, op.level) || same(op.src1, op.level); w = same(op.dst, op.level); break;
+      case EVOMG_OP_RESIDUAL: r = same(op.src0, op.level) || same(op.src1, op.level); w = same(op.dst, op.level); break;
+      case EVOMG_OP_RICHARDSON: r = same(op.dst, op.level) || same(op.src1, op.level); w = same(op.dst, op.level); break;
+      case EVOMG_OP_RESTRICT: r = same(op.src0, op.level + 1); w = same(op.dst, op.level); break;
+      case EVOMG_OP_PROLONG_ADD: r = same(op.src0, op.level - 1) || same(op.dst, op.level); w = same(op.dst, op.level); break;
+      case EVOMG_OP_PROLONG_SET: r = same(op.src0, op.level - 1); w = same(op.dst, op.level); break;
+      case EVOMG_OP_SET_ZERO: w = same(op.dst, op.level); break;
+      case EVOMG_OP_COPY: r = same(op.src0, op.level); w = same(op.dst, op.level); break;
+      case EVOMG_OP_COARSE_SOLVE:
+        r = same(EVOMG_F_CGS_RHS, op.level) || same(EVOMG_F_CORR, op.level);
+        w = same(EVOMG_F_CORR, op.level) || same(EVOMG_F_RES, op.level);
+        break;
+    }
+    *reads = r;
+    return r || w;
+  }
+  bool residual_dead_after(const evomg_op_t* ops, int n_ops, int i) const {
+    const int level = ops[i].level, field = ops[i].dst;
+    for (int k = i + 2; k < n_ops; ++k) {
+      bool reads;
+      if (touches(ops[k], level, field, &reads)) return !reads;
+    }
+    // end of the loop body: the outer loops recompute (overwrite) RES@max before reading it and never read any other
+    // level's fields; afterwards the body starts over
+    if (level == prob_.max_level && canon(level, field) == EVOMG_F_RES) return true;
+    for (int k = 0; k < i; ++k) {
+      bool reads;
+      if (touches(ops[k], level, field, &reads)) return !reads;
+    }
+    return true;   // nothing else touches it: the same pair overwrites it in the next pass
+  }
+  bool fusable_residual_restrict(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || i + 1 >= n_ops) return false;
+    const evomg_op_t &a = ops[i], &b = ops[i + 1];
+    if (a.opcode != EVOMG_OP_RESIDUAL || b.opcode != EVOMG_OP_RESTRICT) return false;
+    if (b.level != a.level - 1 || canon(a.level, b.src0) != canon(a.level, a.dst)) return false;
+    if (canon(a.level, a.dst) == canon(a.level, a.src0) || canon(a.level, a.dst) == canon(a.level, a.src1)) return false;
+    if (!use_strip(lv_[a.level].g)) return false;
+    if ((a.opcode == prof_opcode_ && a.level == prof_level_) || (b.opcode == prof_opcode_ && b.level == prof_level_)) return false;
+    return true;
+  }
+  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic) {
+    for (int i = 0; i < n_ops; ++i) {
+      if (fusable_residual_restrict(ops, n_ops, i)) {
+        const bool write_r = !(cyclic && residual_dead_after(ops, n_ops, i));
+        const int L = ops[i].level;
+        launch_residual_restrict(L, fieldptr(L, ops[i].src0), fieldptr(L, ops[i].src1), fieldptr(L, ops[i].dst),
+                                 fieldptr(L - 1, ops[i + 1].dst), write_r);
+        if (write_r) apply_bc(L, fieldptr(L, ops[i].dst));
+        apply_bc(L - 1, fieldptr(L - 1, ops[i + 1].dst));
+        HIP_TRY(hipGetLastError());
+        ++i;
+        continue;
+      }
+      int rc = exec(ops[i]);
+      if (rc != EVOMG_OK) return rc;
+    }
+    return EVOMG_OK;
+  }
+  void launch_residual_restrict(int L, const T* x, const T* f, T* r, T* coarse, bool write_r) {
+    const Geo& g = lv_[L].g;
+    const Geo& gc = lv_[L - 1].g;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    int rows = strip_rows_ > 0 ? strip_rows_ : 32;
+    while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+    rows = (rows + 1) & ~1;
+    const int chunks = (g.n + rows - 1) / rows;
+    const int waves = strips * chunks;
+    const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
+    const bool nt = strip_streams(g);
+    if (write_r) {
+      if (nt) hipLaunchKernelGGL((evomg_strip_residual_restrict<T, true, true>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
+      else hipLaunchKernelGGL((evomg_strip_residual_restrict<T, true, false>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
+    } else {
+      if (nt) hipLaunchKernelGGL((evomg_strip_residual_restrict<T, false, true>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
+      else hipLaunchKernelGGL((evomg_strip_residual_restrict<T, false, false>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
+    }
+  }
+  void launch_strip_prolong(int L, const T* coarse, T* fine, bool acc, double om) {
+    const Geo& g = lv_[L].g;
+    const Geo& gc = lv_[L - 1].g;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    int rows = strip_rows_ > 0 ? strip_rows_ : 32;
+    while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+    rows = (rows + 1) & ~1;
+    const int chunks = (g.n + rows - 1) / rows;
+    const int waves = strips * chunks;
+    const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
+    if (acc) hipLaunchKernelGGL((evomg_strip_prolong<T, true>), grid, block, 0, stream_, g, gc, coarse, fine, om, rows, strips, waves);
+    else hipLaunchKernelGGL((evomg_strip_prolong<T, false>), grid, block, 0, stream_, g, gc, coarse, fine, 1.0, rows, strips, waves);
+  }
+
   int exec(const evomg_op_t& op) {
     const bool timed = op.opcode == prof_opcode_ && op.level == prof_level_;
     if (timed) {
@@ -503,7 +601,9 @@ template <typename T> class Impl : public ImplBase {
         const Geo& gc = lv_[L - 1].g;
         const T* cz = fieldptr(L - 1, op.src0);
         T* fz = fieldptr(L, op.dst);
-        if (op.opcode == EVOMG_OP_PROLONG_ADD) {
+        if (use_strip(g) && cz != fz) {
+          launch_strip_prolong(L, cz, fz, op.opcode == EVOMG_OP_PROLONG_ADD, op.omega);
+        } else if (op.opcode == EVOMG_OP_PROLONG_ADD) {
           if (dim_ == 2) hipLaunchKernelGGL((evomg_prolong<T, 2, true>), grd, blk, 0, stream_, g, gc, cz, fz, op.omega);
           else hipLaunchKernelGGL((evomg_prolong<T, 3, true>), grd, blk, 0, stream_, g, gc, cz, fz, op.omega);
         } else {
@@ -773,10 +873,8 @@ template <typename T> class Impl : public ImplBase {
     if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
     else
       for (it = 1; it <= prob_.max_iterations; ++it) {
-        for (int i = 0; i < n_ops; ++i) {
-          rc = exec(ops[i]);
-          if (rc != EVOMG_OK) return rc;
-        }
+        rc = exec_program(ops, n_ops, /*cyclic=*/true);
+        if (rc != EVOMG_OK) return rc;
         residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
         rc = dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
         if (rc != EVOMG_OK) return rc;
@@ -831,11 +929,7 @@ template <typename T> class Impl : public ImplBase {
     auto precondition = [&](const T* rhs_src) -> int {   // u = 0 ; f = rhs ; gen_mgCycle()
       HIP_TRY(hipMemsetAsync(fieldptr(L, EVOMG_F_SOL), 0, bytes, stream_));
       HIP_TRY(hipMemcpyAsync(fieldptr(L, EVOMG_F_RHS), rhs_src, bytes, hipMemcpyDeviceToDevice, stream_));
-      for (int i = 0; i < n_ops; ++i) {
-        int r2 = exec(ops[i]);
-        if (r2 != EVOMG_OK) return r2;
-      }
-      return EVOMG_OK;
+      return exec_program(ops, n_ops, /*cyclic=*/true);
     };
     if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
     else
@@ -922,6 +1016,7 @@ template <typename T> class Impl : public ImplBase {
   std::vector<hipEvent_t> prof_events_;
   bool use_lds_krylov_ = (getenv("EVOMG_NO_LDS_KRYLOV") == nullptr);
   bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
+  bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;

@@ -226,3 +226,167 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     }
   }
 }
+
+// ---- fused residual + full-weighting restriction (K4 + K5) ------------------------------------------------------
+// The residual of fine row j is computed exactly as in STRIP_RESIDUAL and kept in a three-row register window; every
+// second row the wave emits one coarse row: lane l's pair starts at the even fine column c0, i.e. at coarse column
+// c0/2, whose 3x3 fine neighbourhood is the lane's own pair plus the left lane's second element (one DPP shift per
+// row). Consecutive lanes write consecutive coarse nodes. The residual field itself is written only if WRITE_R
+// (it is skipped when the op program never reads it again before overwriting it): 16 + 8/4 instead of 24 + 10 B/node.
+// Same operation order as evomg_apply<.., true> followed by evomg_restrict => bit-identical coarse right-hand side.
+template <typename T, bool WRITE_R, bool NT_F>
+__global__ void __launch_bounds__(256)
+evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
+                              T* __restrict__ res, T* __restrict__ coarse, int rows_per_chunk, int n_strips, int n_waves) {
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
+  if (wave >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  const int strip = wave % n_strips;
+  const int chunk = wave / n_strips;
+  const int n = g.n, nc = gc.n;
+  const long pitch = g.pitch;
+  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int y0 = chunk * rows_per_chunk;                     // even
+  const int y1 = min(y0 + rows_per_chunk, n);
+  const T zero = scalar_traits<T>::zero();
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= 1 && lane <= 62 && col_ok;
+  const int I = c0 >> 1;                                     // coarse column of element a
+  const bool coarse_col_inner = I >= 1 && I <= nc - 2;
+  const int c_clamped = min(max(c0, 0), n - 1);
+  auto load_row = [&](const T* __restrict__ base, int row) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1);
+    return load_pair<T>(base + pitch * r + c_clamped);
+  };
+  auto load_row_f = [&](const T* __restrict__ base, int row) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1);
+    if constexpr (NT_F) return load_pair_nt<T>(base + pitch * r + c_clamped);
+    else return load_pair<T>(base + pitch * r + c_clamped);
+  };
+  constexpr int PF = 2;
+  const int js = y0 - 1;            // first residual row needed (south neighbour row of the chunk's first coarse row)
+  const int je = y1;                // one past the last
+  Pair<T> xm = load_row(x, js - 1);
+  Pair<T> xc = load_row(x, js);
+  Pair<T> xq[PF], fq[PF];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    xq[d] = load_row(x, js + 1 + d);
+    fq[d] = load_row_f(f, js + d);
+  }
+  Pair<T> r2{zero, zero}, r1{zero, zero};    // residual rows j-2, j-1
+  for (int base = js; base < je; base += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const int j = base + d;
+      if (j < je) {
+        const Pair<T> xp = xq[d];
+        const Pair<T> fc = fq[d];
+        xq[d] = load_row(x, j + 1 + PF);
+        fq[d] = load_row_f(f, j + PF);
+        const bool row_inner = j >= 1 && j <= n - 2;
+        const T wa = from_left(xc.b), eb = from_right(xc.a);
+        Pair<T> rc;
+        rc.a = (row_inner && inner_a) ? residual5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a) : zero;
+        rc.b = (row_inner && inner_b) ? residual5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b) : zero;
+        if constexpr (WRITE_R) {
+          if (row_inner && store_lane && j >= y0) {
+            T* dst = res + pitch * j + c0;
+            if (inner_a && inner_b) store_pair(dst, rc);
+            else if (inner_a) dst[0] = rc.a;
+            else if (inner_b) dst[1] = rc.b;
+          }
+        }
+        // js = y0 - 1 is odd, PF is even: d == 0 <=> j odd <=> rows j-2, j-1, j are a complete coarse neighbourhood
+        if (d == 0) {
+          const int J = (j - 1) >> 1;                        // coarse row; fine centre row j-1 = 2J
+          const T w = from_left(r1.b), sw = from_left(r2.b), nw = from_left(rc.b);
+          const T e4 = sc_add(sc_add(w, r1.b), sc_add(r2.a, rc.a));
+          const T q4 = sc_add(sc_add(sw, r2.b), sc_add(nw, rc.b));
+          T v = sc_rmul(0.25, r1.a);
+          v = sc_add(v, sc_rmul(0.125, e4));
+          v = sc_add(v, sc_rmul(0.0625, q4));
+          if (store_lane && coarse_col_inner && J >= 1 && J <= nc - 2 && 2 * J >= y0) coarse[(long)gc.pitch * J + I] = v;
+        }
+        r2 = r1;
+        r1 = rc;
+        xm = xc;
+        xc = xp;
+      }
+    }
+  }
+}
+
+// ---- bilinear prolongation (+ scaled correction), fine-row marching (K6 / K6') -------------------------------------
+// Lane pair (c0, c0+1) with c0 even: element a sits on coarse column I = c0/2, element b between I and I+1 (the right
+// lane's coarse value, one DPP shift). Each coarse row is loaded once per two fine rows. In place: a lane reads and
+// writes only its own pair. Operation order of interpolate<T,2> + evomg_prolong => bit-identical.
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256)
+evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__ fine, double om, int rows_per_chunk,
+                    int n_strips, int n_waves) {
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
+  if (wave >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  const int strip = wave % n_strips;
+  const int chunk = wave / n_strips;
+  const int n = g.n, nc = gc.n;
+  const long pitch = g.pitch;
+  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int y0 = chunk * rows_per_chunk;                     // even
+  const int y1 = min(y0 + rows_per_chunk, n);
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= 1 && lane <= 62 && col_ok;
+  const int c_clamped = min(max(c0, 0), n - 1);
+  const int I = min(max(c0 >> 1, 0), nc - 1);
+  auto load_fine = [&](int row) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1);
+    return load_pair<T>(fine + pitch * r + c_clamped);
+  };
+  auto load_coarse = [&](int J) -> T {
+    const int r = min(max(J, 0), nc - 1);
+    return coarse[(long)gc.pitch * r + I];
+  };
+  const int J0 = y0 >> 1;
+  T cJ = load_coarse(J0), cJ1 = load_coarse(J0 + 1);
+  Pair<T> x0 = load_fine(y0), x1 = load_fine(y0 + 1);
+  for (int j = y0; j < y1; j += 2) {
+    const int J = j >> 1;
+    // prefetch the next coarse row and the next two fine rows
+    const T cJ2 = load_coarse(J + 2);
+    const Pair<T> x2 = load_fine(j + 2), x3 = load_fine(j + 3);
+    const T cJr = from_right(cJ), cJ1r = from_right(cJ1);
+    // even fine row j = 2J
+    {
+      const bool row_inner = j >= 1 && j <= n - 2;
+      const T va = cJ;
+      const T vb = sc_rmul(0.5, sc_add(cJ, cJr));
+      Pair<T> out;
+      out.a = (row_inner && inner_a) ? (ACC ? sc_add(x0.a, sc_rmul(om, va)) : va) : x0.a;
+      out.b = (row_inner && inner_b) ? (ACC ? sc_add(x0.b, sc_rmul(om, vb)) : vb) : x0.b;
+      if (store_lane) store_pair(fine + pitch * j + c0, out);
+    }
+    // odd fine row j + 1 = 2J + 1
+    if (j + 1 < y1) {
+      const bool row_inner = j + 1 >= 1 && j + 1 <= n - 2;
+      const T va = sc_rmul(0.5, sc_add(cJ, cJ1));
+      const T vb = sc_rmul(0.25, sc_add(sc_add(cJ, cJr), sc_add(cJ1, cJ1r)));
+      Pair<T> out;
+      out.a = (row_inner && inner_a) ? (ACC ? sc_add(x1.a, sc_rmul(om, va)) : va) : x1.a;
+      out.b = (row_inner && inner_b) ? (ACC ? sc_add(x1.b, sc_rmul(om, vb)) : vb) : x1.b;
+      if (store_lane) store_pair(fine + pitch * (j + 1) + c0, out);
+    }
+    cJ = cJ1;
+    cJ1 = cJ2;
+    x0 = x2;
+    x1 = x3;
+  }
+}

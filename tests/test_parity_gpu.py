@@ -304,7 +304,12 @@ def test_marching_strip_kernels_match_generic_kernels(native, pname, level, rows
     seq = [abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.15),
            abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.8),
            abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 0.6),
-           abi.make_op(abi.OP_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)]
+           abi.make_op(abi.OP_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS),
+           # residual immediately followed by its restriction: runs as the fused strip kernel
+           abi.make_op(abi.OP_RESTRICT, level - 1, abi.F_RHS, abi.F_RES),
+           abi.make_op(abi.OP_SMOOTH, level - 1, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.0),
+           abi.make_op(abi.OP_PROLONG_ADD, level, abi.F_SOL, abi.F_SOL, omega=0.85),
+           abi.make_op(abi.OP_PROLONG_SET, level, abi.F_CORR, abi.F_SOL)]
     out = []
     for strip in (True, False):
         if strip:
@@ -318,7 +323,8 @@ def test_marching_strip_kernels_match_generic_kernels(native, pname, level, rows
         h.set_field(level, abi.F_RHS, f0)
         h.set_field(level, abi.F_RES, r0)
         h.run_ops(seq)
-        out.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
+        out.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES), h.get_field(level - 1, abi.F_RHS),
+                    h.get_field(level - 1, abi.F_SOL), h.get_field(level, abi.F_CORR)))
         h.close()
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
