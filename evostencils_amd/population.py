@@ -83,3 +83,40 @@ def evaluate_population(evaluate: Callable[[int], Tuple[float, float, float]], n
         t_ms, rho, its = evaluate(i)
         mine.append((i, float(rho), float(t_ms), float(its)))
     return allgather_fitness(mine, n_candidates, world, local_rank)
+
+
+class ConcurrentEvaluator:
+    """Throughput mode for ONE GPU: `n_workers` independent ProgramGenerator instances (own HIP stream, own set of
+    level fields) driven by as many host threads, so that several candidates are in flight on the device at once.
+    Why it pays: a candidate's coarse-grid Krylov solve is one workgroup on one of 256 CUs; while it runs, the other
+    workers' bandwidth-bound fine-level sweeps use the rest of the chip. ctypes releases the GIL during evomg_evaluate.
+
+    Convergence factor and iteration count are unaffected (deterministic); the measured time-to-solution of a candidate
+    includes contention from its neighbours, so use n_workers=1 (the default everywhere else, and what the reference's
+    sequential `map` does, optimization/program.py:491,577) when the time objective must be isolated."""
+
+    def __init__(self, make_generator: Callable[[], object], n_workers: int):
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        self.generators = [make_generator() for _ in range(n_workers)]
+        self._pool = ThreadPoolExecutor(max_workers=n_workers)
+        self._local = threading.local()
+        self._free = list(self.generators)
+        self._lock = threading.Lock()
+
+    def _generator(self):
+        g = getattr(self._local, "gen", None)
+        if g is None:
+            with self._lock:
+                g = self._free.pop()
+            self._local.gen = g
+        return g
+
+    def map(self, fn: Callable[[object, object], Tuple[float, float, float]], items: Sequence[object]):
+        """fn(generator, item) -> (time_ms, rho, iterations); results in input order."""
+        return list(self._pool.map(lambda it: fn(self._generator(), it), items))
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for g in self.generators:
+            g.close()
