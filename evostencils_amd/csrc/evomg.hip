@@ -752,8 +752,8 @@ template <typename T> class Impl : public ImplBase {
     return EVOMG_OK;
   }
 
-  // LDS-resident CG when the coarsest grid fits one CU's LDS: 2D tile kernel (<= 16 rows per thread), else the
-  // strided kernel (3D, <= 16 nodes per thread); otherwise the caller falls back to the global-memory kernel
+  // LDS-resident CG when the coarsest grid fits one CU's LDS (2D tile kernel, <= 16 rows per thread); otherwise the
+  // caller falls back to the global-memory kernel
   template <typename K> int set_lds_limit(K kern, int slot, size_t lds_bytes) {
     if (!cg_lds_attr_set_[slot]) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
@@ -784,14 +784,6 @@ template <typename T> class Impl : public ImplBase {
     *launched = true;
     return EVOMG_OK;
   }
-  template <int DIM, int ITEMS> int launch_cg_lds_items(const Level<T>& lv, T* x, const T* b, T* r, size_t lds_bytes, int slot) {
-    auto kern = evomg_cg_lds<T, DIM, ITEMS>;
-    int rc = set_lds_limit(kern, slot, lds_bytes);
-    if (rc != EVOMG_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(EVOMG_KRYLOV_THREADS), lds_bytes, stream_, lv.g, lv.st, x, b, r,
-                       prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
-    return EVOMG_OK;
-  }
   template <int DIM> int launch_cg_lds(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
     *launched = false;
     if (!use_lds_krylov_) return EVOMG_OK;
@@ -811,17 +803,7 @@ template <typename T> class Impl : public ImplBase {
       }
       return EVOMG_OK;
     }
-    const size_t lds_bytes = (size_t)(cg_lds_elems<DIM>(lv.g.n) + 32) * sizeof(T);
-    if (lds_bytes > 160 * 1024) return EVOMG_OK;
-    const long items = (own.total + EVOMG_KRYLOV_THREADS - 1) / EVOMG_KRYLOV_THREADS;
-    int rc;
-    if (items <= 1) rc = launch_cg_lds_items<DIM, 1>(lv, x, b, r, lds_bytes, 12);
-    else if (items <= 2) rc = launch_cg_lds_items<DIM, 2>(lv, x, b, r, lds_bytes, 13);
-    else if (items <= 4) rc = launch_cg_lds_items<DIM, 4>(lv, x, b, r, lds_bytes, 14);
-    else if (items <= 8) rc = launch_cg_lds_items<DIM, 8>(lv, x, b, r, lds_bytes, 15);
-    else return EVOMG_OK;
-    *launched = (rc == EVOMG_OK);
-    return rc;
+    return EVOMG_OK;   // 3D: the global-memory kernel with column ownership (z register window)
   }
 
   // ---- reductions ----------------------------------------------------------------------------------------------------

@@ -22,11 +22,26 @@ template <int DIM> __device__ __forceinline__ long inner_index(const Geo& g, lon
   return gidx<3>(g, i, 1 + (int)(t % m), 1 + (int)(t / m));
 }
 
+template <typename T, int DIM>
+__device__ __forceinline__ T apply_stencil_fma(const Stencil<T>& st, const T* __restrict__ x, const Geo& g, long c) {
+  T a = sc_mul(st.c[0], x[c]);
+  a = sc_fma(st.c[1], x[c - 1], a);
+  a = sc_fma(st.c[2], x[c + 1], a);
+  a = sc_fma(st.c[3], x[c - g.pitch], a);
+  a = sc_fma(st.c[4], x[c + g.pitch], a);
+  if (DIM == 3) {
+    a = sc_fma(st.c[5], x[c - g.plane], a);
+    a = sc_fma(st.c[6], x[c + g.plane], a);
+  }
+  return a;
+}
+
 // ---- canonical node ownership ------------------------------------------------------------------------------------
 // 2D "tile": wave w covers the 64 columns of column block w % cb and the R rows of band w / cb; lane = column,
 // rows ascending. Otherwise "strided": thread t owns q = t, t+1024, ... (q x-fastest over the inner nodes).
+// 3D "column" (when m*m <= 1024): thread t owns the z-column (ix, iy) = (t % m, t / m), iz ascending.
 struct KrylovOwn {
-  int tile, m, cb, bands, R;
+  int tile, column, m, cb, bands, R;
   long total;
 };
 template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
@@ -35,6 +50,7 @@ template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
   o.total = (DIM == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
   o.cb = (o.m + 63) / 64;
   o.tile = (DIM == 2 && o.cb <= 16) ? 1 : 0;
+  o.column = (DIM == 3 && (long)o.m * o.m <= EVOMG_KRYLOV_THREADS) ? 1 : 0;
   o.bands = o.tile ? 16 / o.cb : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   return o;
@@ -49,23 +65,60 @@ template <int DIM, typename F> __device__ __forceinline__ void own_each(const Ge
     const int rows = min(o.R, o.m - iy0);
     long c = gidx<2>(g, ix + 1, iy0 + 1, 0);
     for (int i = 0; i < rows; ++i, c += g.pitch) f(c);
+  } else if (DIM == 3 && o.column) {
+    const int t = threadIdx.x;
+    if (t >= o.m * o.m) return;
+    long c = gidx<3>(g, t % o.m + 1, t / o.m + 1, 1);
+    for (int i = 0; i < o.m; ++i, c += g.plane) f(c);
   } else {
     for (long q = threadIdx.x; q < o.total; q += EVOMG_KRYLOV_THREADS) f(inner_index<DIM>(g, q, o.m));
   }
 }
-
-template <typename T, int DIM>
-__device__ __forceinline__ T apply_stencil_fma(const Stencil<T>& st, const T* __restrict__ x, const Geo& g, long c) {
-  T a = sc_mul(st.c[0], x[c]);
-  a = sc_fma(st.c[1], x[c - 1], a);
-  a = sc_fma(st.c[2], x[c + 1], a);
-  a = sc_fma(st.c[3], x[c - g.pitch], a);
-  a = sc_fma(st.c[4], x[c + g.pitch], a);
-  if (DIM == 3) {
-    a = sc_fma(st.c[5], x[c - g.plane], a);
-    a = sc_fma(st.c[6], x[c + g.plane], a);
+// y = A p at this thread's nodes in canonical order, f(c, (A p)[c]); in the tile / column modes the neighbours along
+// the marching direction come from a three-value register window instead of two more loads
+template <typename T, int DIM, typename F>
+__device__ __forceinline__ void own_spmv(const Geo& g, const KrylovOwn& o, const Stencil<T>& st,
+                                         const T* __restrict__ p, F&& f) {
+  if (DIM == 2 && o.tile) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int band = w / o.cb, ix = 64 * (w % o.cb) + l;
+    if (band >= o.bands || ix >= o.m) return;
+    const int iy0 = band * o.R;
+    const int rows = min(o.R, o.m - iy0);
+    long c = gidx<2>(g, ix + 1, iy0 + 1, 0);
+    T ps = p[c - g.pitch], pc = p[c];
+    for (int i = 0; i < rows; ++i, c += g.pitch) {
+      const T pn = p[c + g.pitch];
+      T a = sc_mul(st.c[0], pc);
+      a = sc_fma(st.c[1], p[c - 1], a);
+      a = sc_fma(st.c[2], p[c + 1], a);
+      a = sc_fma(st.c[3], ps, a);
+      a = sc_fma(st.c[4], pn, a);
+      f(c, a);
+      ps = pc;
+      pc = pn;
+    }
+  } else if (DIM == 3 && o.column) {
+    const int t = threadIdx.x;
+    if (t >= o.m * o.m) return;
+    long c = gidx<3>(g, t % o.m + 1, t / o.m + 1, 1);
+    T pd = p[c - g.plane], pc = p[c];
+    for (int i = 0; i < o.m; ++i, c += g.plane) {
+      const T pu = p[c + g.plane];
+      T a = sc_mul(st.c[0], pc);
+      a = sc_fma(st.c[1], p[c - 1], a);
+      a = sc_fma(st.c[2], p[c + 1], a);
+      a = sc_fma(st.c[3], p[c - g.pitch], a);
+      a = sc_fma(st.c[4], p[c + g.pitch], a);
+      a = sc_fma(st.c[5], pd, a);
+      a = sc_fma(st.c[6], pu, a);
+      f(c, a);
+      pd = pc;
+      pc = pu;
+    }
+  } else {
+    own_each<DIM>(g, o, [&](long c) { f(c, apply_stencil_fma<T, DIM>(st, p, g, c)); });
   }
-  return a;
 }
 
 template <typename T, bool ROBIN>
@@ -108,8 +161,7 @@ evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict_
   int it = 0;
   for (; it < maxit; ++it) {
     loc = zero;
-    own_each<DIM>(g, own, [&](long c) {
-      const T v = apply_stencil_fma<T, DIM>(st, p, g, c);
+    own_spmv<T, DIM>(g, own, st, p, [&](long c, T v) {
       ap[c] = v;
       loc = sc_fma(p[c], v, loc);
     });
@@ -191,7 +243,7 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
       p[c] = sc_fma(beta, pv, r[c]);
     });
     wg_apply_bc<T, ROBIN>(g, p, kh);
-    own_each<DIM>(g, own, [&](long c) { nu[c] = apply_stencil_fma<T, DIM>(st, p, g, c); });
+    own_spmv<T, DIM>(g, own, st, p, [&](long c, T v) { nu[c] = v; });
     __syncthreads();
     alpha = sc_div(rho_new, wg_dot<T, DIM>(g, own, rhat, nu, red));
     const T nalpha = sc_neg(alpha);
@@ -200,7 +252,7 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
       s[c] = sc_fma(nalpha, nu[c], r[c]);
     });
     wg_apply_bc<T, ROBIN>(g, s, kh);
-    own_each<DIM>(g, own, [&](long c) { t[c] = apply_stencil_fma<T, DIM>(st, s, g, c); });
+    own_spmv<T, DIM>(g, own, st, s, [&](long c, T v) { t[c] = v; });
     __syncthreads();
     const T ts = wg_dot<T, DIM>(g, own, t, s, red);
     const T tt = wg_dot<T, DIM>(g, own, t, t, red);
@@ -379,158 +431,5 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
 #undef PC
 #undef PW
 #undef PE
-  if (threadIdx.x == 0) info[0] = it;
-}
-
-// ---- CG with the search direction resident in LDS (strided ownership: 3D grids up to 17^3) -------------------------
-template <typename T, int DIM>
-__device__ __forceinline__ T lds_apply_fma(const Stencil<T>& st, const T* __restrict__ p, int o, int row, int plane) {
-  T a = sc_mul(st.c[0], p[o]);
-  a = sc_fma(st.c[1], p[o - 1], a);
-  a = sc_fma(st.c[2], p[o + 1], a);
-  a = sc_fma(st.c[3], p[o - row], a);
-  a = sc_fma(st.c[4], p[o + row], a);
-  if (DIM == 3) {
-    a = sc_fma(st.c[5], p[o - plane], a);
-    a = sc_fma(st.c[6], p[o + plane], a);
-  }
-  return a;
-}
-
-// padded LDS image of p: two spare zero rows in front (the dummy cell of ItemWalk::each_all sits in the second one,
-// so that its own south neighbour is still inside the image), then the halo'ed grid
-template <int DIM> __host__ __device__ inline long cg_lds_elems(int n) {
-  const long m = n - 2, row = m + 1;
-  if (DIM == 2) return (m + 2) * row + 2 * row;
-  return (m + 2) * row * (m + 1) + 3 * row;
-}
-
-// Walks the ITEMS nodes q = t, t+1024, ... owned by a thread, yielding each node's offset in the padded LDS image
-// without storing one offset per node: the (ix, iy) carry arithmetic of "+1024" is replayed in every pass.
-template <int DIM> struct ItemWalk {
-  int m, row, plane;
-  int inc, cx, cy;          // q += 1024  ==>  ix += cx, iy += cy (+ carries), off += inc (+ carries)
-  int ix0, iy0, off0, cnt;
-  __device__ __forceinline__ ItemWalk(const Geo& g, long total) {
-    m = g.n - 2;
-    row = m + 1;
-    plane = row * (m + 1);
-    const int t = threadIdx.x;
-    const int T0 = EVOMG_KRYLOV_THREADS;
-    cx = T0 % m;
-    const int rest = T0 / m;
-    cy = (DIM == 2) ? rest : rest % m;
-    const int cz = (DIM == 2) ? 0 : rest / m;
-    inc = (DIM == 2) ? rest * row + cx : cz * plane + cy * row + cx;
-    ix0 = t % m;
-    const int r0 = t / m;
-    iy0 = (DIM == 2) ? r0 : r0 % m;
-    const int iz0 = (DIM == 2) ? 0 : r0 / m;
-    off0 = 2 * row + ((DIM == 2) ? (iy0 + 1) * row + ix0 + 1 : (iz0 + 1) * plane + (iy0 + 1) * row + ix0 + 1);
-    cnt = (t < total) ? (int)((total - t + T0 - 1) / T0) : 0;
-  }
-  // Branch-free pass over all ITEMS slots: slots beyond this thread's node count are pointed at a dummy LDS cell
-  // (second spare front row, column 1) whose value and neighbours are zero and which no real node ever reads, so they
-  // contribute exact zeros. Without per-slot branches the LDS reads of several nodes are in flight together.
-  template <int ITEMS, int GROUP, typename F> __device__ __forceinline__ void each_all(F&& f) const {
-    int off = off0;
-    int ix = ix0, iy = iy0;
-    // opaque to the optimiser: otherwise LICM hoists all ITEMS offsets out of the CG iteration loop and keeps them live
-    asm volatile("" : "+v"(off), "+v"(ix), "+v"(iy));
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      f(i, (i < cnt) ? off : row + 1);
-      if ((i & (GROUP - 1)) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead
-      off += inc;
-      ix += cx;
-      iy += cy;
-      if (ix >= m) { ix -= m; off += 1; iy += 1; }          // x wraps into the next row: row - m = 1
-      if (DIM == 3 && iy >= m) { iy -= m; off += row; }     // y wraps into the next plane: plane - m*row = row
-    }
-  }
-  template <int ITEMS, typename F> __device__ __forceinline__ void each(F&& f) const {
-    int off = off0, ix = ix0, iy = iy0;
-    asm volatile("" : "+v"(off), "+v"(ix), "+v"(iy));
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      if (i < cnt) f(i, off, ix, iy);
-      off += inc;
-      ix += cx;
-      iy += cy;
-      if (ix >= m) { ix -= m; off += 1; iy += 1; }
-      if (DIM == 3 && iy >= m) { iy -= m; off += row; }
-    }
-  }
-};
-
-template <typename T, int DIM, int ITEMS>
-__global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
-evomg_cg_lds(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
-             double tol, int* __restrict__ info) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
-  T* p = red + 32;
-  const int m = g.n - 2;
-  const long total = (DIM == 2) ? (long)m * m : (long)m * m * m;
-  const long lds_elems = cg_lds_elems<DIM>(g.n);
-  const T zero = scalar_traits<T>::zero();
-  for (long i = threadIdx.x; i < lds_elems; i += blockDim.x) p[i] = zero;
-  __syncthreads();
-  const ItemWalk<DIM> walk(g, total);
-  const int row = walk.row, plane = walk.plane;
-  auto gindex = [&](int off, int ix, int iy) -> long {
-    if (DIM == 2) return gidx<2>(g, ix + 1, iy + 1, 0);
-    const int iz = (off - 2 * row) / plane - 1;
-    return gidx<3>(g, ix + 1, iy + 1, iz + 1);
-  };
-
-  T r[ITEMS], xr[ITEMS];
-  T loc = zero;
-#pragma unroll
-  for (int i = 0; i < ITEMS; ++i) { r[i] = zero; xr[i] = zero; }
-  walk.template each<ITEMS>([&](int i, int off, int ix, int iy) {
-    const long c = gindex(off, ix, iy);
-    const T v = sc_sub(b[c], apply_stencil_fma<T, DIM>(st, x, g, c));
-    r[i] = v;
-    xr[i] = x[c];
-    p[off] = v;
-    loc = sc_fma(v, v, loc);
-  });
-  int red_phase = 0;
-  T rr = block_sum_fast(loc, red, red_phase);
-  const double res0 = sc_norm_from_dot(rr);
-  int it = 0;
-  if (res0 != 0.0) {
-    for (; it < maxit; ++it) {
-      loc = zero;
-      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) {
-        loc = sc_fma(p[off], lds_apply_fma<T, DIM>(st, p, off, row, plane), loc);
-      });
-      const T pap = block_sum_fast(loc, red, red_phase);
-      const T alpha = sc_div(rr, pap);
-      const T nalpha = sc_neg(alpha);
-      loc = zero;
-      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) {
-        const T pv = p[off];
-        const T apv = lds_apply_fma<T, DIM>(st, p, off, row, plane);
-        xr[i] = sc_fma(alpha, pv, xr[i]);
-        const T rv = sc_fma(nalpha, apv, r[i]);
-        r[i] = rv;
-        loc = sc_fma(rv, rv, loc);
-      });
-      const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
-      const double res = sc_norm_from_dot(rrn);
-      if (!(res > tol * res0)) { ++it; break; }
-      const T beta = sc_div(rrn, rr);
-      walk.template each_all<ITEMS, (ITEMS >= 16 ? 2 : 4)>([&](int i, int off) { p[off] = sc_fma(beta, p[off], r[i]); });
-      rr = rrn;
-      __syncthreads();
-    }
-  }
-  walk.template each<ITEMS>([&](int i, int off, int ix, int iy) {
-    const long c = gindex(off, ix, iy);
-    x[c] = xr[i];
-    r_out[c] = r[i];
-  });
   if (threadIdx.x == 0) info[0] = it;
 }

@@ -431,7 +431,8 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *   (i) which inner nodes a thread owns and in which order it accumulates them:
  *       2D "tile" ownership (when cb = ceil(m/64) <= 16): wave w covers the 64 columns of column block w % cb and the
  *       R = ceil(m / bands) rows of band w / cb (bands = 16 / cb); lane l owns column 64*(w % cb) + l, rows ascending;
- *       otherwise (3D, or very wide 2D grids) "strided" ownership: thread t owns q = t, t+1024, ... with q running
+ *       3D "column" ownership (when m*m <= 1024): thread t owns the z-column (t % m, t / m), iz ascending;
+ *       otherwise (large 3D, or very wide 2D grids) "strided" ownership: thread t owns q = t, t+1024, ... with q running
  *       x-fastest over the inner nodes;
  *  (ii) the reduction tree: wave64 tree with offsets 32,16,8,4,2,1, then the same tree over the 16 wave sums;
  * (iii) fused multiply-add arithmetic inside the solvers (SpMV, dots, vector updates), written out explicitly — what
@@ -439,7 +440,7 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *       slots of the device kernels. Pointwise multigrid kernels elsewhere stay unfused. */
 #define KRYLOV_LANES 1024
 typedef struct {
-  int tile, m, cb, bands, R, slots;
+  int tile, column, m, cb, bands, R, slots;
   long total;
 } FN(own_t);
 static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
@@ -450,7 +451,9 @@ static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
   o.tile = (c->dim == 2 && o.cb <= 16);
   o.bands = o.tile ? 16 / o.cb : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
-  o.slots = o.tile ? o.R : (int)((o.total + KRYLOV_LANES - 1) / KRYLOV_LANES);
+  /* 3D "column" ownership when m*m <= 1024: thread t owns the z-column (t % m, t / m), iz ascending */
+  o.column = (c->dim == 3 && (long)o.m * o.m <= KRYLOV_LANES);
+  o.slots = o.tile ? o.R : o.column ? o.m : (int)((o.total + KRYLOV_LANES - 1) / KRYLOV_LANES);
   return o;
 }
 /* dense index of slot i of thread t, or (size_t)-1 if the slot is empty */
@@ -461,6 +464,10 @@ static size_t FN(own_node)(FN(ctx_t)* c, int level, const FN(own_t)* o, int t, i
     const int band = w / o->cb, ix = 64 * (w % o->cb) + l, iy = band * o->R + i;
     if (band >= o->bands || ix >= m || iy >= m) return (size_t)-1;
     return IDX2(n, ix + 1, iy + 1);
+  }
+  if (o->column) {
+    if (t >= m * m || i >= m) return (size_t)-1;
+    return IDX3(n, t % m + 1, t / m + 1, i + 1);
   }
   const long q = t + (long)KRYLOV_LANES * i;
   if (q >= o->total) return (size_t)-1;

@@ -253,7 +253,7 @@ def test_rejects_malformed_programs(native):
     assert rc == abi.ERR_INVALID   # gen_rhs_u exists on the coarsest level only
 
 
-@pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4)])
+@pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4), (3, 5)])
 def test_lds_resident_cg_is_bit_identical(native, oracle, dim, lo, monkeypatch):
     """The LDS-resident CG (p in LDS with a zero halo, r/x in registers), the global-memory single-workgroup CG
     and the oracle follow one summation order: all three give the same bits (129^2 = the C2 coarsest grid)."""

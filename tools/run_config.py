@@ -1,0 +1,30 @@
+"""Developer tool: run one of the BASELINE.json configurations once on the GPU (for rocprofv3).
+usage: python tools/run_config.py c4|c2|c3|c5"""
+import os, sys, dataclasses
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
+from evostencils_amd import abi, native, problems
+from test_full_size_gpu import vcycle
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
+if cfg == "c4":
+    lo, hi = 5, 9
+    pd = problems.poisson_3d(lo, hi)
+    ops = vcycle(lo, hi, 2, 2, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (2, 1, 1), 0.8))
+elif cfg == "c2":
+    lo, hi = 7, 12
+    pd = problems.poisson_2d(lo, hi)
+    ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
+elif cfg == "c5":
+    lo, hi = 7, 11
+    pd = problems.poisson_2d(lo, hi)
+    ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
+else:
+    from test_helmholtz_oracle import reference_vcycle_ops
+    lo, hi = 7, 11
+    pd = dataclasses.replace(problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi)), max_iterations=50)
+    ops = reference_vcycle_ops(lo, hi)
+h = native.create(pd)
+out = h.evaluate(ops, 1, 0, 0)
+out = h.evaluate(ops, 1, 0, 0)
+print(cfg, "iterations", out.n_iterations, "rho %.4f" % out.conv_factor, "time %.2f ms" % out.time_ms, "status", out.status)
