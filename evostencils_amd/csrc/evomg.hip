@@ -727,7 +727,8 @@ template <typename T> class Impl : public ImplBase {
       int rc = tmpvec(L, i, &w[i]);
       if (rc != EVOMG_OK) return rc;
     }
-    const dim3 one(1), thr(EVOMG_KRYLOV_THREADS);
+    const int lanes = (dim_ == 2 ? krylov_own<2>(lv.g.n) : krylov_own<3>(lv.g.n)).lanes;
+    const dim3 one(1), thr(lanes);
     if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
       const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
       if constexpr (scalar_traits<T>::is_complex) {
@@ -752,7 +753,7 @@ template <typename T> class Impl : public ImplBase {
     return EVOMG_OK;
   }
 
-  // LDS-resident CG when the coarsest grid fits one CU's LDS (2D tile kernel, <= 16 rows per thread); otherwise the
+  // LDS-resident CG when the coarsest grid fits one CU's LDS (2D tile kernel, <= 32 rows per thread); otherwise the
   // caller falls back to the global-memory kernel
   template <typename K> int set_lds_limit(K kern, int slot, size_t lds_bytes) {
     if (!cg_lds_attr_set_[slot]) {
@@ -768,8 +769,8 @@ template <typename T> class Impl : public ImplBase {
     // rows every active wave is guaranteed to own: all of own.R except in the last band
     const int last_rows = own.m - (own.bands - 1) * own.R;
     constexpr int kMaskLast = RT > 1 ? RT - 1 : 0;
-    const bool nearly_full = (own.R == RT) && last_rows >= kMaskLast && own.cb * own.bands == 16;
-    const dim3 one(1), thr(EVOMG_KRYLOV_THREADS);
+    const bool nearly_full = (own.R == RT) && last_rows >= kMaskLast && own.cb * own.bands == own.lanes / 64;
+    const dim3 one(1), thr(own.lanes);
     if (nearly_full) {
       auto kern = evomg_cg_lds2d<T, RT, CB, kMaskLast>;
       int rc = set_lds_limit(kern, 2 * slot, lds_bytes);
@@ -789,18 +790,19 @@ template <typename T> class Impl : public ImplBase {
     if (!use_lds_krylov_) return EVOMG_OK;
     const KrylovOwn own = krylov_own<DIM>(lv.g.n);
     if (DIM == 2) {
-      if (!own.tile || own.R > 16) return EVOMG_OK;
-      // one column block (m <= 64): 16 bands; two column blocks (m <= 128): 8 bands of up to 16 rows
+      if (!own.tile) return EVOMG_OK;
+      // 512 threads = 8 waves: one column block (m <= 64) -> 8 bands; two column blocks (m <= 128) -> 4 bands of <= 32 rows
+      if (own.lanes != 512 || own.R > 32) return EVOMG_OK;
       if (own.cb == 1) {
         if (own.R <= 1) return launch_cg_lds2d<1, 1>(lv, x, b, r, own, 0, launched);
         if (own.R <= 2) return launch_cg_lds2d<2, 1>(lv, x, b, r, own, 1, launched);
         if (own.R <= 4) return launch_cg_lds2d<4, 1>(lv, x, b, r, own, 2, launched);
+        if (own.R <= 8) return launch_cg_lds2d<8, 1>(lv, x, b, r, own, 3, launched);
         return EVOMG_OK;
       }
-      if (own.cb == 2) {
-        if (own.R <= 8) return launch_cg_lds2d<8, 2>(lv, x, b, r, own, 3, launched);
-        return launch_cg_lds2d<16, 2>(lv, x, b, r, own, 4, launched);
-      }
+      if (own.R <= 16) return launch_cg_lds2d<16, 2>(lv, x, b, r, own, 4, launched);
+      // complex 127^2 inner nodes do not fit the LDS anyway (16 B per node)
+      if constexpr (!scalar_traits<T>::is_complex) return launch_cg_lds2d<32, 2>(lv, x, b, r, own, 5, launched);
       return EVOMG_OK;
     }
     return EVOMG_OK;   // 3D: the global-memory kernel with column ownership (z register window)

@@ -37,11 +37,13 @@ __device__ __forceinline__ T apply_stencil_fma(const Stencil<T>& st, const T* __
 }
 
 // ---- canonical node ownership ------------------------------------------------------------------------------------
-// 2D "tile": wave w covers the 64 columns of column block w % cb and the R rows of band w / cb; lane = column,
+// 2D "tile": wave w (of lanes/64) covers the 64 columns of column block w % cb and the R rows of band w / cb; lane = column,
 // rows ascending. Otherwise "strided": thread t owns q = t, t+1024, ... (q x-fastest over the inner nodes).
 // 3D "column" (when m*m <= 1024): thread t owns the z-column (ix, iy) = (t % m, t / m), iz ascending.
+// Workgroup size ("lanes"): 512 threads (8 waves, 256 VGPRs each) for 2D grids up to two column blocks — the LDS
+// kernel then keeps r, x AND A p of 32 rows per thread in registers — 1024 threads otherwise.
 struct KrylovOwn {
-  int tile, column, m, cb, bands, R;
+  int tile, column, m, cb, bands, R, lanes;
   long total;
 };
 template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
@@ -50,8 +52,9 @@ template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
   o.total = (DIM == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
   o.cb = (o.m + 63) / 64;
   o.tile = (DIM == 2 && o.cb <= 16) ? 1 : 0;
-  o.column = (DIM == 3 && (long)o.m * o.m <= EVOMG_KRYLOV_THREADS) ? 1 : 0;
-  o.bands = o.tile ? 16 / o.cb : 0;
+  o.lanes = (o.tile && o.cb <= 2) ? 512 : EVOMG_KRYLOV_THREADS;
+  o.column = (DIM == 3 && (long)o.m * o.m <= o.lanes) ? 1 : 0;
+  o.bands = o.tile ? (o.lanes / 64) / o.cb : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   return o;
 }
@@ -71,7 +74,7 @@ template <int DIM, typename F> __device__ __forceinline__ void own_each(const Ge
     long c = gidx<3>(g, t % o.m + 1, t / o.m + 1, 1);
     for (int i = 0; i < o.m; ++i, c += g.plane) f(c);
   } else {
-    for (long q = threadIdx.x; q < o.total; q += EVOMG_KRYLOV_THREADS) f(inner_index<DIM>(g, q, o.m));
+    for (long q = threadIdx.x; q < o.total; q += o.lanes) f(inner_index<DIM>(g, q, o.m));
   }
 }
 // y = A p at this thread's nodes in canonical order, f(c, (A p)[c]); in the tile / column modes the neighbours along
@@ -286,17 +289,19 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
 //     update instead of being stored (at 1024 threads per CU there are 128 VGPRs per thread);
 //   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
 // LDS image rows: [0] top halo, [1 .. bands*R] node rows (rows >= m+1 are slack = zero), then the bottom halo row(s)
-// reached by the unrolled template rows `rt` >= own.R, then a ZERO REGION of rt+2 rows: lanes whose column does not
-// exist (ix >= m) run on it, so that every value they see is zero and they need no masking at all.
+// reached by the unrolled template rows `rt` >= own.R. Lanes whose column does not exist (ix >= m) point all three of
+// their offsets (centre, west, east) at the east halo column W-1, which is never a node: every value they see is zero
+// and what they write back is zero, so they need no masking at all.
 __host__ __device__ inline long cg_lds2d_rows(const KrylovOwn& o, int rt) { return o.bands * o.R + (rt - o.R) + 2; }
 __host__ __device__ inline long cg_lds2d_elems(const KrylovOwn& o, int rt) {
-  return (cg_lds2d_rows(o, rt) + rt + 2) * (long)(64 * o.cb + 2);
+  return cg_lds2d_rows(o, rt) * (long)(64 * o.cb + 2);
 }
 
 // MASK_FROM: first unrolled row that may lie outside the thread's band (needs masking); rows below it are always
 // nodes of the grid for every active wave (host-checked: the last band keeps at least MASK_FROM rows).
+// Launched with own.lanes = 512 threads: 256 VGPRs per thread hold r, x and A p of up to 32 rows.
 template <typename T, int R, int CB, int MASK_FROM>
-__global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
+__global__ void __launch_bounds__(512)
 evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
                double tol, int* __restrict__ info) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -317,14 +322,15 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   const int rows = active ? max(0, min(own.R, own.m - iy0)) : 0;   // wave-uniform
   const bool col_ok = active && ix < own.m;
   // image offset of the thread's first node: image row iy0+1, image column ix+1; threads without a column work on
-  // the zero region below the image instead
+  // the east halo column instead
   // separate, mutually opaque OFFSETS (not pointers: the accesses must stay in the LDS address space) for the centre,
   // west and east neighbours: keeps the compiler from fusing the reads into ds_read2_b64, which moves bytes at half
   // the rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table)
-  int oc = col_ok ? (iy0 + 1) * W + ix + 1 : (int)(cg_lds2d_rows(own, R) + 1) * W + l + 1;
+  int oc = (iy0 + 1) * W + (col_ok ? ix + 1 : W - 1);
   // even and odd rows go through different (opaque) base registers: reads of vertically adjacent rows then cannot be
   // fused either, and rows two apart are 2*W*8 > 2040 bytes apart, beyond ds_read2's offset range
-  int oc2 = oc, ow = oc - 1, ow2 = oc - 1, oe = oc + 1, oe2 = oc + 1;
+  const int dw = col_ok ? 1 : 0;
+  int oc2 = oc, ow = oc - dw, ow2 = oc - dw, oe = oc + dw, oe2 = oc + dw;
   asm volatile("" : "+v"(oc), "+v"(oc2), "+v"(ow), "+v"(ow2), "+v"(oe), "+v"(oe2));
   T* const pcA = p + oc;
   T* const pcB = p + oc2;
@@ -338,7 +344,7 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   T* const pc0 = pcA;
   const long c0 = gidx<2>(g, min(ix, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
 
-  T r[R], xr[R];
+  T r[R], xr[R], ap[R];
   T loc = zero;
   // branch-free: slots that are not nodes of this thread read a clamped (valid) address and are masked to zero
 #pragma unroll
@@ -357,7 +363,7 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   int it = 0;
   if (res0 != 0.0) {
     for (; it < maxit; ++it) {
-      // ---- pass 1: p . A p ----
+      // ---- pass 1: A p (kept in registers) and p . A p ----
       loc = zero;
       {
         T ps = PC(-1), pc = PC(0);
@@ -372,10 +378,10 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
           if (i >= MASK_FROM) {
             // possibly a slack row below the band: p is zero there but A p is not
             const bool ok = i < rows;
-            loc = sc_fma(ok ? pc : zero, ok ? a : zero, loc);
-          } else {
-            loc = sc_fma(pc, a, loc);
+            a = ok ? a : zero;
           }
+          ap[i] = a;
+          loc = sc_fma(pc, a, loc);
           ps = pc;
           pc = pn;
           if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler look-ahead (VGPR budget)
@@ -384,33 +390,20 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       const T pap = block_sum_fast(loc, red, red_phase);
       const T alpha = sc_div(rr, pap);
       const T nalpha = sc_neg(alpha);
-      // ---- pass 2: x += alpha p ; r -= alpha A p ; r . r ----
+      // ---- pass 2 (p from LDS, the rest from registers): x += alpha p ; r -= alpha A p ; r . r ----
       loc = zero;
-      {
-        T ps = PC(-1), pc = PC(0);
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-          const T pn = PC(i + 1), pw = PW(i), pe = PE(i);
-          T a = sc_mul(st.c[0], pc);
-          a = sc_fma(st.c[1], pw, a);
-          a = sc_fma(st.c[2], pe, a);
-          a = sc_fma(st.c[3], ps, a);
-          a = sc_fma(st.c[4], pn, a);
-          xr[i] = sc_fma(alpha, pc, xr[i]);            // only written back for real nodes
-          T rv = sc_fma(nalpha, a, r[i]);
-          if (i >= MASK_FROM) rv = (i < rows) ? rv : zero;
-          r[i] = rv;
-          loc = sc_fma(rv, rv, loc);
-          ps = pc;
-          pc = pn;
-          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int i = 0; i < R; ++i) {
+        xr[i] = sc_fma(alpha, PC(i), xr[i]);             // only written back for real nodes
+        const T rv = sc_fma(nalpha, ap[i], r[i]);         // slack rows: ap = 0, r stays 0
+        r[i] = rv;
+        loc = sc_fma(rv, rv, loc);
       }
       const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);
-      // ---- pass 3: p = r + beta p on the thread's own nodes (column-less threads rewrite zeros in the zero region) ----
+      // ---- pass 3: p = r + beta p on the thread's own nodes (column-less threads rewrite zeros in the halo column) ----
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         const T pv = sc_fma(beta, PC(i), r[i]);

@@ -425,12 +425,13 @@ static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
 static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_from_dot(FN(dot)(c, level, a, a)); }
 
 /* ---- Krylov solvers on the coarsest grid: node ownership, reduction order and arithmetic ----------------------
- * The HIP solvers run as ONE workgroup of KRYLOV_LANES = 1024 threads = 16 wave64s (csrc/evomg_krylov.h). To make
+ * The HIP solvers run as ONE workgroup of `lanes` = 512 or 1024 threads = 8 or 16 wave64s (csrc/evomg_krylov.h). To make
  * the oracle bit-identical to them (a Krylov recurrence amplifies any difference in summation order up to the
  * attainable-accuracy floor) this block restates
  *   (i) which inner nodes a thread owns and in which order it accumulates them:
  *       2D "tile" ownership (when cb = ceil(m/64) <= 16): wave w covers the 64 columns of column block w % cb and the
- *       R = ceil(m / bands) rows of band w / cb (bands = 16 / cb); lane l owns column 64*(w % cb) + l, rows ascending;
+ *       R = ceil(m / bands) rows of band w / cb (bands = (lanes/64) / cb); lane l owns column 64*(w % cb) + l, rows
+ *       ascending; lanes = 512 when cb <= 2 (grids up to 129^2), else 1024;
  *       3D "column" ownership (when m*m <= 1024): thread t owns the z-column (t % m, t / m), iz ascending;
  *       otherwise (large 3D, or very wide 2D grids) "strided" ownership: thread t owns q = t, t+1024, ... with q running
  *       x-fastest over the inner nodes;
@@ -440,7 +441,7 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *       slots of the device kernels. Pointwise multigrid kernels elsewhere stay unfused. */
 #define KRYLOV_LANES 1024
 typedef struct {
-  int tile, column, m, cb, bands, R, slots;
+  int tile, column, m, cb, bands, R, slots, lanes;
   long total;
 } FN(own_t);
 static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
@@ -449,11 +450,13 @@ static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
   o.total = (c->dim == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
   o.cb = (o.m + 63) / 64;
   o.tile = (c->dim == 2 && o.cb <= 16);
-  o.bands = o.tile ? 16 / o.cb : 0;
+  /* workgroup size: 512 threads (8 waves) for 2D grids up to two column blocks, else KRYLOV_LANES = 1024 */
+  o.lanes = (o.tile && o.cb <= 2) ? 512 : KRYLOV_LANES;
+  o.bands = o.tile ? (o.lanes / 64) / o.cb : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   /* 3D "column" ownership when m*m <= 1024: thread t owns the z-column (t % m, t / m), iz ascending */
-  o.column = (c->dim == 3 && (long)o.m * o.m <= KRYLOV_LANES);
-  o.slots = o.tile ? o.R : o.column ? o.m : (int)((o.total + KRYLOV_LANES - 1) / KRYLOV_LANES);
+  o.column = (c->dim == 3 && (long)o.m * o.m <= o.lanes);
+  o.slots = o.tile ? o.R : o.column ? o.m : (int)((o.total + o.lanes - 1) / o.lanes);
   return o;
 }
 /* dense index of slot i of thread t, or (size_t)-1 if the slot is empty */
@@ -469,7 +472,7 @@ static size_t FN(own_node)(FN(ctx_t)* c, int level, const FN(own_t)* o, int t, i
     if (t >= m * m || i >= m) return (size_t)-1;
     return IDX3(n, t % m + 1, t / m + 1, i + 1);
   }
-  const long q = t + (long)KRYLOV_LANES * i;
+  const long q = t + (long)o->lanes * i;
   if (q >= o->total) return (size_t)-1;
   const int ix = (int)(q % m);
   const long r = q / m;
@@ -483,7 +486,7 @@ static SC FN(tree64)(SC* v) {
 static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
   const FN(own_t) o = FN(own_make)(c, level);
   SC part[KRYLOV_LANES];
-  for (int t = 0; t < KRYLOV_LANES; ++t) {
+  for (int t = 0; t < o.lanes; ++t) {
     SC s = sc_zero();
     for (int i = 0; i < o.slots; ++i) {
       const size_t idx = FN(own_node)(c, level, &o, t, i);
@@ -493,7 +496,7 @@ static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
   }
   SC waves[64];
   for (int w = 0; w < 64; ++w) waves[w] = sc_zero();
-  for (int w = 0; w < KRYLOV_LANES / 64; ++w) waves[w] = FN(tree64)(&part[64 * w]);
+  for (int w = 0; w < o.lanes / 64; ++w) waves[w] = FN(tree64)(&part[64 * w]);
   return FN(tree64)(waves);
 }
 /* fused-multiply-add forms used inside the Krylov solvers */
