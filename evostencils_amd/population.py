@@ -85,6 +85,56 @@ def evaluate_population(evaluate: Callable[[int], Tuple[float, float, float]], n
     return allgather_fitness(mine, n_candidates, world, local_rank)
 
 
+_queue_generation = [0]
+
+
+def _work_queue_store():
+    """The process group's key-value store (the TCPStore torch.distributed rendezvoused on): `add` is an atomic
+    fetch-and-add served by rank 0's store daemon, which is all a work queue needs."""
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+def evaluate_population_dynamic(evaluate: Callable[[int], Tuple[float, float, float]], n_candidates: int,
+                                local_rank: int = 0, store=None):
+    """Same result as `evaluate_population`, but candidates are handed out from a shared counter instead of the fixed
+    `i % world == rank` split: a rank that drew cheap candidates fetches more. Candidates differ ~25x in cost
+    (notebooks/tutorial.ipynb:3360: 2-52 ms per iteration), so the static split leaves GPUs idle at the
+    end of a generation. The data path still has no collective; per candidate there is one fetch-and-add on the
+    rendezvous store (host side, tens of microseconds against solves of tens of milliseconds), and per generation
+    one all-reduce of the [n_candidates x 4] fitness table (each row is written by exactly one rank, the others
+    contribute zeros, so the sum is exact).
+    Returns (rows, evaluated_here): rows = [(i, rho, time_ms, iterations)] for all candidates on every rank."""
+    rank, world = world_info()
+    if world <= 1:
+        rows = []
+        for i in range(n_candidates):
+            t_ms, rho, its = evaluate(i)
+            rows.append((i, float(rho), float(t_ms), float(its)))
+        return rows, list(range(n_candidates))
+    import torch
+    dist = _dist()
+    store = store if store is not None else _work_queue_store()
+    key = "evomg/work_queue/%d" % _queue_generation[0]     # same sequence of calls on every rank -> same key
+    _queue_generation[0] += 1
+    table = torch.zeros((n_candidates, 4), dtype=torch.float64)
+    mine = []
+    while True:
+        i = store.add(key, 1) - 1
+        if i >= n_candidates:
+            break
+        t_ms, rho, its = evaluate(i)
+        table[i] = torch.tensor([1.0, float(rho), float(t_ms), float(its)], dtype=torch.float64)
+        mine.append(i)
+    table = table.to(_device(local_rank))
+    dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    rows = table.cpu().tolist()
+    missing = [i for i, r in enumerate(rows) if r[0] != 1.0]
+    if missing:
+        raise RuntimeError("work queue: candidates %s were evaluated %s" % (missing[:8], "not exactly once"))
+    return [(i, r[1], r[2], r[3]) for i, r in enumerate(rows)], mine
+
+
 class ConcurrentEvaluator:
     """Throughput mode for ONE GPU: `n_workers` independent ProgramGenerator instances (own HIP stream, own set of
     level fields) driven by as many host threads, so that several candidates are in flight on the device at once.

@@ -72,8 +72,55 @@ def test_population_is_sharded_round_robin_and_gathered(n_candidates):
     assert results[1][2] == [(1.5, 2.0, 7.0)]
 
 
+def _dynamic_worker(rank, world, port, n_candidates, queue):
+    import time
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        for generation in range(2):                    # two generations: the queue key must advance
+            def evaluate(i):
+                time.sleep(0.05 if rank == 0 else 0.005)    # rank 0 is the slow GPU
+                return _fake_fitness(i)
+            rows, mine = population.evaluate_population_dynamic(evaluate, n_candidates)
+            out.append((rows, mine))
+        queue.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_candidates", [12, 1])
+def test_dynamic_work_queue_hands_every_candidate_out_once(n_candidates):
+    world = 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dynamic_worker, args=(r, world, port, n_candidates, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, out = queue.get(timeout=120)
+        results[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [(i, 0.1 + 0.001 * i, 10.0 + i, float(5 + i % 3)) for i in range(n_candidates)]
+    for generation in range(2):
+        taken = sorted(results[0][generation][1] + results[1][generation][1])
+        assert taken == list(range(n_candidates))                    # each candidate exactly once
+        for rank in range(world):
+            assert results[rank][generation][0] == expected          # exact: the other rank adds zeros
+        if n_candidates >= 12:
+            assert len(results[1][generation][1]) > len(results[0][generation][1])   # the fast rank drew more
+
+
 def test_single_process_is_identity():
     assert population.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     assert population.gather_fitness([(0.1, 2.0, 3.0)], 1) == [(0.1, 2.0, 3.0)]
     rows = population.evaluate_population(_fake_fitness, 3)
     assert [r[0] for r in rows] == [0, 1, 2]
+    rows, mine = population.evaluate_population_dynamic(_fake_fitness, 3)
+    assert [r[0] for r in rows] == [0, 1, 2] and mine == [0, 1, 2]
