@@ -43,16 +43,6 @@ class CycleStorage:
         self.correction = [Field(f"gen_error_{s.name}", g.level, self) for g, s in zip(grids, fields)]
 
 
-def _read_key_values(path):
-    out = {}
-    with open(path, "r") as fh:
-        for line in fh:
-            if "=" in line and not line.lstrip().startswith("//"):
-                k, v = line.split("=", 1)
-                out[k.strip(" \t")] = v.strip(' \t\n"')
-    return out
-
-
 class ProgramGenerator:
     """Same constructor arguments as the reference (exastencils.py:40-43); the ExaStencils-specific
     ones (compiler path, platform file, compiler timeouts) are accepted and ignored. Either pass the
@@ -90,12 +80,21 @@ class ProgramGenerator:
         if problem is None:
             if base_path is None or settings_path is None or knowledge_path is None:
                 raise ValueError("either `problem` or base_path/settings_path/knowledge_path is required")
-            knowledge = _read_key_values(os.path.join(base_path, knowledge_path))
-            settings = _read_key_values(os.path.join(base_path, settings_path))
+            # the problem files themselves are the source (problem_files.py; the reference needs an ExaStencils run
+            # and its debug layer-3 output for this, parser.py:25-143); problems that enter below layer 2
+            # (Helmholtz: complex fields, Robin boundaries, Krylov outer solver) come from the built-in descriptors
+            from evostencils_amd import problem_files
+            knowledge = problem_files.read_key_values(os.path.join(base_path, knowledge_path))
+            settings = problem_files.resolve_settings(problem_files.read_key_values(os.path.join(base_path, settings_path)))
             config = settings.get("configName")
-            if config not in problems.BY_NAME:
-                raise RuntimeError(f"unknown problem {config!r}; known: {sorted(problems.BY_NAME)}")
-            problem = problems.BY_NAME[config](int(knowledge["minLevel"]), int(knowledge["maxLevel"]))
+            l2_path = os.path.join(base_path, settings.get("basePathPrefix", "."), settings.get("l2file", f"{config}.exa2"))
+            if os.path.exists(l2_path):
+                problem = problem_files.load_problem(base_path, settings_path, knowledge_path)
+            elif config in problems.BY_NAME:
+                problem = problems.BY_NAME[config](int(knowledge["minLevel"]), int(knowledge["maxLevel"]))
+            else:
+                raise RuntimeError(f"problem {config!r} has no layer-2 file and is not a built-in descriptor "
+                                   f"(known: {sorted(problems.BY_NAME)})")
             if int(knowledge["dimensionality"]) != problem.dimension:
                 raise RuntimeError("dimensionality mismatch between knowledge file and problem")
         self._problem = problem
@@ -136,7 +135,8 @@ class ProgramGenerator:
         self._equations, self._operators, self._fields = problem.l2_information()
         d, L = problem.dimension, problem.max_level
         self._coarsening_factor = [(2,) * d for _ in self._fields]
-        self._finest_grid = [base.Grid((2 ** L,) * d, (1 / (2 ** L),) * d, L) for _ in self._fields]
+        step = tuple((hi_ - lo_) / (2 ** L) for lo_, hi_ in zip(problem.domain_lower[:d], problem.domain_upper[:d]))
+        self._finest_grid = [base.Grid((2 ** L,) * d, step, L) for _ in self._fields]
 
     # ---- storage handles (exastencils.py:586-592) -------------------------------------------------
     def generate_storage(self, min_level: int, max_level: int, finest_grids: List[base.Grid]):

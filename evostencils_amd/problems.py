@@ -72,6 +72,8 @@ class ProblemDescription:
     initial_solution: Callable[[int], np.ndarray] = None
     right_hand_side: Callable[[int], np.ndarray] = None
     parameters: Dict[str, complex] = field(default_factory=dict)
+    domain_lower: tuple = (0.0, 0.0, 0.0)
+    domain_upper: tuple = (1.0, 1.0, 1.0)
 
     def nodes(self, level):
         return (1 << level) + 1

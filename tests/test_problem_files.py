@@ -1,0 +1,179 @@
+"""Problem-file front end: `.settings/.knowledge/.exa2/.exa3` -> ProblemDescription without an
+ExaStencils run (the reference needs the compiler's debug layer-3 output, code_generation/parser.py:25-143).
+
+Fixtures under tests/golden/problems/ are this repo's own problems (manufactured solutions), written in the same
+layer-2 dialect; when the reference checkout is present its Poisson files must reproduce the built-in descriptors
+bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, problem_files as pf, problems
+from oracle import oracle
+
+import cycles
+from helpers import context_for
+from evostencils_amd.code_generation.hip import ProgramGenerator
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = os.path.join(HERE, "golden", "problems")
+REFERENCE = "/root/reference/example_problems"
+
+
+def test_expression_evaluator_follows_python_precedence():
+    env = {"PI": np.pi, "x": np.linspace(0.0, 1.0, 7), "h": 0.125}
+    x, h = env["x"], env["h"]
+    cases = {
+        "PI**2 * cos ( PI * x ) - 4.0 * PI**2 * sin ( 2.0 * PI * x )":
+            np.pi ** 2 * np.cos(np.pi * x) - 4.0 * np.pi ** 2 * np.sin(2.0 * np.pi * x),
+        "2.0 / ( h ** 2 ) + 2.0 / ( h ** 2 )": 2.0 / (h ** 2) + 2.0 / (h ** 2),
+        "-x ** 2": -x ** 2,
+        "2 ** -1 ** 2": 2 ** -1 ** 2,
+        "1.5e1 - 3 - 2": 1.5e1 - 3 - 2,
+        "8 / 4 / 2 * 3": 8 / 4 / 2 * 3,
+        "-(x - .5) * +x": -(x - .5) * +x,
+        "sqrt(abs(x - 0.5)) + exp(-x)": np.sqrt(np.abs(x - 0.5)) + np.exp(-x),
+    }
+    for text, want in cases.items():
+        got = pf.Expression(text).evaluate(env)
+        assert np.array_equal(np.asarray(got), np.asarray(want)), text
+    assert pf.Expression("a * (b + c)").names() == {"a", "b", "c"}
+
+
+@pytest.mark.parametrize("text", ["1 +", "foo(2)", "2 $ 3", "(1 + 2", "1 2"])
+def test_bad_expressions_are_reported(text):
+    with pytest.raises(pf.UnsupportedProblem):
+        pf.Expression(text).evaluate({})
+
+
+def test_key_value_files_imports_comments_and_placeholders():
+    k = pf.read_key_values(os.path.join(FIXTURES, "Diffusion", "2D_FD_AnisotropicDiffusion.knowledge"))
+    assert k["dimensionality"] == "2" and k["maxLevel"] == "6"
+    assert k["minLevel"] == "2"                       # the later assignment wins, the comment is dropped
+    assert k["omp_numThreads"] == "4"                 # from the imported file
+    s = pf.resolve_settings(pf.read_key_values(os.path.join(FIXTURES, "Diffusion", "2D_FD_AnisotropicDiffusion.settings")))
+    assert s["l2file"] == "2D_FD_AnisotropicDiffusion.exa2"
+    assert s["outputPath"] == "../generated/2D_FD_AnisotropicDiffusion/"
+
+
+def _load(directory, name, **kw):
+    return pf.load_problem(FIXTURES, f"{directory}/{name}.settings", f"{directory}/{name}.knowledge", **kw)
+
+
+def test_descriptor_of_the_2d_fixture():
+    p = _load("Diffusion", "2D_FD_AnisotropicDiffusion")
+    assert (p.name, p.dimension, p.min_level, p.max_level) == ("2D_FD_AnisotropicDiffusion", 2, 2, 6)
+    assert (p.field_name, p.rhs_name, p.operator_name, p.equation_name) == ("v", "load", "Diffusion", "diffusionEq")
+    assert (p.max_iterations, p.cgs_max_iterations) == (60, 500)
+    assert (p.target_res_reduction, p.cgs_target_res_reduction) == (1e-10, 1e-11)
+    assert p.cgs_kind == abi.CGS_CG and p.scalar_kind == abi.REAL_F64 and p.bc_kind == abi.BC_DIRICHLET
+    for level in (2, 6):
+        h = 1.0 / (1 << level)
+        assert p.mg_stencil(level, {}) == [0.2 / (h ** 2) + 2.0 / (h ** 2), -0.1 / (h ** 2), -0.1 / (h ** 2),
+                                           -1.0 / (h ** 2), -1.0 / (h ** 2), 0.0, 0.0]
+    u0 = p.initial_solution(4)
+    x = np.arange(17) / 16.0
+    assert np.array_equal(u0[0, :], x) and np.array_equal(u0[-1, :], x) and np.all(u0[:, -1] == 1.0)
+    assert np.all(u0[1:-1, 1:-1] == 0.0)
+    f = p.right_hand_side(4)
+    assert f.shape == (17, 17) and f[8, 8] == 1.1 * np.pi ** 2 * np.sin(np.pi * 0.5) * np.sin(np.pi * 0.5)
+    # what the grammar sees (parser.py:25-111): names and per-level stencils
+    eqs, ops, fields = p.l2_information()
+    assert [str(f) for f in fields] == ["v"] and eqs[0].name == "diffusionEq" and eqs[0].rhs_name == "load"
+    assert {o.name for o in ops} == {"Diffusion", "gen_restrictionForRes_v", "gen_prolongationForSol_v"}
+
+
+def test_descriptor_of_the_3d_fixture_level_selectors_and_domain():
+    p = _load("Harmonic", "3D_FD_Harmonic")
+    assert (p.dimension, p.min_level, p.max_level) == (3, 2, 4)
+    assert p.domain_upper == (2.0, 1.0, 1.0)
+    h = [2.0 / 16, 1.0 / 16, 1.0 / 16]
+    assert p.mg_stencil(4, {}) == [2.0 / h[0] ** 2 + 2.0 / h[1] ** 2 + 2.0 / h[2] ** 2, -1.0 / h[0] ** 2, -1.0 / h[0] ** 2,
+                                   -1.0 / h[1] ** 2, -1.0 / h[1] ** 2, -1.0 / h[2] ** 2, -1.0 / h[2] ** 2]
+    u0 = p.initial_solution(4)                    # [i2][i1][i0]; boundary = x*y*z with x in (0,2)
+    assert u0[16, 16, 16] == 2.0 and u0[16, 8, 16] == 2.0 * 0.5 * 1.0 and u0[5, 5, 5] == 0.0
+    assert not p.right_hand_side(4).any()
+    bumped = p.with_levels(3, 5)                  # the optimizer's problem-size bump keeps "finest" = the finest level
+    assert bumped.initial_solution(5)[32, 32, 32] == 2.0
+
+
+def _solve(p, smoother):
+    gen = ProgramGenerator(problem=p, library=object())
+    ctx = context_for(gen, p.min_level, p.max_level)
+    depth = p.max_level - p.min_level
+    expression, _ = cycles.v_cycle(ctx, depth, [smoother] * depth, [smoother] * depth, cgc_index=18)
+    ops = gen.generate_op_program(expression, p.min_level, p.max_level)
+    h = oracle.create(p)
+    out = h.evaluate(ops, 1, 0, p.max_iterations)
+    u = h.get_field(p.max_level, abi.F_SOL)
+    h.close()
+    return out, u
+
+
+def test_2d_fixture_solves_to_the_manufactured_solution():
+    p = _load("Diffusion", "2D_FD_AnisotropicDiffusion", min_level=3, max_level=6)
+    out, u = _solve(p, [("rbgs", 18), ("rbgs", 18)])
+    assert out.status == abi.OK and out.final_res_norm <= 1e-10 * out.init_res_norm
+    x = np.arange(65) / 64.0
+    exact = np.sin(np.pi * x)[None, :] * np.sin(np.pi * x)[:, None] + x[None, :]
+    assert np.max(np.abs(u - exact)) < 5e-4              # second-order discretisation error at h = 1/64
+    coarse, uc = _solve(_load("Diffusion", "2D_FD_AnisotropicDiffusion", min_level=3, max_level=5), [("rbgs", 18), ("rbgs", 18)])
+    xc = np.arange(33) / 32.0
+    exact_c = np.sin(np.pi * xc)[None, :] * np.sin(np.pi * xc)[:, None] + xc[None, :]
+    ratio = np.max(np.abs(uc - exact_c)) / np.max(np.abs(u - exact))
+    assert 3.5 < ratio < 4.5                             # O(h^2)
+
+
+def test_3d_fixture_is_solved_exactly():
+    p = _load("Harmonic", "3D_FD_Harmonic")
+    out, u = _solve(p, [("rbgs", 18)])
+    assert out.status == abi.OK and out.n_iterations < p.max_iterations
+    n = 17
+    x = 2.0 * np.arange(n) / 16.0
+    y = np.arange(n) / 16.0
+    exact = x[None, None, :] * y[None, :, None] * y[:, None, None]
+    assert np.max(np.abs(u - exact)) < 1e-11             # trilinear: no discretisation error
+
+
+@pytest.mark.parametrize("edit, message", [
+    (lambda s: s.replace("[ 1,  0] => -0.1", "[ 1,  1] => -0.1"), "outside the star stencil"),
+    (lambda s: s.replace("with Real on Node", "with Real on Cell", 1), "only `Real on Node`"),
+    (lambda s: s.replace("Diffusion * v == load", "Diffusion * v + v == load"), "is supported"),
+    (lambda s: s.replace("-0.1 / ( vf_gridWidth_x ** 2 )", "-0.1 * vf_nodePos_x / ( vf_gridWidth_x ** 2 )", 1), "constant coefficients"),
+    (lambda s: s + "\nEquation second {\n  Diffusion * v == load\n}\n", "exactly one equation"),
+    (lambda s: s + "\nGlobals { Var k : Real = 1.0 }\n", "not understood"),
+])
+def test_unsupported_constructs_are_named(edit, message):
+    with open(os.path.join(FIXTURES, "Diffusion", "2D_FD_AnisotropicDiffusion.exa2")) as fh:
+        text = edit(fh.read())
+    with pytest.raises(pf.UnsupportedProblem, match=message):
+        pf.describe(pf.parse_layer2(text), "edited", 2, 2, 5, {})
+
+
+def test_program_generator_takes_problem_directories():
+    gen = ProgramGenerator("unused.jar", FIXTURES, "Diffusion/2D_FD_AnisotropicDiffusion.settings",
+                           "Diffusion/2D_FD_AnisotropicDiffusion.knowledge", "unused.platform")
+    assert gen.problem_name == "2D_FD_AnisotropicDiffusion" and gen.dimension == 2
+    assert (gen.min_level, gen.max_level) == (2, 6)
+    assert [str(f) for f in gen.fields] == ["v"]
+    assert gen.finest_grid[0].spacing == (1.0 / 64, 1.0 / 64)
+    gen3 = ProgramGenerator("unused.jar", FIXTURES, "Harmonic/3D_FD_Harmonic.settings", "Harmonic/3D_FD_Harmonic.knowledge")
+    assert gen3.finest_grid[0].spacing == (2.0 / 16, 1.0 / 16, 1.0 / 16)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not present")
+@pytest.mark.parametrize("name, builtin", [("2D_FD_Poisson_fromL2", problems.poisson_2d), ("3D_FD_Poisson_fromL2", problems.poisson_3d)])
+def test_reference_poisson_files_reproduce_the_builtin_descriptors(name, builtin):
+    p = pf.load_problem(REFERENCE, f"Poisson/{name}.settings", f"Poisson/{name}.knowledge")
+    b = builtin()
+    assert (p.name, p.dimension, p.min_level, p.max_level) == (b.name, b.dimension, b.min_level, b.max_level)
+    for attr in ("field_name", "rhs_name", "operator_name", "equation_name", "restriction_name", "prolongation_name",
+                 "max_iterations", "cgs_max_iterations", "target_res_reduction", "cgs_target_res_reduction", "cgs_kind",
+                 "scalar_kind", "bc_kind", "outer_kind"):
+        assert getattr(p, attr) == getattr(b, attr), attr
+    for level in range(b.min_level, b.max_level + 1):
+        assert p.mg_stencil(level, {}) == b.mg_stencil(level, {})
+    L = b.max_level
+    assert np.array_equal(p.initial_solution(L), b.initial_solution(L))
+    assert np.array_equal(p.right_hand_side(L), b.right_hand_side(L))
