@@ -264,11 +264,17 @@ template <typename T> class Impl : public ImplBase {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
+        if (cells == 1 && use_strip3d(lv_[op->level].g, op->partitioning == EVOMG_PART_RED_BLACK)) {
+          if (op->partitioning == EVOMG_PART_RED_BLACK) snprintf(buf, len, "evomg_strip3d_rbgs<%s, 4, %s>", type_name<T>::get(), strip_streams3d(lv_[op->level].g) ? "true" : "false");
+          else snprintf(buf, len, "evomg_strip3d<%s, %d, 4, %s>", type_name<T>::get(), STRIP_JACOBI, strip_streams3d(lv_[op->level].g) ? "true" : "false");
+          return EVOMG_OK;
+        }
         break;
       }
       case EVOMG_OP_RESIDUAL:
         base = "evomg_apply";
         if (use_strip(lv_[op->level].g)) { snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), STRIP_RESIDUAL, strip_streams(lv_[op->level].g) ? "true" : "false"); return EVOMG_OK; }
+        if (use_strip3d(lv_[op->level].g, false)) { snprintf(buf, len, "evomg_strip3d<%s, %d, 4, %s>", type_name<T>::get(), STRIP_RESIDUAL, strip_streams3d(lv_[op->level].g) ? "true" : "false"); return EVOMG_OK; }
         break;
       case EVOMG_OP_RICHARDSON: base = "evomg_richardson"; break;
       case EVOMG_OP_RESTRICT: base = "evomg_restrict"; break;
@@ -558,6 +564,13 @@ template <typename T> class Impl : public ImplBase {
           apply_bc(L, y);
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
+        } else if (use_strip3d(g, op.partitioning == EVOMG_PART_RED_BLACK)) {
+          T* y = lv.alt;
+          if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip3d_rbgs(g, lv.st, x, f, y, om, omm);
+          else launch_strip3d<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
+          apply_bc(L, y);
+          lv.alt = x;
+          set_fieldptr(L, op.dst, y);
         } else if (op.partitioning == EVOMG_PART_RED_BLACK) {
           const dim3 hgrd((g.n / 2 + 1 + 63) / 64, grd.y, grd.z);
           for (int colour = 0; colour < 2; ++colour) {
@@ -698,9 +711,58 @@ template <typename T> class Impl : public ImplBase {
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
   }
 
+  // ---- 3D marching tiles (evomg_strip.h) ---------------------------------------------------------------------------
+  // Measured on MI355X (tools/bench_ops.py poisson3d 7|8|9): the fused two-colour RB-GS tiles beat two colour passes
+  // from 129^3 up (23.6 vs 40 us, 112 vs 220 us, 1.06 vs 1.64 ms). The Jacobi / residual tiles beat the
+  // thread-per-node kernels only where the grid fills the chip AND the halo rows re-read by neighbouring tiles come
+  // out of the 256 MiB Infinity Cache (257^3: 82 vs 105 us); at 513^3 those re-reads cost HBM traffic (rocprofv3
+  // FETCH_SIZE 1.30x) and the plain kernel wins (772 vs 895 us). EVOMG_STRIP3D_MIN_N overrides both rules (tests).
+  bool use_strip3d(const Geo& g, bool red_black) const {
+    if (dim_ != 3 || !strip_enabled_) return false;
+    if (strip3d_min_n_ > 0) return g.n >= strip3d_min_n_;
+    if (red_black) return g.n >= 129;
+    return g.n >= 193 && (double)g.plane * g.n * sizeof(T) <= 256.0 * 1024 * 1024;
+  }
+  template <int MODE> void launch_strip3d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
+    constexpr int TY = 4;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    const int ygroups = ((g.n + TY - 1) / TY + 3) / 4;          // a block = 4 y-adjacent tiles
+    // z chunks: long enough to amortise the two halo planes, short enough for several thousand waves; multiples
+    // of 4 (the kernel's plane ring is unrolled four times)
+    int planes = strip_planes_ > 0 ? strip_planes_ : 64;
+    while (planes > 8 && (long)strips * ygroups * ((g.n + planes - 1) / planes) < 1024) planes /= 2;
+    planes = (planes + 3) & ~3;
+    const int chunks = (g.n + planes - 1) / planes;
+    const int blocks = strips * ygroups * chunks;
+    const dim3 grid(((blocks + 7) / 8) * 8), block(256);
+    const bool nt = strip_streams3d(g);
+    if (strip3d_sync_) {
+      if (nt) hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+      else hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+    } else {
+      if (nt) hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, true, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+      else hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, false, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+    }
+  }
+  void launch_strip3d_rbgs(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
+    constexpr int TY = 4;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    const int ygroups = ((g.n + TY - 1) / TY + 3) / 4;
+    int planes = strip_planes_ > 0 ? strip_planes_ : 64;       // halo: 3 planes per chunk
+    while (planes > 8 && (long)strips * ygroups * ((g.n + planes - 1) / planes) < 1024) planes /= 2;
+    planes = (planes + 3) & ~3;
+    const int chunks = (g.n + planes - 1) / planes;
+    const int blocks = strips * ygroups * chunks;
+    const dim3 grid(((blocks + 7) / 8) * 8), block(256);
+    if (strip_streams3d(g)) hipLaunchKernelGGL((evomg_strip3d_rbgs<T, TY, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+    else hipLaunchKernelGGL((evomg_strip3d_rbgs<T, TY, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+  }
+  bool strip_streams3d(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.plane * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
+
   void residual(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
     const Geo& g = lv_[L].g;
     if (use_strip(g)) { launch_strip<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
+    if (use_strip3d(g, false)) { launch_strip3d<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
     if (dim_ == 2) hipLaunchKernelGGL((evomg_apply<T, 2, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
     else hipLaunchKernelGGL((evomg_apply<T, 3, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
   }
@@ -1004,6 +1066,9 @@ template <typename T> class Impl : public ImplBase {
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
+  int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
+  int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
+  bool strip3d_sync_ = getenv("EVOMG_STRIP3D_SYNC") ? atoi(getenv("EVOMG_STRIP3D_SYNC")) != 0 : true;
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
 };
 

@@ -58,70 +58,96 @@ template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   return o;
 }
-// visits the global indices of this thread's nodes in canonical order
-template <int DIM, typename F> __device__ __forceinline__ void own_each(const Geo& g, const KrylovOwn& o, F&& f) {
+// The thread's node sequence in canonical order as (first index, stride, count); `strided` sequences compute the
+// index per node instead.
+struct OwnWalk {
+  long c0, stride;
+  int count, strided;
+};
+template <int DIM> __device__ __forceinline__ OwnWalk own_walk(const Geo& g, const KrylovOwn& o) {
+  OwnWalk wk{0, 0, 0, 0};
   if (DIM == 2 && o.tile) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int band = w / o.cb, ix = 64 * (w % o.cb) + l;
-    if (band >= o.bands || ix >= o.m) return;
+    if (band >= o.bands || ix >= o.m) return wk;
     const int iy0 = band * o.R;
-    const int rows = min(o.R, o.m - iy0);
-    long c = gidx<2>(g, ix + 1, iy0 + 1, 0);
-    for (int i = 0; i < rows; ++i, c += g.pitch) f(c);
+    wk.count = max(0, min(o.R, o.m - iy0));
+    wk.c0 = gidx<2>(g, ix + 1, iy0 + 1, 0);
+    wk.stride = g.pitch;
   } else if (DIM == 3 && o.column) {
     const int t = threadIdx.x;
-    if (t >= o.m * o.m) return;
-    long c = gidx<3>(g, t % o.m + 1, t / o.m + 1, 1);
-    for (int i = 0; i < o.m; ++i, c += g.plane) f(c);
+    if (t >= o.m * o.m) return wk;
+    wk.count = o.m;
+    wk.c0 = gidx<3>(g, t % o.m + 1, t / o.m + 1, 1);
+    wk.stride = g.plane;
   } else {
-    for (long q = threadIdx.x; q < o.total; q += o.lanes) f(inner_index<DIM>(g, q, o.m));
+    wk.strided = 1;
+    wk.count = (int)((o.total - threadIdx.x + o.lanes - 1) / o.lanes);
+    if ((long)threadIdx.x >= o.total) wk.count = 0;
+  }
+  return wk;
+}
+template <int DIM> __device__ __forceinline__ long own_node_at(const Geo& g, const KrylovOwn& o, const OwnWalk& wk, int i) {
+  if (wk.strided) return inner_index<DIM>(g, threadIdx.x + (long)o.lanes * i, o.m);
+  return wk.c0 + wk.stride * i;
+}
+
+// Batched visit: the whole solve runs on ONE compute unit, so what limits it is memory latency (L2, ~1 us), not
+// bandwidth. `load(c)` (pure loads) is called for a batch of nodes before `use(c, loaded)` consumes them in
+// canonical order: the loads of a batch are all in flight together instead of one node's loads at a time. Slots
+// past the end of the sequence re-load the last node (branch-free, so the compiler keeps counted vmcnt waits) and
+// are skipped by `use`.
+// Batch length: about 32 doubles of loaded values in flight per thread (the 1024-thread workgroup leaves 128 VGPRs).
+template <typename V> struct krylov_batch {
+  static constexpr int doubles = (int)(sizeof(V) / sizeof(double));
+  static constexpr int value = 32 / doubles < 2 ? 2 : (32 / doubles > 8 ? 8 : 32 / doubles);
+};
+template <int DIM, typename V, typename L, typename F>
+__device__ __forceinline__ void own_batched(const Geo& g, const KrylovOwn& o, L&& load, F&& use) {
+  constexpr int B = krylov_batch<V>::value;
+  const OwnWalk wk = own_walk<DIM>(g, o);
+  for (int i0 = 0; i0 < wk.count; i0 += B) {
+    V v[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) v[j] = load(own_node_at<DIM>(g, o, wk, min(i0 + j, wk.count - 1)));
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+      if (i0 + j < wk.count) use(own_node_at<DIM>(g, o, wk, i0 + j), v[j]);
   }
 }
-// y = A p at this thread's nodes in canonical order, f(c, (A p)[c]); in the tile / column modes the neighbours along
-// the marching direction come from a three-value register window instead of two more loads
+// visits the global indices of this thread's nodes in canonical order
+template <int DIM, typename F> __device__ __forceinline__ void own_each(const Geo& g, const KrylovOwn& o, F&& f) {
+  const OwnWalk wk = own_walk<DIM>(g, o);
+  for (int i = 0; i < wk.count; ++i) f(own_node_at<DIM>(g, o, wk, i));
+}
+template <typename T> struct KPair { T a, b; };
+template <typename T> struct KTriple { T a, b, c; };
+template <typename T> struct KQuad { T a, b, c, d; };
+template <typename T, int DIM> struct StencilLoads { T v[2 * DIM + 1]; };
+// y = A p at this thread's nodes in canonical order, f(c, (A p)[c]); same operation order as apply_stencil_fma
 template <typename T, int DIM, typename F>
 __device__ __forceinline__ void own_spmv(const Geo& g, const KrylovOwn& o, const Stencil<T>& st,
                                          const T* __restrict__ p, F&& f) {
-  if (DIM == 2 && o.tile) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int band = w / o.cb, ix = 64 * (w % o.cb) + l;
-    if (band >= o.bands || ix >= o.m) return;
-    const int iy0 = band * o.R;
-    const int rows = min(o.R, o.m - iy0);
-    long c = gidx<2>(g, ix + 1, iy0 + 1, 0);
-    T ps = p[c - g.pitch], pc = p[c];
-    for (int i = 0; i < rows; ++i, c += g.pitch) {
-      const T pn = p[c + g.pitch];
-      T a = sc_mul(st.c[0], pc);
-      a = sc_fma(st.c[1], p[c - 1], a);
-      a = sc_fma(st.c[2], p[c + 1], a);
-      a = sc_fma(st.c[3], ps, a);
-      a = sc_fma(st.c[4], pn, a);
-      f(c, a);
-      ps = pc;
-      pc = pn;
-    }
-  } else if (DIM == 3 && o.column) {
-    const int t = threadIdx.x;
-    if (t >= o.m * o.m) return;
-    long c = gidx<3>(g, t % o.m + 1, t / o.m + 1, 1);
-    T pd = p[c - g.plane], pc = p[c];
-    for (int i = 0; i < o.m; ++i, c += g.plane) {
-      const T pu = p[c + g.plane];
-      T a = sc_mul(st.c[0], pc);
-      a = sc_fma(st.c[1], p[c - 1], a);
-      a = sc_fma(st.c[2], p[c + 1], a);
-      a = sc_fma(st.c[3], p[c - g.pitch], a);
-      a = sc_fma(st.c[4], p[c + g.pitch], a);
-      a = sc_fma(st.c[5], pd, a);
-      a = sc_fma(st.c[6], pu, a);
-      f(c, a);
-      pd = pc;
-      pc = pu;
-    }
-  } else {
-    own_each<DIM>(g, o, [&](long c) { f(c, apply_stencil_fma<T, DIM>(st, p, g, c)); });
-  }
+  own_batched<DIM, StencilLoads<T, DIM>>(g, o,
+    [&](long c) {
+      StencilLoads<T, DIM> s;
+      s.v[0] = p[c];
+      s.v[1] = p[c - 1];
+      s.v[2] = p[c + 1];
+      s.v[3] = p[c - g.pitch];
+      s.v[4] = p[c + g.pitch];
+      if constexpr (DIM == 3) {
+        s.v[5] = p[c - g.plane];
+        s.v[6] = p[c + g.plane];
+      }
+      return s;
+    },
+    [&](long c, const StencilLoads<T, DIM>& s) {
+      T a = sc_mul(st.c[0], s.v[0]);
+#pragma unroll
+      for (int e = 1; e < 2 * DIM + 1; ++e) a = sc_fma(st.c[e], s.v[e], a);
+      f(c, a, s.v[0]);
+    });
 }
 
 template <typename T, bool ROBIN>
@@ -164,25 +190,29 @@ evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict_
   int it = 0;
   for (; it < maxit; ++it) {
     loc = zero;
-    own_spmv<T, DIM>(g, own, st, p, [&](long c, T v) {
+    own_spmv<T, DIM>(g, own, st, p, [&](long c, T v, T pc) {
       ap[c] = v;
-      loc = sc_fma(p[c], v, loc);
+      loc = sc_fma(pc, v, loc);
     });
     const T pap = block_sum(loc, red);
     const T alpha = sc_div(rr, pap);
     const T nalpha = sc_neg(alpha);
     loc = zero;
-    own_each<DIM>(g, own, [&](long c) {
-      x[c] = sc_fma(alpha, p[c], x[c]);
-      const T rv = sc_fma(nalpha, ap[c], r[c]);
-      r[c] = rv;
-      loc = sc_fma(rv, rv, loc);
-    });
+    own_batched<DIM, KQuad<T>>(g, own,
+      [&](long c) { return KQuad<T>{p[c], x[c], ap[c], r[c]}; },
+      [&](long c, const KQuad<T>& q) {
+        x[c] = sc_fma(alpha, q.a, q.b);
+        const T rv = sc_fma(nalpha, q.c, q.d);
+        r[c] = rv;
+        loc = sc_fma(rv, rv, loc);
+      });
     const T rrn = block_sum(loc, red);
     const double res = sc_norm_from_dot(rrn);
     if (!(res > tol * res0)) { ++it; break; }
     const T beta = sc_div(rrn, rr);
-    own_each<DIM>(g, own, [&](long c) { p[c] = sc_fma(beta, p[c], r[c]); });
+    own_batched<DIM, KPair<T>>(g, own,
+      [&](long c) { return KPair<T>{p[c], r[c]}; },
+      [&](long c, const KPair<T>& q) { p[c] = sc_fma(beta, q.a, q.b); });
     rr = rrn;
     __syncthreads();
   }
@@ -193,7 +223,9 @@ template <typename T, int DIM>
 __device__ __forceinline__ T wg_dot(const Geo& g, const KrylovOwn& own, const T* __restrict__ a,
                                     const T* __restrict__ b, T* red) {
   T loc = scalar_traits<T>::zero();
-  own_each<DIM>(g, own, [&](long c) { loc = sc_fma(a[c], b[c], loc); });
+  own_batched<DIM, KPair<T>>(g, own,
+    [&](long c) { return KPair<T>{a[c], b[c]}; },
+    [&](long, const KPair<T>& q) { loc = sc_fma(q.a, q.b, loc); });
   return block_sum(loc, red);
 }
 
@@ -241,33 +273,39 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
     rho_new = wg_dot<T, DIM>(g, own, rhat, r, red);
     beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
     const T nomega = sc_neg(omega);
-    own_each<DIM>(g, own, [&](long c) {
-      const T pv = sc_fma(nomega, nu[c], p[c]);
-      p[c] = sc_fma(beta, pv, r[c]);
-    });
+    own_batched<DIM, KTriple<T>>(g, own,
+      [&](long c) { return KTriple<T>{nu[c], p[c], r[c]}; },
+      [&](long c, const KTriple<T>& q) {
+        const T pv = sc_fma(nomega, q.a, q.b);
+        p[c] = sc_fma(beta, pv, q.c);
+      });
     wg_apply_bc<T, ROBIN>(g, p, kh);
-    own_spmv<T, DIM>(g, own, st, p, [&](long c, T v) { nu[c] = v; });
+    own_spmv<T, DIM>(g, own, st, p, [&](long c, T v, T) { nu[c] = v; });
     __syncthreads();
     alpha = sc_div(rho_new, wg_dot<T, DIM>(g, own, rhat, nu, red));
     const T nalpha = sc_neg(alpha);
-    own_each<DIM>(g, own, [&](long c) {
-      hh[c] = sc_fma(alpha, p[c], x[c]);
-      s[c] = sc_fma(nalpha, nu[c], r[c]);
-    });
+    own_batched<DIM, KQuad<T>>(g, own,
+      [&](long c) { return KQuad<T>{p[c], x[c], nu[c], r[c]}; },
+      [&](long c, const KQuad<T>& q) {
+        hh[c] = sc_fma(alpha, q.a, q.b);
+        s[c] = sc_fma(nalpha, q.c, q.d);
+      });
     wg_apply_bc<T, ROBIN>(g, s, kh);
-    own_spmv<T, DIM>(g, own, st, s, [&](long c, T v) { t[c] = v; });
+    own_spmv<T, DIM>(g, own, st, s, [&](long c, T v, T) { t[c] = v; });
     __syncthreads();
     const T ts = wg_dot<T, DIM>(g, own, t, s, red);
     const T tt = wg_dot<T, DIM>(g, own, t, t, red);
     omega = sc_div(ts, tt);
     const T nomega2 = sc_neg(omega);
     loc = zero;
-    own_each<DIM>(g, own, [&](long c) {
-      x[c] = sc_fma(omega, s[c], hh[c]);
-      const T rv = sc_fma(nomega2, t[c], s[c]);
-      r[c] = rv;
-      loc = sc_fma(rv, rv, loc);
-    });
+    own_batched<DIM, KTriple<T>>(g, own,
+      [&](long c) { return KTriple<T>{s[c], hh[c], t[c]}; },
+      [&](long c, const KTriple<T>& q) {
+        x[c] = sc_fma(omega, q.a, q.b);
+        const T rv = sc_fma(nomega2, q.c, q.a);
+        r[c] = rv;
+        loc = sc_fma(rv, rv, loc);
+      });
     const double res = sc_norm_from_dot(block_sum(loc, red));
     wg_apply_bc<T, ROBIN>(g, x, kh);
     wg_apply_bc<T, ROBIN>(g, r, kh);

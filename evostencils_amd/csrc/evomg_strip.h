@@ -390,3 +390,255 @@ evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__
     x1 = x3;
   }
 }
+
+// ---- 3D marching tiles: Jacobi (K1) and residual (K4) for 7-point stencils -----------------------------------------
+// The 2D strip idea with one more dimension: a wave owns 128 columns (lane = column pair, 16-byte accesses, x
+// neighbours by DPP) x TY rows and marches along z. It keeps a ring of four planes of its tile in registers — k-1, k,
+// k+1 and the prefetched k+2 — each with one halo row above and below (rows y0-1 .. y0+TY), so every plane of x is
+// loaded once per tile, (TY+2)/TY times overall; the halo rows are the neighbouring tiles' own rows, fetched at
+// about the same time by the adjacent waves of the same workgroup (tiles of one workgroup are y-neighbours) and
+// served by L1/L2. The ring is addressed with compile-time indices (the z loop is unrolled four times), so
+// advancing a plane costs no register moves. No LDS, no barriers.
+// Operation order = relax_point / apply_stencil (evomg_kernels.h) = the oracle's FN(relax3) / FN(apply_st3).
+template <typename T>
+__device__ __forceinline__ T relax7(const Stencil<T>& st, T c, T w, T e, T s, T n, T d, T u, T f, double om, double omm) {
+  T r = f;
+  r = sc_sub(r, sc_mul(st.c[1], w));
+  r = sc_sub(r, sc_mul(st.c[2], e));
+  r = sc_sub(r, sc_mul(st.c[3], s));
+  r = sc_sub(r, sc_mul(st.c[4], n));
+  r = sc_sub(r, sc_mul(st.c[5], d));
+  r = sc_sub(r, sc_mul(st.c[6], u));
+  const T xs = sc_div(r, st.c[0]);
+  return sc_add(sc_rmul(omm, c), sc_rmul(om, xs));
+}
+template <typename T>
+__device__ __forceinline__ T residual7(const Stencil<T>& st, T c, T w, T e, T s, T n, T d, T u, T f) {
+  T a = sc_mul(st.c[0], c);
+  a = sc_add(a, sc_mul(st.c[1], w));
+  a = sc_add(a, sc_mul(st.c[2], e));
+  a = sc_add(a, sc_mul(st.c[3], s));
+  a = sc_add(a, sc_mul(st.c[4], n));
+  a = sc_add(a, sc_mul(st.c[5], d));
+  a = sc_add(a, sc_mul(st.c[6], u));
+  return sc_sub(f, a);
+}
+
+// grid: n_blocks (rounded up to a multiple of 8) blocks of 256 threads; block -> (group of 4 y tiles fastest, strip,
+// z chunk), wave w of the block = y tile 4*group + w. The four waves of a block are y neighbours and walk the same
+// planes: SYNC makes them do so in lock step (one barrier per plane), so that a halo row and the neighbour's own
+// copy of it are requested within the same few hundred cycles and meet in L1/L2 instead of being fetched twice.
+template <typename T, int MODE, int TY, bool NT_F, bool SYNC>
+__global__ void __launch_bounds__(256)
+evomg_strip3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
+              double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
+  static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL, "3D tiles: Jacobi and residual");
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (logical_block >= n_blocks) return;                       // whole block: no barrier is left waiting
+  const int lane = threadIdx.x & 63;
+  const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = (logical_block / n_ygroups) % n_strips;
+  const int chunk = logical_block / (n_ygroups * n_strips);
+  const int n = g.n;
+  const long pitch = g.pitch, plane = g.plane;
+  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int y0 = ytile * TY;
+  const int z0 = chunk * planes_per_chunk;
+  const int z1 = min(z0 + planes_per_chunk, n);
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= 1 && lane <= 62 && col_ok;
+  const int c_clamped = min(max(c0, 0), n - 1);
+  // branch-free clamped loads (see evomg_strip2d): whatever an out-of-domain slot delivers only feeds non-inner nodes
+  auto load_x = [&](int row, int pl) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);      // wave-uniform
+    return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+  };
+  auto load_f = [&](int row, int pl) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
+    if constexpr (NT_F) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
+    else return load_pair<T>(f + plane * p + pitch * r + c_clamped);
+  };
+  Pair<T> xr[4][TY + 2];      // ring slot (k + 1) & 3 holds plane k; rows y0-1 .. y0+TY
+  Pair<T> fr[2][TY];          // ring slot k & 1 holds f of plane k; rows y0 .. y0+TY-1
+  // z0 is a multiple of 4 (host side), so ring slots are compile-time constants inside the unrolled loop
+#pragma unroll
+  for (int t = 0; t < TY + 2; ++t) {
+    xr[0][t] = load_x(y0 - 1 + t, z0 - 1);
+    xr[1][t] = load_x(y0 - 1 + t, z0);
+    xr[2][t] = load_x(y0 - 1 + t, z0 + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < TY; ++t) fr[0][t] = load_f(y0 + t, z0);
+
+  for (int kb = z0; kb < z1; kb += 4) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int k = kb + d;
+      if (k < z1) {                                            // uniform over the block (same chunk)
+        if constexpr (SYNC) __syncthreads();
+        // prefetch plane k+2 of x and plane k+1 of f
+#pragma unroll
+        for (int t = 0; t < TY + 2; ++t) xr[(d + 3) & 3][t] = load_x(y0 - 1 + t, k + 2);
+#pragma unroll
+        for (int t = 0; t < TY; ++t) fr[(d + 1) & 1][t] = load_f(y0 + t, k + 1);
+        const Pair<T>* below = xr[d & 3];
+        const Pair<T>* here = xr[(d + 1) & 3];
+        const Pair<T>* above = xr[(d + 2) & 3];
+        const Pair<T>* fk = fr[d & 1];
+        const bool plane_inner = k >= 1 && k <= n - 2;
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          const int row = y0 + t;
+          if (row < n) {                                       // wave-uniform
+            const Pair<T> c = here[t + 1], s = here[t], nn = here[t + 2], dn = below[t + 1], up = above[t + 1];
+            const T wa = from_left(c.b), eb = from_right(c.a);
+            const bool row_inner = plane_inner && row >= 1 && row <= n - 2;
+            T* dst = y + plane * k + pitch * row + c0;
+            Pair<T> out;
+            if constexpr (MODE == STRIP_JACOBI) {
+              out.a = (row_inner && inner_a) ? relax7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
+              out.b = (row_inner && inner_b) ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
+              if (store_lane) store_pair(dst, out);
+            } else {
+              if (row_inner && store_lane) {
+                out.a = residual7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
+                out.b = residual7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
+                if (inner_a && inner_b) store_pair(dst, out);
+                else if (inner_a) dst[0] = out.a;
+                else if (inner_b) dst[1] = out.b;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- 3D fused two-colour red-black Gauss-Seidel (K2), out of place ---------------------------------------------------
+// Same tiles as evomg_strip3d. Marching along z, step k relaxes the RED nodes of plane k from old values and then the
+// BLACK nodes of plane k-1 from the new reds of planes k-2, k-1, k (the 2D kernel's lag, one dimension up). In the y
+// direction there is no lag to exploit, so the wave also relaxes the reds of one halo row below and above its tile
+// (rows y0-1 and y0+TY, needed by its first and last black row) and therefore loads x with a halo of two rows:
+// (TY+4)/TY for x, (TY+2)/TY for f — 16.9 + 12.4 + 8 = 37 B/node at TY = 4 against 48 B/node for two in-place colour
+// passes, and one launch instead of two. Colour 0 = even index sum; c0 is even, so element a of a pair is red iff
+// row + plane is even: static inside the twice-unrolled z loop (y0 and z0 are even).
+// Operation order = relax_point, so the result is bit-identical to the two-pass form (evomg_rbgs_colour x 2).
+template <typename T, int TY, bool NT_F>
+__global__ void __launch_bounds__(256)
+evomg_strip3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
+                   double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
+  static_assert(TY % 2 == 0, "even tile heights keep the colour of a row static");
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (logical_block >= n_blocks) return;
+  const int lane = threadIdx.x & 63;
+  const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = (logical_block / n_ygroups) % n_strips;
+  const int chunk = logical_block / (n_ygroups * n_strips);
+  const int n = g.n;
+  const long pitch = g.pitch, plane = g.plane;
+  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int y0 = ytile * TY;
+  const int z0 = chunk * planes_per_chunk;                     // even (host side)
+  const int z1 = min(z0 + planes_per_chunk, n);
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= 1 && lane <= 62 && col_ok;
+  const int c_clamped = min(max(c0, 0), n - 1);
+  const T zero = scalar_traits<T>::zero();
+  auto load_x = [&](int row, int pl) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
+    return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+  };
+  auto load_f = [&](int row, int pl) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
+    if constexpr (NT_F) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
+    else return load_pair<T>(f + plane * p + pitch * r + c_clamped);
+  };
+  const int ks = z0 - 1;                 // first plane whose reds are relaxed (odd)
+  const int ke = z1 + 1;                 // one past the last
+  Pair<T> xb[TY + 2];                    // old x, plane k-1, rows y0-1 .. y0+TY
+  Pair<T> xc[TY + 4], xa[TY + 4], xq[TY + 4];   // old x, planes k, k+1, k+2 (prefetch), rows y0-2 .. y0+TY+1
+  Pair<T> fb[TY];                        // f, plane k-1, rows y0 .. y0+TY-1
+  Pair<T> fc[TY + 2], fq[TY + 2];        // f, planes k, k+1 (prefetch), rows y0-1 .. y0+TY
+  T r2[TY], r1[TY + 2], rc[TY + 2];      // new reds: plane k-2 (rows y0 ..), planes k-1 and k (rows y0-1 .. y0+TY)
+#pragma unroll
+  for (int t = 0; t < TY + 2; ++t) xb[t] = load_x(y0 - 1 + t, ks - 1);
+#pragma unroll
+  for (int u = 0; u < TY + 4; ++u) {
+    xc[u] = load_x(y0 - 2 + u, ks);
+    xa[u] = load_x(y0 - 2 + u, ks + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < TY + 2; ++t) fc[t] = load_f(y0 - 1 + t, ks);
+#pragma unroll
+  for (int t = 0; t < TY; ++t) { fb[t] = Pair<T>{zero, zero}; r2[t] = zero; }
+#pragma unroll
+  for (int t = 0; t < TY + 2; ++t) r1[t] = zero;
+
+  for (int kb = ks; kb < ke; kb += 2) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int k = kb + d;                                    // d == 0: k odd, d == 1: k even
+      if (k < ke) {
+#pragma unroll
+        for (int u = 0; u < TY + 4; ++u) xq[u] = load_x(y0 - 2 + u, k + 2);
+#pragma unroll
+        for (int t = 0; t < TY + 2; ++t) fq[t] = load_f(y0 - 1 + t, k + 1);
+        const bool plane_inner = k >= 1 && k <= n - 2;
+        // ---- reds of plane k, rows y0-1 .. y0+TY ----
+#pragma unroll
+        for (int t = 0; t < TY + 2; ++t) {
+          const int row = y0 - 1 + t;
+          const bool row_inner = plane_inner && row >= 1 && row <= n - 2;
+          const Pair<T> c = xc[t + 1], s = xc[t], nn = xc[t + 2], dn = xb[t], up = xa[t + 1];
+          // row parity: y0 even => row = y0 - 1 + t has the parity of t + 1; k has the parity of d + 1
+          if (((t + 1 + d + 1) & 1) == 0) {                    // a is red
+            const T w = from_left(c.b);
+            rc[t] = (row_inner && inner_a) ? relax7(st, c.a, w, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
+          } else {                                             // b is red
+            const T e = from_right(c.a);
+            rc[t] = (row_inner && inner_b) ? relax7(st, c.b, c.a, e, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
+          }
+        }
+        // ---- blacks of plane k-1, rows y0 .. y0+TY-1, from the new reds ----
+        const int kbk = k - 1;
+        const bool bplane_inner = kbk >= 1 && kbk <= n - 2;
+        const bool bplane_stored = kbk >= z0 && kbk < z1;
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          const int row = y0 + t;
+          const bool row_inner = bplane_inner && row >= 1 && row <= n - 2;
+          const Pair<T> old = xb[t + 1];
+          const T red = r1[t + 1];
+          Pair<T> out;
+          // row = y0 + t has the parity of t; plane k-1 has the parity of d
+          if (((t + d) & 1) == 0) {                            // a red, b black
+            const T e = from_right(red);
+            const T bl = (row_inner && inner_b) ? relax7(st, old.b, red, e, r1[t], r1[t + 2], r2[t], rc[t + 1], fb[t].b, om, omm) : old.b;
+            out.a = red;
+            out.b = bl;
+          } else {                                             // b red, a black
+            const T w = from_left(red);
+            const T bl = (row_inner && inner_a) ? relax7(st, old.a, w, red, r1[t], r1[t + 2], r2[t], rc[t + 1], fb[t].a, om, omm) : old.a;
+            out.a = bl;
+            out.b = red;
+          }
+          if (store_lane && bplane_stored && row < n) store_pair(y + plane * kbk + pitch * row + c0, out);
+        }
+        // ---- advance one plane ----
+#pragma unroll
+        for (int t = 0; t < TY; ++t) { r2[t] = r1[t + 1]; fb[t] = fc[t + 1]; }
+#pragma unroll
+        for (int t = 0; t < TY + 2; ++t) { r1[t] = rc[t]; xb[t] = xc[t + 1]; fc[t] = fq[t]; }
+#pragma unroll
+        for (int u = 0; u < TY + 4; ++u) { xc[u] = xa[u]; xa[u] = xq[u]; }
+      }
+    }
+  }
+}

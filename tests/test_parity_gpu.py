@@ -328,3 +328,42 @@ def test_marching_strip_kernels_match_generic_kernels(native, pname, level, rows
         h.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("level,planes", [(4, 4), (5, 8), (6, 64), (6, 12), (7, 16), (7, 0)])
+def test_marching_tile_kernels_3d_match_generic_kernels(native, level, planes, monkeypatch):
+    """3D marching-tile kernels (lane = column pair, TY rows per wave, four-plane register ring along z) against the
+    thread-per-node kernels (bit-exact vs the oracle) on grids with partial strips, partial y tiles and several z
+    chunks."""
+    pd = problems.poisson_3d(level - 1, level)
+    rng = np.random.default_rng(level * 100 + planes)
+    shape = ((1 << level) + 1,) * 3
+    x0, f0, r0 = (random_field(rng, shape, False) for _ in range(3))
+    one = (1, 1, 1)
+    seq = [abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.8),
+           abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.1),
+           abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.6),
+           abi.make_op(abi.OP_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS),
+           abi.make_op(abi.OP_RESTRICT, level - 1, abi.F_RHS, abi.F_RES),
+           abi.make_op(abi.OP_SMOOTH, level - 1, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 1.0),
+           abi.make_op(abi.OP_SMOOTH, level - 1, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.0),
+           abi.make_op(abi.OP_PROLONG_ADD, level, abi.F_SOL, abi.F_SOL, omega=0.85),
+           abi.make_op(abi.OP_PROLONG_SET, level, abi.F_CORR, abi.F_SOL)]
+    out = []
+    for strip in (True, False):
+        if strip:
+            monkeypatch.delenv("EVOMG_NO_STRIP", raising=False)
+            monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "9")
+            monkeypatch.setenv("EVOMG_STRIP_PLANES", str(planes))
+        else:
+            monkeypatch.setenv("EVOMG_NO_STRIP", "1")
+        h = native.create(pd)
+        h.set_field(level, abi.F_SOL, x0)
+        h.set_field(level, abi.F_RHS, f0)
+        h.set_field(level, abi.F_RES, r0)
+        h.run_ops(seq)
+        out.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES), h.get_field(level - 1, abi.F_RHS),
+                    h.get_field(level - 1, abi.F_SOL), h.get_field(level, abi.F_CORR)))
+        h.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

@@ -7,8 +7,14 @@ from evostencils_amd import abi, native, problems
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-pd = problems.poisson_2d(level - 1, level)
+kind = sys.argv[3] if len(sys.argv) > 3 else "poisson2d"          # poisson2d | poisson3d
+smoother = sys.argv[4] if len(sys.argv) > 4 else "rbgs"            # rbgs | jacobi | residual
+pd = (problems.poisson_3d if kind == "poisson3d" else problems.poisson_2d)(level - 1, level)
 h = native.create(pd)
-op = abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0)
+if smoother == "residual":
+    op = abi.make_op(abi.OP_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)
+else:
+    op = abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS,
+                     abi.PART_RED_BLACK if smoother == "rbgs" else abi.PART_SINGLE, (1, 1, 1), 1.0)
 h.run_ops([op] * reps)
-print("kernel", h.kernel_name(op), "launches", reps, "nodes", ((1 << level) + 1) ** 2)
+print("kernel", h.kernel_name(op), "launches", reps, "nodes", ((1 << level) + 1) ** pd.dimension)
