@@ -93,6 +93,9 @@ template <typename T> class Impl : public ImplBase {
     if (partials_) (void)hipFree(partials_);
     if (dscalar_) (void)hipFree(dscalar_);
     if (dinfo_) (void)hipFree(dinfo_);
+    if (cg_xpart_) (void)hipFree(cg_xpart_);
+    if (cg_xface_) (void)hipFree(cg_xface_);
+    if (cg_flags_) (void)hipFree(cg_flags_);
     if (hscalar_) (void)hipHostFree(hscalar_);
     for (auto e : prof_events_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -114,6 +117,11 @@ template <typename T> class Impl : public ImplBase {
     HIP_TRY(hipMalloc(&partials_, sizeof(T) * kDotBlocks));
     HIP_TRY(hipMalloc(&dscalar_, sizeof(T) * 8));
     HIP_TRY(hipMalloc(&dinfo_, sizeof(int) * 4));
+    HIP_TRY(hipMemset(dinfo_, 0, sizeof(int) * 4));
+    // multi-workgroup CG exchange area: [2][G] partial sums, [G][2][1024] face planes, [2][G] sequence flags
+    HIP_TRY(hipMalloc(&cg_xpart_, sizeof(T) * 2 * EVOMG_CG_GROUPS));
+    HIP_TRY(hipMalloc(&cg_xface_, sizeof(T) * EVOMG_CG_GROUPS * 2048));
+    HIP_TRY(hipMalloc(&cg_flags_, sizeof(unsigned) * 2 * EVOMG_CG_GROUPS));
     HIP_TRY(hipHostMalloc(&hscalar_, sizeof(T) * 8));
     const int align = 128 / (int)sizeof(T);
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
@@ -187,6 +195,18 @@ template <typename T> class Impl : public ImplBase {
     rc = exec_program(ops, n_ops, /*cyclic=*/false);
     if (rc != EVOMG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream_));
+    return coarse_solver_health();
+  }
+
+  // the multi-workgroup coarse solver reports a missed rendezvous in info[1] instead of hanging
+  int coarse_solver_health() {
+    if (!cg_multi_used_) return EVOMG_OK;
+    int info[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(info, dinfo_, sizeof info, hipMemcpyDeviceToHost));
+    if (info[1] != 0) {
+      snprintf(err, sizeof err, "coarse-grid CG: the %d workgroups did not rendezvous (GPU oversubscribed?)", EVOMG_CG_GROUPS);
+      return EVOMG_ERR_DEVICE;
+    }
     return EVOMG_OK;
   }
 
@@ -225,7 +245,7 @@ template <typename T> class Impl : public ImplBase {
     }
     *out = r;
     out->time_ms = tsum / (double)done;
-    return EVOMG_OK;
+    return coarse_solver_health();
   }
 
   int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) override {
@@ -801,6 +821,23 @@ template <typename T> class Impl : public ImplBase {
         if (dim_ == 2) hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 2, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
         else hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 3, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
       }
+    } else if (!scalar_traits<T>::is_complex && dim_ == 3 && krylov_cg_groups<3>(lv.g.n) > 1) {
+      // 33^3: eight co-resident workgroups (evomg_cg_multi_wg3d); the canonical reduction order of this grid is the
+      // grouped one, so there is no single-workgroup alternative
+      const KrylovOwn own = krylov_own<3>(lv.g.n);
+      const size_t lds_bytes = sizeof(T) * (34 + EVOMG_CG_GROUPS + (size_t)EVOMG_CG_SLAB * (own.m + 2) * (own.m + 2));
+      auto kern = evomg_cg_multi_wg3d<double>;   // complex problems are 2D only
+      if (!cg_multi_attr_set_) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        cg_multi_attr_set_ = true;
+      }
+      cg_multi_used_ = true;
+      HIP_TRY(hipMemsetAsync(cg_flags_, 0, sizeof(unsigned) * 2 * EVOMG_CG_GROUPS, stream_));
+      const int blocks = EVOMG_CG_GROUPS;
+      if constexpr (!scalar_traits<T>::is_complex)
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
+                           prob_.cgs_target_res_reduction, dinfo_, cg_xpart_, cg_xface_, cg_flags_);
+      apply_bc(L, x);
     } else {
       bool launched = false;
       int rc = (dim_ == 2) ? launch_cg_lds<2>(lv, x, b, r, &launched) : launch_cg_lds<3>(lv, x, b, r, &launched);
@@ -1055,6 +1092,11 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  T* cg_xpart_ = nullptr;
+  T* cg_xface_ = nullptr;
+  unsigned* cg_flags_ = nullptr;
+  bool cg_multi_attr_set_ = false;
+  bool cg_multi_used_ = false;
   bool cg_lds_attr_set_[24] = {};
   int prof_opcode_ = -1, prof_level_ = -1;
   size_t prof_used_ = 0;

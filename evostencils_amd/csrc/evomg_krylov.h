@@ -464,3 +464,216 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
 #undef PE
   if (threadIdx.x == 0) info[0] = it;
 }
+
+// ---- CG on 33^3 across EVOMG_CG_GROUPS compute units (3D column ownership, m >= 16) ------------------------------------
+// One CU moves 64 B/clk: with 29 791 unknowns and 17 vector accesses per unknown and iteration the single-workgroup
+// kernel above needs ~60 us per iteration, and the 3D configuration spends half its time there. Here the grid is cut
+// into G slabs of z planes, one 1024-thread workgroup each: thread t owns the column (t % m, t / m) of its slab
+// (<= 4 nodes), so r, x, p and A p of the whole slab live in registers and p additionally in LDS (zero halo image,
+// in-plane neighbours). What crosses workgroups per iteration:
+//   exchange A: the G partial sums of p . A p;
+//   exchange B: the G partial sums of r . r  +  the slab's first and last plane of r.
+// The neighbour planes of p are never sent: p_new = r + beta p_old is recomputed from the neighbour's r plane and the
+// previous neighbour p plane with the same fused multiply-add the owner executes, so it is bit-identical — two
+// grid-wide synchronisations per iteration instead of three.
+// Synchronisation: per workgroup and exchange kind one monotonically increasing sequence flag in global memory;
+// data is published with agent-scope atomic stores, then the flag is released; consumers poll the G flags with
+// acquire loads (bounded: a workgroup that never arrives turns into status info[1] = 1, not a hang). Every workgroup
+// forms the global sums in the same order (group 0, 1, ..., G-1), so all of them take the same branch at the
+// stopping test and leave the loop together. The G workgroups must be co-resident: G = 8 of 256 CUs.
+// Reduction order restated by the oracle: FN(dot_canon) with groups (oracle/evomg_oracle_impl.h).
+#define EVOMG_CG_GROUPS 8
+template <int DIM> __host__ __device__ inline int krylov_cg_groups(int n) {
+  if (DIM != 3) return 1;
+  const KrylovOwn o = krylov_own<3>(n);
+  return (o.column && o.m >= 2 * EVOMG_CG_GROUPS) ? EVOMG_CG_GROUPS : 1;
+}
+#define EVOMG_CG_SLAB 4   // planes per slab: ceil(31 / 8)
+
+__device__ __forceinline__ void krylov_opaque(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void krylov_opaque(cplx& v) { asm volatile("" : "+v"(v.re), "+v"(v.im)); }
+__device__ __forceinline__ void xchg_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xchg_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xchg_store(cplx* p, cplx v) { xchg_store(&p->re, v.re); xchg_store(&p->im, v.im); }
+__device__ __forceinline__ cplx xchg_load(const cplx* p) { return cplx{xchg_load(&p->re), xchg_load(&p->im)}; }
+
+// Exchange protocol (all threads of the workgroup call both functions):
+//   publish: every published value has been written with an agent-scope atomic store; the workgroup barrier orders
+//            those stores before thread 0's agent-scope RELEASE store of the sequence flag;
+//   collect: thread q < G polls flag q with ACQUIRE loads (bounded), then fetches group q's partial sum with an
+//            agent-scope atomic load and parks it in LDS; after the barrier every thread adds the G partial sums in
+//            the order 0 .. G-1. Returns false when a peer did not arrive within the poll budget.
+__device__ __forceinline__ void grid_publish(unsigned* flags, int w, unsigned seq) {
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flags + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ bool grid_collect(const unsigned* flags, const T* part, int groups, unsigned seq,
+                                             T* lds_part, int* lds_flag, T* sum) {
+  if (threadIdx.x == 0) *lds_flag = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < groups) {
+    int budget = 1 << 22;
+    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+      if (--budget == 0) { *lds_flag = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    lds_part[threadIdx.x] = xchg_load(part + threadIdx.x);
+  }
+  __syncthreads();
+  T s = lds_part[0];
+  for (int q = 1; q < groups; ++q) s = sc_add(s, lds_part[q]);
+  *sum = s;
+  return *lds_flag == 0;
+}
+
+// xpart: [2][G] partial sums (A, B); xface: [G][2][1024] first / last r plane of each slab; flags: [2][G], zeroed by the host
+template <typename T>
+__global__ void __launch_bounds__(1024)
+evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
+                    double tol, int* __restrict__ info, T* xpart, T* xface, unsigned* flags) {
+  constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
+  // G blocks land on G different XCDs (blocks are dealt round-robin); packing them onto one XCD (tried: only every
+  // eighth block of a larger grid works) is not faster, the exchanges are latency- not L2-bound
+  const int w = (int)blockIdx.x;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* red = reinterpret_cast<T*>(lds_raw);              // 2 x 16 wave sums
+  int* lds_flag = reinterpret_cast<int*>(red + 32);
+  T* lds_part = red + 34;                              // G partial sums of the current exchange
+  T* img = red + 34 + G;                               // S planes x (m+2) x (m+2), zero halo
+  const KrylovOwn own = krylov_own<3>(g.n);
+  const int m = own.m, W = m + 2, PS = W * W;
+  const int zs = (w * m) / G, ze = ((w + 1) * m) / G, cnt = ze - zs;      // 1 <= cnt <= S (m >= 2 G)
+  const T zero = scalar_traits<T>::zero();
+  for (int i = threadIdx.x; i < S * PS; i += blockDim.x) img[i] = zero;
+  const int t = threadIdx.x;
+  const bool col = t < m * m;
+  const int ix = col ? t % m : 0, iy = col ? t / m : 0;
+  const int o0 = col ? (iy + 1) * W + ix + 1 : 0;      // column-less threads sit on the halo corner (always zero)
+  const long c0 = gidx<3>(g, ix + 1, iy + 1, zs + 1);
+  unsigned* flagA = flags;
+  unsigned* flagB = flags + G;
+  T* partA = xpart;
+  T* partB = xpart + G;
+  T* face_lo = xface + (size_t)w * 2048;               // this slab's first plane of r
+  T* face_hi = face_lo + 1024;                         // ... and last plane
+  __syncthreads();
+
+  T r[S], xr[S], pr[S], ap[S];
+  T loc = zero;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const bool ok = col && i < cnt;
+    const long c = c0 + g.plane * (i < cnt ? i : 0);
+    const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 3>(st, x, g, c)) : zero;
+    r[i] = v;
+    xr[i] = x[c];
+    loc = sc_fma(v, v, loc);
+  }
+  int red_phase = 0;
+  // a[cnt - 1] as a chain of selects over registers; the opaque copies keep the compiler from turning the chain
+  // back into a dynamically indexed (scratch) array
+  auto last_of = [&](const T (&a)[S]) -> T {
+    T v = a[0];
+#pragma unroll
+    for (int i = 1; i < S; ++i) {
+      T cand = a[i];
+      krylov_opaque(cand);
+      v = (i < cnt) ? cand : v;
+    }
+    return v;
+  };
+  // ---- exchange B #0: r . r and the r faces ----
+  unsigned seqA = 0, seqB = 0;
+  bool alive = true;
+  T part = block_sum_fast(loc, red, red_phase);
+  if (t == 0) xchg_store(partB + w, part);
+  if (col) { xchg_store(face_lo + t, r[0]); xchg_store(face_hi + t, last_of(r)); }
+  grid_publish(flagB, w, ++seqB);
+  T rr;
+  alive = grid_collect(flagB, partB, G, seqB, lds_part, lds_flag, &rr);
+  T rn_lo = (col && w > 0) ? xchg_load(xface + (size_t)(w - 1) * 2048 + 1024 + t) : zero;
+  T rn_hi = (col && w < G - 1) ? xchg_load(xface + (size_t)(w + 1) * 2048 + t) : zero;
+  T p_lo = rn_lo, p_hi = rn_hi;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    pr[i] = r[i];
+    if (col && i < cnt) img[i * PS + o0] = r[i];
+  }
+  __syncthreads();
+  const double res0 = sc_norm_from_dot(rr);
+  int it = 0;
+  if (alive && res0 != 0.0) {
+    for (; it < maxit; ++it) {
+      loc = zero;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const bool ok = col && i < cnt;
+        const T* q = img + i * PS + o0;
+        const T pc = pr[i];
+        const T pd = (i == 0) ? p_lo : pr[i - 1];
+        const T pu = (i + 1 < cnt) ? pr[(i + 1 < S) ? i + 1 : i] : p_hi;
+        T a = sc_mul(st.c[0], pc);
+        a = sc_fma(st.c[1], q[-1], a);
+        a = sc_fma(st.c[2], q[1], a);
+        a = sc_fma(st.c[3], q[-W], a);
+        a = sc_fma(st.c[4], q[W], a);
+        a = sc_fma(st.c[5], pd, a);
+        a = sc_fma(st.c[6], pu, a);
+        a = ok ? a : zero;
+        ap[i] = a;
+        loc = sc_fma(pc, a, loc);
+      }
+      part = block_sum_fast(loc, red, red_phase);
+      if (t == 0) xchg_store(partA + w, part);
+      grid_publish(flagA, w, ++seqA);
+      T pap;
+      if (!grid_collect(flagA, partA, G, seqA, lds_part, lds_flag, &pap)) { alive = false; break; }
+      const T alpha = sc_div(rr, pap);
+      const T nalpha = sc_neg(alpha);
+      loc = zero;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        xr[i] = sc_fma(alpha, pr[i], xr[i]);
+        const T rv = sc_fma(nalpha, ap[i], r[i]);
+        r[i] = rv;
+        loc = sc_fma(rv, rv, loc);
+      }
+      part = block_sum_fast(loc, red, red_phase);
+      if (t == 0) xchg_store(partB + w, part);
+      if (col) { xchg_store(face_lo + t, r[0]); xchg_store(face_hi + t, last_of(r)); }
+      grid_publish(flagB, w, ++seqB);
+      T rrn;
+      if (!grid_collect(flagB, partB, G, seqB, lds_part, lds_flag, &rrn)) { alive = false; break; }
+      rn_lo = (col && w > 0) ? xchg_load(xface + (size_t)(w - 1) * 2048 + 1024 + t) : zero;
+      rn_hi = (col && w < G - 1) ? xchg_load(xface + (size_t)(w + 1) * 2048 + t) : zero;
+      const double res = sc_norm_from_dot(rrn);
+      if (!(res > tol * res0)) { ++it; break; }
+      const T beta = sc_div(rrn, rr);
+      p_lo = sc_fma(beta, p_lo, rn_lo);
+      p_hi = sc_fma(beta, p_hi, rn_hi);
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        pr[i] = sc_fma(beta, pr[i], r[i]);
+        if (col && i < cnt) img[i * PS + o0] = pr[i];
+      }
+      rr = rrn;
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+    if (col && i < cnt) {
+      const long c = c0 + g.plane * i;
+      x[c] = xr[i];
+      r_out[c] = r[i];
+    }
+  if (w == 0 && t == 0) {
+    info[0] = it;
+    info[1] = alive ? 0 : 1;
+  }
+}

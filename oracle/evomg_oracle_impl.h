@@ -432,7 +432,8 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *       2D "tile" ownership (when cb = ceil(m/64) <= 16): wave w covers the 64 columns of column block w % cb and the
  *       R = ceil(m / bands) rows of band w / cb (bands = (lanes/64) / cb); lane l owns column 64*(w % cb) + l, rows
  *       ascending; lanes = 512 when cb <= 2 (grids up to 129^2), else 1024;
- *       3D "column" ownership (when m*m <= 1024): thread t owns the z-column (t % m, t / m), iz ascending;
+ *       3D "column" ownership (when m*m <= 1024): thread t owns the z-column (t % m, t / m), iz ascending (CG on 33^3:
+ *       split into 8 slabs of planes, one workgroup each, see dot_canon_grouped);
  *       otherwise (large 3D, or very wide 2D grids) "strided" ownership: thread t owns q = t, t+1024, ... with q running
  *       x-fastest over the inner nodes;
  *  (ii) the reduction tree: wave64 tree with offsets 32,16,8,4,2,1, then the same tree over the 16 wave sums;
@@ -482,6 +483,39 @@ static SC FN(tree64)(SC* v) {
   for (int off = 32; off > 0; off >>= 1)
     for (int l = 0; l < off; ++l) v[l] = sc_add(v[l], v[l + off]);
   return v[0];
+}
+/* CG on 3D column grids with at least 2 planes per group (33^3) runs as KRYLOV_GROUPS = 8 workgroups, one per slab of
+ * z planes [g*m/8, (g+1)*m/8) (csrc/evomg_krylov.h: evomg_cg_multi_wg3d): thread t accumulates its column WITHIN the
+ * slab (iz ascending), each workgroup reduces its 1024 partials with the wave/16-wave trees, and the group sums are
+ * added in the order 0, 1, ..., 7. */
+#define KRYLOV_GROUPS 8
+static int FN(cg_groups)(FN(ctx_t)* c, int level) {
+  const FN(own_t) o = FN(own_make)(c, level);
+  return (c->dim == 3 && o.column && o.m >= 2 * KRYLOV_GROUPS) ? KRYLOV_GROUPS : 1;
+}
+static SC FN(dot_canon_grouped)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
+  const FN(own_t) o = FN(own_make)(c, level);
+  const int n = c->lv[level].n, m = o.m;
+  SC total = sc_zero();
+  for (int g = 0; g < KRYLOV_GROUPS; ++g) {
+    const int zs = (g * m) / KRYLOV_GROUPS, ze = ((g + 1) * m) / KRYLOV_GROUPS;
+    SC part[KRYLOV_LANES];
+    for (int t = 0; t < KRYLOV_LANES; ++t) {
+      SC s = sc_zero();
+      if (t < m * m)
+        for (int iz = zs; iz < ze; ++iz) {
+          const size_t idx = IDX3(n, t % m + 1, t / m + 1, iz + 1);
+          s = sc_fma(a[idx], b[idx], s);
+        }
+      part[t] = s;
+    }
+    SC waves[64];
+    for (int w = 0; w < 64; ++w) waves[w] = sc_zero();
+    for (int w = 0; w < KRYLOV_LANES / 64; ++w) waves[w] = FN(tree64)(&part[64 * w]);
+    const SC gs = FN(tree64)(waves);
+    total = (g == 0) ? gs : sc_add(total, gs);
+  }
+  return total;
 }
 static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
   const FN(own_t) o = FN(own_make)(c, level);
@@ -592,8 +626,10 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   SC* r = FN(field)(c, L, EVOMG_F_RES);
   SC* p = FN(tmpvec)(c, L, 0);
   SC* ap = FN(tmpvec)(c, L, 1);
+  const int grouped = FN(cg_groups)(c, L) > 1;
+#define CG_DOT(u, v) (grouped ? FN(dot_canon_grouped)(c, L, u, v) : FN(dot_canon)(c, L, u, v))
   FN(krylov_apply)(c, L, lv->st, x, b, r, 1);
-  SC rr = FN(dot_canon)(c, L, r, r);
+  SC rr = CG_DOT(r, r);
   const double res0 = sc_norm_from_dot(rr);
   if (res0 == 0.0) return 0;
   /* p = r on the inner nodes; p keeps its homogeneous boundary (an error-type field) */
@@ -601,11 +637,11 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   int it = 0;
   for (; it < c->prob.cgs_max_iterations; ++it) {
     FN(krylov_apply)(c, L, lv->st, p, NULL, ap, 0);
-    const SC pap = FN(dot_canon)(c, L, p, ap);
+    const SC pap = CG_DOT(p, ap);
     const SC alpha = sc_div(rr, pap);
     FN(krylov_axpy)(c, L, x, alpha, p, x);
     FN(krylov_axpy)(c, L, r, sc_neg(alpha), ap, r);
-    const SC rr_new = FN(dot_canon)(c, L, r, r);
+    const SC rr_new = CG_DOT(r, r);
     const double res = sc_norm_from_dot(rr_new);
     if (!(res > c->prob.cgs_target_res_reduction * res0)) { ++it; break; }
     const SC beta = sc_div(rr_new, rr);
@@ -614,6 +650,7 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   }
   FN(apply_bc)(c, L, x);
   if (getenv("EVOMG_ORACLE_DEBUG")) fprintf(stderr, "[oracle] coarse CG: %d iterations (cap %d)\n", it, c->prob.cgs_max_iterations);
+#undef CG_DOT
   return it;
 }
 

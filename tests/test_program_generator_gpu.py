@@ -102,3 +102,34 @@ def test_helmholtz_wavenumber_sweep(native):
     got = total / 3
     assert got[2] == want[2]
     assert got[1] == pytest.approx(want[1], rel=1e-6)
+
+
+def test_concurrent_3d_candidates_with_multi_workgroup_coarse_solver(native):
+    """Throughput mode on 3D problems: each candidate's coarse solve on 33^3 is EIGHT co-resident workgroups that
+    rendezvous through global memory (evomg_cg_multi_wg3d). Four candidates in flight must neither dead-lock nor
+    change any result (every handle has its own exchange area)."""
+    from evostencils_amd import population
+    lo, hi = 5, 6
+    pd = problems.poisson_3d(lo, hi)
+
+    def make():
+        g = ProgramGenerator(problem=pd, library=native.library())
+        g.initialize_code_generation(lo, hi)
+        return g
+
+    specs = [[("jacobi", 12)], [("rbgs", 18)], [("jacobi", 14), ("jacobi", 14)], [("rbgs", 21)], [("block", 12, (2, 1, 1))],
+             [("rbgs", 16), ("jacobi", 12)]] * 2
+
+    def evaluate(gen, spec):
+        ctx = context_for(gen, lo, hi)
+        expression, _ = cycles.v_cycle(ctx, hi - lo, [spec] * (hi - lo), [spec] * (hi - lo))
+        return gen.generate_and_evaluate(expression, None, lo, hi, "", infinity=INF, evaluation_samples=1)
+
+    solo = make()
+    want = [evaluate(solo, s) for s in specs]
+    solo.close()
+    workers = population.ConcurrentEvaluator(make, 4)
+    got = workers.map(evaluate, specs)
+    workers.close()
+    for (t0, rho0, its0), (t1, rho1, its1) in zip(want, got):
+        assert its0 == its1 and rho0 == rho1 and its0 < INF
