@@ -698,6 +698,23 @@ template <typename T> class Impl : public ImplBase {
   template <int DIM> void launch_block_fast(int cells, dim3 grid, dim3 block, const Geo& g, const Stencil<T>& st, const T* x,
                                             const T* f, T* y, double om, double omm, int bx, int by, int bz, int tx, int ty, int tz) {
     const BlockPlan<T> pl = make_block_plan<T, DIM>(st, bx, by, bz);
+    // the shapes with one or two cells per dimension get their own instantiation (compile-time shape)
+#define EVOMG_BJ_STATIC(BX, BY, BZ)                                                                                        \
+    if (bx == BX && by == BY && (DIM == 2 || bz == BZ)) {                                                                  \
+      hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, BX * BY * BZ, BX, BY, BZ>), grid, block, 0, stream_, g, st, pl,  \
+                         x, f, y, om, omm, tx, ty, tz);                                                                    \
+      return;                                                                                                              \
+    }
+    EVOMG_BJ_STATIC(2, 1, 1)
+    EVOMG_BJ_STATIC(1, 2, 1)
+    EVOMG_BJ_STATIC(2, 2, 1)
+    if (DIM == 3) {
+      EVOMG_BJ_STATIC(1, 1, 2)
+      EVOMG_BJ_STATIC(2, 1, 2)
+      EVOMG_BJ_STATIC(1, 2, 2)
+      EVOMG_BJ_STATIC(2, 2, 2)
+    }
+#undef EVOMG_BJ_STATIC
     switch (cells) {
       case 2: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 2>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;
       case 3: hipLaunchKernelGGL((evomg_block_jacobi_fast<T, DIM, 3>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, tx, ty, tz); break;

@@ -208,7 +208,10 @@ template <typename T, int DIM> inline BlockPlan<T> make_block_plan(const Stencil
   }
   return pl;
 }
-template <typename T, int DIM, int M>
+// BX, BY, BZ > 0: the tile shape is a compile-time constant (the common shapes), so cell offsets and the
+// inside-the-tile tests fold away and the compiler merges the x-adjacent cells' accesses into 16-byte loads/stores;
+// BX == 0: shape taken from the plan at run time (any other shape with <= 8 cells).
+template <typename T, int DIM, int M, int BX = 0, int BY = 0, int BZ = 0>
 __global__ void __launch_bounds__(256) evomg_block_jacobi_fast(Geo g, Stencil<T> st, BlockPlan<T> pl, const T* __restrict__ x,
                                                                const T* __restrict__ f, T* __restrict__ y, double om,
                                                                double omm, int tx, int ty, int tz) {
@@ -217,22 +220,34 @@ __global__ void __launch_bounds__(256) evomg_block_jacobi_fast(Geo g, Stencil<T>
   const int tk = (DIM == 3) ? (int)blockIdx.z : 0;
   if (ti >= tx || tj >= ty || tk >= tz) return;
   const int n = g.n;
-  const int i0 = 1 + ti * pl.bx, j0 = 1 + tj * pl.by, k0 = (DIM == 3) ? 1 + tk * pl.bz : 0;
-  if (i0 + pl.bx > n - 1 || j0 + pl.by > n - 1 || (DIM == 3 && k0 + pl.bz > n - 1)) return;   // truncated: generic kernel
+  constexpr bool kStatic = BX > 0;
+  const int bx = kStatic ? BX : pl.bx, by = kStatic ? BY : pl.by, bz = kStatic ? BZ : pl.bz;
+  const int i0 = 1 + ti * bx, j0 = 1 + tj * by, k0 = (DIM == 3) ? 1 + tk * bz : 0;
+  if (i0 + bx > n - 1 || j0 + by > n - 1 || (DIM == 3 && k0 + bz > n - 1)) return;   // truncated: generic kernel
   const long base = gidx<DIM>(g, i0, j0, k0);
   T r[M];
   long gc[M];
 #pragma unroll
   for (int p = 0; p < M; ++p) {
-    gc[p] = base + pl.ci[p] + (long)g.pitch * pl.cj[p] + g.plane * pl.ck[p];
+    // unknown order: i0 outermost (make_block_plan)
+    const int ci = kStatic ? p / (BY * BZ > 0 ? BY * BZ : 1) : pl.ci[p];
+    const int cj = kStatic ? (p / (BZ > 0 ? BZ : 1)) % (BY > 0 ? BY : 1) : pl.cj[p];
+    const int ck = kStatic ? p % (BZ > 0 ? BZ : 1) : pl.ck[p];
+    const bool in1 = kStatic ? ci - 1 >= 0 : pl.inside[p][1];
+    const bool in2 = kStatic ? ci + 1 < BX : pl.inside[p][2];
+    const bool in3 = kStatic ? cj - 1 >= 0 : pl.inside[p][3];
+    const bool in4 = kStatic ? cj + 1 < BY : pl.inside[p][4];
+    const bool in5 = kStatic ? ck - 1 >= 0 : pl.inside[p][5];
+    const bool in6 = kStatic ? ck + 1 < BZ : pl.inside[p][6];
+    gc[p] = base + ci + (long)g.pitch * cj + g.plane * ck;
     T s = f[gc[p]];
-    if (!pl.inside[p][1]) s = sc_sub(s, sc_mul(st.c[1], x[gc[p] - 1]));
-    if (!pl.inside[p][2]) s = sc_sub(s, sc_mul(st.c[2], x[gc[p] + 1]));
-    if (!pl.inside[p][3]) s = sc_sub(s, sc_mul(st.c[3], x[gc[p] - g.pitch]));
-    if (!pl.inside[p][4]) s = sc_sub(s, sc_mul(st.c[4], x[gc[p] + g.pitch]));
+    if (!in1) s = sc_sub(s, sc_mul(st.c[1], x[gc[p] - 1]));
+    if (!in2) s = sc_sub(s, sc_mul(st.c[2], x[gc[p] + 1]));
+    if (!in3) s = sc_sub(s, sc_mul(st.c[3], x[gc[p] - g.pitch]));
+    if (!in4) s = sc_sub(s, sc_mul(st.c[4], x[gc[p] + g.pitch]));
     if (DIM == 3) {
-      if (!pl.inside[p][5]) s = sc_sub(s, sc_mul(st.c[5], x[gc[p] - g.plane]));
-      if (!pl.inside[p][6]) s = sc_sub(s, sc_mul(st.c[6], x[gc[p] + g.plane]));
+      if (!in5) s = sc_sub(s, sc_mul(st.c[5], x[gc[p] - g.plane]));
+      if (!in6) s = sc_sub(s, sc_mul(st.c[6], x[gc[p] + g.plane]));
     }
     r[p] = s;
   }
