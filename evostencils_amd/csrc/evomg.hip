@@ -298,7 +298,11 @@ template <typename T> class Impl : public ImplBase {
         break;
       case EVOMG_OP_RICHARDSON: base = "evomg_richardson"; break;
       case EVOMG_OP_RESTRICT: base = "evomg_restrict"; break;
-      case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: base = "evomg_prolong"; break;
+      case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET:
+        base = "evomg_prolong";
+        if (use_strip(lv_[op->level].g)) { snprintf(buf, len, "evomg_strip_prolong<%s, %s>", type_name<T>::get(), op->opcode == EVOMG_OP_PROLONG_ADD ? "true" : "false"); return EVOMG_OK; }
+        if (dim_ == 3 && strip_enabled_) { snprintf(buf, len, "evomg_prolong_cell3d<%s, %s>", type_name<T>::get(), op->opcode == EVOMG_OP_PROLONG_ADD ? "true" : "false"); return EVOMG_OK; }
+        break;
       case EVOMG_OP_SET_ZERO: base = "evomg_zero_inner"; break;
       case EVOMG_OP_COPY: base = "hipMemcpyAsync"; break;
       case EVOMG_OP_COARSE_SOLVE: base = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? "evomg_bicgstab_single_wg" : "evomg_cg_single_wg"; break;
@@ -636,6 +640,11 @@ template <typename T> class Impl : public ImplBase {
         T* fz = fieldptr(L, op.dst);
         if (use_strip(g) && cz != fz) {
           launch_strip_prolong(L, cz, fz, op.opcode == EVOMG_OP_PROLONG_ADD, op.omega);
+        } else if (dim_ == 3 && strip_enabled_) {
+          const int cells = gc.n - 1;
+          const dim3 cgrid((cells + 63) / 64, (cells + 3) / 4, cells);
+          if (op.opcode == EVOMG_OP_PROLONG_ADD) hipLaunchKernelGGL((evomg_prolong_cell3d<T, true>), cgrid, blk, 0, stream_, g, gc, cz, fz, op.omega);
+          else hipLaunchKernelGGL((evomg_prolong_cell3d<T, false>), cgrid, blk, 0, stream_, g, gc, cz, fz, 1.0);
         } else if (op.opcode == EVOMG_OP_PROLONG_ADD) {
           if (dim_ == 2) hipLaunchKernelGGL((evomg_prolong<T, 2, true>), grd, blk, 0, stream_, g, gc, cz, fz, op.omega);
           else hipLaunchKernelGGL((evomg_prolong<T, 3, true>), grd, blk, 0, stream_, g, gc, cz, fz, op.omega);

@@ -386,6 +386,58 @@ __global__ void __launch_bounds__(256) evomg_prolong(Geo gf, Geo gc, const T* __
   fine[c] = ACC ? sc_add(fine[c], sc_rmul(om, v)) : v;
 }
 
+// 3D, coarse-CELL driven: thread (I, J, K) owns the 2x2x2 fine nodes (2I+a, 2J+b, 2K+c) of one coarse cell. It loads
+// the cell's 8 corner values once (instead of up to 8 loads for every fine node) and touches the fine array in
+// x-adjacent pairs (2I, 2I+1): aligned 16-byte accesses. Sums are formed exactly as interpolate<T,3> forms them
+// (start from zero, add corners in dz, dy, dx order, scale once), so the result is bit-identical to evomg_prolong.
+// Only fine index 0 needs masking (a = 0 with I = 0 etc.): 2I+1 <= n-2 for every cell and n-1 is never produced.
+// grid: (ceil(cells/64), ceil(cells/4), cells), cells = coarse n - 1
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256) evomg_prolong_cell3d(Geo gf, Geo gc, const T* __restrict__ coarse, T* __restrict__ fine, double om) {
+  const int I = blockIdx.x * blockDim.x + threadIdx.x;
+  const int J = blockIdx.y * blockDim.y + threadIdx.y;
+  const int K = blockIdx.z;
+  const int cells = gc.n - 1;
+  if (I >= cells || J >= cells || K >= cells) return;
+  T cv[2][2][2];
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) cv[dz][dy][dx] = coarse[gidx<3>(gc, I + dx, J + dy, K + dz)];
+  const T zero = scalar_traits<T>::zero();
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = 2 * J + b, k = 2 * K + c;
+      if (j < 1 || k < 1) continue;                     // boundary row / plane of the fine grid
+      T s0 = zero, s1 = zero;
+#pragma unroll
+      for (int dz = 0; dz <= c; ++dz)
+#pragma unroll
+        for (int dy = 0; dy <= b; ++dy) {
+          s0 = sc_add(s0, cv[dz][dy][0]);
+          s1 = sc_add(s1, cv[dz][dy][0]);
+          s1 = sc_add(s1, cv[dz][dy][1]);
+        }
+      const double w0 = (b + c == 0) ? 1.0 : (b + c == 1) ? 0.5 : 0.25;
+      const T v0 = sc_rmul(w0, s0), v1 = sc_rmul(0.5 * w0, s1);
+      T* dst = fine + gidx<3>(gf, 2 * I, j, k);
+      if (ACC) {
+        const T o0 = dst[0], o1 = dst[1];
+        const T n1 = sc_add(o1, sc_rmul(om, v1));
+        const T n0 = (I >= 1) ? sc_add(o0, sc_rmul(om, v0)) : o0;
+        dst[0] = n0;
+        dst[1] = n1;
+      } else {
+        if (I >= 1) dst[0] = v0;
+        dst[1] = v1;
+      }
+    }
+}
+
 // ---- K7: zero the inner nodes ---------------------------------------------------------------------------------
 template <typename T, int DIM>
 __global__ void __launch_bounds__(256) evomg_zero_inner(Geo g, T* __restrict__ x) {
