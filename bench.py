@@ -58,11 +58,13 @@ def cpu_baseline(ops, lo, hi, threads):
         h.evaluate(ops, 1, 0, 128)
         wall4 = time.time() - t0
     h.close()
-    return {"value": 1.0 / wall, "unit": "solves/s", "cores": threads, "kind": "port",
-            "sample": f"1 full solve of the same workload ({int(out.n_iterations)} V-cycles, {wall:.1f} s wall, "
+    # report the faster of the two as the baseline (memory-bound sweeps do not always scale to all host cores)
+    best_wall, best_threads = (wall4, 4) if (wall4 is not None and wall4 < wall) else (wall, threads)
+    return {"value": 1.0 / best_wall, "unit": "solves/s", "cores": best_threads, "kind": "port",
+            "sample": f"1 full solve of the same workload ({int(out.n_iterations)} V-cycles, {best_wall:.1f} s wall, "
                       f"gcc -O3 -fopenmp -ffp-contract=off)",
             "iterations": out.n_iterations, "final_res_norm": out.final_res_norm,
-            "value_4_threads": (1.0 / wall4) if wall4 else None}
+            "by_threads": {str(threads): 1.0 / wall, **({"4": 1.0 / wall4} if wall4 else {})}}
 
 
 def main():

@@ -888,21 +888,22 @@ template <typename T> class Impl : public ImplBase {
     (void)lds_bytes;
     return EVOMG_OK;
   }
-  template <int RT, int CB> int launch_cg_lds2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
-    const size_t lds_bytes = (size_t)(cg_lds2d_elems(own, RT) + 32) * sizeof(T);
-    if (lds_bytes > 160 * 1024 || own.cb != CB) return EVOMG_OK;
-    // rows every active wave is guaranteed to own: all of own.R except in the last band
+  template <int RT, int E> int launch_cg_lds2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
+    const size_t lds_bytes = (size_t)(cg_lds2d_elems(RT, E) + 32) * sizeof(T);
+    // the kernel assumes one band per wave of the 512-thread workgroup and exactly RT rows per band
+    if (lds_bytes > 160 * 1024 || own.lanes != 512 || own.bands != 8 || own.R != RT || E != (own.pair ? 2 : 1)) return EVOMG_OK;
+    // rows every wave is guaranteed to own: all of own.R except in the last band(s)
     const int last_rows = own.m - (own.bands - 1) * own.R;
     constexpr int kMaskLast = RT > 1 ? RT - 1 : 0;
-    const bool nearly_full = (own.R == RT) && last_rows >= kMaskLast && own.cb * own.bands == own.lanes / 64;
+    const bool nearly_full = last_rows >= kMaskLast;
     const dim3 one(1), thr(own.lanes);
     if (nearly_full) {
-      auto kern = evomg_cg_lds2d<T, RT, CB, kMaskLast>;
+      auto kern = evomg_cg_lds2d<T, RT, E, kMaskLast>;
       int rc = set_lds_limit(kern, 2 * slot, lds_bytes);
       if (rc != EVOMG_OK) return rc;
       hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
     } else {
-      auto kern = evomg_cg_lds2d<T, RT, CB, 0>;
+      auto kern = evomg_cg_lds2d<T, RT, E, 0>;
       int rc = set_lds_limit(kern, 2 * slot + 1, lds_bytes);
       if (rc != EVOMG_OK) return rc;
       hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
@@ -915,22 +916,22 @@ template <typename T> class Impl : public ImplBase {
     if (!use_lds_krylov_) return EVOMG_OK;
     const KrylovOwn own = krylov_own<DIM>(lv.g.n);
     if (DIM == 2) {
-      if (!own.tile) return EVOMG_OK;
-      // 512 threads = 8 waves: one column block (m <= 64) -> 8 bands; two column blocks (m <= 128) -> 4 bands of <= 32 rows
-      if (own.lanes != 512 || own.R > 32) return EVOMG_OK;
-      if (own.cb == 1) {
-        if (own.R <= 1) return launch_cg_lds2d<1, 1>(lv, x, b, r, own, 0, launched);
-        if (own.R <= 2) return launch_cg_lds2d<2, 1>(lv, x, b, r, own, 1, launched);
-        if (own.R <= 4) return launch_cg_lds2d<4, 1>(lv, x, b, r, own, 2, launched);
-        if (own.R <= 8) return launch_cg_lds2d<8, 1>(lv, x, b, r, own, 3, launched);
+      if (!own.tile || own.lanes != 512) return EVOMG_OK;
+      // 512 threads = 8 waves = 8 bands; up to 65^2: one column per lane, 129^2: a column pair per lane
+      if (!own.pair) {
+        if (own.R == 1) return launch_cg_lds2d<1, 1>(lv, x, b, r, own, 0, launched);
+        if (own.R == 2) return launch_cg_lds2d<2, 1>(lv, x, b, r, own, 1, launched);
+        if (own.R == 4) return launch_cg_lds2d<4, 1>(lv, x, b, r, own, 2, launched);
+        if (own.R == 8) return launch_cg_lds2d<8, 1>(lv, x, b, r, own, 3, launched);
         return EVOMG_OK;
       }
-      if (own.R <= 16) return launch_cg_lds2d<16, 2>(lv, x, b, r, own, 4, launched);
-      // complex 127^2 inner nodes do not fit the LDS anyway (16 B per node)
-      if constexpr (!scalar_traits<T>::is_complex) return launch_cg_lds2d<32, 2>(lv, x, b, r, own, 5, launched);
+      // complex 127^2: 48 values of 16 B per thread do not fit the register file
+      if constexpr (!scalar_traits<T>::is_complex) {
+        if (own.R == 16) return launch_cg_lds2d<16, 2>(lv, x, b, r, own, 4, launched);
+      }
       return EVOMG_OK;
     }
-    return EVOMG_OK;   // 3D: the global-memory kernel with column ownership (z register window)
+    return EVOMG_OK;   // 3D: evomg_cg_multi_wg3d (33^3) or the global-memory kernel with column ownership
   }
 
   // ---- reductions ----------------------------------------------------------------------------------------------------

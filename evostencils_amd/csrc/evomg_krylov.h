@@ -38,12 +38,13 @@ __device__ __forceinline__ T apply_stencil_fma(const Stencil<T>& st, const T* __
 
 // ---- canonical node ownership ------------------------------------------------------------------------------------
 // 2D "tile": wave w (of lanes/64) covers the 64 columns of column block w % cb and the R rows of band w / cb; lane = column,
-// rows ascending. Otherwise "strided": thread t owns q = t, t+1024, ... (q x-fastest over the inner nodes).
+// rows ascending. 2D "pair" tile (two column blocks): wave w = band w, lane l owns columns 2l and 2l+1, visited row by
+// row (row i: column 2l, then 2l+1). Otherwise "strided": thread t owns q = t, t+1024, ... (q x-fastest over the inner nodes).
 // 3D "column" (when m*m <= 1024): thread t owns the z-column (ix, iy) = (t % m, t / m), iz ascending.
 // Workgroup size ("lanes"): 512 threads (8 waves, 256 VGPRs each) for 2D grids up to two column blocks — the LDS
 // kernel then keeps r, x AND A p of 32 rows per thread in registers — 1024 threads otherwise.
 struct KrylovOwn {
-  int tile, column, m, cb, bands, R, lanes;
+  int tile, pair, column, m, cb, bands, R, lanes;
   long total;
 };
 template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
@@ -52,9 +53,13 @@ template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
   o.total = (DIM == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
   o.cb = (o.m + 63) / 64;
   o.tile = (DIM == 2 && o.cb <= 16) ? 1 : 0;
+  // "pair" tiles (65 <= m <= 128, i.e. 129^2): a lane owns the column PAIR (2l, 2l+1), a wave spans the whole width
+  // and is one band. The horizontal neighbours of a node are then the lane's other element or ONE DPP shift away,
+  // which is what lets the register-resident CG below run without touching memory for them.
+  o.pair = (o.tile && o.cb == 2) ? 1 : 0;
   o.lanes = (o.tile && o.cb <= 2) ? 512 : EVOMG_KRYLOV_THREADS;
   o.column = (DIM == 3 && (long)o.m * o.m <= o.lanes) ? 1 : 0;
-  o.bands = o.tile ? (o.lanes / 64) / o.cb : 0;
+  o.bands = o.tile ? (o.pair ? o.lanes / 64 : (o.lanes / 64) / o.cb) : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   return o;
 }
@@ -62,16 +67,18 @@ template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
 // index per node instead.
 struct OwnWalk {
   long c0, stride;
-  int count, strided;
+  int count, strided, ncol;    // ncol: nodes per step of `stride` (2 for a lane that owns a column pair)
 };
 template <int DIM> __device__ __forceinline__ OwnWalk own_walk(const Geo& g, const KrylovOwn& o) {
-  OwnWalk wk{0, 0, 0, 0};
+  OwnWalk wk{0, 0, 0, 0, 1};
   if (DIM == 2 && o.tile) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int band = w / o.cb, ix = 64 * (w % o.cb) + l;
+    const int band = o.pair ? w : w / o.cb;
+    const int ix = o.pair ? 2 * l : 64 * (w % o.cb) + l;
     if (band >= o.bands || ix >= o.m) return wk;
     const int iy0 = band * o.R;
-    wk.count = max(0, min(o.R, o.m - iy0));
+    wk.ncol = (o.pair && ix + 1 < o.m) ? 2 : 1;
+    wk.count = max(0, min(o.R, o.m - iy0)) * wk.ncol;
     wk.c0 = gidx<2>(g, ix + 1, iy0 + 1, 0);
     wk.stride = g.pitch;
   } else if (DIM == 3 && o.column) {
@@ -89,6 +96,7 @@ template <int DIM> __device__ __forceinline__ OwnWalk own_walk(const Geo& g, con
 }
 template <int DIM> __device__ __forceinline__ long own_node_at(const Geo& g, const KrylovOwn& o, const OwnWalk& wk, int i) {
   if (wk.strided) return inner_index<DIM>(g, threadIdx.x + (long)o.lanes * i, o.m);
+  if (wk.ncol == 2) return wk.c0 + wk.stride * (i >> 1) + (i & 1);
   return wk.c0 + wk.stride * i;
 }
 
@@ -315,88 +323,81 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
   if (threadIdx.x == 0) info[0] = it;
 }
 
-// ---- CG with the search direction resident in LDS (2D tile ownership) ----------------------------------------------
-// For coarsest grids up to 129^2 (real) the whole iteration runs out of LDS + registers:
-//   * p lives in LDS as an image of (bands*R + 2) rows x (64*cb + 2) columns with a zero halo (the homogeneous boundary
-//     of an error-type field plus the slack of incomplete tiles), so the SpMV needs no boundary tests;
-//   * a thread owns R consecutive rows of one column: the LDS addresses of all its nodes are base + constant, i.e.
-//     immediate offsets (no per-node address arithmetic), consecutive lanes hit consecutive banks, and the south /
-//     north neighbours are the thread's own previous / next node, kept in a three-value register window: 3 LDS reads
-//     per node and SpMV (centre of the next row, west, east) instead of 5;
-//   * the residual r and the iterate x of the thread's nodes stay in registers; A p is recomputed for the residual
-//     update instead of being stored (at 1024 threads per CU there are 128 VGPRs per thread);
+// ---- CG held in registers (2D tile ownership) ------------------------------------------------------------------------
+// For coarsest grids up to 129^2 (real) one 512-thread workgroup (8 waves = 8 bands of rows) runs the whole solve out
+// of registers:
+//   * a thread owns R rows of E columns (E = 2: the column pair of a "pair" tile, R = 16 at 129^2; E = 1 up to 65^2)
+//     and keeps p, r and A p of all of them in registers (192 of its 256 VGPRs); south / north neighbours are the
+//     thread's own previous / next row;
+//   * west / east neighbours are the lane's other element or live in the adjacent lane: ONE DPP wave shift per
+//     element pair and direction, no memory access (an LDS-resident p was bound by LDS bandwidth: 6 accesses x 8 B
+//     per node and iteration = 2.5 us of a 3.4 us iteration; single-column lanes with DPP were VALU bound by the
+//     shifts). What is left in LDS:
+//       - x, thread-private, touched once per iteration (x += alpha p): LDS as spill space, conflict-free layout;
+//       - the band seams: every wave publishes its first and last row of p after each update, 2 KB, and reads the
+//         neighbouring bands' rows once per iteration;
+//   * column-less elements and slack rows keep p = r = 0 by construction: their alpha is zero (per-lane copy of the
+//     step length), and A p of slack rows is forced to zero; nothing else needs masking;
 //   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
-// LDS image rows: [0] top halo, [1 .. bands*R] node rows (rows >= m+1 are slack = zero), then the bottom halo row(s)
-// reached by the unrolled template rows `rt` >= own.R. Lanes whose column does not exist (ix >= m) point all three of
-// their offsets (centre, west, east) at the east halo column W-1, which is never a node: every value they see is zero
-// and what they write back is zero, so they need no masking at all.
-__host__ __device__ inline long cg_lds2d_rows(const KrylovOwn& o, int rt) { return o.bands * o.R + (rt - o.R) + 2; }
-__host__ __device__ inline long cg_lds2d_elems(const KrylovOwn& o, int rt) {
-  return cg_lds2d_rows(o, rt) * (long)(64 * o.cb + 2);
-}
+// Arithmetic and summation order are those of evomg_cg_single_wg with the same ownership, and of the oracle.
+// LDS (elements of T): 32 reduction slots | row seams [8 waves][first, last][E][64] | x [R * E][512].
+__host__ __device__ inline long cg_lds2d_elems(int rt, int e) { return 32 + 8L * 2 * e * 64 + (long)rt * e * 512; }
 
 // MASK_FROM: first unrolled row that may lie outside the thread's band (needs masking); rows below it are always
-// nodes of the grid for every active wave (host-checked: the last band keeps at least MASK_FROM rows).
-// Launched with own.lanes = 512 threads: 256 VGPRs per thread hold r, x and A p of up to 32 rows.
-template <typename T, int R, int CB, int MASK_FROM>
+// rows of the grid for every wave (host-checked: own.R == R and the last band keeps at least MASK_FROM rows).
+template <typename T, int R, int E, int MASK_FROM>
 __global__ void __launch_bounds__(512)
 evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
                double tol, int* __restrict__ info) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
-  T* p = red + 32;
+  T* row_seam = red + 32;                          // [wave][0: first row, 1: row R-1][element][lane]
+  T* xs = row_seam + 8 * 2 * E * 64;               // [row * E + element][thread]
   const KrylovOwn own = krylov_own<2>(g.n);
-  constexpr int W = 64 * CB + 2;                   // row stride of the LDS image: compile-time, so that every node's
-                                                   // LDS address is base + immediate offset (own.cb == CB, host-checked)
-  const long lds_elems = cg_lds2d_elems(own, R);
   const T zero = scalar_traits<T>::zero();
-  for (long i = threadIdx.x; i < lds_elems; i += blockDim.x) p[i] = zero;
-  __syncthreads();
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int band = w;                              // host-checked: own.bands == 8 waves, E == (own.pair ? 2 : 1)
+  const int iy0 = band * own.R;
+  const int rows = max(0, min(own.R, own.m - iy0));   // wave-uniform
+  const int ix0 = E * l;
+  bool ok_e[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) ok_e[e] = ix0 + e < own.m;
+  const bool has_south = band > 0, has_north = band + 1 < own.bands;       // wave-uniform
+  const T* south_src = row_seam + (((w - 1) * 2 + 1) * E) * 64 + l;          // row R-1 of the band below
+  const T* north_src = row_seam + (((w + 1) * 2) * E) * 64 + l;              // first row of the band above
+  T* const my_seam = row_seam + ((w * 2) * E) * 64 + l;
+  T* const myx = xs + tid;
+  const long c0 = gidx<2>(g, min(ix0, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
 
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int band = w / own.cb, ix = 64 * (w % own.cb) + l;
-  const bool active = band < own.bands;            // wave-uniform: waves beyond cb*bands own nothing
-  const int iy0 = active ? band * own.R : 0;
-  const int rows = active ? max(0, min(own.R, own.m - iy0)) : 0;   // wave-uniform
-  const bool col_ok = active && ix < own.m;
-  // image offset of the thread's first node: image row iy0+1, image column ix+1; threads without a column work on
-  // the east halo column instead
-  // separate, mutually opaque OFFSETS (not pointers: the accesses must stay in the LDS address space) for the centre,
-  // west and east neighbours: keeps the compiler from fusing the reads into ds_read2_b64, which moves bytes at half
-  // the rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table)
-  int oc = (iy0 + 1) * W + (col_ok ? ix + 1 : W - 1);
-  // even and odd rows go through different (opaque) base registers: reads of vertically adjacent rows then cannot be
-  // fused either, and rows two apart are 2*W*8 > 2040 bytes apart, beyond ds_read2's offset range
-  const int dw = col_ok ? 1 : 0;
-  int oc2 = oc, ow = oc - dw, ow2 = oc - dw, oe = oc + dw, oe2 = oc + dw;
-  asm volatile("" : "+v"(oc), "+v"(oc2), "+v"(ow), "+v"(ow2), "+v"(oe), "+v"(oe2));
-  T* const pcA = p + oc;
-  T* const pcB = p + oc2;
-  const T* const pwA = p + ow;
-  const T* const pwB = p + ow2;
-  const T* const peA = p + oe;
-  const T* const peB = p + oe2;
-#define PC(i) (((i) & 1) ? pcB : pcA)[(i) * W]
-#define PW(i) (((i) & 1) ? pwB : pwA)[(i) * W]
-#define PE(i) (((i) & 1) ? peB : peA)[(i) * W]
-  T* const pc0 = pcA;
-  const long c0 = gidx<2>(g, min(ix, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
-
-  T r[R], xr[R], ap[R];
+  T r[R][E], p[R][E], ap[R][E];
   T loc = zero;
   // branch-free: slots that are not nodes of this thread read a clamped (valid) address and are masked to zero
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const bool ok = col_ok && i < rows;
-    const long c = c0 + (long)g.pitch * (i < rows ? i : 0);
-    const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
-    r[i] = v;
-    xr[i] = x[c];
-    if (ok) pc0[i * W] = v;
-    loc = sc_fma(v, v, loc);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool ok = ok_e[e] && i < rows;
+      const long c = c0 + (long)g.pitch * (i < rows ? i : 0) + (ok_e[e] ? e : 0);
+      const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
+      r[i][e] = v;
+      p[i][e] = v;
+      myx[(i * E + e) * 512] = x[c];
+      loc = sc_fma(v, v, loc);
+    }
+    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
+  auto publish_seams = [&]() {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      my_seam[e * 64] = p[0][e];
+      my_seam[(E + e) * 64] = p[R - 1][e];
+    }
+  };
+  publish_seams();
   int red_phase = 0;
-  T rr = block_sum_fast(loc, red, red_phase);
+  T rr = block_sum_fast(loc, red, red_phase);      // its barrier also publishes the seams
   const double res0 = sc_norm_from_dot(rr);
   int it = 0;
   if (res0 != 0.0) {
@@ -404,64 +405,80 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       // ---- pass 1: A p (kept in registers) and p . A p ----
       loc = zero;
       {
-        T ps = PC(-1), pc = PC(0);
+        T south_in[E], north_in[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          south_in[e] = has_south ? south_src[e * 64] : zero;
+          north_in[e] = has_north ? north_src[e * 64] : zero;
+        }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const T pn = PC(i + 1), pw = PW(i), pe = PE(i);
-          T a = sc_mul(st.c[0], pc);
-          a = sc_fma(st.c[1], pw, a);
-          a = sc_fma(st.c[2], pe, a);
-          a = sc_fma(st.c[3], ps, a);
-          a = sc_fma(st.c[4], pn, a);
-          if (i >= MASK_FROM) {
-            // possibly a slack row below the band: p is zero there but A p is not
-            const bool ok = i < rows;
-            a = ok ? a : zero;
+          const T from_w = from_left(p[i][E - 1]);      // west of the lane's first element
+          const T from_e = from_right(p[i][0]);         // east of the lane's last element
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const T pc = p[i][e];
+            const T pw = (e == 0) ? from_w : p[i][e > 0 ? e - 1 : 0];
+            const T pe = (e == E - 1) ? from_e : p[i][e < E - 1 ? e + 1 : e];
+            const T ps = (i == 0) ? south_in[e] : p[i > 0 ? i - 1 : 0][e];
+            const T pn = (i == R - 1) ? north_in[e] : p[i < R - 1 ? i + 1 : i][e];
+            T a = sc_mul(st.c[0], pc);
+            a = sc_fma(st.c[1], pw, a);
+            a = sc_fma(st.c[2], pe, a);
+            a = sc_fma(st.c[3], ps, a);
+            a = sc_fma(st.c[4], pn, a);
+            if (i >= MASK_FROM) a = (i < rows) ? a : zero;   // slack row: p is zero there but the stencil sum is not
+            ap[i][e] = a;
+            loc = sc_fma(pc, a, loc);                        // column-less elements: p = 0, contributes exactly 0
           }
-          ap[i] = a;
-          loc = sc_fma(pc, a, loc);
-          ps = pc;
-          pc = pn;
           if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler look-ahead (VGPR budget)
         }
       }
       const T pap = block_sum_fast(loc, red, red_phase);
       const T alpha = sc_div(rr, pap);
       const T nalpha = sc_neg(alpha);
-      // ---- pass 2 (p from LDS, the rest from registers): x += alpha p ; r -= alpha A p ; r . r ----
+      T alpha_e[E], nalpha_e[E];                   // zero step for column-less elements: their r, p and x never move
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        alpha_e[e] = ok_e[e] ? alpha : zero;
+        nalpha_e[e] = ok_e[e] ? nalpha : zero;
+      }
+      // ---- pass 2: x += alpha p (LDS) ; r -= alpha A p ; r . r ----
       loc = zero;
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        xr[i] = sc_fma(alpha, PC(i), xr[i]);             // only written back for real nodes
-        const T rv = sc_fma(nalpha, ap[i], r[i]);         // slack rows: ap = 0, r stays 0
-        r[i] = rv;
-        loc = sc_fma(rv, rv, loc);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          myx[(i * E + e) * 512] = sc_fma(alpha_e[e], p[i][e], myx[(i * E + e) * 512]);
+          const T rv = sc_fma(nalpha_e[e], ap[i][e], r[i][e]);     // slack rows: A p = 0, r stays 0
+          r[i][e] = rv;
+          loc = sc_fma(rv, rv, loc);
+        }
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-      const T rrn = block_sum_fast(loc, red, red_phase);   // its barrier: all reads of p are done before p is rewritten
+      const T rrn = block_sum_fast(loc, red, red_phase);    // its barrier: all seam reads of pass 1 are done
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);
-      // ---- pass 3: p = r + beta p on the thread's own nodes (column-less threads rewrite zeros in the halo column) ----
+      // ---- pass 3: p = r + beta p in registers; publish the seams ----
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const T pv = sc_fma(beta, PC(i), r[i]);
-        if (i >= MASK_FROM) { if (i < rows) PC(i) = pv; }
-        else PC(i) = pv;
-      }
+      for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[i][e] = sc_fma(beta, p[i][e], r[i][e]);
+      publish_seams();
       rr = rrn;
       __syncthreads();
     }
   }
 #pragma unroll
   for (int i = 0; i < R; ++i)
-    if (col_ok && i < rows) {
-      const long c = c0 + (long)g.pitch * i;
-      x[c] = xr[i];
-      r_out[c] = r[i];
-    }
-#undef PC
-#undef PW
-#undef PE
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (ok_e[e] && i < rows) {
+        const long c = c0 + (long)g.pitch * i + e;
+        x[c] = myx[(i * E + e) * 512];
+        r_out[c] = r[i][e];
+      }
   if (threadIdx.x == 0) info[0] = it;
 }
 

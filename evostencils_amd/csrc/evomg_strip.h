@@ -27,19 +27,6 @@ template <typename T> struct Pair {
   T a, b;
 };
 
-__device__ __forceinline__ int dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
-// value held by lane-1 (lane 0 receives 0)
-__device__ __forceinline__ double from_left(double v) {
-  return __hiloint2double(dpp_shr1(__double2hiint(v)), dpp_shr1(__double2loint(v)));
-}
-// value held by lane+1 (lane 63 receives 0)
-__device__ __forceinline__ double from_right(double v) {
-  return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
-}
-__device__ __forceinline__ cplx from_left(cplx v) { return cplx{from_left(v.re), from_left(v.im)}; }
-__device__ __forceinline__ cplx from_right(cplx v) { return cplx{from_right(v.re), from_right(v.im)}; }
-
 template <typename T> __device__ __forceinline__ Pair<T> load_pair(const T* __restrict__ p);
 template <> __device__ __forceinline__ Pair<double> load_pair<double>(const double* __restrict__ p) {
   const double2 v = *reinterpret_cast<const double2*>(p);

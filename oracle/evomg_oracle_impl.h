@@ -431,7 +431,8 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *   (i) which inner nodes a thread owns and in which order it accumulates them:
  *       2D "tile" ownership (when cb = ceil(m/64) <= 16): wave w covers the 64 columns of column block w % cb and the
  *       R = ceil(m / bands) rows of band w / cb (bands = (lanes/64) / cb); lane l owns column 64*(w % cb) + l, rows
- *       ascending; lanes = 512 when cb <= 2 (grids up to 129^2), else 1024;
+ *       ascending; lanes = 512 when cb <= 2 (grids up to 129^2), else 1024; with cb = 2 ("pair" tiles) wave w is band w
+ *       and lane l owns the columns 2l, 2l+1, row by row;
  *       3D "column" ownership (when m*m <= 1024): thread t owns the z-column (t % m, t / m), iz ascending (CG on 33^3:
  *       split into 8 slabs of planes, one workgroup each, see dot_canon_grouped);
  *       otherwise (large 3D, or very wide 2D grids) "strided" ownership: thread t owns q = t, t+1024, ... with q running
@@ -442,7 +443,7 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *       slots of the device kernels. Pointwise multigrid kernels elsewhere stay unfused. */
 #define KRYLOV_LANES 1024
 typedef struct {
-  int tile, column, m, cb, bands, R, slots, lanes;
+  int tile, pair, column, m, cb, bands, R, slots, lanes;
   long total;
 } FN(own_t);
 static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
@@ -453,16 +454,27 @@ static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
   o.tile = (c->dim == 2 && o.cb <= 16);
   /* workgroup size: 512 threads (8 waves) for 2D grids up to two column blocks, else KRYLOV_LANES = 1024 */
   o.lanes = (o.tile && o.cb <= 2) ? 512 : KRYLOV_LANES;
-  o.bands = o.tile ? (o.lanes / 64) / o.cb : 0;
+  /* "pair" tiles (two column blocks, i.e. 129^2): wave w = band w, lane l owns the columns 2l and 2l+1 and visits
+   * them row by row (row i: column 2l, then 2l+1) */
+  o.pair = (o.tile && o.cb == 2);
+  o.bands = o.tile ? (o.pair ? o.lanes / 64 : (o.lanes / 64) / o.cb) : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   /* 3D "column" ownership when m*m <= 1024: thread t owns the z-column (t % m, t / m), iz ascending */
   o.column = (c->dim == 3 && (long)o.m * o.m <= o.lanes);
-  o.slots = o.tile ? o.R : o.column ? o.m : (int)((o.total + o.lanes - 1) / o.lanes);
+  o.slots = o.pair ? 2 * o.R : o.tile ? o.R : o.column ? o.m : (int)((o.total + o.lanes - 1) / o.lanes);
   return o;
 }
 /* dense index of slot i of thread t, or (size_t)-1 if the slot is empty */
 static size_t FN(own_node)(FN(ctx_t)* c, int level, const FN(own_t)* o, int t, int i) {
   const int n = c->lv[level].n, m = o->m;
+  if (o->pair) {
+    const int w = t >> 6, l = t & 63;
+    if (w >= o->bands || 2 * l >= m) return (size_t)-1;
+    const int ncol = (2 * l + 1 < m) ? 2 : 1;
+    const int row = i / ncol, ix = 2 * l + i % ncol, iy = w * o->R + row;
+    if (row >= o->R || iy >= m) return (size_t)-1;
+    return IDX2(n, ix + 1, iy + 1);
+  }
   if (o->tile) {
     const int w = t >> 6, l = t & 63;
     const int band = w / o->cb, ix = 64 * (w % o->cb) + l, iy = band * o->R + i;
