@@ -458,8 +458,8 @@ __global__ void __launch_bounds__(256) evomg_robin_bc(Geo g, cplx* __restrict__ 
 }
 
 // ---- neighbouring lanes by DPP wave shifts (no LDS round trip) -----------------------------------------------------
-__device__ __forceinline__ int dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // bound_ctrl: lanes without a source read 0
+__device__ __forceinline__ int dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 // value held by lane-1 (lane 0 receives 0)
 __device__ __forceinline__ double from_left(double v) {
   return __hiloint2double(dpp_shr1(__double2hiint(v)), dpp_shr1(__double2loint(v)));
@@ -468,18 +468,6 @@ __device__ __forceinline__ double from_left(double v) {
 __device__ __forceinline__ double from_right(double v) {
   return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
 }
-// same, but lane 0 / lane 63 (which have no neighbour in the wave) receive THEIR OWN element of `edge` instead of 0:
-// the DPP shift leaves the destination untouched where the source lane does not exist (bound_ctrl off)
-__device__ __forceinline__ int dpp_shr1_keep(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_shl1_keep(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ double from_left_or(double edge, double v) {
-  return __hiloint2double(dpp_shr1_keep(__double2hiint(edge), __double2hiint(v)), dpp_shr1_keep(__double2loint(edge), __double2loint(v)));
-}
-__device__ __forceinline__ double from_right_or(double edge, double v) {
-  return __hiloint2double(dpp_shl1_keep(__double2hiint(edge), __double2hiint(v)), dpp_shl1_keep(__double2loint(edge), __double2loint(v)));
-}
-__device__ __forceinline__ cplx from_left_or(cplx e, cplx v) { return cplx{from_left_or(e.re, v.re), from_left_or(e.im, v.im)}; }
-__device__ __forceinline__ cplx from_right_or(cplx e, cplx v) { return cplx{from_right_or(e.re, v.re), from_right_or(e.im, v.im)}; }
 __device__ __forceinline__ cplx from_left(cplx v) { return cplx{from_left(v.re), from_left(v.im)}; }
 __device__ __forceinline__ cplx from_right(cplx v) { return cplx{from_right(v.re), from_right(v.im)}; }
 

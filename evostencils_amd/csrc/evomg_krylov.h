@@ -334,8 +334,9 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
 //     per node and iteration = 2.5 us of a 3.4 us iteration; single-column lanes with DPP were VALU bound by the
 //     shifts). What is left in LDS:
 //       - x, thread-private, touched once per iteration (x += alpha p): LDS as spill space, conflict-free layout;
-//       - the band seams: every wave publishes its first and last row of p after each update, 2 KB, and reads the
-//         neighbouring bands' rows once per iteration;
+//       - the band seams: every wave publishes its first and last row of r before the r . r reduction and reads the
+//         neighbouring bands' rows after it (2 KB); the neighbours' p rows are recomputed, not exchanged, so an
+//         iteration has exactly two barriers (the two reductions);
 //   * column-less elements and slack rows keep p = r = 0 by construction: their alpha is zero (per-lane copy of the
 //     step length), and A p of slack rows is forced to zero; nothing else needs masking;
 //   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
@@ -388,16 +389,31 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
     }
     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
+  // Band seams: what crosses waves is the first and the last row of r, published before the r . r reduction (its
+  // barrier makes them visible). The neighbouring bands' rows of p are never exchanged: p_new = r + beta p_old is
+  // recomputed from the neighbour's r row and the previous neighbour p row with the very fused multiply-add the
+  // owner executes (bit-identical), which saves the barrier a p exchange would need after every update of p.
   auto publish_seams = [&]() {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      my_seam[e * 64] = p[0][e];
-      my_seam[(E + e) * 64] = p[R - 1][e];
+      my_seam[e * 64] = r[0][e];
+      my_seam[(E + e) * 64] = r[R - 1][e];
+    }
+  };
+  T p_south[E], p_north[E], r_south[E], r_north[E];
+  auto read_seams = [&]() {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      r_south[e] = has_south ? south_src[e * 64] : zero;
+      r_north[e] = has_north ? north_src[e * 64] : zero;
     }
   };
   publish_seams();
   int red_phase = 0;
   T rr = block_sum_fast(loc, red, red_phase);      // its barrier also publishes the seams
+  read_seams();
+#pragma unroll
+  for (int e = 0; e < E; ++e) { p_south[e] = r_south[e]; p_north[e] = r_north[e]; }
   const double res0 = sc_norm_from_dot(rr);
   int it = 0;
   if (res0 != 0.0) {
@@ -405,12 +421,6 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       // ---- pass 1: A p (kept in registers) and p . A p ----
       loc = zero;
       {
-        T south_in[E], north_in[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          south_in[e] = has_south ? south_src[e * 64] : zero;
-          north_in[e] = has_north ? north_src[e * 64] : zero;
-        }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           const T from_w = from_left(p[i][E - 1]);      // west of the lane's first element
@@ -420,8 +430,8 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
             const T pc = p[i][e];
             const T pw = (e == 0) ? from_w : p[i][e > 0 ? e - 1 : 0];
             const T pe = (e == E - 1) ? from_e : p[i][e < E - 1 ? e + 1 : e];
-            const T ps = (i == 0) ? south_in[e] : p[i > 0 ? i - 1 : 0][e];
-            const T pn = (i == R - 1) ? north_in[e] : p[i < R - 1 ? i + 1 : i][e];
+            const T ps = (i == 0) ? p_south[e] : p[i > 0 ? i - 1 : 0][e];
+            const T pn = (i == R - 1) ? p_north[e] : p[i < R - 1 ? i + 1 : i][e];
             T a = sc_mul(st.c[0], pc);
             a = sc_fma(st.c[1], pw, a);
             a = sc_fma(st.c[2], pe, a);
@@ -456,18 +466,25 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
         }
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-      const T rrn = block_sum_fast(loc, red, red_phase);    // its barrier: all seam reads of pass 1 are done
+      // the previous r seams were read right after the previous r . r reduction, i.e. before every wave passed the
+      // p . A p barrier of this iteration: overwriting them here is safe
+      publish_seams();
+      const T rrn = block_sum_fast(loc, red, red_phase);    // its barrier publishes the seams
+      read_seams();
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
       const T beta = sc_div(rrn, rr);
-      // ---- pass 3: p = r + beta p in registers; publish the seams ----
+      // ---- pass 3: p = r + beta p in registers, own rows and the neighbouring bands' seam rows ----
 #pragma unroll
       for (int i = 0; i < R; ++i)
 #pragma unroll
         for (int e = 0; e < E; ++e) p[i][e] = sc_fma(beta, p[i][e], r[i][e]);
-      publish_seams();
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        p_south[e] = sc_fma(beta, p_south[e], r_south[e]);
+        p_north[e] = sc_fma(beta, p_north[e], r_north[e]);
+      }
       rr = rrn;
-      __syncthreads();
     }
   }
 #pragma unroll
