@@ -914,7 +914,7 @@ template <typename T> class Impl : public ImplBase {
   template <int DIM> int launch_cg_lds(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
     *launched = false;
     if (!use_lds_krylov_) return EVOMG_OK;
-    const KrylovOwn own = krylov_own<DIM>(lv.g.n);
+    const KrylovOwn own = krylov_own<DIM>(lv.g.n, !scalar_traits<T>::is_complex);
     if (DIM == 2) {
       if (!own.tile || own.lanes != 512) return EVOMG_OK;
       // 512 threads = 8 waves = 8 bands; up to 65^2: one column per lane, 129^2: a column pair per lane

@@ -47,7 +47,9 @@ struct KrylovOwn {
   int tile, pair, column, m, cb, bands, R, lanes;
   long total;
 };
-template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
+// allow_pair: real-valued CG only (the pair tiles exist for the register-resident CG; the global-memory BiCGStab
+// and complex kernels keep one column per lane, whose 8-byte accesses are contiguous across the wave)
+template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n, bool allow_pair = false) {
   KrylovOwn o;
   o.m = n - 2;
   o.total = (DIM == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
@@ -56,7 +58,7 @@ template <int DIM> __host__ __device__ inline KrylovOwn krylov_own(int n) {
   // "pair" tiles (65 <= m <= 128, i.e. 129^2): a lane owns the column PAIR (2l, 2l+1), a wave spans the whole width
   // and is one band. The horizontal neighbours of a node are then the lane's other element or ONE DPP shift away,
   // which is what lets the register-resident CG below run without touching memory for them.
-  o.pair = (o.tile && o.cb == 2) ? 1 : 0;
+  o.pair = (allow_pair && o.tile && o.cb == 2) ? 1 : 0;
   o.lanes = (o.tile && o.cb <= 2) ? 512 : EVOMG_KRYLOV_THREADS;
   o.column = (DIM == 3 && (long)o.m * o.m <= o.lanes) ? 1 : 0;
   o.bands = o.tile ? (o.pair ? o.lanes / 64 : (o.lanes / 64) / o.cb) : 0;
@@ -179,7 +181,7 @@ __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r,
                    T* __restrict__ p, T* __restrict__ ap, int maxit, double tol, int* __restrict__ info) {
   __shared__ T red[17];
-  const KrylovOwn own = krylov_own<DIM>(g.n);
+  const KrylovOwn own = krylov_own<DIM>(g.n, !scalar_traits<T>::is_complex);
   const T zero = scalar_traits<T>::zero();
   T loc = zero;
   own_each<DIM>(g, own, [&](long c) {
@@ -354,7 +356,7 @@ evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
   T* row_seam = red + 32;                          // [wave][0: first row, 1: row R-1][element][lane]
   T* xs = row_seam + 8 * 2 * E * 64;               // [row * E + element][thread]
-  const KrylovOwn own = krylov_own<2>(g.n);
+  const KrylovOwn own = krylov_own<2>(g.n, !scalar_traits<T>::is_complex);
   const T zero = scalar_traits<T>::zero();
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;

@@ -446,7 +446,8 @@ typedef struct {
   int tile, pair, column, m, cb, bands, R, slots, lanes;
   long total;
 } FN(own_t);
-static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
+/* for_cg: the pair tiles are used by the real-valued CG only (BiCGStab and complex solvers: one column per lane) */
+static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level, int for_cg) {
   FN(own_t) o;
   o.m = c->lv[level].n - 2;
   o.total = (c->dim == 2) ? (long)o.m * o.m : (long)o.m * o.m * o.m;
@@ -456,7 +457,7 @@ static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level) {
   o.lanes = (o.tile && o.cb <= 2) ? 512 : KRYLOV_LANES;
   /* "pair" tiles (two column blocks, i.e. 129^2): wave w = band w, lane l owns the columns 2l and 2l+1 and visits
    * them row by row (row i: column 2l, then 2l+1) */
-  o.pair = (o.tile && o.cb == 2);
+  o.pair = (o.tile && o.cb == 2 && for_cg && !SC_IS_COMPLEX);
   o.bands = o.tile ? (o.pair ? o.lanes / 64 : (o.lanes / 64) / o.cb) : 0;
   o.R = o.tile ? (o.m + o.bands - 1) / o.bands : 0;
   /* 3D "column" ownership when m*m <= 1024: thread t owns the z-column (t % m, t / m), iz ascending */
@@ -502,11 +503,11 @@ static SC FN(tree64)(SC* v) {
  * added in the order 0, 1, ..., 7. */
 #define KRYLOV_GROUPS 8
 static int FN(cg_groups)(FN(ctx_t)* c, int level) {
-  const FN(own_t) o = FN(own_make)(c, level);
+  const FN(own_t) o = FN(own_make)(c, level, 1);
   return (c->dim == 3 && o.column && o.m >= 2 * KRYLOV_GROUPS) ? KRYLOV_GROUPS : 1;
 }
 static SC FN(dot_canon_grouped)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
-  const FN(own_t) o = FN(own_make)(c, level);
+  const FN(own_t) o = FN(own_make)(c, level, 1);
   const int n = c->lv[level].n, m = o.m;
   SC total = sc_zero();
   for (int g = 0; g < KRYLOV_GROUPS; ++g) {
@@ -529,8 +530,8 @@ static SC FN(dot_canon_grouped)(FN(ctx_t)* c, int level, const SC* a, const SC* 
   }
   return total;
 }
-static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
-  const FN(own_t) o = FN(own_make)(c, level);
+static SC FN(dot_canon_for)(FN(ctx_t)* c, int level, const SC* a, const SC* b, int for_cg) {
+  const FN(own_t) o = FN(own_make)(c, level, for_cg);
   SC part[KRYLOV_LANES];
   for (int t = 0; t < o.lanes; ++t) {
     SC s = sc_zero();
@@ -545,6 +546,7 @@ static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
   for (int w = 0; w < o.lanes / 64; ++w) waves[w] = FN(tree64)(&part[64 * w]);
   return FN(tree64)(waves);
 }
+static SC FN(dot_canon)(FN(ctx_t)* c, int level, const SC* a, const SC* b) { return FN(dot_canon_for)(c, level, a, b, 0); }
 /* fused-multiply-add forms used inside the Krylov solvers */
 static inline SC FN(apply_fma2)(const SC* st, const SC* x, int n, int i, int j) {
   SC a = sc_mul(st[0], x[IDX2(n, i, j)]);
@@ -639,7 +641,7 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   SC* p = FN(tmpvec)(c, L, 0);
   SC* ap = FN(tmpvec)(c, L, 1);
   const int grouped = FN(cg_groups)(c, L) > 1;
-#define CG_DOT(u, v) (grouped ? FN(dot_canon_grouped)(c, L, u, v) : FN(dot_canon)(c, L, u, v))
+#define CG_DOT(u, v) (grouped ? FN(dot_canon_grouped)(c, L, u, v) : FN(dot_canon_for)(c, L, u, v, 1))
   FN(krylov_apply)(c, L, lv->st, x, b, r, 1);
   SC rr = CG_DOT(r, r);
   const double res0 = sc_norm_from_dot(rr);
