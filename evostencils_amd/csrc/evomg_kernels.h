@@ -276,13 +276,14 @@ __global__ void __launch_bounds__(256) evomg_copy_boundary(Geo g, const T* __res
   const long c = gidx<DIM>(g, i, j, k);
   y[c] = x[c];
 }
-// same, but launched over one pair of opposite faces only: face = 0 (i0 = 0, n-1), 1 (i1), 2 (i2);
-// grid: (ceil(n/64), ceil(n/4), 2)
+// same, but launched over the faces only: blockIdx.z = 2 * face + side, face = 0 (i0 = 0, n-1), 1 (i1), 2 (i2);
+// grid: (ceil(n/64), ceil(n/4) or 1, 2 * DIM)
 template <typename T, int DIM>
-__global__ void __launch_bounds__(256) evomg_copy_faces(Geo g, const T* __restrict__ x, T* __restrict__ y, int face) {
+__global__ void __launch_bounds__(256) evomg_copy_faces(Geo g, const T* __restrict__ x, T* __restrict__ y) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y * blockDim.y + threadIdx.y;
-  const int side = blockIdx.z ? g.n - 1 : 0;
+  const int face = blockIdx.z >> 1;                // all 2 * DIM faces in one launch
+  const int side = (blockIdx.z & 1) ? g.n - 1 : 0;
   if (a >= g.n || b >= ((DIM == 3) ? g.n : 1)) return;
   int i, j, k;
   if (face == 0) { i = side; j = a; k = b; }
