@@ -93,6 +93,7 @@ template <typename T> class Impl : public ImplBase {
     if (partials_) (void)hipFree(partials_);
     if (dscalar_) (void)hipFree(dscalar_);
     if (dinfo_) (void)hipFree(dinfo_);
+    if (norm_partials_) (void)hipFree(norm_partials_);
     if (cg_xpart_) (void)hipFree(cg_xpart_);
     if (cg_xface_) (void)hipFree(cg_xface_);
     if (cg_flags_) (void)hipFree(cg_flags_);
@@ -752,8 +753,33 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh);
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr);
+  }
+  // Fused residual + squared norm (the solver loop's residual check): the residual field is still written, the norm
+  // costs no second pass. The summation order — per (strip, 16-row chunk) wave, lane = column pair, rows ascending —
+  // is canonical for 2D levels of at least 33 nodes (the oracle's FN(norm_strip2d)) and does NOT depend on
+  // EVOMG_NO_STRIP or the tuning knobs.
+  bool norm_fused(const Geo& g) const { return dim_ == 2 && g.n >= 33; }
+  int residual_norm_to_host(int L, const Stencil<T>& st, const T* x, const T* f, T* r, T* out) {
+    const Geo& g = lv_[L].g;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    const int chunks = (g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS;
+    const int waves = strips * chunks;
+    if ((size_t)waves > norm_partials_cap_) {
+      if (norm_partials_) (void)hipFree(norm_partials_);
+      norm_partials_ = nullptr;
+      HIP_TRY(hipMalloc(&norm_partials_, sizeof(T) * waves));
+      norm_partials_cap_ = waves;
+    }
+    const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_);
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_);
+    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
+    HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = hscalar_[0];
+    return EVOMG_OK;
   }
 
   // ---- 3D marching tiles (evomg_strip.h) ---------------------------------------------------------------------------
@@ -970,9 +996,13 @@ template <typename T> class Impl : public ImplBase {
     Level<T>& lv = lv_[L];
     int nh = 0;
     const double t0 = wall_ms();
-    residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
     T d;
-    int rc = dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
+    auto residual_norm = [&]() -> int {
+      if (norm_fused(lv.g)) return residual_norm_to_host(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), &d);
+      residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+      return dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
+    };
+    int rc = residual_norm();
     if (rc != EVOMG_OK) return rc;
     const double res0 = sc_norm_from_dot(d);
     if (hist && nh < cap) hist[nh] = res0;
@@ -984,8 +1014,7 @@ template <typename T> class Impl : public ImplBase {
       for (it = 1; it <= prob_.max_iterations; ++it) {
         rc = exec_program(ops, n_ops, /*cyclic=*/true);
         if (rc != EVOMG_OK) return rc;
-        residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
-        rc = dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
+        rc = residual_norm();
         if (rc != EVOMG_OK) return rc;
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
@@ -1118,6 +1147,8 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  T* norm_partials_ = nullptr;
+  size_t norm_partials_cap_ = 0;
   T* cg_xpart_ = nullptr;
   T* cg_xface_ = nullptr;
   unsigned* cg_flags_ = nullptr;

@@ -21,7 +21,8 @@
 
 #define EVOMG_STRIP_COLS 124   // stored columns per strip (62 interior lane pairs)
 
-enum { STRIP_JACOBI = 0, STRIP_RBGS = 1, STRIP_RESIDUAL = 2 };
+enum { STRIP_JACOBI = 0, STRIP_RBGS = 1, STRIP_RESIDUAL = 2, STRIP_RESNORM = 3 };
+#define EVOMG_NORM_ROWS 16   // chunk height of the fused residual + norm pass: part of the canonical summation order
 
 template <typename T> struct Pair {
   T a, b;
@@ -81,7 +82,8 @@ __device__ __forceinline__ T residual5(const Stencil<T>& st, T c, T w, T e, T s,
 template <typename T, int MODE, int PF, bool NT_F>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
-              double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh) {
+              double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
+              T* __restrict__ partials) {
   // XCD-aware block order: the dispatcher deals blocks round-robin over the 8 XCDs (block b -> XCD b % 8), each
   // with a private L2. Remap so that every XCD works on one contiguous band of rows: vertically adjacent chunks
   // then share their halo rows through that XCD's L2 instead of re-reading them from HBM. gridDim.x is a multiple
@@ -135,6 +137,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   }
   Pair<T> fm = zpair;          // f of row j-1 (black phase)
   T rm2 = zero, rm1 = zero;    // new red of rows j-2, j-1 (this lane's pair)
+  T nrm = zero;                // STRIP_RESNORM: this lane's sum of squared residuals (rows ascending, a then b)
 
   for (int base = js; base < je; base += PF) {
 #pragma unroll
@@ -148,7 +151,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
         const bool row_inner = j >= 1 && j <= n - 2;
         // chunk heights are even and js = y0 - LEAD, so with an even prefetch depth the row parity is static
         const int parity = (PF % 2 == 0) ? ((LEAD + d) & 1) : (j & 1);
-        if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL) {
+        if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == STRIP_RESNORM) {
           const T wa = from_left(xc.b), eb = from_right(xc.a);
           Pair<T> out;
           if constexpr (MODE == STRIP_JACOBI) {
@@ -164,6 +167,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
               if (inner_a && inner_b) store_pair(dst, out);
               else if (inner_a) dst[0] = out.a;
               else if (inner_b) dst[1] = out.b;
+              if constexpr (MODE == STRIP_RESNORM) {
+                // unconjugated dot(r, r), unfused multiply + add like evomg_dot_partial
+                if (inner_a) nrm = sc_add(nrm, sc_mul(out.a, out.a));
+                if (inner_b) nrm = sc_add(nrm, sc_mul(out.b, out.b));
+              }
             }
           }
         } else {
@@ -211,6 +219,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
         xc = xp;
       }
     }
+  }
+  if constexpr (MODE == STRIP_RESNORM) {
+    // one partial sum per wave = (strip, chunk): wave64 tree (offsets 32 .. 1), restated by the oracle's norm
+    const T tot = wave_sum(nrm);
+    if (lane == 0) partials[wave] = tot;
   }
 }
 

@@ -830,6 +830,52 @@ static void FN(reset_fields)(FN(ctx_t)* c) {
 
 /* ---- outer loop A: "generate solver for u in solEq" [EXTERNAL: App. B.8]
  * residual -> initRes; repeat { cycle; residual; norm } until res <= target*initRes or maxNumIts. */
+/* Residual norm of the solver loop on 2D levels with at least 33 nodes: the device fuses it into the residual sweep
+ * (csrc/evomg_strip.h, STRIP_RESNORM), which fixes the summation order: one partial sum per wave = (strip of 124
+ * stored columns, chunk of NORM_ROWS rows), lane l of the wave holds the column pair (c0, c0+1), c0 = 124*strip - 2 + 2l
+ * (lanes 0 and 63 are halo lanes and contribute nothing) and adds r(c0,j)^2 then r(c0+1,j)^2 for the rows j of the
+ * chunk in ascending order (unfused multiply + add); the 64 lane sums go through the wave tree; the wave partials
+ * (wave = chunk * strips + strip) are then combined like the partials of FN(dot). */
+#define NORM_STRIP_COLS 124
+#define NORM_ROWS 16
+static int FN(norm_is_fused)(FN(ctx_t)* c, int level) { return c->dim == 2 && c->lv[level].n >= 33; }
+static double FN(norm_strip2d)(FN(ctx_t)* c, int level, const SC* r) {
+  const int n = c->lv[level].n;
+  const int strips = (n + NORM_STRIP_COLS - 1) / NORM_STRIP_COLS, chunks = (n + NORM_ROWS - 1) / NORM_ROWS;
+  const int waves = strips * chunks;
+  SC* partial = (SC*)malloc(sizeof(SC) * (size_t)waves);
+#pragma omp parallel for schedule(static) if (OMP_WORTH(n))
+  for (int wave = 0; wave < waves; ++wave) {
+    const int strip = wave % strips, chunk = wave / strips;
+    const int y0 = chunk * NORM_ROWS, y1 = (y0 + NORM_ROWS < n) ? y0 + NORM_ROWS : n;
+    SC lane[64];
+    for (int l = 0; l < 64; ++l) {
+      SC acc = sc_zero();
+      const int c0 = strip * NORM_STRIP_COLS - 2 + 2 * l;
+      if (l >= 1 && l <= 62 && c0 >= 0 && c0 < n)
+        for (int j = y0; j < y1; ++j) {
+          if (j < 1 || j > n - 2) continue;
+          for (int e = 0; e < 2; ++e) {
+            const int i = c0 + e;
+            if (i < 1 || i > n - 2) continue;
+            const SC v = r[IDX2(n, i, j)];
+            acc = sc_add(acc, sc_mul(v, v));
+          }
+        }
+      lane[l] = acc;
+    }
+    partial[wave] = FN(tree64)(lane);
+  }
+  SC th[DOT_THREADS];
+  for (int t = 0; t < DOT_THREADS; ++t) th[t] = sc_zero();
+  for (int i = 0; i < waves; ++i) th[i % DOT_THREADS] = sc_add(th[i % DOT_THREADS], partial[i]);
+  free(partial);
+  return sc_norm_from_dot(FN(block_tree)(th));
+}
+static double FN(solver_res_norm)(FN(ctx_t)* c, int level, const SC* r) {
+  return FN(norm_is_fused)(c, level) ? FN(norm_strip2d)(c, level, r) : FN(norm)(c, level, r);
+}
+
 static void FN(solve_mg)(FN(ctx_t)* c, const evomg_op_t* ops, int n_ops, double wall_limit_ms,
                          evomg_result_t* out, double* hist, int cap) {
   const int L = c->prob.max_level;
@@ -837,7 +883,7 @@ static void FN(solve_mg)(FN(ctx_t)* c, const evomg_op_t* ops, int n_ops, double 
   int nh = 0;
   const double t0 = now_ms();
   FN(residual_st)(c, L, lv->st, FN(field)(c, L, EVOMG_F_SOL), FN(field)(c, L, EVOMG_F_RHS), FN(field)(c, L, EVOMG_F_RES));
-  const double res0 = FN(norm)(c, L, FN(field)(c, L, EVOMG_F_RES));
+  const double res0 = FN(solver_res_norm)(c, L, FN(field)(c, L, EVOMG_F_RES));
   if (hist && nh < cap) hist[nh] = res0;
   ++nh;
   double res = res0;
@@ -847,7 +893,7 @@ static void FN(solve_mg)(FN(ctx_t)* c, const evomg_op_t* ops, int n_ops, double 
     for (it = 1; it <= c->prob.max_iterations; ++it) {
       for (int i = 0; i < n_ops; ++i) FN(exec_op)(c, &ops[i]);
       FN(residual_st)(c, L, lv->st, FN(field)(c, L, EVOMG_F_SOL), FN(field)(c, L, EVOMG_F_RHS), FN(field)(c, L, EVOMG_F_RES));
-      res = FN(norm)(c, L, FN(field)(c, L, EVOMG_F_RES));
+      res = FN(solver_res_norm)(c, L, FN(field)(c, L, EVOMG_F_RES));
       if (hist && nh < cap) hist[nh] = res;
       ++nh;
       if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
