@@ -497,8 +497,10 @@ template <typename T> class Impl : public ImplBase {
         const int L = ops[i].level;
         launch_residual_restrict(L, fieldptr(L, ops[i].src0), fieldptr(L, ops[i].src1), fieldptr(L, ops[i].dst),
                                  fieldptr(L - 1, ops[i + 1].dst), write_r);
-        if (write_r) apply_bc(L, fieldptr(L, ops[i].dst));
-        apply_bc(L - 1, fieldptr(L - 1, ops[i + 1].dst));
+        if (!strip_bc_) {                                   // otherwise the kernel wrote the Robin columns itself
+          if (write_r) apply_bc(L, fieldptr(L, ops[i].dst));
+          apply_bc(L - 1, fieldptr(L - 1, ops[i + 1].dst));
+        }
         HIP_TRY(hipGetLastError());
         ++i;
         continue;
@@ -519,12 +521,14 @@ template <typename T> class Impl : public ImplBase {
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
     const bool nt = strip_streams(g);
+    const bool robin = strip_bc_ && prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
+    const double rkh = robin ? kh(L) : 0.0, rkhc = robin ? kh(L - 1) : 0.0;
     if (write_r) {
-      if (nt) hipLaunchKernelGGL((evomg_strip_residual_restrict<T, true, true>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
-      else hipLaunchKernelGGL((evomg_strip_residual_restrict<T, true, false>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
+      if (nt) hipLaunchKernelGGL((evomg_strip_residual_restrict<T, true, true>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves, rkh, rkhc);
+      else hipLaunchKernelGGL((evomg_strip_residual_restrict<T, true, false>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves, rkh, rkhc);
     } else {
-      if (nt) hipLaunchKernelGGL((evomg_strip_residual_restrict<T, false, true>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
-      else hipLaunchKernelGGL((evomg_strip_residual_restrict<T, false, false>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves);
+      if (nt) hipLaunchKernelGGL((evomg_strip_residual_restrict<T, false, true>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves, rkh, rkhc);
+      else hipLaunchKernelGGL((evomg_strip_residual_restrict<T, false, false>), grid, block, 0, stream_, g, gc, lv_[L].st, x, f, r, coarse, rows, strips, waves, rkh, rkhc);
     }
   }
   void launch_strip_prolong(int L, const T* coarse, T* fine, bool acc, double om) {
@@ -537,8 +541,9 @@ template <typename T> class Impl : public ImplBase {
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (acc) hipLaunchKernelGGL((evomg_strip_prolong<T, true>), grid, block, 0, stream_, g, gc, coarse, fine, om, rows, strips, waves);
-    else hipLaunchKernelGGL((evomg_strip_prolong<T, false>), grid, block, 0, stream_, g, gc, coarse, fine, 1.0, rows, strips, waves);
+    const double rkh = (strip_bc_ && prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN) ? kh(L) : 0.0;
+    if (acc) hipLaunchKernelGGL((evomg_strip_prolong<T, true>), grid, block, 0, stream_, g, gc, coarse, fine, om, rows, strips, waves, rkh);
+    else hipLaunchKernelGGL((evomg_strip_prolong<T, false>), grid, block, 0, stream_, g, gc, coarse, fine, 1.0, rows, strips, waves, rkh);
   }
 
   int exec(const evomg_op_t& op) {
@@ -586,7 +591,7 @@ template <typename T> class Impl : public ImplBase {
           T* y = lv.alt;
           if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip<STRIP_RBGS>(g, lv.st, x, f, y, om, omm);
           else launch_strip<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
-          apply_bc(L, y);
+          if (!strip_bc_) apply_bc(L, y);                   // the strip kernels write the Robin columns themselves
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
         } else if (use_strip3d(g, op.partitioning == EVOMG_PART_RED_BLACK)) {
@@ -614,8 +619,8 @@ template <typename T> class Impl : public ImplBase {
         break;
       }
       case EVOMG_OP_RESIDUAL:
-        residual(L, lv.st, fieldptr(L, op.src0), fieldptr(L, op.src1), fieldptr(L, op.dst));
-        apply_bc(L, fieldptr(L, op.dst));
+        residual(L, lv.st, fieldptr(L, op.src0), fieldptr(L, op.src1), fieldptr(L, op.dst), /*bc_out=*/true);
+        if (!(strip_bc_ && use_strip(g))) apply_bc(L, fieldptr(L, op.dst));
         break;
       case EVOMG_OP_RICHARDSON: {
         T* x = fieldptr(L, op.dst);
@@ -641,6 +646,7 @@ template <typename T> class Impl : public ImplBase {
         T* fz = fieldptr(L, op.dst);
         if (use_strip(g) && cz != fz) {
           launch_strip_prolong(L, cz, fz, op.opcode == EVOMG_OP_PROLONG_ADD, op.omega);
+          if (strip_bc_) break;                             // Robin columns written by the kernel
         } else if (dim_ == 3 && strip_enabled_) {
           const int cells = gc.n - 1;
           const dim3 cgrid((cells + 63) / 64, (cells + 3) / 4, cells);
@@ -658,9 +664,11 @@ template <typename T> class Impl : public ImplBase {
       }
       case EVOMG_OP_SET_ZERO: {
         T* x = fieldptr(L, op.dst);
-        if (dim_ == 2) hipLaunchKernelGGL((evomg_zero_inner<T, 2>), grd, blk, 0, stream_, g, x);
-        else hipLaunchKernelGGL((evomg_zero_inner<T, 3>), grd, blk, 0, stream_, g, x);
-        apply_bc(L, x);
+        // Robin of a zeroed interior = zero side columns: one launch instead of two
+        const int side = (scalar_traits<T>::is_complex && prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN) ? 1 : 0;
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_zero_inner<T, 2>), grd, blk, 0, stream_, g, x, side);
+        else hipLaunchKernelGGL((evomg_zero_inner<T, 3>), grd, blk, 0, stream_, g, x, 0);
+        if (!side) apply_bc(L, x);
         break;
       }
       case EVOMG_OP_COPY: {
@@ -738,7 +746,7 @@ template <typename T> class Impl : public ImplBase {
   // ---- 2D marching-strip kernels (evomg_strip.h) ------------------------------------------------------------------
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
   bool strip_streams(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.pitch * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
-  template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
+  template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
     // enough waves to fill 256 CUs several times over, but chunks tall enough to amortise the vertical halo
     // measured on MI355X at 4097^2 (tools/tune_strip.py, interleaved A/B): smoothers are fastest with tall chunks
@@ -753,8 +761,8 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr);
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0);
   }
   // Fused residual + squared norm (the solver loop's residual check): the residual field is still written, the norm
   // costs no second pass. The summation order — per (strip, 16-row chunk) wave, lane = column pair, rows ascending —
@@ -773,8 +781,8 @@ template <typename T> class Impl : public ImplBase {
       norm_partials_cap_ = waves;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_);
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_);
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0);
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0);
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -830,9 +838,10 @@ template <typename T> class Impl : public ImplBase {
   }
   bool strip_streams3d(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.plane * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
 
-  void residual(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
+  // bc_out: the caller applies the boundary condition to r afterwards (the strip kernel then does it itself)
+  void residual(int L, const Stencil<T>& st, const T* x, const T* f, T* r, bool bc_out = false) {
     const Geo& g = lv_[L].g;
-    if (use_strip(g)) { launch_strip<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
+    if (use_strip(g)) { launch_strip<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0, bc_out); return; }
     if (use_strip3d(g, false)) { launch_strip3d<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
     if (dim_ == 2) hipLaunchKernelGGL((evomg_apply<T, 2, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
     else hipLaunchKernelGGL((evomg_apply<T, 3, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
@@ -1147,6 +1156,7 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
   T* norm_partials_ = nullptr;
   size_t norm_partials_cap_ = 0;
   T* cg_xpart_ = nullptr;

@@ -441,10 +441,14 @@ __global__ void __launch_bounds__(256) evomg_prolong_cell3d(Geo gf, Geo gc, cons
 
 // ---- K7: zero the inner nodes ---------------------------------------------------------------------------------
 template <typename T, int DIM>
-__global__ void __launch_bounds__(256) evomg_zero_inner(Geo g, T* __restrict__ x) {
+// side_columns (2D Helmholtz): also the first and last column of the inner rows, which is what the Robin condition
+// x_b = x_in / (1 - i k h) yields for a zeroed interior
+__global__ void __launch_bounds__(256) evomg_zero_inner(Geo g, T* __restrict__ x, int side_columns) {
   int i, j, k;
   if (!node_of_thread<DIM>(g, i, j, k)) return;
-  if (!is_inner<DIM>(g, i, j, k)) return;
+  if (!is_inner<DIM>(g, i, j, k)) {
+    if (!(DIM == 2 && side_columns && j >= 1 && j <= g.n - 2)) return;
+  }
   x[gidx<DIM>(g, i, j, k)] = scalar_traits<T>::zero();
 }
 

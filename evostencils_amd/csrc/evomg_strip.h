@@ -83,7 +83,7 @@ template <typename T, int MODE, int PF, bool NT_F>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
               double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
-              T* __restrict__ partials) {
+              T* __restrict__ partials, int robin_out) {
   // XCD-aware block order: the dispatcher deals blocks round-robin over the 8 XCDs (block b -> XCD b % 8), each
   // with a private L2. Remap so that every XCD works on one contiguous band of rows: vertically adjacent chunks
   // then share their halo rows through that XCD's L2 instead of re-reading them from HBM. gridDim.x is a multiple
@@ -124,6 +124,22 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     else return load_pair<T>(base + pitch * r + c_clamped);
   };
 
+  // Helmholtz Robin boundary (K8) applied to what the sweep produced: x_b = x_in / (1 - i k h) in the first and the
+  // last column of every inner row. The lane holding column 0 has its inner neighbour as second element; column n-1
+  // is the first element of its lane and column n-2 the second element of the lane to the left (one DPP shift).
+  // Must be called by the whole wave (DPP). robin_out = 0: the caller wants the boundary left alone (e.g. the
+  // residual of the outer Krylov solver).
+  const bool robin_a = scalar_traits<T>::is_complex && robin_out && robin_kh != 0.0 && (c0 == 0 || c0 == n - 1);
+  auto robin_fix = [&](Pair<T>& out) {
+    if constexpr (scalar_traits<T>::is_complex) {
+      if (robin_out && robin_kh != 0.0) {                     // kernel arguments: uniform
+        const cplx den{1.0, -robin_kh};
+        const T lb = from_left(out.b);
+        if (c0 == 0) out.a = sc_div(out.b, den);
+        if (c0 == n - 1) out.a = sc_div(lb, den);
+      }
+    }
+  };
   constexpr int LEAD = (MODE == STRIP_RBGS) ? 1 : 0;        // RB-GS relaxes red one row ahead of black
   const int js = y0 - LEAD;                                 // first row relaxed (red)
   const int je = y1 + LEAD;                                 // one past the last row relaxed
@@ -157,20 +173,25 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           if constexpr (MODE == STRIP_JACOBI) {
             out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm) : xc.a;
             out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm) : xc.b;
+            if (row_inner) robin_fix(out);
             if (store_lane && j >= 0 && j < n) store_pair(y + pitch * j + c0, out);
           } else {
-            // residual: only inner nodes are written (the boundary of the residual field is never touched)
-            if (row_inner && store_lane) {
+            // residual: only inner nodes are written (plus the Robin columns of a Helmholtz residual field)
+            if (row_inner) {                                     // wave-uniform
               out.a = residual5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a);
               out.b = residual5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b);
-              T* dst = y + pitch * j + c0;
-              if (inner_a && inner_b) store_pair(dst, out);
-              else if (inner_a) dst[0] = out.a;
-              else if (inner_b) dst[1] = out.b;
-              if constexpr (MODE == STRIP_RESNORM) {
-                // unconjugated dot(r, r), unfused multiply + add like evomg_dot_partial
-                if (inner_a) nrm = sc_add(nrm, sc_mul(out.a, out.a));
-                if (inner_b) nrm = sc_add(nrm, sc_mul(out.b, out.b));
+              robin_fix(out);
+              if (store_lane) {
+                T* dst = y + pitch * j + c0;
+                const bool sa = inner_a || robin_a;
+                if (sa && inner_b) store_pair(dst, out);
+                else if (sa) dst[0] = out.a;
+                else if (inner_b) dst[1] = out.b;
+                if constexpr (MODE == STRIP_RESNORM) {
+                  // unconjugated dot(r, r), unfused multiply + add like evomg_dot_partial
+                  if (inner_a) nrm = sc_add(nrm, sc_mul(out.a, out.a));
+                  if (inner_b) nrm = sc_add(nrm, sc_mul(out.b, out.b));
+                }
               }
             }
           }
@@ -210,6 +231,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             out.a = bl;
             out.b = rm1;
           }
+          if (brow_inner) robin_fix(out);
           if (store_lane && jb >= y0 && jb < y1) store_pair(y + pitch * jb + c0, out);
           rm2 = rm1;
           rm1 = rc;
@@ -237,7 +259,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
 template <typename T, bool WRITE_R, bool NT_F>
 __global__ void __launch_bounds__(256)
 evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
-                              T* __restrict__ res, T* __restrict__ coarse, int rows_per_chunk, int n_strips, int n_waves) {
+                              T* __restrict__ res, T* __restrict__ coarse, int rows_per_chunk, int n_strips, int n_waves,
+                              double robin_kh, double robin_kh_coarse) {
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
@@ -294,11 +317,25 @@ evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict_
         rc.a = (row_inner && inner_a) ? residual5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a) : zero;
         rc.b = (row_inner && inner_b) ? residual5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b) : zero;
         if constexpr (WRITE_R) {
+          // Helmholtz: the residual field carries the Robin condition too (stored copy only; the restriction below
+          // never reads the boundary columns)
+          Pair<T> rs = rc;
+          bool robin_a = false;
+          if constexpr (scalar_traits<T>::is_complex) {
+            if (robin_kh != 0.0 && row_inner) {               // uniform
+              const cplx den{1.0, -robin_kh};
+              const T lb = from_left(rc.b);
+              if (c0 == 0) rs.a = sc_div(rc.b, den);
+              if (c0 == n - 1) rs.a = sc_div(lb, den);
+              robin_a = c0 == 0 || c0 == n - 1;
+            }
+          }
           if (row_inner && store_lane && j >= y0) {
             T* dst = res + pitch * j + c0;
-            if (inner_a && inner_b) store_pair(dst, rc);
-            else if (inner_a) dst[0] = rc.a;
-            else if (inner_b) dst[1] = rc.b;
+            const bool sa = inner_a || robin_a;
+            if (sa && inner_b) store_pair(dst, rs);
+            else if (sa) dst[0] = rs.a;
+            else if (inner_b) dst[1] = rs.b;
           }
         }
         // js = y0 - 1 is odd, PF is even: d == 0 <=> j odd <=> rows j-2, j-1, j are a complete coarse neighbourhood
@@ -310,7 +347,18 @@ evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict_
           T v = sc_rmul(0.25, r1.a);
           v = sc_add(v, sc_rmul(0.125, e4));
           v = sc_add(v, sc_rmul(0.0625, q4));
-          if (store_lane && coarse_col_inner && J >= 1 && J <= nc - 2 && 2 * J >= y0) coarse[(long)gc.pitch * J + I] = v;
+          T vs = v;
+          bool coarse_robin = false;
+          if constexpr (scalar_traits<T>::is_complex) {
+            if (robin_kh_coarse != 0.0) {                      // Robin columns of the coarse right-hand side
+              const cplx den{1.0, -robin_kh_coarse};
+              const T vr = from_right(v), vl = from_left(v);
+              if (I == 0) vs = sc_div(vr, den);
+              if (I == nc - 1) vs = sc_div(vl, den);
+              coarse_robin = (I == 0 || I == nc - 1) && c0 >= 0 && c0 < n;
+            }
+          }
+          if (store_lane && (coarse_col_inner || coarse_robin) && J >= 1 && J <= nc - 2 && 2 * J >= y0) coarse[(long)gc.pitch * J + I] = vs;
         }
         r2 = r1;
         r1 = rc;
@@ -328,7 +376,7 @@ evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict_
 template <typename T, bool ACC>
 __global__ void __launch_bounds__(256)
 evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__ fine, double om, int rows_per_chunk,
-                    int n_strips, int n_waves) {
+                    int n_strips, int n_waves, double robin_kh) {
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
@@ -355,6 +403,17 @@ evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__
     const int r = min(max(J, 0), nc - 1);
     return coarse[(long)gc.pitch * r + I];
   };
+  // Helmholtz Robin columns of the updated fine field (see evomg_strip2d): whole-wave call
+  auto robin_fix = [&](Pair<T>& out) {
+    if constexpr (scalar_traits<T>::is_complex) {
+      if (robin_kh != 0.0) {
+        const cplx den{1.0, -robin_kh};
+        const T lb = from_left(out.b);
+        if (c0 == 0) out.a = sc_div(out.b, den);
+        if (c0 == n - 1) out.a = sc_div(lb, den);
+      }
+    }
+  };
   const int J0 = y0 >> 1;
   T cJ = load_coarse(J0), cJ1 = load_coarse(J0 + 1);
   Pair<T> x0 = load_fine(y0), x1 = load_fine(y0 + 1);
@@ -372,6 +431,7 @@ evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__
       Pair<T> out;
       out.a = (row_inner && inner_a) ? (ACC ? sc_add(x0.a, sc_rmul(om, va)) : va) : x0.a;
       out.b = (row_inner && inner_b) ? (ACC ? sc_add(x0.b, sc_rmul(om, vb)) : vb) : x0.b;
+      if (row_inner) robin_fix(out);
       if (store_lane) store_pair(fine + pitch * j + c0, out);
     }
     // odd fine row j + 1 = 2J + 1
@@ -382,6 +442,7 @@ evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__
       Pair<T> out;
       out.a = (row_inner && inner_a) ? (ACC ? sc_add(x1.a, sc_rmul(om, va)) : va) : x1.a;
       out.b = (row_inner && inner_b) ? (ACC ? sc_add(x1.b, sc_rmul(om, vb)) : vb) : x1.b;
+      if (row_inner) robin_fix(out);
       if (store_lane) store_pair(fine + pitch * (j + 1) + c0, out);
     }
     cJ = cJ1;
