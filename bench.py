@@ -122,9 +122,12 @@ def main():
         import threading
         extra_lock = threading.Lock()
 
-    def step():
+    def evaluate_one():
         t, rho, its = gen.generate_and_evaluate(expression, storages, lo, hi, "", evaluation_samples=1)
-        return population.gather_fitness([(rho, t, its)], world, local_rank)
+        return (rho, t, its)
+
+    def step():
+        return population.gather_fitness([evaluate_one()], world, local_rank)
 
     def run_steps(n, in_flight=None):
         """n candidate evaluations with `in_flight` candidates on the GPU at once (extra workers pull from the same
@@ -152,11 +155,13 @@ def main():
         last = None
         with cf.ThreadPoolExecutor(max_workers=len(workers.generators)) as pool:
             futs = [pool.submit(worker, g2, e2) for g2, e2 in list(zip(workers.generators, expressions))[:in_flight - 1]]
+            # no collective inside this loop: how many of the n evaluations the main thread gets depends on thread
+            # timing and differs between ranks; the fitness gather happens once, after the pool has drained
             while take():
-                last = step()
+                last = evaluate_one()
             for f_ in futs:
                 f_.result()
-        return last if last is not None else step()
+        return population.gather_fitness([last if last is not None else evaluate_one()], world, local_rank)
 
     def fence():
         if world > 1:
