@@ -93,10 +93,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    # EVOMG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives on host tensors); the real multi-GPU run uses nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("EVOMG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     from evostencils_amd import abi, native, problems
     from evostencils_amd.code_generation.hip import ProgramGenerator
@@ -183,7 +192,7 @@ def main():
     elapsed = time.perf_counter() - t0
     live = handle.profile_end()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -211,7 +220,7 @@ def main():
         fence()
         el2 = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([el2], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
         throughput = {"candidates_in_flight_per_gpu": k, "steps": n, "value": world * n / el2, "unit": "solves/s",
@@ -236,7 +245,7 @@ def main():
         }
         if throughput is not None:
             line["throughput_mode"] = throughput
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N = 1 only
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(ops, lo, hi, threads)
         print(json.dumps(line), flush=True)
