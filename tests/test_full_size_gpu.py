@@ -52,6 +52,29 @@ def test_c2_poisson2d_4096_six_level_rbgs(native):
     assert np.array_equal(a.history, b.history)
 
 
+def test_c2_full_size_against_the_oracle(native):
+    """The headline configuration at FULL size against the CPU oracle (one oracle solve of 4097^2 takes a couple of
+    seconds on the host cores): same iteration count, residual history within 1e-10 relative, final solution
+    bit-identical."""
+    from oracle import oracle
+    lo, hi = 7, 12
+    pd = problems.poisson_2d(lo, hi)
+    ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
+    hg = native.create(pd)
+    got = hg.evaluate(ops, 1, 0, 128)
+    ug = hg.get_field(hi, abi.F_SOL)
+    hg.close()
+    ho = oracle.create(pd)
+    want = ho.evaluate(ops, 1, 0, 128)
+    uo = ho.get_field(hi, abi.F_SOL)
+    ho.close()
+    assert got.status == want.status == abi.SOLVE_CONVERGED
+    assert got.n_iterations == want.n_iterations
+    assert len(got.history) == len(want.history)
+    assert np.all(np.abs(got.history - want.history) <= 1e-10 * want.history)
+    assert np.array_equal(ug, uo)
+
+
 def test_c4_poisson3d_512_v22_block_jacobi(native):
     """configs[3]: 3D Poisson 512^3, V(2,2) block-Jacobi (2,1,1), w = 0.8, 5 levels."""
     lo, hi = 5, 9

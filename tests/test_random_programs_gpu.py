@@ -87,3 +87,24 @@ def test_seeded_candidate_population_matches_oracle(native):
         assert rho == pytest.approx(rrho, rel=1e-10)
         usable += its < 1e100
     assert usable >= 6      # the stable-range generator mostly yields convergent solvers
+
+
+def test_seeded_3d_candidates_match_oracle(native):
+    """Seeded 3D candidates on 65^3 with the coarsest grid at 33^3: exercises the fused 3D RB-GS tiles, the cell
+    prolongation, static-shape block smoothers and the eight-workgroup coarse CG in whole solves."""
+    from oracle import oracle
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    lo, hi = 5, 6
+    gen = generator_for("3D_FD_Poisson_fromL2", lo, hi, library=native.library())
+    gen.initialize_code_generation(lo, hi)
+    pop = candidates.population(lambda: context_for(gen, lo, hi), hi - lo, 3, 6, seed=7)
+    ref = oracle.create(problems.poisson_3d(lo, hi))
+    usable = 0
+    for expression in pop:
+        ops = gen.generate_op_program(expression, lo, hi)
+        t, rho, its = gen.generate_and_evaluate(expression, None, lo, hi, "", evaluation_samples=1)
+        rt, rrho, rits = ProgramGenerator.interpret_outcome(ref.evaluate(ops, 1, 0, 128), 1e100)
+        assert its == rits
+        assert rho == pytest.approx(rrho, rel=1e-10)
+        usable += its < 1e100
+    assert usable >= 3
