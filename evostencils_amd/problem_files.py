@@ -439,7 +439,8 @@ def describe(l2: Layer2, name: str, dimension: int, min_level: int, max_level: i
         field_name=field_name, rhs_name=rhs_name, operator_name=op_name, equation_name=eq_name,
         restriction_name=f"gen_restrictionForRes_{field_name}", prolongation_name=f"gen_prolongationForSol_{field_name}",
         mg_stencil=stencil, initial_solution=initial_solution, right_hand_side=right_hand_side,
-        domain_lower=tuple(lower) + (0.0,) * (3 - dimension), domain_upper=tuple(upper) + (1.0,) * (3 - dimension))
+        domain_lower=tuple(lower) + (0.0,) * (3 - dimension), domain_upper=tuple(upper) + (1.0,) * (3 - dimension),
+        solver_hints={k: v for k, v in hints.items() if k.startswith("solver_")})
 
 
 def load_problem(base_path: str, settings_path: str, knowledge_path: str,

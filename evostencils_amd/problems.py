@@ -74,6 +74,8 @@ class ProblemDescription:
     parameters: Dict[str, complex] = field(default_factory=dict)
     domain_lower: tuple = (0.0, 0.0, 0.0)
     domain_upper: tuple = (1.0, 1.0, 1.0)
+    # `generate solver ... with { ... }` settings of the problem's .exa3 file (reference_solver.py)
+    solver_hints: Dict[str, str] = field(default_factory=dict)
 
     def nodes(self, level):
         return (1 << level) + 1

@@ -1,0 +1,53 @@
+"""The problem's own reference solver as an op program: what `generate solver for u in solEq with { ... }` configures
+(example_problems/*/*.exa3: solver_smoother_numPre / numPost / damping / coloring / jacobiType) — the V-cycle the
+reference measures new candidates against (scripts/evaluate_reference_solver.py runs exactly this generated solver) and
+the hand-written V(2,1) cycle of the Helmholtz problem (Helmholtz/2D_FD_Helmholtz_fromL3.exa3:202-272)."""
+from typing import Dict, List, Optional
+
+from evostencils_amd import abi
+
+# the settings of the three example problems (exa3 files), used when a descriptor carries no hints of its own
+DEFAULT_HINTS = {
+    "2D_FD_Poisson_fromL2": {"solver_smoother_numPre": 2, "solver_smoother_numPost": 1, "solver_smoother_damping": 1.15,
+                             "solver_smoother_coloring": "red-black", "solver_smoother_jacobiType": "false"},
+    "3D_FD_Poisson_fromL2": {"solver_smoother_numPre": 2, "solver_smoother_numPost": 1, "solver_smoother_damping": 1.25,
+                             "solver_smoother_coloring": "red-black", "solver_smoother_jacobiType": "false"},
+    "2D_FD_Helmholtz_fromL3": {"solver_smoother_numPre": 2, "solver_smoother_numPost": 1, "solver_smoother_damping": 0.6,
+                               "solver_smoother_coloring": "red-black", "solver_smoother_jacobiType": "false"},
+}
+
+
+def v_cycle_ops(min_level: int, max_level: int, pre: int, post: int, omega: float, red_black: bool = True) -> List[abi.Op]:
+    """V(pre, post) point-smoother cycle over levels max..min with the coarse-grid solver on `min_level`; statement
+    order as ExaStencils' generated gen_mgCycle: smooth, residual, restrict, zero the coarse error, recurse,
+    prolongate-and-correct, smooth."""
+    one = (1, 1, 1)
+    part = abi.PART_RED_BLACK if red_black else abi.PART_SINGLE
+    ops = []
+    for L in range(max_level, min_level, -1):
+        ops += [abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, one, omega) for _ in range(pre)]
+        ops.append(abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS))
+        ops.append(abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES))
+        if L - 1 > min_level:
+            ops.append(abi.make_op(abi.OP_SET_ZERO, L - 1, abi.F_SOL))
+    ops.append(abi.make_op(abi.OP_COPY, min_level, abi.F_CGS_RHS, abi.F_RHS))
+    ops.append(abi.make_op(abi.OP_SET_ZERO, min_level, abi.F_CORR))
+    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, min_level))
+    for L in range(min_level + 1, max_level + 1):
+        ops.append(abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=1.0))
+        ops += [abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, one, omega) for _ in range(post)]
+    return ops
+
+
+def reference_solver_ops(problem, hints: Optional[Dict[str, object]] = None) -> List[abi.Op]:
+    """Op program of the reference solver of `problem` (a problems.ProblemDescription)."""
+    h = dict(DEFAULT_HINTS.get(problem.name, {}))
+    h.update(getattr(problem, "solver_hints", None) or {})
+    h.update(hints or {})
+    if not h:
+        raise ValueError(f"no solver hints for problem {problem.name!r}")
+    jacobi = str(h.get("solver_smoother_jacobiType", "false")).lower() == "true"
+    coloured = str(h.get("solver_smoother_coloring", "red-black")).lower() in ("red-black", "rb", "2-way")
+    return v_cycle_ops(problem.min_level, problem.max_level, int(h.get("solver_smoother_numPre", 2)),
+                       int(h.get("solver_smoother_numPost", 1)), float(h.get("solver_smoother_damping", 1.0)),
+                       red_black=coloured and not jacobi)
