@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--concurrency", type=int, default=1,
                     help="candidates in flight per GPU inside the HEADLINE timed region (1 = isolated timing, the "
                          "reference's sequential semantics)")
-    ap.add_argument("--throughput-workers", type=int, default=4,
+    ap.add_argument("--throughput-workers", type=int, default=6,
                     help="after the headline region, also time a throughput-mode region with this many candidates in "
                          "flight per GPU and report it as `throughput_mode` (0/1 = skip)")
     args = ap.parse_args()
