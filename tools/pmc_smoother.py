@@ -11,7 +11,10 @@ kind = sys.argv[3] if len(sys.argv) > 3 else "poisson2d"          # poisson2d | 
 smoother = sys.argv[4] if len(sys.argv) > 4 else "rbgs"            # rbgs | jacobi | residual
 pd = (problems.poisson_3d if kind == "poisson3d" else problems.poisson_2d)(level - 1, level)
 h = native.create(pd)
-if smoother == "residual":
+if smoother.startswith("block"):                                   # block211 etc.
+    shape = tuple(int(c) for c in smoother[5:]) if len(smoother) > 5 else (2, 1, 1)
+    op = abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, shape, 0.8)
+elif smoother == "residual":
     op = abi.make_op(abi.OP_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)
 else:
     op = abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS,
