@@ -815,13 +815,8 @@ template <typename T> class Impl : public ImplBase {
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8), block(256);
     const bool nt = strip_streams3d(g);
-    if (strip3d_sync_) {
-      if (nt) hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
-      else hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
-    } else {
-      if (nt) hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, true, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
-      else hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, false, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
-    }
+    if (nt) hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+    else hipLaunchKernelGGL((evomg_strip3d<T, MODE, TY, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
   }
   void launch_strip3d_rbgs(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
     constexpr int TY = 4;
@@ -900,7 +895,7 @@ template <typename T> class Impl : public ImplBase {
       apply_bc(L, x);
     } else {
       bool launched = false;
-      int rc = (dim_ == 2) ? launch_cg_lds<2>(lv, x, b, r, &launched) : launch_cg_lds<3>(lv, x, b, r, &launched);
+      int rc = (dim_ == 2) ? launch_cg_reg<2>(lv, x, b, r, &launched) : launch_cg_reg<3>(lv, x, b, r, &launched);
       if (rc != EVOMG_OK) return rc;
       if (!launched) {
         if (dim_ == 2) hipLaunchKernelGGL((evomg_cg_single_wg<T, 2>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
@@ -912,7 +907,7 @@ template <typename T> class Impl : public ImplBase {
     return EVOMG_OK;
   }
 
-  // LDS-resident CG when the coarsest grid fits one CU's LDS (2D tile kernel, <= 32 rows per thread); otherwise the
+  // register-resident CG when a thread's share of the coarsest grid fits its registers (2D, up to 129^2); otherwise the
   // caller falls back to the global-memory kernel
   template <typename K> int set_lds_limit(K kern, int slot, size_t lds_bytes) {
     if (!cg_lds_attr_set_[slot]) {
@@ -922,8 +917,8 @@ template <typename T> class Impl : public ImplBase {
     (void)lds_bytes;
     return EVOMG_OK;
   }
-  template <int RT, int E> int launch_cg_lds2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
-    const size_t lds_bytes = (size_t)(cg_lds2d_elems(RT, E) + 32) * sizeof(T);
+  template <int RT, int E> int launch_cg_reg2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
+    const size_t lds_bytes = (size_t)(cg_reg2d_lds_elems(RT, E) + 32) * sizeof(T);
     // the kernel assumes one band per wave of the 512-thread workgroup and exactly RT rows per band
     if (lds_bytes > 160 * 1024 || own.lanes != 512 || own.bands != 8 || own.R != RT || E != (own.pair ? 2 : 1)) return EVOMG_OK;
     // rows every wave is guaranteed to own: all of own.R except in the last band(s)
@@ -932,12 +927,12 @@ template <typename T> class Impl : public ImplBase {
     const bool nearly_full = last_rows >= kMaskLast;
     const dim3 one(1), thr(own.lanes);
     if (nearly_full) {
-      auto kern = evomg_cg_lds2d<T, RT, E, kMaskLast>;
+      auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast>;
       int rc = set_lds_limit(kern, 2 * slot, lds_bytes);
       if (rc != EVOMG_OK) return rc;
       hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
     } else {
-      auto kern = evomg_cg_lds2d<T, RT, E, 0>;
+      auto kern = evomg_cg_reg2d<T, RT, E, 0>;
       int rc = set_lds_limit(kern, 2 * slot + 1, lds_bytes);
       if (rc != EVOMG_OK) return rc;
       hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
@@ -945,23 +940,23 @@ template <typename T> class Impl : public ImplBase {
     *launched = true;
     return EVOMG_OK;
   }
-  template <int DIM> int launch_cg_lds(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
+  template <int DIM> int launch_cg_reg(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
     *launched = false;
-    if (!use_lds_krylov_) return EVOMG_OK;
+    if (!use_reg_krylov_) return EVOMG_OK;
     const KrylovOwn own = krylov_own<DIM>(lv.g.n, !scalar_traits<T>::is_complex);
     if (DIM == 2) {
       if (!own.tile || own.lanes != 512) return EVOMG_OK;
       // 512 threads = 8 waves = 8 bands; up to 65^2: one column per lane, 129^2: a column pair per lane
       if (!own.pair) {
-        if (own.R == 1) return launch_cg_lds2d<1, 1>(lv, x, b, r, own, 0, launched);
-        if (own.R == 2) return launch_cg_lds2d<2, 1>(lv, x, b, r, own, 1, launched);
-        if (own.R == 4) return launch_cg_lds2d<4, 1>(lv, x, b, r, own, 2, launched);
-        if (own.R == 8) return launch_cg_lds2d<8, 1>(lv, x, b, r, own, 3, launched);
+        if (own.R == 1) return launch_cg_reg2d<1, 1>(lv, x, b, r, own, 0, launched);
+        if (own.R == 2) return launch_cg_reg2d<2, 1>(lv, x, b, r, own, 1, launched);
+        if (own.R == 4) return launch_cg_reg2d<4, 1>(lv, x, b, r, own, 2, launched);
+        if (own.R == 8) return launch_cg_reg2d<8, 1>(lv, x, b, r, own, 3, launched);
         return EVOMG_OK;
       }
       // complex 127^2: 48 values of 16 B per thread do not fit the register file
       if constexpr (!scalar_traits<T>::is_complex) {
-        if (own.R == 16) return launch_cg_lds2d<16, 2>(lv, x, b, r, own, 4, launched);
+        if (own.R == 16) return launch_cg_reg2d<16, 2>(lv, x, b, r, own, 4, launched);
       }
       return EVOMG_OK;
     }
@@ -1169,7 +1164,7 @@ template <typename T> class Impl : public ImplBase {
   size_t prof_used_ = 0;
   double prof_bytes_ = 0.0;
   std::vector<hipEvent_t> prof_events_;
-  bool use_lds_krylov_ = (getenv("EVOMG_NO_LDS_KRYLOV") == nullptr);
+  bool use_reg_krylov_ = (getenv("EVOMG_NO_REG_KRYLOV") == nullptr);
   bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
@@ -1177,7 +1172,6 @@ template <typename T> class Impl : public ImplBase {
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
   int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
   int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
-  bool strip3d_sync_ = getenv("EVOMG_STRIP3D_SYNC") ? atoi(getenv("EVOMG_STRIP3D_SYNC")) != 0 : true;
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
 };
 

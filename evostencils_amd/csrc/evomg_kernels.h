@@ -510,7 +510,7 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* red) {
   return red[16];
 }
 
-// ---- fast variants of the same reduction trees (used by the LDS-resident Krylov kernels) ---------------------------
+// ---- fast variants of the same reduction trees (used by the register-resident Krylov kernels) ---------------------------
 // Same summation order as wave_sum / block_sum (v[l] += v[l+off], off = 32,16,8,4,2,1; then the same tree over the
 // wave sums padded with zeros) but without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) bring
 // lane l+32 / l+16, DPP row_shl:n brings lane l+n inside a 16-lane row. Only lane 0's value is meaningful.

@@ -9,7 +9,7 @@
 // Algorithms: CG as configured in Poisson/2D_FD_Poisson_fromL2.exa3:12-14; BiCGStab literally as written in
 // Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433. Node ownership, reduction order and the fused-multiply-add
 // arithmetic are the ones the oracle restates (oracle/evomg_oracle_impl.h, "Krylov solvers on the coarsest grid"),
-// so every variant below (global-memory, LDS-resident) produces the same bits as the oracle.
+// so every variant below (global-memory, register-resident, multi-workgroup) produces the same bits as the oracle.
 #pragma once
 #include "evomg_kernels.h"
 
@@ -344,13 +344,13 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
 //   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
 // Arithmetic and summation order are those of evomg_cg_single_wg with the same ownership, and of the oracle.
 // LDS (elements of T): 32 reduction slots | row seams [8 waves][first, last][E][64] | x [R * E][512].
-__host__ __device__ inline long cg_lds2d_elems(int rt, int e) { return 32 + 8L * 2 * e * 64 + (long)rt * e * 512; }
+__host__ __device__ inline long cg_reg2d_lds_elems(int rt, int e) { return 32 + 8L * 2 * e * 64 + (long)rt * e * 512; }
 
 // MASK_FROM: first unrolled row that may lie outside the thread's band (needs masking); rows below it are always
 // rows of the grid for every wave (host-checked: own.R == R and the last band keeps at least MASK_FROM rows).
 template <typename T, int R, int E, int MASK_FROM>
 __global__ void __launch_bounds__(512)
-evomg_cg_lds2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
+evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
                double tol, int* __restrict__ info) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)

@@ -486,17 +486,16 @@ __device__ __forceinline__ T residual7(const Stencil<T>& st, T c, T w, T e, T s,
 }
 
 // grid: n_blocks (rounded up to a multiple of 8) blocks of 256 threads; block -> (group of 4 y tiles fastest, strip,
-// z chunk), wave w of the block = y tile 4*group + w. The four waves of a block are y neighbours and walk the same
-// planes: SYNC makes them do so in lock step (one barrier per plane), so that a halo row and the neighbour's own
-// copy of it are requested within the same few hundred cycles and meet in L1/L2 instead of being fetched twice.
-template <typename T, int MODE, int TY, bool NT_F, bool SYNC>
+// z chunk), wave w of the block = y tile 4*group + w. (Lock-stepping the four waves with a barrier per plane so that
+// shared halo rows meet in L1/L2 was measured and does not help: profiles/r01_pmc_3d.md.)
+template <typename T, int MODE, int TY, bool NT_F>
 __global__ void __launch_bounds__(256)
 evomg_strip3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
               double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL, "3D tiles: Jacobi and residual");
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (logical_block >= n_blocks) return;                       // whole block: no barrier is left waiting
+  if (logical_block >= n_blocks) return;
   const int lane = threadIdx.x & 63;
   const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = (logical_block / n_ygroups) % n_strips;
@@ -539,7 +538,6 @@ evomg_strip3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     for (int d = 0; d < 4; ++d) {
       const int k = kb + d;
       if (k < z1) {                                            // uniform over the block (same chunk)
-        if constexpr (SYNC) __syncthreads();
         // prefetch plane k+2 of x and plane k+1 of f
 #pragma unroll
         for (int t = 0; t < TY + 2; ++t) xr[(d + 3) & 3][t] = load_x(y0 - 1 + t, k + 2);

@@ -254,8 +254,8 @@ def test_rejects_malformed_programs(native):
 
 
 @pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4), (3, 5)])
-def test_lds_resident_cg_is_bit_identical(native, oracle, dim, lo, monkeypatch):
-    """The LDS-resident CG (p in LDS with a zero halo, r/x in registers), the global-memory single-workgroup CG
+def test_coarse_cg_variants_are_bit_identical(native, oracle, dim, lo, monkeypatch):
+    """The register-resident CG (2D) / the eight-workgroup CG (33^3), the global-memory single-workgroup CG
     and the oracle follow one summation order: all three give the same bits (129^2 = the C2 coarsest grid)."""
     pd = problems.poisson_2d(lo, lo + 1) if dim == 2 else problems.poisson_3d(lo, lo + 1)
     rng = np.random.default_rng(lo * 10 + dim)
@@ -266,9 +266,9 @@ def test_lds_resident_cg_is_bit_identical(native, oracle, dim, lo, monkeypatch):
     results = []
     for no_lds in (False, True):
         if no_lds:
-            monkeypatch.setenv("EVOMG_NO_LDS_KRYLOV", "1")
+            monkeypatch.setenv("EVOMG_NO_REG_KRYLOV", "1")
         else:
-            monkeypatch.delenv("EVOMG_NO_LDS_KRYLOV", raising=False)
+            monkeypatch.delenv("EVOMG_NO_REG_KRYLOV", raising=False)
         h = native.create(pd)
         h.set_field(lo, abi.F_CGS_RHS, rhs)
         h.set_field(lo, abi.F_CORR, x0)
