@@ -505,6 +505,23 @@ template <typename T> class Impl : public ImplBase {
         ++i;
         continue;
       }
+      if (fusable_prolong_smooth(ops, n_ops, i)) {
+        const evomg_op_t &pr = ops[i], &sm = ops[i + 1];
+        const int L = pr.level;
+        Level<T>& lv = lv_[L];
+        T* x = fieldptr(L, sm.dst);
+        T* y = lv.alt;
+        const double om = sm.omega, omm = 1.0 - sm.omega;
+        if (sm.partitioning == EVOMG_PART_RED_BLACK)
+          launch_strip_prolonged<STRIP_RBGS>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, fieldptr(L - 1, pr.src0), pr.omega);
+        else
+          launch_strip_prolonged<STRIP_JACOBI>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, fieldptr(L - 1, pr.src0), pr.omega);
+        lv.alt = x;
+        set_fieldptr(L, sm.dst, y);
+        HIP_TRY(hipGetLastError());
+        ++i;
+        continue;
+      }
       int rc = exec(ops[i]);
       if (rc != EVOMG_OK) return rc;
     }
@@ -761,8 +778,33 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0);
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0});
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0});
+  }
+  // PROLONG_ADD@L immediately followed by a point smoother on the same field: one sweep that forms the corrected
+  // input on the fly (evomg_strip2d<.., PRO>)
+  template <int MODE> void launch_strip_prolonged(const Geo& g, const Geo& gc, const Stencil<T>& st, const T* x, const T* f, T* y,
+                                                   double om, double omm, const T* coarse, double om_p) {
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    int rows = strip_rows_ > 0 ? strip_rows_ : 64;
+    while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+    rows = (rows + 1) & ~1;
+    const int chunks = (g.n + rows - 1) / rows;
+    const int waves = strips * chunks;
+    const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
+    const ProlongIn<T> pro{coarse, gc, om_p};
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
+  }
+  bool fusable_prolong_smooth(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || i + 1 >= n_ops || scalar_traits<T>::is_complex || dim_ != 2) return false;
+    if (prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    const evomg_op_t &a = ops[i], &b = ops[i + 1];
+    if (a.opcode != EVOMG_OP_PROLONG_ADD || b.opcode != EVOMG_OP_SMOOTH || a.level != b.level) return false;
+    if (canon(a.level, a.dst) != canon(b.level, b.dst)) return false;
+    if (b.block[0] * b.block[1] != 1) return false;                        // point smoothers only
+    if (canon(b.level, b.src1) == canon(b.level, b.dst)) return false;
+    return use_strip(lv_[a.level].g);
   }
   // Fused residual + squared norm (the solver loop's residual check): the residual field is still written, the norm
   // costs no second pass. The summation order — per (strip, 16-row chunk) wave, lane = column pair, rows ascending —
@@ -781,8 +823,8 @@ template <typename T> class Impl : public ImplBase {
       norm_partials_cap_ = waves;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0);
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0);
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));

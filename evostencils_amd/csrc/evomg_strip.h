@@ -78,12 +78,21 @@ __device__ __forceinline__ T residual5(const Stencil<T>& st, T c, T w, T e, T s,
   return sc_sub(f, a);
 }
 
+// PRO: the sweep's input is x + om * P(coarse) instead of x — the prolongation-and-correction that precedes a
+// post-smoothing sweep, formed on the fly from the coarse rows (8 B per lane and fine row) with the formulas and masks
+// of evomg_strip_prolong, so the result is bit-identical to running PROLONG_ADD and then the sweep, while the
+// corrected field is neither written nor read back (2 x 8 B/node less traffic). Real Dirichlet problems only.
+template <typename T> struct ProlongIn {
+  const T* coarse;
+  Geo gc;
+  double om;
+};
 // grid: ceil(strips * chunks / 4) blocks of 256 threads (4 independent waves); rows_per_chunk = H
-template <typename T, int MODE, int PF, bool NT_F>
+template <typename T, int MODE, int PF, bool NT_F, bool PRO = false>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
               double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
-              T* __restrict__ partials, int robin_out) {
+              T* __restrict__ partials, int robin_out, ProlongIn<T> pro) {
   // XCD-aware block order: the dispatcher deals blocks round-robin over the 8 XCDs (block b -> XCD b % 8), each
   // with a private L2. Remap so that every XCD works on one contiguous band of rows: vertically adjacent chunks
   // then share their halo rows through that XCD's L2 instead of re-reading them from HBM. gridDim.x is a multiple
@@ -143,13 +152,56 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   constexpr int LEAD = (MODE == STRIP_RBGS) ? 1 : 0;        // RB-GS relaxes red one row ahead of black
   const int js = y0 - LEAD;                                 // first row relaxed (red)
   const int je = y1 + LEAD;                                 // one past the last row relaxed
+  static_assert(!PRO || PF % 2 == 0, "PRO relies on the static row parity of an even prefetch depth");
+  const int nc = PRO ? pro.gc.n : 1;
+  const int Ic = min(max(c0 >> 1, 0), nc - 1);              // coarse column of the lane's first element
+  // coarse row `row` at the lane's column and the next one (8-byte aligned 16-byte load; column nc lies inside the
+  // row pitch). Every lane loads its own right neighbour — not a DPP shift as in evomg_strip_prolong — because here
+  // the halo lane 63 must be right as well: its second element is the east neighbour of its first.
+  auto load_coarse = [&](int row) -> Pair<T> {
+    const int r = min(max(row, 0), nc - 1);
+    return load_pair<T>(pro.coarse + (long)pro.gc.pitch * r + Ic);
+  };
+  const Pair<T> zcoarse{zero, zero};
+  // fine row `row` of x + om P coarse; odd: the row lies between the coarse rows cJ and cJ1
+  auto corrected = [&](const Pair<T>& raw, int row, bool odd, const Pair<T>& cJp, const Pair<T>& cJ1p) -> Pair<T> {
+    const bool row_in = row >= 1 && row <= n - 2;
+    const T cJ = cJp.a, cJr = cJp.b;
+    T va, vb;
+    if (!odd) {
+      va = cJ;
+      vb = sc_rmul(0.5, sc_add(cJ, cJr));
+    } else {
+      const T cJ1 = cJ1p.a, cJ1r = cJ1p.b;
+      va = sc_rmul(0.5, sc_add(cJ, cJ1));
+      vb = sc_rmul(0.25, sc_add(sc_add(cJ, cJr), sc_add(cJ1, cJ1r)));
+    }
+    Pair<T> out;
+    out.a = (row_in && inner_a) ? sc_add(raw.a, sc_rmul(pro.om, va)) : raw.a;
+    out.b = (row_in && inner_b) ? sc_add(raw.b, sc_rmul(pro.om, vb)) : raw.b;
+    return out;
+  };
   Pair<T> xm = load_row(x, js - 1);
   Pair<T> xc = load_row(x, js);
+  if constexpr (PRO) {
+    // y0 is even: row js has the parity of LEAD, row js - 1 the other one
+    constexpr bool odd_c = (LEAD & 1) != 0, odd_m = !odd_c;
+    const int rm = max(js - 1, 0), rc = max(js, 0);
+    xm = corrected(xm, js - 1, odd_m, load_coarse(rm >> 1), odd_m ? load_coarse((rm >> 1) + 1) : zcoarse);
+    xc = corrected(xc, js, odd_c, load_coarse(rc >> 1), odd_c ? load_coarse((rc >> 1) + 1) : zcoarse);
+  }
   Pair<T> xq[PF], fq[PF];
+  Pair<T> cq[PF], cq1[PF];     // PRO: coarse rows below / above the prefetched fine row
 #pragma unroll
   for (int d = 0; d < PF; ++d) {
     xq[d] = load_row(x, js + 1 + d);
     fq[d] = load_row_f(f, js + d);
+    if constexpr (PRO) {
+      const int r = max(js + 1 + d, 0);
+      const bool odd = ((LEAD + 1 + d) & 1) != 0;
+      cq[d] = load_coarse(r >> 1);
+      cq1[d] = odd ? load_coarse((r >> 1) + 1) : zcoarse;
+    }
   }
   Pair<T> fm = zpair;          // f of row j-1 (black phase)
   T rm2 = zero, rm1 = zero;    // new red of rows j-2, j-1 (this lane's pair)
@@ -160,13 +212,20 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     for (int d = 0; d < PF; ++d) {
       const int j = base + d;
       if (j < je) {                                          // wave-uniform
-        const Pair<T> xp = xq[d];
+        Pair<T> xp = xq[d];
         const Pair<T> fc = fq[d];
         xq[d] = load_row(x, j + 1 + PF);
         fq[d] = load_row_f(f, j + PF);
         const bool row_inner = j >= 1 && j <= n - 2;
         // chunk heights are even and js = y0 - LEAD, so with an even prefetch depth the row parity is static
         const int parity = (PF % 2 == 0) ? ((LEAD + d) & 1) : (j & 1);
+        if constexpr (PRO) {
+          const bool odd_next = ((parity + 1) & 1) != 0;         // row j + 1 (static); slot d always holds this parity
+          xp = corrected(xp, j + 1, odd_next, cq[d], cq1[d]);
+          const int r = max(j + 1 + PF, 0);
+          cq[d] = load_coarse(r >> 1);
+          cq1[d] = odd_next ? load_coarse((r >> 1) + 1) : zcoarse;
+        }
         if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == STRIP_RESNORM) {
           const T wa = from_left(xc.b), eb = from_right(xc.a);
           Pair<T> out;

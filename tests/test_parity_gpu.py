@@ -309,7 +309,12 @@ def test_marching_strip_kernels_match_generic_kernels(native, pname, level, rows
            abi.make_op(abi.OP_RESTRICT, level - 1, abi.F_RHS, abi.F_RES),
            abi.make_op(abi.OP_SMOOTH, level - 1, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 1.0),
            abi.make_op(abi.OP_PROLONG_ADD, level, abi.F_SOL, abi.F_SOL, omega=0.85),
-           abi.make_op(abi.OP_PROLONG_SET, level, abi.F_CORR, abi.F_SOL)]
+           abi.make_op(abi.OP_PROLONG_SET, level, abi.F_CORR, abi.F_SOL),
+           # prolongation + correction immediately followed by a point smoother: one fused sweep (real problems)
+           abi.make_op(abi.OP_PROLONG_ADD, level, abi.F_SOL, abi.F_SOL, omega=1.1),
+           abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, 0.9),
+           abi.make_op(abi.OP_PROLONG_ADD, level, abi.F_SOL, abi.F_SOL, omega=0.7),
+           abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, one, 0.8)]
     out = []
     for strip in (True, False):
         if strip:
