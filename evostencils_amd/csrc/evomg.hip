@@ -93,6 +93,7 @@ template <typename T> class Impl : public ImplBase {
     if (partials_) (void)hipFree(partials_);
     if (dscalar_) (void)hipFree(dscalar_);
     if (dinfo_) (void)hipFree(dinfo_);
+    if (norm_event_) (void)hipEventDestroy(norm_event_);
     if (norm_partials_) (void)hipFree(norm_partials_);
     if (cg_xpart_) (void)hipFree(cg_xpart_);
     if (cg_xface_) (void)hipFree(cg_xface_);
@@ -490,8 +491,8 @@ template <typename T> class Impl : public ImplBase {
     if ((a.opcode == prof_opcode_ && a.level == prof_level_) || (b.opcode == prof_opcode_ && b.level == prof_level_)) return false;
     return true;
   }
-  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic) {
-    for (int i = 0; i < n_ops; ++i) {
+  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0) {
+    for (int i = first; i < n_ops; ++i) {
       if (fusable_residual_restrict(ops, n_ops, i)) {
         const bool write_r = !(cyclic && residual_dead_after(ops, n_ops, i));
         const int L = ops[i].level;
@@ -811,7 +812,7 @@ template <typename T> class Impl : public ImplBase {
   // is canonical for 2D levels of at least 33 nodes (the oracle's FN(norm_strip2d)) and does NOT depend on
   // EVOMG_NO_STRIP or the tuning knobs.
   bool norm_fused(const Geo& g) const { return dim_ == 2 && g.n >= 33; }
-  int residual_norm_to_host(int L, const Stencil<T>& st, const T* x, const T* f, T* r, T* out) {
+  int residual_norm_launch(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
     const Geo& g = lv_[L].g;
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
     const int chunks = (g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS;
@@ -826,9 +827,6 @@ template <typename T> class Impl : public ImplBase {
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
     else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
-    HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    *out = hscalar_[0];
     return EVOMG_OK;
   }
 
@@ -1037,19 +1035,64 @@ template <typename T> class Impl : public ImplBase {
   }
 
   // ---- outer loop A: generated MG iteration (oracle FN(solve_mg)) ----------------------------------------------------------
+  // an out-of-place smoother reads its field and writes the level's spare array; only the host-side pointer swap makes
+  // the result current, so launching it speculatively is free of side effects
+  bool smoother_is_out_of_place(const evomg_op_t& op) const {
+    if (op.opcode != EVOMG_OP_SMOOTH) return false;
+    const Geo& g = lv_[op.level].g;
+    const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
+    const bool rb = op.partitioning == EVOMG_PART_RED_BLACK;
+    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || !rb;
+  }
   int solve_mg(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
     const int L = prob_.max_level;
     Level<T>& lv = lv_[L];
     int nh = 0;
     const double t0 = wall_ms();
     T d;
-    auto residual_norm = [&]() -> int {
-      if (norm_fused(lv.g)) return residual_norm_to_host(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), &d);
-      residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
-      return dot_to_host(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), &d);
+    if (!norm_event_) HIP_TRY(hipEventCreateWithFlags(&norm_event_, hipEventDisableTiming));
+    // residual + norm of the current iterate: launched, the scalar copied back asynchronously, an event recorded
+    auto residual_norm_launch_all = [&]() -> int {
+      int rc = EVOMG_OK;
+      if (norm_fused(lv.g)) rc = residual_norm_launch(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+      else {
+        residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+        dot_async(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), dscalar_);
+      }
+      if (rc != EVOMG_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+      HIP_TRY(hipEventRecord(norm_event_, stream_));
+      return EVOMG_OK;
     };
-    int rc = residual_norm();
+    // While the host waits for that scalar the GPU would idle. If the cycle starts with an out-of-place smoother, its
+    // launch is queued behind the norm right away (speculatively): should the norm say "converged", the pointer swap
+    // is simply undone and the sweep's output discarded; otherwise the cycle continues from its second op.
+    T *saved_alt = nullptr, *saved_x = nullptr;
+    auto speculate = [&](bool* launched) -> int {
+      *launched = false;
+      if (!speculate_ || n_ops < 1 || !smoother_is_out_of_place(ops[0])) return EVOMG_OK;
+      const int l0 = ops[0].level;
+      saved_alt = lv_[l0].alt;
+      saved_x = fieldptr(l0, ops[0].dst);
+      const int rc = exec(ops[0]);
+      *launched = rc == EVOMG_OK;
+      return rc;
+    };
+    auto undo_speculation = [&]() {
+      const int l0 = ops[0].level;
+      lv_[l0].alt = saved_alt;
+      set_fieldptr(l0, ops[0].dst, saved_x);
+    };
+    auto wait_norm = [&]() -> int {
+      HIP_TRY(hipEventSynchronize(norm_event_));
+      d = hscalar_[0];
+      return EVOMG_OK;
+    };
+    bool ahead = false;
+    int rc = residual_norm_launch_all();
     if (rc != EVOMG_OK) return rc;
+    if ((rc = speculate(&ahead)) != EVOMG_OK) return rc;
+    if ((rc = wait_norm()) != EVOMG_OK) return rc;
     const double res0 = sc_norm_from_dot(d);
     if (hist && nh < cap) hist[nh] = res0;
     ++nh;
@@ -1058,10 +1101,12 @@ template <typename T> class Impl : public ImplBase {
     if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
     else
       for (it = 1; it <= prob_.max_iterations; ++it) {
-        rc = exec_program(ops, n_ops, /*cyclic=*/true);
+        rc = exec_program(ops, n_ops, /*cyclic=*/true, ahead ? 1 : 0);
+        ahead = false;
         if (rc != EVOMG_OK) return rc;
-        rc = residual_norm();
-        if (rc != EVOMG_OK) return rc;
+        if ((rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
+        if (it < prob_.max_iterations && (rc = speculate(&ahead)) != EVOMG_OK) return rc;
+        if ((rc = wait_norm()) != EVOMG_OK) return rc;
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
         ++nh;
@@ -1069,6 +1114,8 @@ template <typename T> class Impl : public ImplBase {
         if (res <= prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
         if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
       }
+    if (ahead) undo_speculation();                 // the sweep queued for an iteration that is not going to happen
+    HIP_TRY(hipStreamSynchronize(stream_));
     if (it > prob_.max_iterations) it = prob_.max_iterations;
     out->time_ms = wall_ms() - t0;
     out->n_iterations = (double)it;
@@ -1193,6 +1240,8 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  hipEvent_t norm_event_ = nullptr;
+  bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
   T* norm_partials_ = nullptr;
   size_t norm_partials_cap_ = 0;
