@@ -22,7 +22,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 # HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
 # gfx950 correction FETCH_SIZE x2; see profiles/README.md). None until measured for the current kernel build.
-TRAFFIC_BYTES_PER_LAUNCH = 434.17e6   # 2 x FETCH_SIZE (299.5 MB) + WRITE_SIZE (134.7 MB), profiles/r01_pmc_smoother.md
+TRAFFIC_BYTES_PER_LAUNCH = 483.8e6      # fused finest-level sweeps inside solves (profiles/r01_pmc_smoother.md); plain sweep: 434.2e6   # 2 x FETCH_SIZE (299.5 MB) + WRITE_SIZE (134.7 MB), profiles/r01_pmc_smoother.md
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -199,15 +199,25 @@ def main():
     # ---- roofline of the dominant kernel: finest-level fused RB-GS sweep, 24 B/node algorithmic ----
     kname = handle.kernel_name(smooth)
     n_nodes = ((1 << hi) + 1) ** 2
+    plain_bytes = 24.0 * n_nodes
+    fused = live.bytes > 1.001 * plain_bytes
+    if fused:
+        # inside a solve both finest-level sweeps of the V(1,1) cycle run fused with their neighbours: the
+        # pre-smoother with residual + restriction, the post-smoother with prolongation and the loop's residual norm
+        kname = (kname.replace(">", ", ...>") + " fused sweeps: <.., false, false, true> = smoother + residual + restriction, "
+                 "<.., true, true, false> = prolongation + smoother + residual norm")
     b2b = handle.bench_op(smooth, warmup=10, reps=100)     # SURVEY 8(d) procedure: back-to-back ping-pong sweeps
     roofline = {"bound": "hbm", "achieved": live.gbps, "peak": 8000.0, "unit": "GB/s", "frac": live.gbps / 8000.0,
-                "traffic": TRAFFIC_BYTES_PER_LAUNCH, "kernel": kname,
+                "traffic": TRAFFIC_BYTES_PER_LAUNCH if fused else 434.17e6, "kernel": kname,
                 "bytes_per_launch": live.bytes, "ms_per_launch": live.ms, "launches_timed": live.launches,
-                "back_to_back": {"ms_per_launch": b2b.ms, "achieved": b2b.gbps, "frac": b2b.gbps / 8000.0},
-                "note": f"algorithmic 24 B/node x {n_nodes} nodes per fused red+black sweep; 'achieved' = mean over the "
-                        f"{live.launches} finest-level sweeps inside the timed solves (HIP events on the backend stream); "
-                        f"'back_to_back' = 100 consecutive ping-pong sweeps; 'traffic' = HBM bytes/launch from "
-                        f"rocprofv3 PMC (profiles/), null if not collected for this build"}
+                "back_to_back": {"kernel": handle.kernel_name(smooth), "bytes_per_launch": plain_bytes,
+                                 "ms_per_launch": b2b.ms, "achieved": b2b.gbps, "frac": b2b.gbps / 8000.0},
+                "note": f"'achieved' = algorithmic bytes / mean duration over the {live.launches} launches that execute the "
+                        f"finest-level smoothing ops inside the timed solves (HIP events on the backend stream). "
+                        f"Algorithmic bytes per launch: 24 B/node x {n_nodes} nodes for a plain fused red+black sweep; "
+                        f"the fused sweeps additionally write / read the coarse level (8 B per coarse node): "
+                        f"{live.bytes / 1e6:.1f} MB. 'back_to_back' = 100 consecutive plain ping-pong sweeps. "
+                        f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC (profiles/r01_pmc_smoother.md)"}
 
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:

@@ -19,6 +19,9 @@
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
+#ifndef EVOMG_FUSED_PF
+#define EVOMG_FUSED_PF 2   // prefetch depth of the fused sweeps (fewer waves per SIMD than the plain ones)
+#endif
 
 namespace {
 
@@ -335,8 +338,8 @@ template <typename T> class Impl : public ImplBase {
     const int launches = (int)(prof_used_ / 2);
     out->launches = launches;
     out->ms = launches ? total / launches : 0.0;
-    out->bytes = prof_bytes_;
-    out->gbps = (launches && total > 0) ? prof_bytes_ / (out->ms * 1e-3) * 1e-9 : 0.0;
+    out->bytes = launches ? prof_bytes_ / launches : 0.0;      // mean over the launches (fused ones move more)
+    out->gbps = (launches && total > 0) ? prof_bytes_ / (total * 1e-3) * 1e-9 : 0.0;
     prof_opcode_ = -1;
     return EVOMG_OK;
   }
@@ -496,6 +499,27 @@ template <typename T> class Impl : public ImplBase {
   int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0, bool* tail_norm = nullptr) {
     if (tail_norm) *tail_norm = false;
     for (int i = first; i < n_ops; ++i) {
+      if (fusable_smooth_residual_restrict(ops, n_ops, i, cyclic)) {
+        const evomg_op_t &sm = ops[i], &rs = ops[i + 2];
+        const int L = sm.level;
+        Level<T>& lv = lv_[L];
+        T* x = fieldptr(L, sm.dst);
+        T* y = lv.alt;
+        const double om = sm.omega, omm = 1.0 - sm.omega;
+        const bool timed = prof_matches(sm);
+        if (timed) { const int rc = prof_open(); if (rc != EVOMG_OK) return rc; }
+        if (sm.partitioning == EVOMG_PART_RED_BLACK)
+          launch_strip_restrict_tail<STRIP_RBGS>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, fieldptr(L - 1, rs.dst));
+        else
+          launch_strip_restrict_tail<STRIP_JACOBI>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, fieldptr(L - 1, rs.dst));
+        // x, f read + y written + the coarse right-hand side written
+        if (timed) { const int rc = prof_close(algorithmic_bytes(sm) + (double)sizeof(T) * lv_[L - 1].g.n * lv_[L - 1].g.n); if (rc != EVOMG_OK) return rc; }
+        lv.alt = x;
+        set_fieldptr(L, sm.dst, y);
+        HIP_TRY(hipGetLastError());
+        i += 2;
+        continue;
+      }
       if (fusable_residual_restrict(ops, n_ops, i)) {
         const bool write_r = !(cyclic && residual_dead_after(ops, n_ops, i));
         const int L = ops[i].level;
@@ -520,12 +544,16 @@ template <typename T> class Impl : public ImplBase {
         const bool tail = tail_norm && tail_norm_candidate(ops, n_ops, i + 1);
         const T* f = fieldptr(L, sm.src1);
         const T* cz = fieldptr(L - 1, pr.src0);
+        const bool timed = prof_matches(sm);
+        if (timed) { const int rc0 = prof_open(); if (rc0 != EVOMG_OK) return rc0; }
         int rc;
         if (tail) rc = rb ? launch_strip_fused<STRIP_RBGS, true, true>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega)
                           : launch_strip_fused<STRIP_JACOBI, true, true>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega);
         else rc = rb ? launch_strip_fused<STRIP_RBGS, true, false>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega)
                      : launch_strip_fused<STRIP_JACOBI, true, false>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, cz, pr.omega);
         if (rc != EVOMG_OK) return rc;
+        // x, f read + y written + the coarse correction read
+        if (timed) { const int rc2 = prof_close(algorithmic_bytes(sm) + (double)sizeof(T) * lv_[L - 1].g.n * lv_[L - 1].g.n); if (rc2 != EVOMG_OK) return rc2; }
         if (tail) *tail_norm = true;
         lv.alt = x;
         set_fieldptr(L, sm.dst, y);
@@ -540,10 +568,13 @@ template <typename T> class Impl : public ImplBase {
         T* x = fieldptr(L, sm.dst);
         T* y = lv.alt;
         const double om = sm.omega, omm = 1.0 - sm.omega;
+        const bool timed = prof_matches(sm);
+        if (timed) { const int rc0 = prof_open(); if (rc0 != EVOMG_OK) return rc0; }
         const int rc = sm.partitioning == EVOMG_PART_RED_BLACK
                          ? launch_strip_fused<STRIP_RBGS, false, true>(lv.g, lv.g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, nullptr, 0.0)
                          : launch_strip_fused<STRIP_JACOBI, false, true>(lv.g, lv.g, lv.st, x, fieldptr(L, sm.src1), y, om, omm, nullptr, 0.0);
         if (rc != EVOMG_OK) return rc;
+        if (timed) { const int rc2 = prof_close(algorithmic_bytes(sm)); if (rc2 != EVOMG_OK) return rc2; }
         *tail_norm = true;
         lv.alt = x;
         set_fieldptr(L, sm.dst, y);
@@ -591,21 +622,34 @@ template <typename T> class Impl : public ImplBase {
     else hipLaunchKernelGGL((evomg_strip_prolong<T, false>), grid, block, 0, stream_, g, gc, coarse, fine, 1.0, rows, strips, waves, rkh);
   }
 
+  // live profiling (evomg_profile_begin/end): HIP events around every launch that executes an op of the selected
+  // (opcode, level), fused launches included; bytes = algorithmic bytes of what that launch does
+  bool prof_matches(const evomg_op_t& op) const { return op.opcode == prof_opcode_ && op.level == prof_level_; }
+  int prof_open() {
+    while (prof_events_.size() < prof_used_ + 2) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      prof_events_.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(prof_events_[prof_used_], stream_));
+    return EVOMG_OK;
+  }
+  int prof_close(double bytes) {
+    HIP_TRY(hipEventRecord(prof_events_[prof_used_ + 1], stream_));
+    prof_used_ += 2;
+    prof_bytes_ += bytes;
+    return EVOMG_OK;
+  }
   int exec(const evomg_op_t& op) {
-    const bool timed = op.opcode == prof_opcode_ && op.level == prof_level_;
+    const bool timed = prof_matches(op);
     if (timed) {
-      while (prof_events_.size() < prof_used_ + 2) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreate(&e));
-        prof_events_.push_back(e);
-      }
-      HIP_TRY(hipEventRecord(prof_events_[prof_used_], stream_));
+      const int rc = prof_open();
+      if (rc != EVOMG_OK) return rc;
     }
     const int rc = exec_impl(op);
     if (timed) {
-      HIP_TRY(hipEventRecord(prof_events_[prof_used_ + 1], stream_));
-      prof_used_ += 2;
-      prof_bytes_ = algorithmic_bytes(op);
+      const int rc2 = prof_close(algorithmic_bytes(op));
+      if (rc2 != EVOMG_OK) return rc2;
     }
     return rc;
   }
@@ -806,8 +850,8 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0});
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0});
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
   }
   // PROLONG_ADD@L immediately followed by a point smoother on the same field: one sweep that forms the corrected
   // input on the fly (evomg_strip2d<.., PRO>)
@@ -832,11 +876,37 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{coarse, gc, om_p};
+    const ProlongIn<T> pro{coarse, gc, om_p, nullptr};
     T* parts = TAIL ? norm_partials_ : (T*)nullptr;
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
     return EVOMG_OK;
+  }
+  // SMOOTH@L + RESIDUAL@L + RESTRICT@(L-1) with a residual nobody else reads: one sweep (evomg_strip2d<.., TAIL_RESTRICT>)
+  template <int MODE> void launch_strip_restrict_tail(const Geo& g, const Geo& gc, const Stencil<T>& st, const T* x, const T* f, T* y,
+                                                       double om, double omm, T* coarse_out) {
+    const int strips = (g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS;     // two halo lanes per side
+    int rows = strip_rows_ > 0 ? strip_rows_ : 64;
+    while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+    rows = (rows + 1) & ~1;
+    const int chunks = (g.n + rows - 1) / rows;
+    const int waves = strips * chunks;
+    const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
+    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out};
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
+  }
+  bool fusable_smooth_residual_restrict(const evomg_op_t* ops, int n_ops, int i, bool cyclic) const {
+    if (!fuse_enabled_ || !tail_restrict_enabled_ || !cyclic || i + 2 >= n_ops) return false;
+    if (scalar_traits<T>::is_complex || dim_ != 2 || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    const evomg_op_t &sm = ops[i], &a = ops[i + 1];
+    if (sm.opcode != EVOMG_OP_SMOOTH || sm.block[0] * sm.block[1] != 1) return false;
+    if (!fusable_residual_restrict(ops, n_ops, i + 1) || !residual_dead_after(ops, n_ops, i + 1)) return false;
+    if (a.level != sm.level) return false;
+    // the residual is taken of what the sweep produces, with the sweep's right-hand side
+    if (canon(a.level, a.src0) != canon(sm.level, sm.dst) || canon(a.level, a.src1) != canon(sm.level, sm.src1)) return false;
+    if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
+    return use_strip(lv_[sm.level].g);
   }
   int ensure_norm_partials(int count) {
     if ((size_t)count > norm_partials_cap_) {
@@ -891,8 +961,8 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0});
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     return EVOMG_OK;
   }
@@ -1138,6 +1208,9 @@ template <typename T> class Impl : public ImplBase {
     auto speculate = [&](bool* launched) -> int {
       *launched = false;
       if (!speculate_ || n_ops < 1 || !smoother_is_out_of_place(ops[0])) return EVOMG_OK;
+      // a sweep that fuses with the residual + restriction behind it is worth more than the overlap (and the fused
+      // kernel writes the coarse right-hand side, which a speculative launch must not)
+      if (fusable_smooth_residual_restrict(ops, n_ops, 0, true)) return EVOMG_OK;
       const int l0 = ops[0].level;
       saved_alt = lv_[l0].alt;
       saved_x = fieldptr(l0, ops[0].dst);
@@ -1323,6 +1396,7 @@ template <typename T> class Impl : public ImplBase {
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
   bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
+  bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
   hipEvent_t norm_event_ = nullptr;
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;

@@ -88,9 +88,10 @@ __device__ __forceinline__ T residual5(const Stencil<T>& st, T c, T w, T e, T s,
 // of evomg_strip_prolong, so the result is bit-identical to running PROLONG_ADD and then the sweep, while the
 // corrected field is neither written nor read back (2 x 8 B/node less traffic). Real Dirichlet problems only.
 template <typename T> struct ProlongIn {
-  const T* coarse;
-  Geo gc;
-  double om;
+  const T* coarse;     // PRO: coarse correction to prolongate into the input
+  Geo gc;              // geometry of the coarse level (PRO and TAIL_RESTRICT)
+  double om;           // PRO: weight of the correction
+  T* coarse_out;       // TAIL_RESTRICT: coarse right-hand side to write
 };
 // TAIL_NORM (smoother modes): the sweep is the last op of a solver-loop iteration, so the squared norm of the residual
 // of its OUTPUT is accumulated in the same pass: the rows the sweep has finalised are kept in a three-row register
@@ -98,7 +99,10 @@ template <typename T> struct ProlongIn {
 // chunk side). Partial sums follow the canonical order of STRIP_RESNORM (one per strip and 16-row chunk; a wave
 // covering a taller chunk emits several), so the solver loop needs no separate residual sweep: 24 B/node less.
 // grid: ceil(strips * chunks / 4) blocks of 256 threads (4 independent waves); rows_per_chunk = H
-template <typename T, int MODE, int PF, bool NT_F, bool PRO = false, bool TAIL_NORM = false>
+// TAIL_RESTRICT (smoother modes): the sweep is followed by RESIDUAL + RESTRICT of a residual nobody else reads. Same
+// finalised-row window, one more halo row per side; the residual rows feed a three-row residual window from which
+// every second step emits one row of the coarse right-hand side exactly as evomg_strip_residual_restrict does.
+template <typename T, int MODE, int PF, bool NT_F, bool PRO = false, bool TAIL_NORM = false, bool TAIL_RESTRICT = false>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
               double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
@@ -117,7 +121,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int n = g.n;
   const long pitch = g.pitch;
   // halo lanes per side: 1 (124 stored columns), 2 for the kernels that carry the residual norm (120 columns)
-  constexpr int HALO = (TAIL_NORM || MODE == STRIP_RESNORM) ? 2 : 1;
+  constexpr int HALO = (TAIL_NORM || TAIL_RESTRICT || MODE == STRIP_RESNORM) ? 2 : 1;
   constexpr int COLS = 128 - 4 * HALO;
   static_assert(HALO == 1 ? COLS == EVOMG_STRIP_COLS : COLS == EVOMG_NORM_STRIP_COLS, "strip widths");
   const int c0 = strip * COLS - 2 * HALO + 2 * lane;        // first column of this lane's pair (even)
@@ -164,9 +168,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     }
   };
   constexpr int LEAD = (MODE == STRIP_RBGS) ? 1 : 0;        // RB-GS relaxes red one row ahead of black
-  constexpr int EXT = TAIL_NORM ? 1 : 0;                    // extra finalised row on each side for the residual
-  static_assert(!TAIL_NORM || MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "TAIL_NORM is a smoother option");
-  static_assert(!TAIL_NORM || PF % 2 == 0, "TAIL_NORM relies on the static row parity");
+  constexpr int EXT = TAIL_RESTRICT ? 2 : (TAIL_NORM ? 1 : 0);   // extra finalised rows on each side for the residual
+  constexpr bool TAIL = TAIL_NORM || TAIL_RESTRICT;
+  static_assert(!(TAIL_NORM && TAIL_RESTRICT), "one tail at a time");
+  static_assert(!TAIL || MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "tails are smoother options");
+  static_assert(!TAIL || PF % 2 == 0, "tails rely on the static row parity");
   const int js = y0 - LEAD - EXT;                           // first row relaxed (red)
   const int je = y1 + LEAD + EXT;                           // one past the last row relaxed
   static_assert(!PRO || PF % 2 == 0, "PRO relies on the static row parity of an even prefetch depth");
@@ -225,22 +231,47 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   T nrm = zero;                // STRIP_RESNORM: this lane's sum of squared residuals (rows ascending, a then b)
   Pair<T> fin1 = zpair, fin2 = zpair;   // TAIL_NORM: the two rows finalised before the current one
   Pair<T> fprev = zpair;                // TAIL_NORM: f of the row whose residual is formed (two / one step behind)
-  // residual of finalised row rr from the window (fin2, fin1, newest) and its contribution to the canonical partials
-  auto tail_norm = [&](const Pair<T>& newest, int rr, const Pair<T>& frow) {
-    if constexpr (TAIL_NORM) {
+  Pair<T> res1 = zpair, res2 = zpair;   // TAIL_RESTRICT: residual rows rr - 1, rr - 2
+  const int ncr = TAIL_RESTRICT ? pro.gc.n : 1;
+  const int Icr = c0 >> 1;                // coarse column of the lane's first element
+  // residual of finalised row rr from the window (fin2, fin1, newest); rr_odd is static at the call sites
+  auto tail = [&](const Pair<T>& newest, int rr, bool rr_odd, const Pair<T>& frow) {
+    if constexpr (TAIL) {
       const T wa = from_left(fin1.b), eb = from_right(fin1.a);          // whole wave
-      if (rr >= y0 && rr < y1) {                                         // wave-uniform
-        if (rr >= 1 && rr <= n - 2 && store_lane) {
-          const T ra = residual5(st, fin1.a, wa, fin1.b, fin2.a, newest.a, frow.a);
-          const T rb = residual5(st, fin1.b, fin1.a, eb, fin2.b, newest.b, frow.b);
-          if (inner_a) nrm = sc_add(nrm, sc_mul(ra, ra));
-          if (inner_b) nrm = sc_add(nrm, sc_mul(rb, rb));
+      if constexpr (TAIL_NORM) {
+        if (rr >= y0 && rr < y1) {                                       // wave-uniform
+          if (rr >= 1 && rr <= n - 2 && store_lane) {
+            const T ra = residual5(st, fin1.a, wa, fin1.b, fin2.a, newest.a, frow.a);
+            const T rb = residual5(st, fin1.b, fin1.a, eb, fin2.b, newest.b, frow.b);
+            if (inner_a) nrm = sc_add(nrm, sc_mul(ra, ra));
+            if (inner_b) nrm = sc_add(nrm, sc_mul(rb, rb));
+          }
+          if ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1) {
+            const T tot = wave_sum(nrm);
+            if (lane == 0) partials[(rr / EVOMG_NORM_ROWS) * n_strips + strip] = tot;
+            nrm = zero;
+          }
         }
-        if ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1) {
-          const T tot = wave_sum(nrm);
-          if (lane == 0) partials[(rr / EVOMG_NORM_ROWS) * n_strips + strip] = tot;
-          nrm = zero;
+      } else {
+        // residual of row rr, zero outside the inner nodes (as evomg_strip_residual_restrict forms it)
+        const bool rin = rr >= 1 && rr <= n - 2;
+        Pair<T> rcur;
+        rcur.a = (rin && inner_a) ? residual5(st, fin1.a, wa, fin1.b, fin2.a, newest.a, frow.a) : zero;
+        rcur.b = (rin && inner_b) ? residual5(st, fin1.b, fin1.a, eb, fin2.b, newest.b, frow.b) : zero;
+        if (rr_odd) {
+          // rows rr-2, rr-1, rr = 2J-1, 2J, 2J+1: a complete coarse neighbourhood
+          const int J = (rr - 1) >> 1;
+          const T w = from_left(res1.b), sw = from_left(res2.b), nw = from_left(rcur.b);
+          const T e4 = sc_add(sc_add(w, res1.b), sc_add(res2.a, rcur.a));
+          const T q4 = sc_add(sc_add(sw, res2.b), sc_add(nw, rcur.b));
+          T v = sc_rmul(0.25, res1.a);
+          v = sc_add(v, sc_rmul(0.125, e4));
+          v = sc_add(v, sc_rmul(0.0625, q4));
+          if (store_lane && Icr >= 1 && Icr <= ncr - 2 && J >= 1 && J <= ncr - 2 && 2 * J >= y0 && 2 * J < y1)
+            pro.coarse_out[(long)pro.gc.pitch * J + Icr] = v;
         }
+        res2 = res1;
+        res1 = rcur;
       }
       fin2 = fin1;
       fin1 = newest;
@@ -274,8 +305,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm) : xc.b;
             if (row_inner) robin_fix(out);
             if (store_lane && j >= y0 && j < y1) store_pair(y + pitch * j + c0, out);
-            if constexpr (TAIL_NORM) {
-              tail_norm(out, j - 1, fprev);                      // row j is final now: residual of row j - 1
+            if constexpr (TAIL) {
+              tail(out, j - 1, ((parity + 1) & 1) != 0, fprev);  // row j is final now: residual of row j - 1
               fprev = fc;
             }
           } else {
@@ -336,8 +367,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           }
           if (brow_inner) robin_fix(out);
           if (store_lane && jb >= y0 && jb < y1) store_pair(y + pitch * jb + c0, out);
-          if constexpr (TAIL_NORM) {
-            tail_norm(out, jb - 1, fprev);                       // row j - 1 is final now: residual of row j - 2
+          if constexpr (TAIL) {
+            tail(out, jb - 1, (parity & 1) != 0, fprev);         // row j - 1 is final now: residual of row j - 2
             fprev = fm;
           }
           rm2 = rm1;
