@@ -214,17 +214,19 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     xc = corrected(xc, js, odd_c, load_coarse(rc >> 1), odd_c ? load_coarse((rc >> 1) + 1) : zcoarse);
   }
   Pair<T> xq[PF], fq[PF];
-  Pair<T> cq[PF], cq1[PF];     // PRO: coarse rows below / above the prefetched fine row
 #pragma unroll
   for (int d = 0; d < PF; ++d) {
     xq[d] = load_row(x, js + 1 + d);
     fq[d] = load_row_f(f, js + d);
-    if constexpr (PRO) {
-      const int r = max(js + 1 + d, 0);
-      const bool odd = ((LEAD + EXT + 1 + d) & 1) != 0;
-      cq[d] = load_coarse(r >> 1);
-      cq1[d] = odd ? load_coarse((r >> 1) + 1) : zcoarse;
-    }
+  }
+  // PRO: the coarse rows around the fine row that is corrected next (row j + 1 at step j) live in a two-row register
+  // window: c_lo = coarse row floor(r / 2), c_hi the one above; an odd fine row uses both and then shifts the window,
+  // whose new top row is loaded two steps before it is needed — one coarse row load per two fine rows
+  Pair<T> c_lo = zcoarse, c_hi = zcoarse;
+  if constexpr (PRO) {
+    const int r0 = js + 1;                                   // may be negative: >> floors, load_coarse clamps
+    c_lo = load_coarse(r0 >> 1);
+    c_hi = load_coarse((r0 >> 1) + 1);
   }
   Pair<T> fm = zpair;          // f of row j-1 (black phase)
   T rm2 = zero, rm1 = zero;    // new red of rows j-2, j-1 (this lane's pair)
@@ -291,11 +293,12 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
         // chunk heights are even and js = y0 - LEAD, so with an even prefetch depth the row parity is static
         const int parity = (PF % 2 == 0) ? ((LEAD + EXT + d) & 1) : (j & 1);
         if constexpr (PRO) {
-          const bool odd_next = ((parity + 1) & 1) != 0;         // row j + 1 (static); slot d always holds this parity
-          xp = corrected(xp, j + 1, odd_next, cq[d], cq1[d]);
-          const int r = max(j + 1 + PF, 0);
-          cq[d] = load_coarse(r >> 1);
-          cq1[d] = odd_next ? load_coarse((r >> 1) + 1) : zcoarse;
+          const bool odd_next = ((parity + 1) & 1) != 0;         // row j + 1 (static)
+          xp = corrected(xp, j + 1, odd_next, c_lo, c_hi);
+          if (odd_next) {
+            c_lo = c_hi;
+            c_hi = load_coarse(((j + 1) >> 1) + 2);
+          }
         }
         if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == STRIP_RESNORM) {
           const T wa = from_left(xc.b), eb = from_right(xc.a);
