@@ -833,6 +833,14 @@ template <typename T> class Impl : public ImplBase {
   }
 
   // ---- 2D marching-strip kernels (evomg_strip.h) ------------------------------------------------------------------
+  // exact reciprocal of the centre coefficient when that is a (normal) power of two, else 0 (kernels then divide)
+  static double inv_c0(const Stencil<double>& st) {
+    int e = 0;
+    const double m = frexp(st.c[0], &e);
+    if (!(m == 0.5 || m == -0.5) || e < -900 || e > 900 || !pow2_reciprocal_) return 0.0;
+    return 1.0 / st.c[0];
+  }
+  static double inv_c0(const Stencil<cplx>&) { return 0.0; }
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
   bool strip_streams(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.pitch * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
@@ -850,8 +858,8 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
   }
   // PROLONG_ADD@L immediately followed by a point smoother on the same field: one sweep that forms the corrected
   // input on the fly (evomg_strip2d<.., PRO>)
@@ -876,7 +884,7 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{coarse, gc, om_p, nullptr};
+    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st)};
     T* parts = TAIL ? norm_partials_ : (T*)nullptr;
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
@@ -892,7 +900,7 @@ template <typename T> class Impl : public ImplBase {
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out};
+    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st)};
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
   }
@@ -961,8 +969,8 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr});
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     return EVOMG_OK;
   }
@@ -1395,6 +1403,7 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
   bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
   bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
   hipEvent_t norm_event_ = nullptr;

@@ -63,14 +63,21 @@ __device__ __forceinline__ void store_pair(cplx* __restrict__ p, const Pair<cplx
 }
 
 // same operation order as relax_point / apply_stencil (evomg_kernels.h) and the oracle's FN(relax2)/FN(apply_st2)
+// inv_c0 != 0: the centre coefficient is a power of two (4 / h^2 of the 2D Poisson stencil on a dyadic mesh), so the
+// division is an exact scaling and r * (1 / c0) gives the same bits as r / c0 at a tenth of the instructions
+// (host-checked, real scalars only)
+__device__ __forceinline__ double div_c0(double r, double c0, double inv_c0) {
+  return inv_c0 != 0.0 ? r * inv_c0 : r / c0;
+}
+__device__ __forceinline__ cplx div_c0(cplx r, cplx c0, double) { return sc_div(r, c0); }
 template <typename T>
-__device__ __forceinline__ T relax5(const Stencil<T>& st, T c, T w, T e, T s, T n, T f, double om, double omm) {
+__device__ __forceinline__ T relax5(const Stencil<T>& st, T c, T w, T e, T s, T n, T f, double om, double omm, double inv_c0 = 0.0) {
   T r = f;
   r = sc_sub(r, sc_mul(st.c[1], w));
   r = sc_sub(r, sc_mul(st.c[2], e));
   r = sc_sub(r, sc_mul(st.c[3], s));
   r = sc_sub(r, sc_mul(st.c[4], n));
-  const T xs = sc_div(r, st.c[0]);
+  const T xs = div_c0(r, st.c[0], inv_c0);
   return sc_add(sc_rmul(omm, c), sc_rmul(om, xs));
 }
 template <typename T>
@@ -92,6 +99,7 @@ template <typename T> struct ProlongIn {
   Geo gc;              // geometry of the coarse level (PRO and TAIL_RESTRICT)
   double om;           // PRO: weight of the correction
   T* coarse_out;       // TAIL_RESTRICT: coarse right-hand side to write
+  double inv_c0;       // 1 / centre coefficient when that is a power of two (exact), else 0
 };
 // TAIL_NORM (smoother modes): the sweep is the last op of a solver-loop iteration, so the squared norm of the residual
 // of its OUTPUT is accumulated in the same pass: the rows the sweep has finalised are kept in a three-row register
@@ -304,8 +312,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           const T wa = from_left(xc.b), eb = from_right(xc.a);
           Pair<T> out;
           if constexpr (MODE == STRIP_JACOBI) {
-            out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm) : xc.a;
-            out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm) : xc.b;
+            out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm, pro.inv_c0) : xc.a;
+            out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm, pro.inv_c0) : xc.b;
             if (row_inner) robin_fix(out);
             if (store_lane && j >= y0 && j < y1) store_pair(y + pitch * j + c0, out);
             if constexpr (TAIL) {
@@ -337,10 +345,10 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           T rc;
           if (parity == 0) {
             const T w = from_left(xc.b);
-            rc = (row_inner && inner_a) ? relax5(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm) : xc.a;
+            rc = (row_inner && inner_a) ? relax5(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, pro.inv_c0) : xc.a;
           } else {
             const T e = from_right(xc.a);
-            rc = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm) : xc.b;
+            rc = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, pro.inv_c0) : xc.b;
           }
           // ---- black nodes of row j-1 from the new reds of rows j-2 (rm2), j-1 (rm1), j (rc) ----
           const int jb = j - 1;
@@ -359,12 +367,12 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
                 if (c0 + 1 == n - 2) e = sc_div(xm.b, den);
               }
             }
-            const T bl = (brow_inner && inner_b) ? relax5(st, xm.b, w, e, rm2, rc, fm.b, om, omm) : xm.b;
+            const T bl = (brow_inner && inner_b) ? relax5(st, xm.b, w, e, rm2, rc, fm.b, om, omm, pro.inv_c0) : xm.b;
             out.a = rm1;
             out.b = bl;
           } else {                      // red = b, black = a
             const T w = from_left(rm1);
-            const T bl = (brow_inner && inner_a) ? relax5(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm) : xm.a;
+            const T bl = (brow_inner && inner_a) ? relax5(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, pro.inv_c0) : xm.a;
             out.a = bl;
             out.b = rm1;
           }
