@@ -372,3 +372,35 @@ def test_marching_tile_kernels_3d_match_generic_kernels(native, level, planes, m
         h.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("smoother,pre,post", [("rbgs", 1, 1), ("rbgs", 2, 2), ("jacobi", 1, 2), ("rbgs", 0, 1), ("jacobi", 2, 0)])
+def test_sweep_fusions_do_not_change_a_bit(native, smoother, pre, post, monkeypatch):
+    """Whole solves with every optimisation of the interpreter (residual+restriction, prolongation+smoother,
+    smoother+residual+restriction, norm on the last sweep, speculative first sweep, power-of-two reciprocal) against
+    the same solves with all of them switched off: identical residual histories, iteration counts, solution and
+    residual fields, and coarse right-hand sides."""
+    from test_full_size_gpu import vcycle
+    lo, hi = 5, 9
+    pd = problems.poisson_2d(lo, hi)
+    part, om = (abi.PART_RED_BLACK, 1.1) if smoother == "rbgs" else (abi.PART_SINGLE, 0.8)
+    ops = vcycle(lo, hi, pre, post, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, (1, 1, 1), om))
+    knobs = ["EVOMG_NO_FUSE", "EVOMG_NO_TAIL_NORM", "EVOMG_NO_TAIL_RESTRICT", "EVOMG_NO_SPECULATION",
+             "EVOMG_NO_POW2_RECIPROCAL"]
+    results = []
+    for plain in (False, True):
+        for k in knobs:
+            if plain:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 128)
+        results.append((out, h.get_field(hi, abi.F_SOL), h.get_field(hi, abi.F_RES), h.get_field(hi - 1, abi.F_RHS),
+                        h.get_field(lo, abi.F_RHS)))
+        h.close()
+    (a, *fa), (b, *fb) = results
+    assert a.status == b.status and a.n_iterations == b.n_iterations
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
