@@ -715,6 +715,7 @@ static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
     if (res < c->prob.cgs_target_res_reduction * res0) { ++it; break; }
     if (!(res == res)) { ++it; break; }  /* NaN guard: the DSL would spin to the iteration cap */
   }
+  if (getenv("EVOMG_ORACLE_DEBUG")) fprintf(stderr, "[oracle] coarse BiCGStab: %d iterations (cap %d)\n", it, c->prob.cgs_max_iterations);
   return it;
 }
 
