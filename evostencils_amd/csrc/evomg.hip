@@ -886,8 +886,11 @@ template <typename T> class Impl : public ImplBase {
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
     const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st)};
     T* parts = TAIL ? norm_partials_ : (T*)nullptr;
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, parts, 0, pro);
+    const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
+    const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
+    const int rout = (robin && strip_bc_) ? 1 : 0;
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, parts, rout, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, parts, rout, pro);
     return EVOMG_OK;
   }
   // SMOOTH@L + RESIDUAL@L + RESTRICT@(L-1) with a residual nobody else reads: one sweep (evomg_strip2d<.., TAIL_RESTRICT>)
@@ -945,8 +948,9 @@ template <typename T> class Impl : public ImplBase {
     return use_strip(g) && norm_fused(g) && loop_residual_is_dead(ops, n_ops);
   }
   bool fusable_prolong_smooth(const evomg_op_t* ops, int n_ops, int i) const {
-    if (!fuse_enabled_ || i + 1 >= n_ops || scalar_traits<T>::is_complex || dim_ != 2) return false;
-    if (prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    if (!fuse_enabled_ || i + 1 >= n_ops || dim_ != 2) return false;
+    // Robin problems: only when the strip kernels own the boundary columns (strip_bc_)
+    if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && strip_bc_)) return false;
     const evomg_op_t &a = ops[i], &b = ops[i + 1];
     if (a.opcode != EVOMG_OP_PROLONG_ADD || b.opcode != EVOMG_OP_SMOOTH || a.level != b.level) return false;
     if (canon(a.level, a.dst) != canon(b.level, b.dst)) return false;

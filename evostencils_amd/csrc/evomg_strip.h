@@ -93,7 +93,8 @@ __device__ __forceinline__ T residual5(const Stencil<T>& st, T c, T w, T e, T s,
 // PRO: the sweep's input is x + om * P(coarse) instead of x — the prolongation-and-correction that precedes a
 // post-smoothing sweep, formed on the fly from the coarse rows (8 B per lane and fine row) with the formulas and masks
 // of evomg_strip_prolong, so the result is bit-identical to running PROLONG_ADD and then the sweep, while the
-// corrected field is neither written nor read back (2 x 8 B/node less traffic). Real Dirichlet problems only.
+// corrected field is neither written nor read back (2 x 8 B/node less traffic). With the Helmholtz Robin condition the
+// boundary columns of the corrected rows are re-derived as the prolongation op's apply_bc would.
 template <typename T> struct ProlongIn {
   const T* coarse;     // PRO: coarse correction to prolongate into the input
   Geo gc;              // geometry of the coarse level (PRO and TAIL_RESTRICT)
@@ -210,6 +211,15 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     Pair<T> out;
     out.a = (row_in && inner_a) ? sc_add(raw.a, sc_rmul(pro.om, va)) : raw.a;
     out.b = (row_in && inner_b) ? sc_add(raw.b, sc_rmul(pro.om, vb)) : raw.b;
+    if constexpr (scalar_traits<T>::is_complex) {
+      // Helmholtz: the prolongation op is followed by the Robin condition on the corrected field (whole-wave DPP)
+      if (robin_kh != 0.0) {
+        const cplx den{1.0, -robin_kh};
+        const T lb = from_left(out.b);
+        if (row_in && c0 == 0) out.a = sc_div(out.b, den);
+        if (row_in && c0 == n - 1) out.a = sc_div(lb, den);
+      }
+    }
     return out;
   };
   Pair<T> xm = load_row(x, js - 1);
