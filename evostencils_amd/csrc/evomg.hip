@@ -858,8 +858,8 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
   }
   // PROLONG_ADD@L immediately followed by a point smoother on the same field: one sweep that forms the corrected
   // input on the fly (evomg_strip2d<.., PRO>)
@@ -884,7 +884,7 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st)};
+    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st), 0.0};
     T* parts = TAIL ? norm_partials_ : (T*)nullptr;
     const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
@@ -903,13 +903,17 @@ template <typename T> class Impl : public ImplBase {
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st)};
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, 0.0, (T*)nullptr, 0, pro);
+    const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
+    const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
+    const double rkhc = robin ? prob_.wavenumber / (double)(gc.n - 1) : 0.0;
+    const int rout = (robin && strip_bc_) ? 1 : 0;
+    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc};
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
   }
   bool fusable_smooth_residual_restrict(const evomg_op_t* ops, int n_ops, int i, bool cyclic) const {
-    if (!fuse_enabled_ || !tail_restrict_enabled_ || !cyclic || i + 2 >= n_ops) return false;
-    if (scalar_traits<T>::is_complex || dim_ != 2 || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    if (!fuse_enabled_ || !tail_restrict_enabled_ || !cyclic || i + 2 >= n_ops || dim_ != 2) return false;
+    if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && strip_bc_)) return false;
     const evomg_op_t &sm = ops[i], &a = ops[i + 1];
     if (sm.opcode != EVOMG_OP_SMOOTH || sm.block[0] * sm.block[1] != 1) return false;
     if (!fusable_residual_restrict(ops, n_ops, i + 1) || !residual_dead_after(ops, n_ops, i + 1)) return false;
@@ -973,8 +977,8 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st)});
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     return EVOMG_OK;
   }

@@ -101,6 +101,7 @@ template <typename T> struct ProlongIn {
   double om;           // PRO: weight of the correction
   T* coarse_out;       // TAIL_RESTRICT: coarse right-hand side to write
   double inv_c0;       // 1 / centre coefficient when that is a power of two (exact), else 0
+  double robin_kh_coarse;   // TAIL_RESTRICT on Helmholtz problems: k h of the coarse level
 };
 // TAIL_NORM (smoother modes): the sweep is the last op of a solver-loop iteration, so the squared norm of the residual
 // of its OUTPUT is accumulated in the same pass: the rows the sweep has finalised are kept in a three-row register
@@ -287,8 +288,19 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           T v = sc_rmul(0.25, res1.a);
           v = sc_add(v, sc_rmul(0.125, e4));
           v = sc_add(v, sc_rmul(0.0625, q4));
-          if (store_lane && Icr >= 1 && Icr <= ncr - 2 && J >= 1 && J <= ncr - 2 && 2 * J >= y0 && 2 * J < y1)
-            pro.coarse_out[(long)pro.gc.pitch * J + Icr] = v;
+          T vs = v;
+          bool coarse_robin = false;
+          if constexpr (scalar_traits<T>::is_complex) {
+            if (pro.robin_kh_coarse != 0.0) {                    // Robin columns of the coarse right-hand side
+              const cplx den{1.0, -pro.robin_kh_coarse};
+              const T vr = from_right(v), vl = from_left(v);
+              if (Icr == 0) vs = sc_div(vr, den);
+              if (Icr == ncr - 1) vs = sc_div(vl, den);
+              coarse_robin = (Icr == 0 || Icr == ncr - 1) && c0 >= 0 && c0 < n;
+            }
+          }
+          if (store_lane && ((Icr >= 1 && Icr <= ncr - 2) || coarse_robin) && J >= 1 && J <= ncr - 2 && 2 * J >= y0 && 2 * J < y1)
+            pro.coarse_out[(long)pro.gc.pitch * J + Icr] = vs;
         }
         res2 = res1;
         res1 = rcur;
