@@ -136,6 +136,7 @@ template <typename T> class Impl : public ImplBase {
       lv.g.pitch = ((n + align - 1) / align) * align;
       lv.g.plane = (dim_ == 3) ? (long)lv.g.pitch * n : 0;
       lv.elems = (size_t)lv.g.pitch * n * (dim_ == 3 ? n : 1);
+      for (int f = 0; f < EVOMG_F_COUNT; ++f) bnd_zero_[L][f] = true;
       for (int f : {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES}) HIP_TRY(alloc_zero(&lv.f[f], lv.elems));
       if (L == prob_.max_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_F_CORR], lv.elems));
       if (L == prob_.min_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_F_CGS_RHS], lv.elems));
@@ -153,6 +154,7 @@ template <typename T> class Impl : public ImplBase {
     Level<T>& lv = lv_[level];
     if (field < 0 || !lv.f[field]) return invalid("set_initial_field: no such field on this level");
     if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
+    bnd_zero_[level][field] = false;
     HIP_TRY(upload(lv, lv.init[field], host));
     HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -164,6 +166,7 @@ template <typename T> class Impl : public ImplBase {
     HIP_TRY(hipSetDevice(device_));
     T* d = fieldptr(level, field);
     if (!d) return invalid("set_field: no such field on this level");
+    bnd_zero_[level][canon(level, field)] = false;
     HIP_TRY(upload(lv_[level], d, host));
     HIP_TRY(hipStreamSynchronize(stream_));
     return EVOMG_OK;
@@ -499,6 +502,10 @@ template <typename T> class Impl : public ImplBase {
   int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0, bool* tail_norm = nullptr) {
     if (tail_norm) *tail_norm = false;
     for (int i = first; i < n_ops; ++i) {
+      if (elidable_zero(ops, n_ops, i)) {
+        x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
+        continue;
+      }
       if (fusable_smooth_residual_restrict(ops, n_ops, i, cyclic)) {
         const evomg_op_t &sm = ops[i], &rs = ops[i + 2];
         const int L = sm.level;
@@ -764,6 +771,7 @@ template <typename T> class Impl : public ImplBase {
         T* d = fieldptr(L, op.dst);
         const T* s = fieldptr(L, op.src0);
         if (d != s) HIP_TRY(hipMemcpyAsync(d, s, lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        bnd_zero_[L][canon(L, op.dst)] = bnd_zero_[L][canon(L, op.src0)];
         break;
       }
       case EVOMG_OP_COARSE_SOLVE: return coarse_solve();
@@ -841,6 +849,20 @@ template <typename T> class Impl : public ImplBase {
     return 1.0 / st.c[0];
   }
   static double inv_c0(const Stencil<cplx>&) { return 0.0; }
+  // SET_ZERO elision: set by the interpreter right before the sweep that consumes it
+  int take_x_zero() { const int z = x_zero_next_ ? 1 : 0; x_zero_next_ = false; return z; }
+  // SET_ZERO(L, X) immediately followed by a strip point smoother on X whose boundary is known to be zero: the zero
+  // launch is skipped and the sweep reads no x at all (same arithmetic on literal zeros => same bits)
+  bool elidable_zero(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || !zero_elision_ || dim_ != 2 || i + 1 >= n_ops) return false;
+    const evomg_op_t &z = ops[i], &sm = ops[i + 1];
+    if (z.opcode != EVOMG_OP_SET_ZERO || sm.opcode != EVOMG_OP_SMOOTH || z.level != sm.level) return false;
+    if (canon(z.level, z.dst) != canon(sm.level, sm.dst) || sm.block[0] * sm.block[1] != 1) return false;
+    if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
+    if (!bnd_zero_[z.level][canon(z.level, z.dst)]) return false;
+    if (prof_matches(z)) return false;
+    return use_strip(lv_[z.level].g);
+  }
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
   bool strip_streams(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.pitch * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
@@ -858,8 +880,8 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, take_x_zero()});
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, take_x_zero()});
   }
   // PROLONG_ADD@L immediately followed by a point smoother on the same field: one sweep that forms the corrected
   // input on the fly (evomg_strip2d<.., PRO>)
@@ -884,7 +906,7 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st), 0.0};
+    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st), 0.0, take_x_zero()};
     T* parts = TAIL ? norm_partials_ : (T*)nullptr;
     const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
@@ -907,7 +929,7 @@ template <typename T> class Impl : public ImplBase {
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
     const double rkhc = robin ? prob_.wavenumber / (double)(gc.n - 1) : 0.0;
     const int rout = (robin && strip_bc_) ? 1 : 0;
-    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc};
+    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc, take_x_zero()};
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
   }
@@ -977,8 +999,8 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, 0});
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, 0});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     return EVOMG_OK;
   }
@@ -1180,7 +1202,10 @@ template <typename T> class Impl : public ImplBase {
       for (int f = 0; f < EVOMG_F_COUNT; ++f) {
         if (!lv.f[f]) continue;
         if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-        else HIP_TRY(hipMemsetAsync(lv.f[f], 0, lv.elems * sizeof(T), stream_));
+        else {
+          HIP_TRY(hipMemsetAsync(lv.f[f], 0, lv.elems * sizeof(T), stream_));
+          bnd_zero_[L][f] = true;
+        }
       }
     }
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -1411,6 +1436,9 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  bool x_zero_next_ = false;
+  bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
+  bool bnd_zero_[24][EVOMG_F_COUNT];   // boundary of the field's current array is known to be all zero
   static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
   bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
   bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;

@@ -102,6 +102,7 @@ template <typename T> struct ProlongIn {
   T* coarse_out;       // TAIL_RESTRICT: coarse right-hand side to write
   double inv_c0;       // 1 / centre coefficient when that is a power of two (exact), else 0
   double robin_kh_coarse;   // TAIL_RESTRICT on Helmholtz problems: k h of the coarse level
+  int x_zero;          // the input field is known to be zero everywhere (SET_ZERO elided): no x loads
 };
 // TAIL_NORM (smoother modes): the sweep is the last op of a solver-loop iteration, so the squared norm of the residual
 // of its OUTPUT is accumulated in the same pass: the rows the sweep has finalised are kept in a three-row register
@@ -150,6 +151,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   // with counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every predicated block.
   const int c_clamped = min(max(c0, 0), n - 1);             // n-1 is even; (n-1, n) is still inside the row pitch
   auto load_row = [&](const T* __restrict__ base, int row) -> Pair<T> {
+    if (pro.x_zero) return zpair;                           // kernel argument: uniform (only x goes through here)
     const int r = min(max(row, 0), n - 1);                  // wave-uniform
     return load_pair<T>(base + pitch * r + c_clamped);
   };

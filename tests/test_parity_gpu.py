@@ -386,7 +386,7 @@ def test_sweep_fusions_do_not_change_a_bit(native, smoother, pre, post, monkeypa
     part, om = (abi.PART_RED_BLACK, 1.1) if smoother == "rbgs" else (abi.PART_SINGLE, 0.8)
     ops = vcycle(lo, hi, pre, post, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, (1, 1, 1), om))
     knobs = ["EVOMG_NO_FUSE", "EVOMG_NO_TAIL_NORM", "EVOMG_NO_TAIL_RESTRICT", "EVOMG_NO_SPECULATION",
-             "EVOMG_NO_POW2_RECIPROCAL"]
+             "EVOMG_NO_POW2_RECIPROCAL", "EVOMG_NO_ZERO_ELISION"]
     results = []
     for plain in (False, True):
         for k in knobs:
