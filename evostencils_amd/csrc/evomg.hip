@@ -72,6 +72,7 @@ template <typename T> struct Level {
   T* f[EVOMG_F_COUNT] = {};
   T* init[EVOMG_F_COUNT] = {};  // device copies of the initial contents (nullptr = zero)
   T* alt = nullptr;             // ping-pong twin for out-of-place smoothers
+  const T* alt_mirror = nullptr;   // array whose boundary values `alt` is known to share (nullptr: unknown)
   T* tmp[kTmpVectors] = {};     // Krylov work vectors, allocated on demand
   Stencil<T> st{};
 };
@@ -155,6 +156,7 @@ template <typename T> class Impl : public ImplBase {
     if (field < 0 || !lv.f[field]) return invalid("set_initial_field: no such field on this level");
     if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
     bnd_zero_[level][field] = false;
+    lv.alt_mirror = nullptr;
     HIP_TRY(upload(lv, lv.init[field], host));
     HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -167,6 +169,7 @@ template <typename T> class Impl : public ImplBase {
     T* d = fieldptr(level, field);
     if (!d) return invalid("set_field: no such field on this level");
     bnd_zero_[level][canon(level, field)] = false;
+    lv_[level].alt_mirror = nullptr;
     HIP_TRY(upload(lv_[level], d, host));
     HIP_TRY(hipStreamSynchronize(stream_));
     return EVOMG_OK;
@@ -523,6 +526,7 @@ template <typename T> class Impl : public ImplBase {
         if (timed) { const int rc = prof_close(algorithmic_bytes(sm) + (double)sizeof(T) * lv_[L - 1].g.n * lv_[L - 1].g.n); if (rc != EVOMG_OK) return rc; }
         lv.alt = x;
         set_fieldptr(L, sm.dst, y);
+        lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         HIP_TRY(hipGetLastError());
         i += 2;
         continue;
@@ -564,6 +568,7 @@ template <typename T> class Impl : public ImplBase {
         if (tail) *tail_norm = true;
         lv.alt = x;
         set_fieldptr(L, sm.dst, y);
+        lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         HIP_TRY(hipGetLastError());
         ++i;
         continue;
@@ -585,6 +590,7 @@ template <typename T> class Impl : public ImplBase {
         *tail_norm = true;
         lv.alt = x;
         set_fieldptr(L, sm.dst, y);
+        lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         HIP_TRY(hipGetLastError());
         continue;
       }
@@ -678,11 +684,13 @@ template <typename T> class Impl : public ImplBase {
           const int inner = g.n - 2;
           const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by, tz = dim_ == 3 ? (inner + bz - 1) / bz : 1;
           const dim3 tgrid((tx + 63) / 64, (ty + 3) / 4, dim_ == 3 ? tz : 1);
-          if (dim_ == 2) block_smooth<2>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
-          else block_smooth<3>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
+          const bool mir = lv.alt_mirror == x;
+          if (dim_ == 2) block_smooth<2>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, mir);
+          else block_smooth<3>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, mir);
           apply_bc(L, y);
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
+          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         } else if (use_strip(g)) {
           T* y = lv.alt;
           if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip<STRIP_RBGS>(g, lv.st, x, f, y, om, omm);
@@ -690,6 +698,7 @@ template <typename T> class Impl : public ImplBase {
           if (!strip_bc_) apply_bc(L, y);                   // the strip kernels write the Robin columns themselves
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
+          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         } else if (use_strip3d(g, op.partitioning == EVOMG_PART_RED_BLACK)) {
           T* y = lv.alt;
           if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip3d_rbgs(g, lv.st, x, f, y, om, omm);
@@ -697,6 +706,7 @@ template <typename T> class Impl : public ImplBase {
           apply_bc(L, y);
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
+          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         } else if (op.partitioning == EVOMG_PART_RED_BLACK) {
           const dim3 hgrd((g.n / 2 + 1 + 63) / 64, grd.y, grd.z);
           for (int colour = 0; colour < 2; ++colour) {
@@ -711,6 +721,7 @@ template <typename T> class Impl : public ImplBase {
           apply_bc(L, y);
           lv.alt = x;
           set_fieldptr(L, op.dst, y);
+          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         }
         break;
       }
@@ -726,6 +737,7 @@ template <typename T> class Impl : public ImplBase {
         apply_bc(L, y);
         lv.alt = x;
         set_fieldptr(L, op.dst, y);
+        lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
         break;
       }
       case EVOMG_OP_RESTRICT: {
@@ -772,6 +784,7 @@ template <typename T> class Impl : public ImplBase {
         const T* s = fieldptr(L, op.src0);
         if (d != s) HIP_TRY(hipMemcpyAsync(d, s, lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
         bnd_zero_[L][canon(L, op.dst)] = bnd_zero_[L][canon(L, op.src0)];
+        lv.alt_mirror = nullptr;
         break;
       }
       case EVOMG_OP_COARSE_SOLVE: return coarse_solve();
@@ -784,10 +797,14 @@ template <typename T> class Impl : public ImplBase {
   // block-Jacobi sweep = boundary faces copied to y + full tiles (fast kernel) + the layers of tiles cut by the far
   // boundary (generic kernel, pinned to the last tile layer of each truncated dimension)
   template <int DIM> void block_smooth(int cells, dim3 tgrid, const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y,
-                                       double om, double omm, int bx, int by, int bz, int tx, int ty, int tz) {
+                                       double om, double omm, int bx, int by, int bz, int tx, int ty, int tz, bool y_mirrors_x) {
     const dim3 blk = node_block();
-    const dim3 fgrid((g.n + 63) / 64, DIM == 3 ? (g.n + 3) / 4 : 1, 2 * DIM);
-    hipLaunchKernelGGL((evomg_copy_faces<T, DIM>), fgrid, blk, 0, stream_, g, x, y);
+    // the block kernels write inner nodes only; y needs x's boundary values — unless y is the array this field lived
+    // in before its last out-of-place sweep (ping-pong), whose boundary is the same by construction
+    if (!(mirror_enabled_ && prob_.bc_kind == EVOMG_BC_DIRICHLET && y_mirrors_x)) {
+      const dim3 fgrid((g.n + 63) / 64, DIM == 3 ? (g.n + 3) / 4 : 1, 2 * DIM);
+      hipLaunchKernelGGL((evomg_copy_faces<T, DIM>), fgrid, blk, 0, stream_, g, x, y);
+    }
     if (!block_fast_) {
       hipLaunchKernelGGL((evomg_block_jacobi<T, DIM>), tgrid, blk, 0, stream_, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, 0, -1);
       return;
@@ -1199,6 +1216,7 @@ template <typename T> class Impl : public ImplBase {
   int reset_fields() {
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
       Level<T>& lv = lv_[L];
+      lv.alt_mirror = nullptr;
       for (int f = 0; f < EVOMG_F_COUNT; ++f) {
         if (!lv.f[f]) continue;
         if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
@@ -1246,6 +1264,7 @@ template <typename T> class Impl : public ImplBase {
     // launch is queued behind the norm right away (speculatively): should the norm say "converged", the pointer swap
     // is simply undone and the sweep's output discarded; otherwise the cycle continues from its second op.
     T *saved_alt = nullptr, *saved_x = nullptr;
+    const T* saved_mirror = nullptr;
     auto speculate = [&](bool* launched) -> int {
       *launched = false;
       if (!speculate_ || n_ops < 1 || !smoother_is_out_of_place(ops[0])) return EVOMG_OK;
@@ -1254,6 +1273,7 @@ template <typename T> class Impl : public ImplBase {
       if (fusable_smooth_residual_restrict(ops, n_ops, 0, true)) return EVOMG_OK;
       const int l0 = ops[0].level;
       saved_alt = lv_[l0].alt;
+      saved_mirror = lv_[l0].alt_mirror;
       saved_x = fieldptr(l0, ops[0].dst);
       const int rc = exec(ops[0]);
       *launched = rc == EVOMG_OK;
@@ -1262,6 +1282,7 @@ template <typename T> class Impl : public ImplBase {
     auto undo_speculation = [&]() {
       const int l0 = ops[0].level;
       lv_[l0].alt = saved_alt;
+      lv_[l0].alt_mirror = saved_mirror;
       set_fieldptr(l0, ops[0].dst, saved_x);
     };
     auto wait_norm = [&]() -> int {
@@ -1436,6 +1457,7 @@ template <typename T> class Impl : public ImplBase {
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
   int* dinfo_ = nullptr;
+  bool mirror_enabled_ = getenv("EVOMG_NO_BOUNDARY_MIRROR") == nullptr;
   bool x_zero_next_ = false;
   bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
   bool bnd_zero_[24][EVOMG_F_COUNT];   // boundary of the field's current array is known to be all zero
