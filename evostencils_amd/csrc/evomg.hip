@@ -813,6 +813,8 @@ template <typename T> class Impl : public ImplBase {
     const int inner = g.n - 2;
     const int b[3] = {bx, by, bz};
     const int t[3] = {tx, ty, tz};
+    // two-cell shapes: the fast kernel relaxes the single leftover node of a cut tile itself
+    if (bx * by * (DIM == 3 ? bz : 1) == 2) return;
     for (int d = 0; d < DIM; ++d) {
       if (inner % b[d] == 0) continue;                 // no tile is cut in this dimension
       const int ta = (d == 0) ? t[1] : t[0];            // the two free tile coordinates

@@ -223,8 +223,14 @@ __global__ void __launch_bounds__(256) evomg_block_jacobi_fast(Geo g, Stencil<T>
   constexpr bool kStatic = BX > 0;
   const int bx = kStatic ? BX : pl.bx, by = kStatic ? BY : pl.by, bz = kStatic ? BZ : pl.bz;
   const int i0 = 1 + ti * bx, j0 = 1 + tj * by, k0 = (DIM == 3) ? 1 + tk * bz : 0;
-  if (i0 + bx > n - 1 || j0 + by > n - 1 || (DIM == 3 && k0 + bz > n - 1)) return;   // truncated: generic kernel
   const long base = gidx<DIM>(g, i0, j0, k0);
+  if (i0 + bx > n - 1 || j0 + by > n - 1 || (DIM == 3 && k0 + bz > n - 1)) {
+    // Tile cut by the far boundary. With a static two-cell shape what is left is a single node and the local system
+    // a point relaxation (same operation order as the generic kernel's one-unknown elimination = relax_point);
+    // every other case is left to the generic kernel, launched over the last tile layer.
+    if constexpr (kStatic && BX * BY * BZ == 2) y[base] = relax_point<T, DIM>(st, x, f, g, base, om, omm);
+    return;
+  }
   T r[M];
   long gc[M];
 #pragma unroll
