@@ -880,6 +880,9 @@ template <typename T> class Impl : public ImplBase {
     if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
     if (!bnd_zero_[z.level][canon(z.level, z.dst)]) return false;
     if (prof_matches(z)) return false;
+    // the zero-input variants exist for the plain sweep and the sweep + residual + restriction; a sweep that is the
+    // tail of the iteration (norm) would go another way
+    if (tail_norm_candidate(ops, n_ops, i + 1)) return false;
     return use_strip(lv_[z.level].g);
   }
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
@@ -899,8 +902,16 @@ template <typename T> class Impl : public ImplBase {
     // stream the right-hand side past the 256 MiB Infinity Cache only where x, y and f together exceed it; on
     // smaller levels all three stay cache-resident and a streaming hint would only evict f
     const bool nt = strip_streams(g);
-    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, take_x_zero()});
-    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, (bc_out && strip_bc_) ? 1 : 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, take_x_zero()});
+    const ProlongIn<T> pro{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0};
+    const int rout = (bc_out && strip_bc_) ? 1 : 0;
+    if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RBGS) {
+      if (take_x_zero()) {      // SET_ZERO elided: zero-input variant (small levels: never streams)
+        hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, rout, pro);
+        return;
+      }
+    }
+    if (nt) hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, rout, pro);
+    else hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, rout, pro);
   }
   // PROLONG_ADD@L immediately followed by a point smoother on the same field: one sweep that forms the corrected
   // input on the fly (evomg_strip2d<.., PRO>)
@@ -925,7 +936,7 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st), 0.0, take_x_zero()};
+    const ProlongIn<T> pro{coarse, gc, om_p, nullptr, inv_c0(st), 0.0};
     T* parts = TAIL ? norm_partials_ : (T*)nullptr;
     const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
@@ -948,7 +959,11 @@ template <typename T> class Impl : public ImplBase {
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
     const double rkhc = robin ? prob_.wavenumber / (double)(gc.n - 1) : 0.0;
     const int rout = (robin && strip_bc_) ? 1 : 0;
-    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc, take_x_zero()};
+    const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc};
+    if (take_x_zero()) {
+      hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
+      return;
+    }
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
   }
@@ -1018,8 +1033,8 @@ template <typename T> class Impl : public ImplBase {
       if (rc != EVOMG_OK) return rc;
     }
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
-    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, 0});
-    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0, 0});
+    if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
+    else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
     hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
     return EVOMG_OK;
   }

@@ -102,7 +102,6 @@ template <typename T> struct ProlongIn {
   T* coarse_out;       // TAIL_RESTRICT: coarse right-hand side to write
   double inv_c0;       // 1 / centre coefficient when that is a power of two (exact), else 0
   double robin_kh_coarse;   // TAIL_RESTRICT on Helmholtz problems: k h of the coarse level
-  int x_zero;          // the input field is known to be zero everywhere (SET_ZERO elided): no x loads
 };
 // TAIL_NORM (smoother modes): the sweep is the last op of a solver-loop iteration, so the squared norm of the residual
 // of its OUTPUT is accumulated in the same pass: the rows the sweep has finalised are kept in a three-row register
@@ -113,7 +112,8 @@ template <typename T> struct ProlongIn {
 // TAIL_RESTRICT (smoother modes): the sweep is followed by RESIDUAL + RESTRICT of a residual nobody else reads. Same
 // finalised-row window, one more halo row per side; the residual rows feed a three-row residual window from which
 // every second step emits one row of the coarse right-hand side exactly as evomg_strip_residual_restrict does.
-template <typename T, int MODE, int PF, bool NT_F, bool PRO = false, bool TAIL_NORM = false, bool TAIL_RESTRICT = false>
+template <typename T, int MODE, int PF, bool NT_F, bool PRO = false, bool TAIL_NORM = false, bool TAIL_RESTRICT = false,
+          bool XZERO = false>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
               double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
@@ -150,8 +150,11 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   // the old value — and straight-line code is what lets the compiler keep the PF-deep prefetch ring in flight
   // with counted s_waitcnt vmcnt(N) instead of draining to vmcnt(0) at every predicated block.
   const int c_clamped = min(max(c0, 0), n - 1);             // n-1 is even; (n-1, n) is still inside the row pitch
+  // XZERO (SET_ZERO elided): the input field is known to be zero everywhere, nothing is loaded. A compile-time
+  // switch on purpose: a run-time flag, even a uniform one, makes the compiler wrap the x loads in branches (and split
+  // them), which costs every variant of this kernel its counted-vmcnt pipelining.
   auto load_row = [&](const T* __restrict__ base, int row) -> Pair<T> {
-    if (pro.x_zero) return zpair;                           // kernel argument: uniform (only x goes through here)
+    if constexpr (XZERO) return zpair;
     const int r = min(max(row, 0), n - 1);                  // wave-uniform
     return load_pair<T>(base + pitch * r + c_clamped);
   };
