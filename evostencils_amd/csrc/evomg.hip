@@ -926,6 +926,7 @@ template <typename T> class Impl : public ImplBase {
     constexpr int cols = TAIL ? EVOMG_NORM_STRIP_COLS : EVOMG_STRIP_COLS;
     const int strips = (g.n + cols - 1) / cols;
     int rows = strip_rows_ > 0 ? strip_rows_ : 64;
+    if (TAIL && rows > 4 * EVOMG_NORM_ROWS) rows = 4 * EVOMG_NORM_ROWS;   // the kernel parks at most four chunk sums
     const int min_rows = TAIL ? EVOMG_NORM_ROWS : 8;
     while (rows > min_rows && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
     rows = TAIL ? ((rows + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : ((rows + 1) & ~1);

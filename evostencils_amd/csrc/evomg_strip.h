@@ -256,6 +256,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   T rm2 = zero, rm1 = zero;    // new red of rows j-2, j-1 (this lane's pair)
   T nrm = zero;                // STRIP_RESNORM: this lane's sum of squared residuals (rows ascending, a then b)
   Pair<T> fin1 = zpair, fin2 = zpair;   // TAIL_NORM: the two rows finalised before the current one
+  T done0 = zero, done1 = zero, done2 = zero, done3 = zero;   // lane sums of the completed 16-row chunks, newest first
+  int n_done = 0;                       // (host: a TAIL_NORM chunk has at most 4 x 16 rows)
   Pair<T> fprev = zpair;                // TAIL_NORM: f of the row whose residual is formed (two / one step behind)
   Pair<T> res1 = zpair, res2 = zpair;   // TAIL_RESTRICT: residual rows rr - 1, rr - 2
   const int ncr = TAIL_RESTRICT ? pro.gc.n : 1;
@@ -273,8 +275,10 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             if (inner_b) nrm = sc_add(nrm, sc_mul(rb, rb));
           }
           if ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1) {
-            const T tot = wave_sum(nrm);
-            if (lane == 0) partials[(rr / EVOMG_NORM_ROWS) * n_strips + strip] = tot;
+            // a canonical 16-row chunk is complete: park its lane sum (register shuffle only — reducing and storing
+            // it here would drain the prefetch pipeline with a vmcnt(0) every 16 rows); flushed after the loop
+            done3 = done2; done2 = done1; done1 = done0; done0 = nrm;
+            ++n_done;
             nrm = zero;
           }
         }
@@ -415,6 +419,18 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
         }
         xm = xc;
         xc = xp;
+      }
+    }
+  }
+  if constexpr (TAIL_NORM) {
+    // completed 16-row chunks: y0 / 16 + (n_done - 1 - k) for done_k; wave64 tree as in STRIP_RESNORM
+    const int c16 = y0 / EVOMG_NORM_ROWS;
+    const T d[4] = {done0, done1, done2, done3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < n_done) {                                      // wave-uniform
+        const T tot = wave_sum(d[k]);
+        if (lane == 0) partials[(c16 + n_done - 1 - k) * n_strips + strip] = tot;
       }
     }
   }
