@@ -30,5 +30,27 @@ for name, make, lo, hi, n, dim in (("2D_FD_Poisson_fromL2", problems.poisson_2d,
             print("MISMATCH", name, lo, hi, k, (rho, its), (rrho, rits), flush=True)
     print(name, lo, hi, "checked", n, flush=True)
     gen.close()
+# Helmholtz (complex, Robin, MG-preconditioned BiCGStab outer solver): capped outer iterations, histories compared
+import dataclasses
+import numpy as np
+nh = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+lo, hi = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (3, 6)
+pdh = dataclasses.replace(problems.helmholtz_2d(lo, hi, k=20.0), max_iterations=40)
+gen = ProgramGenerator(problem=pdh, library=native.library())
+gen.initialize_code_generation(lo, hi)
+pop = candidates.population(lambda: context_for(gen, lo, hi), hi - lo, 2, nh, seed=seed + 1)
+ref = oracle.create(pdh)
+for k, expression in enumerate(pop):
+    ops = gen.generate_op_program(expression, lo, hi)
+    got = gen._ensure_handle(lo, hi, None).evaluate(ops, 1, 0, 64)
+    want = ref.evaluate(ops, 1, 0, 64)
+    m = min(len(got.history), len(want.history))
+    finite = np.isfinite(want.history[:m]) & (want.history[:m] < 1e200)
+    ok = got.n_iterations == want.n_iterations and got.status == want.status and \
+        np.all(np.abs(got.history[:m][finite] - want.history[:m][finite]) <= 1e-6 * np.abs(want.history[:m][finite]))
+    if not ok:
+        bad += 1
+        print("MISMATCH helmholtz", k, got.n_iterations, want.n_iterations, got.status, want.status, flush=True)
+print("helmholtz", lo, hi, "checked", nh, flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
