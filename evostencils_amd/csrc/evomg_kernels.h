@@ -533,8 +533,9 @@ __device__ __forceinline__ double lanes_plus16(double v) {
   return __hiloint2double((int)b[1], (int)a[1]);
 }
 template <int N> __device__ __forceinline__ double row_plus(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, false);
+  // bound_ctrl: lanes whose source lies outside the 16-lane row read 0 — no zero-initialised destination needed
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double row_tree(double v) {   // offsets 8,4,2,1 inside row 0
