@@ -20,8 +20,17 @@ class UnsupportedExpression(RuntimeError):
     """The DAG is well-formed for the reference but outside what this backend implements."""
 
 
+_TAGS = {}
+
+
 def _tags(obj):
-    return {(c.__module__.rsplit(".", 1)[-1], c.__name__) for c in type(obj).__mro__}
+    """(module tail, class name) of every class in the object's MRO; cached per type (the lowering asks ~2000 times
+    per candidate)."""
+    t = type(obj)
+    tags = _TAGS.get(t)
+    if tags is None:
+        tags = _TAGS[t] = frozenset((c.__module__.rsplit(".", 1)[-1], c.__name__) for c in t.__mro__)
+    return tags
 
 
 def isa(obj, module_tail: str, name: str) -> bool:
