@@ -106,6 +106,7 @@ class ProgramGenerator:
         self._handle_levels = None
         self._handle_params = None
         self._solver_cache = {}
+        self._verified = {}
         self._set_problem(problem)
 
     # ---- read-only attributes the optimizer reads (scripts/optimize.py:60-68) ------------------
@@ -217,8 +218,15 @@ class ProgramGenerator:
 
     def _verify_operators(self, stmts):
         """The op program carries no coefficients: make sure the DAG's operator IS the problem's."""
+        params = tuple(sorted((k, complex(v)) for k, v in self._problem.parameters.items()))
         for st in stmts:
             if st.kind not in ("smooth", "residual", "richardson"):
+                continue
+            # the operator terminals of the grammar are long-lived objects shared by all candidates: verify each
+            # (object, level, PDE parameters) once; the cache keeps the object alive so that its id stays unique
+            source = st.operator_entry if st.operator_entry is not None else st.operator_stencil
+            key = (id(source), st.level, params)
+            if source is not None and self._verified.get(key) is source:
                 continue
             stencil = st.operator_stencil
             if stencil is None and st.operator_entry is not None and hasattr(st.operator_entry, "generate_stencil"):
@@ -234,6 +242,8 @@ class ProgramGenerator:
                 if got.get(o, 0j) != complex(v):
                     raise lowering.UnsupportedExpression(
                         f"operator {st.operator_name}@{st.level} differs from the problem's operator")
+            if source is not None:
+                self._verified[key] = source
 
     # ---- THE call (exastencils.py:485-537) -----------------------------------------------------------
     def generate_and_evaluate(self, expression, storages, min_level: int, max_level: int, solver_program: str,

@@ -266,8 +266,11 @@ class Lowering:
 
 def reset_valid_flags(expression):
     """exastencils.py:330-334: clear the `valid` marks the pass left on shared sub-expressions."""
+    seen = set()          # the DAG shares sub-expressions: visit every node once, not once per path
+
     def rec(e):
-        if e is not None:
+        if e is not None and id(e) not in seen:
+            seen.add(id(e))
             e.valid = False
             e.mutate(rec)
     rec(expression)
