@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
@@ -21,6 +21,10 @@ REAL_F64, COMPLEX_F64 = 0, 1
 BC_DIRICHLET, BC_HELMHOLTZ_ROBIN = 0, 1
 OUTER_MG_ITERATION, OUTER_PBICGSTAB = 0, 1
 CGS_CG, CGS_BICGSTAB = 0, 1
+# `with jacobi` slot handling (include/evomg.h EVOMG_JACOBI_*): TEXTBOOK = the sweep's result becomes the field;
+# EXASTENCILS_V11 = the next slot is never advanced, as in the reference's pipeline (notebooks/tutorial.ipynb:3373)
+JACOBI_TEXTBOOK, JACOBI_EXASTENCILS_V11 = 1, 2
+JACOBI_SEMANTICS = {"textbook": JACOBI_TEXTBOOK, "exastencils-v1.1": JACOBI_EXASTENCILS_V11}
 F_SOL, F_RHS, F_RES, F_CORR, F_CGS_RHS, F_COUNT = 0, 1, 2, 3, 4, 5
 (OP_SMOOTH, OP_RESIDUAL, OP_RESTRICT, OP_PROLONG_ADD, OP_PROLONG_SET, OP_SET_ZERO, OP_COPY,
  OP_COARSE_SOLVE, OP_RICHARDSON) = range(1, 10)
@@ -45,6 +49,7 @@ class Problem(C.Structure):
         ("mg_stencil", (C64 * STENCIL_ENTRIES) * MAX_LEVELS),
         ("outer_stencil", C64 * STENCIL_ENTRIES),
         ("wavenumber", C.c_double),
+        ("jacobi_semantics", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -100,9 +105,6 @@ def ops_array(ops: Sequence[Op]):
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
             "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
             "profile_begin", "profile_end"]
-# the oracle implements the numerical subset
-ORACLE_EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
-                   "set_field", "set_operators", "evaluate", "run_ops", "norm"]
 
 
 class BackendError(RuntimeError):
@@ -194,6 +196,10 @@ class Handle:
         if rc != OK:
             msg = self.L.fn["last_error"](self._h)
             raise BackendError(f"{self.L.prefix}_{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+    def last_error(self) -> str:
+        msg = self.L.fn["last_error"](self._h)
+        return msg.decode() if msg else ""
 
     def nodes(self, level: int) -> int:
         return (1 << level) + 1

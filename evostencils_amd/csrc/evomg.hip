@@ -667,6 +667,23 @@ template <typename T> class Impl : public ImplBase {
     return rc;
   }
 
+  // `with jacobi` slot handling after an out-of-place sweep x -> y (EVOMG_JACOBI_* in include/evomg.h): the sweep of
+  // a Single-partitioned smoother wrote the next slot; under EVOMG_JACOBI_EXASTENCILS_V11 that slot never becomes the
+  // active one (the reference's pipeline never advances it: notebooks/tutorial.ipynb:3373 is reproduced only this
+  // way), so the launch has happened — and cost its time, as in the reference — but the field keeps x.
+  bool jacobi_lost(const evomg_op_t& sm) const {
+    return prob_.jacobi_semantics == EVOMG_JACOBI_EXASTENCILS_V11 && sm.partitioning == EVOMG_PART_SINGLE;
+  }
+  void advance(Level<T>& lv, int L, const evomg_op_t& sm, T* x, T* y) {
+    if (jacobi_lost(sm)) {
+      lv.alt_mirror = x;             // the spare array now carries x's boundary values
+      return;
+    }
+    lv.alt = x;
+    set_fieldptr(L, sm.dst, y);
+    lv.alt_mirror = y;               // the old array (now the spare one) has the same boundary values
+  }
+
   int exec_impl(const evomg_op_t& op) {
     const int L = op.level;
     Level<T>& lv = lv_[L];
@@ -688,25 +705,19 @@ template <typename T> class Impl : public ImplBase {
           if (dim_ == 2) block_smooth<2>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, mir);
           else block_smooth<3>(cells, tgrid, g, lv.st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, mir);
           apply_bc(L, y);
-          lv.alt = x;
-          set_fieldptr(L, op.dst, y);
-          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
+          advance(lv, L, op, x, y);
         } else if (use_strip(g)) {
           T* y = lv.alt;
           if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip<STRIP_RBGS>(g, lv.st, x, f, y, om, omm);
           else launch_strip<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
           if (!strip_bc_) apply_bc(L, y);                   // the strip kernels write the Robin columns themselves
-          lv.alt = x;
-          set_fieldptr(L, op.dst, y);
-          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
+          advance(lv, L, op, x, y);
         } else if (use_strip3d(g, op.partitioning == EVOMG_PART_RED_BLACK)) {
           T* y = lv.alt;
           if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip3d_rbgs(g, lv.st, x, f, y, om, omm);
           else launch_strip3d<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
           apply_bc(L, y);
-          lv.alt = x;
-          set_fieldptr(L, op.dst, y);
-          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
+          advance(lv, L, op, x, y);
         } else if (op.partitioning == EVOMG_PART_RED_BLACK) {
           const dim3 hgrd((g.n / 2 + 1 + 63) / 64, grd.y, grd.z);
           for (int colour = 0; colour < 2; ++colour) {
@@ -719,9 +730,7 @@ template <typename T> class Impl : public ImplBase {
           if (dim_ == 2) hipLaunchKernelGGL((evomg_jacobi<T, 2>), grd, blk, 0, stream_, g, lv.st, x, f, y, om, omm);
           else hipLaunchKernelGGL((evomg_jacobi<T, 3>), grd, blk, 0, stream_, g, lv.st, x, f, y, om, omm);
           apply_bc(L, y);
-          lv.alt = x;
-          set_fieldptr(L, op.dst, y);
-          lv.alt_mirror = y;             // the old array (now the spare one) has the same boundary values
+          advance(lv, L, op, x, y);
         }
         break;
       }
@@ -876,6 +885,7 @@ template <typename T> class Impl : public ImplBase {
     if (!fuse_enabled_ || !zero_elision_ || dim_ != 2 || i + 1 >= n_ops) return false;
     const evomg_op_t &z = ops[i], &sm = ops[i + 1];
     if (z.opcode != EVOMG_OP_SET_ZERO || sm.opcode != EVOMG_OP_SMOOTH || z.level != sm.level) return false;
+    if (jacobi_lost(sm)) return false;        // the sweep's output is discarded: the field has to be zeroed for real
     if (canon(z.level, z.dst) != canon(sm.level, sm.dst) || sm.block[0] * sm.block[1] != 1) return false;
     if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
     if (!bnd_zero_[z.level][canon(z.level, z.dst)]) return false;
@@ -972,7 +982,7 @@ template <typename T> class Impl : public ImplBase {
     if (!fuse_enabled_ || !tail_restrict_enabled_ || !cyclic || i + 2 >= n_ops || dim_ != 2) return false;
     if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && strip_bc_)) return false;
     const evomg_op_t &sm = ops[i], &a = ops[i + 1];
-    if (sm.opcode != EVOMG_OP_SMOOTH || sm.block[0] * sm.block[1] != 1) return false;
+    if (sm.opcode != EVOMG_OP_SMOOTH || sm.block[0] * sm.block[1] != 1 || jacobi_lost(sm)) return false;
     if (!fusable_residual_restrict(ops, n_ops, i + 1) || !residual_dead_after(ops, n_ops, i + 1)) return false;
     if (a.level != sm.level) return false;
     // the residual is taken of what the sweep produces, with the sweep's right-hand side
@@ -1003,7 +1013,7 @@ template <typename T> class Impl : public ImplBase {
     if (!tail_norm_enabled_ || scalar_traits<T>::is_complex || dim_ != 2 || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
     if (i != n_ops - 1) return false;
     const evomg_op_t& b = ops[i];
-    if (b.opcode != EVOMG_OP_SMOOTH || b.level != prob_.max_level || b.block[0] * b.block[1] != 1) return false;
+    if (b.opcode != EVOMG_OP_SMOOTH || b.level != prob_.max_level || b.block[0] * b.block[1] != 1 || jacobi_lost(b)) return false;
     if (canon(b.level, b.dst) != EVOMG_F_SOL || canon(b.level, b.src1) != EVOMG_F_RHS) return false;
     const Geo& g = lv_[b.level].g;
     return use_strip(g) && norm_fused(g) && loop_residual_is_dead(ops, n_ops);
@@ -1013,7 +1023,7 @@ template <typename T> class Impl : public ImplBase {
     // Robin problems: only when the strip kernels own the boundary columns (strip_bc_)
     if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && strip_bc_)) return false;
     const evomg_op_t &a = ops[i], &b = ops[i + 1];
-    if (a.opcode != EVOMG_OP_PROLONG_ADD || b.opcode != EVOMG_OP_SMOOTH || a.level != b.level) return false;
+    if (a.opcode != EVOMG_OP_PROLONG_ADD || b.opcode != EVOMG_OP_SMOOTH || a.level != b.level || jacobi_lost(b)) return false;
     if (canon(a.level, a.dst) != canon(b.level, b.dst)) return false;
     if (b.block[0] * b.block[1] != 1) return false;                        // point smoothers only
     if (canon(b.level, b.src1) == canon(b.level, b.dst)) return false;
@@ -1518,6 +1528,7 @@ int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (p->bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && p->scalar_kind != EVOMG_COMPLEX_F64) { snprintf(err, len, "Robin BC needs complex fields"); return EVOMG_ERR_INVALID; }
   if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) { snprintf(err, len, "PBiCGStab outer solver is 2D only"); return EVOMG_ERR_UNSUPPORTED; }
   if (p->max_iterations < 1 || p->cgs_max_iterations < 1) { snprintf(err, len, "iteration limits must be positive"); return EVOMG_ERR_INVALID; }
+  if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) { snprintf(err, len, "jacobi_semantics must be EVOMG_JACOBI_TEXTBOOK or EVOMG_JACOBI_EXASTENCILS_V11"); return EVOMG_ERR_INVALID; }
   return EVOMG_OK;
 }
 

@@ -23,9 +23,10 @@ def library() -> abi.Library:
     return _library
 
 
-def create(problem_description, device_id=0, parameters=None) -> abi.Handle:
-    """Native solver instance with the problem's initial fields uploaded."""
-    h = abi.Handle(library(), problem_description.to_c(parameters), device_id)
+def create(problem_description, device_id=0, parameters=None, jacobi_semantics=None) -> abi.Handle:
+    """Native solver instance with the problem's initial fields uploaded. `jacobi_semantics`: None = the
+    descriptor's, else "textbook" | "exastencils-v1.1" (abi.JACOBI_SEMANTICS)."""
+    h = abi.Handle(library(), problem_description.to_c(parameters, jacobi_semantics), device_id)
     L = problem_description.max_level
     h.set_initial_field(L, abi.F_SOL, problem_description.initial_solution(L))
     h.set_initial_field(L, abi.F_RHS, problem_description.right_hand_side(L))

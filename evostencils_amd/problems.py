@@ -76,6 +76,10 @@ class ProblemDescription:
     domain_upper: tuple = (1.0, 1.0, 1.0)
     # `generate solver ... with { ... }` settings of the problem's .exa3 file (reference_solver.py)
     solver_hints: Dict[str, str] = field(default_factory=dict)
+    # what a `with jacobi` sweep does to its field (abi.JACOBI_*, include/evomg.h). The descriptors describe the
+    # numerical problem and default to the textbook meaning; the drop-in ProgramGenerator overrides this with the
+    # reference pipeline's behaviour unless told otherwise (code_generation/hip.py).
+    jacobi_semantics: int = abi.JACOBI_TEXTBOOK
 
     def nodes(self, level):
         return (1 << level) + 1
@@ -86,7 +90,7 @@ class ProblemDescription:
                                    parameters=dict(self.parameters))
 
     # ---- C-ABI descriptor -------------------------------------------------------------------
-    def to_c(self, parameters: Optional[Dict[str, complex]] = None) -> abi.Problem:
+    def to_c(self, parameters: Optional[Dict[str, complex]] = None, jacobi_semantics=None) -> abi.Problem:
         params = dict(self.parameters)
         if parameters:
             params.update(parameters)
@@ -107,6 +111,9 @@ class ProblemDescription:
                 v = complex(v)
                 p.outer_stencil[e].re, p.outer_stencil[e].im = v.real, v.imag
         p.wavenumber = float(np.real(params.get("k", 0.0)))
+        if jacobi_semantics is None:
+            jacobi_semantics = self.jacobi_semantics
+        p.jacobi_semantics = abi.JACOBI_SEMANTICS.get(jacobi_semantics, jacobi_semantics)
         return p
 
     # ---- what the reference's parser would extract (parser.py:25-111) -------------------------

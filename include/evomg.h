@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EVOMG_ABI_VERSION 1
+#define EVOMG_ABI_VERSION 2
 #define EVOMG_MAX_LEVELS 24       /* levels are absolute: grid level L has 2^L+1 nodes per dimension */
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
@@ -71,6 +71,20 @@ enum {
   EVOMG_CGS_BICGSTAB = 1  /* explicit BiCGStab text, Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 */
 };
 
+/* What a `with jacobi` sweep — every smoother with Single partitioning, point or block
+ * (exastencils.py:64-70,778-822) — does to the field it relaxes. The sweep itself is the same in both modes
+ * (reads the active slot, writes the next slot); the modes differ in whether the next slot ever becomes active. */
+enum {
+  EVOMG_JACOBI_TEXTBOOK = 1,        /* ONE advance after the sweep: its result is the field from then on (the IR / LFA
+                                       meaning, stencils/multiple.py:204-217; what exastencils.py:338-359 intends) */
+  EVOMG_JACOBI_EXASTENCILS_V11 = 2  /* the next slot is never advanced: the sweep runs (and costs its time) but the field
+                                       keeps its old values. This is what the reference's pipeline does with the
+                                       ExaStencils version it pins (README.md:19-21, v1.1): the one numeric it records,
+                                       notebooks/tutorial.ipynb:3373 (rho = 0.9212764170210773, 100 iterations), is
+                                       reproduced to the last digit in this mode and by no other convention
+                                       (oracle/APPB_MATRIX.md). */
+};
+
 typedef struct { double re, im; } evomg_c64;
 
 /*
@@ -100,6 +114,8 @@ typedef struct {
   evomg_c64 outer_stencil[EVOMG_STENCIL_ENTRIES];
   /* Robin factor numerator data: wavenumber k (Helmholtz). */
   double wavenumber;
+  int32_t jacobi_semantics;     /* EVOMG_JACOBI_*; 0 is rejected: the caller has to choose */
+  int32_t reserved;
 } evomg_problem_t;
 
 /* field slots of one level (exastencils.py:14-26,295-316) */

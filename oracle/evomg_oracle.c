@@ -125,6 +125,9 @@ static int check_problem(const evomg_problem_t* p) {
   if (p->scalar_kind == EVOMG_COMPLEX_F64 && p->dimension != 2) { snprintf(g_err, sizeof g_err, "complex 3D"); return EVOMG_ERR_UNSUPPORTED; }
   if (p->bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && p->scalar_kind != EVOMG_COMPLEX_F64) return EVOMG_ERR_INVALID;
   if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) return EVOMG_ERR_UNSUPPORTED;
+  if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) {
+    snprintf(g_err, sizeof g_err, "jacobi_semantics must be chosen"); return EVOMG_ERR_INVALID;
+  }
   return EVOMG_OK;
 }
 

@@ -121,6 +121,16 @@ static inline SC FN(relax3)(const SC* st, const SC* x, const SC* f, int n, int i
   return sc_add(sc_rmul(omm, x[IDX3(n, i, j, k)]), sc_rmul(om, xs));
 }
 
+/* ---- `with jacobi` slot handling. The sweep has written the next slot y from the active slot x.
+ * TEXTBOOK: one advance, y becomes the field (what exastencils.py:338-359 intends by inserting `advance`).
+ * EXASTENCILS_V11: no advance ever happens, the field keeps x and y stays the spare slot — the behaviour of the
+ * reference's pipeline with ExaStencils v1.1, pinned by notebooks/tutorial.ipynb:3373 (oracle/APPB_MATRIX.md). */
+static void FN(advance_slot)(FN(ctx_t)* c, int level, int dstf, SC* x, SC* y) {
+  if (c->prob.jacobi_semantics == EVOMG_JACOBI_EXASTENCILS_V11) return;
+  c->lv[level].alt = x;
+  FN(set_fieldptr)(c, level, dstf, y);
+}
+
 /* ---- K1: damped Jacobi ("with jacobi": writes the next slot, then advance; exastencils.py:338-359) */
 static void FN(smooth_jacobi)(FN(ctx_t)* c, int level, int dstf, int rhsf, double om) {
   FN(level_t)* lv = &c->lv[level];
@@ -147,8 +157,7 @@ static void FN(smooth_jacobi)(FN(ctx_t)* c, int level, int dstf, int rhsf, doubl
         }
   }
   FN(apply_bc)(c, level, y);
-  lv->alt = (SC*)x;
-  FN(set_fieldptr)(c, level, dstf, y);
+  FN(advance_slot)(c, level, dstf, (SC*)x, y);
 }
 
 /* ---- K2: red-black Gauss-Seidel: colour 0 = even index sum first, then colour 1, in place,
@@ -254,8 +263,7 @@ static void FN(smooth_block)(FN(ctx_t)* c, int level, int dstf, int rhsf, double
             }
       }
   FN(apply_bc)(c, level, y);
-  lv->alt = (SC*)x;
-  FN(set_fieldptr)(c, level, dstf, y);
+  FN(advance_slot)(c, level, dstf, (SC*)x, y);
 }
 
 /* ---- generic y = A x on inner nodes (boundary of y untouched) -------------------------------- */

@@ -20,6 +20,10 @@ def build(force=False):
     return LIB_PATH
 
 
+# the oracle implements the numerical subset of include/evomg.h (prefix oracle_)
+ORACLE_EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
+                   "set_field", "set_operators", "evaluate", "run_ops", "norm"]
+
 _lib = None
 
 
@@ -28,13 +32,14 @@ def library() -> abi.Library:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
-        _lib = abi.Library(LIB_PATH, "oracle", abi.ORACLE_EXPORTED)
+        _lib = abi.Library(LIB_PATH, "oracle", ORACLE_EXPORTED)
     return _lib
 
 
-def create(problem_description, parameters=None) -> abi.Handle:
-    """Oracle solver instance with the problem's initial fields loaded."""
-    h = abi.Handle(library(), problem_description.to_c(parameters), 0)
+def create(problem_description, parameters=None, jacobi_semantics=None) -> abi.Handle:
+    """Oracle solver instance with the problem's initial fields loaded. `jacobi_semantics`: None = the
+    descriptor's, else "textbook" | "exastencils-v1.1" (abi.JACOBI_SEMANTICS)."""
+    h = abi.Handle(library(), problem_description.to_c(parameters, jacobi_semantics), 0)
     L = problem_description.max_level
     h.set_initial_field(L, abi.F_SOL, problem_description.initial_solution(L))
     h.set_initial_field(L, abi.F_RHS, problem_description.right_hand_side(L))

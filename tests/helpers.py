@@ -16,6 +16,10 @@ class _NoLibrary:
 
 
 def generator_for(problem_name, min_level, max_level, library=None, **kw):
+    """Generators of the test-suite run `with jacobi` sweeps with their textbook meaning unless a test asks for the
+    reference pipeline's ("exastencils-v1.1", the ProgramGenerator default): otherwise every Jacobi / block-Jacobi
+    kernel check would compare two untouched fields."""
+    kw.setdefault("jacobi_semantics", "textbook")
     pd = problems.BY_NAME[problem_name](min_level, max_level)
     return ProgramGenerator(problem=pd, library=library or _NoLibrary(), **kw)
 
@@ -30,10 +34,10 @@ def context_for(gen: ProgramGenerator, min_level, max_level):
                                         equations, gen.operators, fields, depth=max_level - min_level)
 
 
-def build_case(name, library=None):
+def build_case(name, library=None, **kw):
     """(generator, expression, min_level, max_level) for a named case of cycles.CASES."""
     problem, min_level, max_level, builder = cycles.CASES[name]
-    gen = generator_for(problem, min_level, max_level, library)
+    gen = generator_for(problem, min_level, max_level, library, **kw)
     ctx = context_for(gen, min_level, max_level)
     expression, _ = builder(ctx)
     return gen, expression, min_level, max_level

@@ -29,7 +29,8 @@ CASES = {
 def test_file_defined_problem_matches_oracle(case):
     from oracle import oracle
     stem, smoother, lo, hi = CASES[case]
-    gen = ProgramGenerator("unused.jar", FIXTURES, stem + ".settings", stem + ".knowledge", "unused.platform")
+    gen = ProgramGenerator("unused.jar", FIXTURES, stem + ".settings", stem + ".knowledge", "unused.platform",
+                           jacobi_semantics="textbook")
     gen.reinitialize(lo, hi, {})
     pd = gen.problem
     assert (pd.min_level, pd.max_level) == (lo, hi)
