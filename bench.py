@@ -11,21 +11,66 @@ resident in HBM. With --gpus N each rank evaluates its own candidates (weak scal
 the two fitness scalars (convergence factor, time) of every rank are gathered to rank 0 with one tiny RCCL
 gather per step, as the optimizer's per-generation allgather does (optimization/program.py:582).
 
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (a torch.distributed.run
+child process, decided before anything touches the GPU) and exits with the child's status.
+
+Besides the headline, the JSON line carries `population`: BASELINE.json configs[4] (256 seeded candidates, 2D Poisson
+2048^2, levels 11..7) evaluated once with the static round-robin split (32 per GPU at N = 8) and once through the dynamic
+work queue, with per-rank busy/idle time — the numbers the >= 6x @ 8 GPUs target is about (candidates differ ~25x in
+cost, so the static split's wall time is its slowest rank).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
-# HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-# gfx950 correction FETCH_SIZE x2; see profiles/README.md). None until measured for the current kernel build.
-TRAFFIC_BYTES_PER_LAUNCH = 483.8e6      # fused finest-level sweeps inside solves (profiles/r01_pmc_smoother.md); plain sweep: 434.2e6   # 2 x FETCH_SIZE (299.5 MB) + WRITE_SIZE (134.7 MB), profiles/r01_pmc_smoother.md
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
+# HBM-side bytes per launch of the dominant kernel, from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE separately;
+# gfx950 correction FETCH_SIZE x 2): one entry per (kernel family, level) with the profile file it came from. Emitted
+# only when the entry matches what this run launched, else null.
+TRAFFIC_TABLE = os.path.join(REPO, "profiles", "pmc_traffic.json")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--max-level", type=int, default=12)
+    ap.add_argument("--min-level", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--concurrency", type=int, default=1,
+                    help="candidates in flight per GPU inside the HEADLINE timed region (1 = isolated timing, the "
+                         "reference's sequential semantics)")
+    ap.add_argument("--throughput-workers", type=int, default=6,
+                    help="after the headline region, also time a throughput-mode region with this many candidates in "
+                         "flight per GPU and report it as `throughput_mode` (0/1 = skip)")
+    ap.add_argument("--population", type=int, default=256,
+                    help="size of the seeded C5 population evaluated after the headline region (0 = skip)")
+    ap.add_argument("--population-level", type=int, default=11)
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N outside a torchrun environment: start the N ranks as a child torch.distributed.run (never exec: nothing
+    here has touched the GPU, but the child must stay a child) and hand its exit status on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def build_candidate(gen, lo, hi):
@@ -61,36 +106,102 @@ def cpu_baseline(ops, lo, hi, threads):
     # report the faster of the two as the baseline (memory-bound sweeps do not always scale to all host cores)
     best_wall, best_threads = (wall4, 4) if (wall4 is not None and wall4 < wall) else (wall, threads)
     return {"value": 1.0 / best_wall, "unit": "solves/s", "cores": best_threads, "kind": "port",
-            "sample": f"1 full solve of the same workload ({int(out.n_iterations)} V-cycles, {best_wall:.1f} s wall, "
-                      f"gcc -O3 -fopenmp -ffp-contract=off)",
+            "sample": f"1 full solve of the same workload ({int(out.n_iterations)} V-cycles, {best_wall:.1f} s wall)",
+            "build": "oracle/Makefile: gcc -O3 -fopenmp -ffp-contract=off, no -march=native; the Krylov half of the oracle "
+                     "sums in the device's reduction-tree order (parity infrastructure, not a tuned CPU solver)",
             "iterations": out.n_iterations, "final_res_norm": out.final_res_norm,
             "by_threads": {str(threads): 1.0 / wall, **({"4": 1.0 / wall4} if wall4 else {})}}
 
 
+def measured_traffic(kernel_key):
+    try:
+        table = json.load(open(TRAFFIC_TABLE))
+    except (OSError, ValueError):
+        return None, None
+    entry = table.get(kernel_key)
+    return (entry["bytes_per_launch"], entry["source"]) if entry else (None, None)
+
+
+def population_section(args, dist, torch, rank, world, local_rank, reduce_device):
+    """BASELINE.json configs[4]: `--population` seeded candidates (candidates.population, seed 2024) on 2D Poisson
+    level 11, five levels, through generate_and_evaluate with default settings (evaluation_samples = 1); once with the
+    static `i % world == rank` split (optimization/program.py:534-535), once through the dynamic work queue."""
+    from evostencils_amd import candidates, native, population, problems
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    from helpers import context_for
+    hi = args.population_level
+    lo = hi - 4
+    gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library())
+    gen.initialize_code_generation(lo, hi)
+    pop = candidates.population(lambda: context_for(gen, lo, hi), hi - lo, 2, args.population, seed=2024)
+    busy = [0.0]
+
+    def evaluate(i):
+        t0 = time.perf_counter()
+        out = gen.generate_and_evaluate(pop[i], None, lo, hi, "", evaluation_samples=1)
+        busy[0] += time.perf_counter() - t0
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_ranks(value):
+        if world <= 1:
+            return [value]
+        t = torch.tensor([value], dtype=torch.float64, device=reduce_device)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    evaluate(rank % args.population)           # warm-up: first launch of every kernel of this level window
+    modes = {}
+    for mode in (("static", "dynamic") if world > 1 else ("static",)):
+        busy[0] = 0.0
+        fence()
+        t0 = time.perf_counter()
+        if mode == "static":
+            rows = population.evaluate_population(evaluate, args.population, local_rank)
+            mine = len(population.shard_indices(args.population, rank, world))
+        else:
+            rows, mine_idx = population.evaluate_population_dynamic(evaluate, args.population, local_rank)
+            mine = len(mine_idx)
+        fence()
+        wall = max(all_ranks(time.perf_counter() - t0))
+        busy_all, count_all = all_ranks(busy[0]), all_ranks(float(mine))
+        modes[mode] = {"solves_per_s": args.population / wall, "wall_s": wall,
+                       "busy_s_per_rank": [round(b, 4) for b in busy_all],
+                       "idle_s_per_rank": [round(wall - b, 4) for b in busy_all],
+                       "candidates_per_rank": [int(c) for c in count_all]}
+        if mode == "static":
+            finite = [r for r in rows if r[3] < 1e99]
+            costs = sorted(r[2] for r in rows)
+            summary = {"converged_below_cap": sum(1 for r in rows if r[3] < gen.problem.max_iterations and r[1] < 1),
+                       "finite": len(finite), "best_rho": min(r[1] for r in rows),
+                       "solve_ms_min_median_max": [costs[0], costs[len(costs) // 2], costs[-1]]}
+    gen.close()
+    return {"workload": f"G3P population = {args.population} seeded candidates (numpy default_rng(2024)), 2D Poisson "
+                        f"{1 << hi}^2 (level {hi}), levels {hi}..{lo}, evaluation_samples = 1, "
+                        f"jacobi_semantics = {gen.jacobi_semantics}",
+            "n_gpus": world, **summary, **modes,
+            "note": "static = round-robin i % N == rank (the reference's split); dynamic = shared counter on the rendezvous "
+                    "store, one all-reduce of the fitness table per generation; idle = wall - time spent inside "
+                    "generate_and_evaluate on that rank. At N = 1 both modes coincide."}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--max-level", type=int, default=12)
-    ap.add_argument("--min-level", type=int, default=7)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--concurrency", type=int, default=1,
-                    help="candidates in flight per GPU inside the HEADLINE timed region (1 = isolated timing, the "
-                         "reference's sequential semantics)")
-    ap.add_argument("--throughput-workers", type=int, default=6,
-                    help="after the headline region, also time a throughput-mode region with this many candidates in "
-                         "flight per GPU and report it as `throughput_mode` (0/1 = skip)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report n_gpus != --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     # EVOMG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
@@ -98,6 +209,8 @@ def main():
     backend = os.environ.get("EVOMG_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -201,6 +314,7 @@ def main():
     n_nodes = ((1 << hi) + 1) ** 2
     plain_bytes = 24.0 * n_nodes
     fused = live.bytes > 1.001 * plain_bytes
+    traffic, traffic_source = measured_traffic(f"strip2d_rbgs_{'fused' if fused else 'plain'}_L{hi}")
     if fused:
         # inside a solve both finest-level sweeps of the V(1,1) cycle run fused with their neighbours: the
         # pre-smoother with residual + restriction, the post-smoother with prolongation and the loop's residual norm
@@ -209,7 +323,7 @@ def main():
     # SURVEY 8(d) procedure: >= 10 warm-up launches, 100 timed back-to-back ping-pong sweeps, median of 5 batches
     b2b = sorted((handle.bench_op(smooth, warmup=10, reps=100) for _ in range(5)), key=lambda b: b.ms)[2]
     roofline = {"bound": "hbm", "achieved": live.gbps, "peak": 8000.0, "unit": "GB/s", "frac": live.gbps / 8000.0,
-                "traffic": TRAFFIC_BYTES_PER_LAUNCH if fused else 434.17e6, "kernel": kname,
+                "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
                 "bytes_per_launch": live.bytes, "ms_per_launch": live.ms, "launches_timed": live.launches,
                 "back_to_back": {"kernel": handle.kernel_name(smooth), "bytes_per_launch": plain_bytes,
                                  "ms_per_launch": b2b.ms, "achieved": b2b.gbps, "frac": b2b.gbps / 8000.0},
@@ -218,7 +332,8 @@ def main():
                         f"Algorithmic bytes per launch: 24 B/node x {n_nodes} nodes for a plain fused red+black sweep; "
                         f"the fused sweeps additionally write / read the coarse level (8 B per coarse node): "
                         f"{live.bytes / 1e6:.1f} MB. 'back_to_back' = median of 5 batches of 100 consecutive plain ping-pong sweeps. "
-                        f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC (profiles/r01_pmc_smoother.md)"}
+                        f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC passes (profiles/pmc_traffic.json names the "
+                        f"profile), null when no profile matches the launched kernel and level"}
 
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:
@@ -239,6 +354,12 @@ def main():
                       "note": "same workload, several candidates in flight per GPU (own stream + fields each): the "
                               "single-workgroup coarse-grid solve of one candidate overlaps the bandwidth-bound sweeps "
                               "of the others; rho/iterations unchanged, per-candidate time includes contention"}
+    if workers is not None:
+        workers.close()
+
+    pop_section = None
+    if args.population > 0:
+        pop_section = population_section(args, dist, torch, rank, world, local_rank, reduce_device)
 
     if rank == 0:
         rho, t_ms, its = last[0]
@@ -256,6 +377,8 @@ def main():
         }
         if throughput is not None:
             line["throughput_mode"] = throughput
+        if pop_section is not None:
+            line["population"] = pop_section
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N = 1 only
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(ops, lo, hi, threads)

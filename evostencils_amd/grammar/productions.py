@@ -113,6 +113,32 @@ def generate_context(approximation, rhs, dimension, coarsening_factors, max_leve
 
 def compile_individual(individual_string: str, context: dict):
     """DAG of a stored individual, e.g. `str(individual)` as written to hof/individual_<j>.txt
-    (scripts/optimize.py:176-179). Returns the (Cycle expression, rhs) state like gp.compile does."""
+    (scripts/optimize.py:176-179). Returns the (Cycle expression, rhs) state like gp.compile does.
+
+    The string is parsed, not evaluated: only calls of names found in `context`, those names themselves, integer
+    constants and tuples of them are accepted (the whole vocabulary DEAP prints for this grammar). The reference
+    hands such strings to `eval` (gp.compile; optimization/program.py:904-933), which would execute whatever a
+    tampered checkpoint or hall-of-fame file contains."""
+    import ast
     env = {k: v for k, v in context.items() if k != "relaxation_factors"}
-    return eval(individual_string, {"__builtins__": {}}, env)  # noqa: S307 — the grammar's own prefix strings
+
+    def value(node):
+        if isinstance(node, ast.Call):
+            if not isinstance(node.func, ast.Name) or node.keywords:
+                raise ValueError("individual string: only plain calls of grammar productions are allowed")
+            fn = value(node.func)
+            if not callable(fn):
+                raise ValueError(f"individual string: {node.func.id!r} is not a production")
+            return fn(*[value(a) for a in node.args])
+        if isinstance(node, ast.Name):
+            if node.id not in env:
+                raise ValueError(f"individual string: unknown symbol {node.id!r}")
+            return env[node.id]
+        if isinstance(node, ast.Constant) and type(node.value) is int:
+            return node.value
+        if isinstance(node, ast.Tuple):
+            return tuple(value(e) for e in node.elts)
+        raise ValueError(f"individual string: {type(node).__name__} is not part of the grammar's vocabulary")
+
+    tree = ast.parse(individual_string.strip(), mode="eval")
+    return value(tree.body)

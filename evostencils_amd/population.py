@@ -79,10 +79,28 @@ def evaluate_population(evaluate: Callable[[int], Tuple[float, float, float]], n
     [(i, rho, time_ms, iterations)] for ALL candidates."""
     rank, world = world_info()
     mine = []
+    failure = None
     for i in shard_indices(n_candidates, rank, world):
-        t_ms, rho, its = evaluate(i)
+        t_ms, rho, its, failure = _guarded(evaluate, i, failure)
         mine.append((i, float(rho), float(t_ms), float(its)))
-    return allgather_fitness(mine, n_candidates, world, local_rank)
+    rows = allgather_fitness(mine, n_candidates, world, local_rank)
+    if failure is not None:
+        raise failure
+    return rows
+
+
+FAILED = 1e100      # the reference's `infinity` sentinel (optimization/program.py:71)
+
+
+def _guarded(evaluate, i, failure):
+    """A rank whose evaluator breaks (device error, ...) must still reach the generation's collective, or every other
+    rank blocks in it forever: the candidate is recorded with the sentinel triple, the first exception is kept and
+    re-raised on this rank AFTER the collective."""
+    try:
+        t_ms, rho, its = evaluate(i)
+        return t_ms, rho, its, failure
+    except Exception as exc:        # noqa: BLE001 — re-raised by the caller once the collective is done
+        return FAILED, FAILED, FAILED, failure if failure is not None else exc
 
 
 _queue_generation = [0]
@@ -119,16 +137,19 @@ def evaluate_population_dynamic(evaluate: Callable[[int], Tuple[float, float, fl
     _queue_generation[0] += 1
     table = torch.zeros((n_candidates, 4), dtype=torch.float64)
     mine = []
+    failure = None
     while True:
         i = store.add(key, 1) - 1
         if i >= n_candidates:
             break
-        t_ms, rho, its = evaluate(i)
+        t_ms, rho, its, failure = _guarded(evaluate, i, failure)
         table[i] = torch.tensor([1.0, float(rho), float(t_ms), float(its)], dtype=torch.float64)
         mine.append(i)
     table = table.to(_device(local_rank))
     dist.all_reduce(table, op=dist.ReduceOp.SUM)
     rows = table.cpu().tolist()
+    if failure is not None:
+        raise failure
     missing = [i for i, r in enumerate(rows) if r[0] != 1.0]
     if missing:
         raise RuntimeError("work queue: candidates %s were evaluated %s" % (missing[:8], "not exactly once"))

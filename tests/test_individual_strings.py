@@ -29,9 +29,14 @@ def test_tutorial_individual_string_compiles_to_the_recorded_cycle():
            [o.key() for o in _gen.generate_op_program(built, lo, hi)]
 
 
-def test_compile_has_no_builtins():
+def test_individual_strings_are_parsed_not_evaluated():
+    """Anything outside the grammar's vocabulary is rejected before it runs (the reference evals these strings)."""
     gen = generator_for("2D_FD_Poisson_fromL2", 6, 8)
     ctx = context_for(gen, 6, 8)
     import pytest
-    with pytest.raises(Exception):
-        productions.compile_individual("__import__('os').system('true')", ctx)
+    for text in ("__import__('os').system('true')", "residual_0.__class__", "[c for c in ().__class__.__base__.__subclasses__()]",
+                 "residual_0(u_and_f) if 1 else 0", "residual_0(state=u_and_f)", "(lambda: 0)()", "u_and_f[0]", "1.5", "'x'"):
+        with pytest.raises(ValueError):
+            productions.compile_individual(text, ctx)
+    with pytest.raises(ValueError, match="unknown symbol"):
+        productions.compile_individual("residual_9(u_and_f)", ctx)
