@@ -121,6 +121,7 @@ class ProgramGenerator:
         self._handle_params = None
         self._solver_cache = {}
         self._verified = {}
+        self._cycle_functions = {}       # text of a generated cycle function -> (level, window min, op program)
         self._set_problem(problem)
 
     # ---- read-only attributes the optimizer reads (scripts/optimize.py:60-68) ------------------
@@ -222,14 +223,84 @@ class ProgramGenerator:
                                 use_global_weights=False):
         """exastencils.py:318-336: `Function <cycle_name>@<level> { ... }`."""
         program = f"Function {self._cycle_name}@{level} {{\n"
-        program += self.generate_multigrid(expression, storages, min_level, max_level, use_global_weights)
+        stmts = self.lower(expression, min_level, max_level, use_global_weights)
+        program += exaslang.render(stmts, self._names(), max_level, self.dimension, self._use_jacobi_prefix)
         program += "}\n\n"
+        if not use_global_weights:
+            # multi-run optimisation hands this text back as part of `solver_program` (optimization/program.py:891-898):
+            # remember what it means, so that it never has to be parsed
+            try:
+                self._verify_operators(stmts)
+                self._cycle_functions[program] = (level, min_level, opprogram.encode(stmts))
+            except lowering.UnsupportedExpression:
+                pass
         return program
 
-    def generate_op_program(self, expression, min_level, max_level) -> List[abi.Op]:
-        stmts = self.lower(expression, min_level, max_level)
+    def generate_op_program(self, expression, min_level, max_level, solver_program: str = "") -> List[abi.Op]:
+        """Op program of ONE multigrid cycle on the problem's finest level, as the generated solver would run it.
+
+        Whole-hierarchy optimisation (`min_level`..`max_level` = the problem's levels, empty `solver_program`): the
+        lowering of `expression`. Multi-run optimisation (optimization/program.py:811-898): `expression` covers the
+        window `min_level`..`max_level` only; the levels above come from the cycle functions in `solver_program`
+        (texts this generator produced earlier), each of which calls `gen_mgCycle@<its coarsest level>()`; below the
+        window the template's own functions remain, i.e. the problem's generated reference cycle
+        (exastencils.py:927-969 strips only the levels min_level+1..max). Calls are expanded in place."""
+        top = self._problem.max_level
+        stmts = self.lower(expression, min_level, top if (solver_program or max_level < top) else max_level)
         self._verify_operators(stmts)
-        return opprogram.encode(stmts)
+        functions = self._functions_of(solver_program)
+        functions[max_level] = (min_level, opprogram.encode(stmts))
+        if not solver_program and max_level == top and min_level == self._problem.min_level:
+            return functions[max_level][1]
+        if top not in functions:
+            raise lowering.UnsupportedExpression(f"no cycle function for level {top}: solver_program must hold the "
+                                                 f"functions of the levels above {max_level}")
+        return self._expand_calls(functions, top, set())
+
+    def _functions_of(self, solver_program: str):
+        """{level: (window min, op program)} of the cycle functions concatenated in `solver_program`."""
+        functions = {}
+        rest = solver_program or ""
+        marker = f"Function {self._cycle_name}@"
+        while rest.strip():
+            start = rest.find(marker)
+            if start < 0:
+                raise lowering.UnsupportedExpression("solver_program holds text that is not a cycle function")
+            end = rest.find("}\n\n", start)
+            text = rest[start:end + 3] if end >= 0 else rest[start:]
+            known = self._cycle_functions.get(text)
+            if known is None:
+                raise lowering.UnsupportedExpression("solver_program holds a cycle function this generator did not produce")
+            level, window_min, ops = known
+            functions[level] = (window_min, ops)
+            rest = rest[start + len(text):]
+        return functions
+
+    def _expand_calls(self, functions, level, active):
+        """Body of gen_mgCycle@level with every `gen_mgCycle@l()` below it expanded: an evolved function where one is
+        defined, else the template's generated cycle from l down (reference_solver.py); on the problem's coarsest level
+        the call IS the coarse-grid solver."""
+        from evostencils_amd import reference_solver
+        coarsest = self._problem.min_level
+        if level in active:
+            raise lowering.UnsupportedExpression(f"cycle function of level {level} calls itself")
+        if level not in functions:
+            return reference_solver.reference_solver_ops(self._problem, top_level=level)
+        _window_min, ops = functions[level]
+        out = []
+        for op in ops:
+            if op.opcode == abi.OP_COPY and op.dst == abi.F_CGS_RHS and op.level != coarsest:
+                # `gen_rhs_u@l = RHS_u@l` in front of a call above the coarsest level: the callee reads its right-hand
+                # side from the slot the caller restricted into (evolved callees use RHS_u@l anyway,
+                # exastencils.py:303-307; for the template's cycle the two arrays are aliased here)
+                continue
+            if op.opcode == abi.OP_COARSE_SOLVE and op.level != coarsest:
+                if op.level >= level:
+                    raise lowering.UnsupportedExpression("a cycle function may only call coarser levels")
+                out += self._expand_calls(functions, op.level, active | {level})
+                continue
+            out.append(op)
+        return out
 
     def _verify_operators(self, stmts):
         """The op program carries no coefficients: make sure the DAG's operator IS the problem's."""
@@ -265,14 +336,13 @@ class ProgramGenerator:
                               infinity=1e100, evaluation_samples=3, global_variable_values=None):
         if global_variable_values is None:
             global_variable_values = {}
-        if solver_program and "Function" in solver_program:
-            # multi-run optimisation (levels_per_run < max-min) splices earlier evolved cycles in as text;
-            # this backend evaluates whole level windows only.
-            raise NotImplementedError("solver_program with pre-evolved cycle functions is not supported")
         try:
-            ops = self.generate_op_program(expression, min_level, max_level)
+            ops = self.generate_op_program(expression, min_level, max_level, solver_program)
         except lowering.UnsupportedExpression:
             return infinity, infinity, infinity
+        if solver_program or max_level < self._problem.max_level or min_level > self._problem.min_level:
+            # the executable always solves the problem on its finest level with the whole hierarchy underneath
+            min_level, max_level = self._problem.min_level, self._problem.max_level
         self._counter += 1
         mapping = dict(global_variable_values)
         n = 3 if "k" in mapping else 1          # Helmholtz: k, 2k, 4k (exastencils.py:518-532)

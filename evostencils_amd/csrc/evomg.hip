@@ -19,6 +19,7 @@
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
+#include "evomg_tile3d.h"
 #ifndef EVOMG_FUSED_PF
 #define EVOMG_FUSED_PF 2   // prefetch depth of the fused sweeps (fewer waves per SIMD than the plain ones)
 #endif
@@ -203,6 +204,7 @@ template <typename T> class Impl : public ImplBase {
     HIP_TRY(hipSetDevice(device_));
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
+    if (cg_multi_used_) HIP_TRY(hipMemsetAsync(dinfo_, 0, sizeof(int) * 4, stream_));
     rc = exec_program(ops, n_ops, /*cyclic=*/false);
     if (rc != EVOMG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -240,12 +242,28 @@ template <typename T> class Impl : public ImplBase {
     memset(out, 0, sizeof *out);
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
+    // The eight-workgroup coarse solver (evomg_cg_multi_wg3d) needs its workgroups co-resident; with several candidates
+    // in flight on one GPU (population.ConcurrentEvaluator) or another tenant on the device they can miss their
+    // rendezvous. That is a property of the moment, not of the candidate: quiesce the device and evaluate once more,
+    // alone, before reporting a device error (the solve is deterministic, a clean second attempt is the answer).
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (cg_multi_used_ || attempt > 0) HIP_TRY(hipMemsetAsync(dinfo_, 0, sizeof(int) * 4, stream_));
+      rc = evaluate_attempt(ops, n_ops, samples, wall_limit_ms, out, hist, cap);
+      if (rc != EVOMG_OK) return rc;
+      rc = coarse_solver_health();
+      if (rc == EVOMG_OK) return rc;
+      if (attempt == 0) HIP_TRY(hipDeviceSynchronize());
+    }
+    return rc;
+  }
+  int evaluate_attempt(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out,
+                       double* hist, int cap) {
     double tsum = 0.0;
     evomg_result_t r;
     int done = 0;
     for (int s = 0; s < samples; ++s) {
       memset(&r, 0, sizeof r);
-      rc = reset_fields();
+      int rc = reset_fields();
       if (rc != EVOMG_OK) return rc;
       if (prob_.outer_kind == EVOMG_OUTER_PBICGSTAB) rc = solve_pbicgstab(ops, n_ops, wall_limit_ms, &r, hist, cap);
       else rc = solve_mg(ops, n_ops, wall_limit_ms, &r, hist, cap);
@@ -256,7 +274,7 @@ template <typename T> class Impl : public ImplBase {
     }
     *out = r;
     out->time_ms = tsum / (double)done;
-    return coarse_solver_health();
+    return EVOMG_OK;
   }
 
   int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) override {
@@ -295,6 +313,10 @@ template <typename T> class Impl : public ImplBase {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
+        if (cells == 1 && op->partitioning != EVOMG_PART_RED_BLACK && use_tile3d(lv_[op->level].g)) {
+          snprintf(buf, len, "evomg_tile3d<%s, %d, ", type_name<T>::get(), STRIP_JACOBI);
+          return EVOMG_OK;
+        }
         if (cells == 1 && use_strip3d(lv_[op->level].g, op->partitioning == EVOMG_PART_RED_BLACK)) {
           if (op->partitioning == EVOMG_PART_RED_BLACK) snprintf(buf, len, "evomg_strip3d_rbgs<%s, 4, %s>", type_name<T>::get(), strip_streams3d(lv_[op->level].g) ? "true" : "false");
           else snprintf(buf, len, "evomg_strip3d<%s, %d, 4, %s>", type_name<T>::get(), STRIP_JACOBI, strip_streams3d(lv_[op->level].g) ? "true" : "false");
@@ -305,6 +327,7 @@ template <typename T> class Impl : public ImplBase {
       case EVOMG_OP_RESIDUAL:
         base = "evomg_apply";
         if (use_strip(lv_[op->level].g)) { snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), STRIP_RESIDUAL, strip_streams(lv_[op->level].g) ? "true" : "false"); return EVOMG_OK; }
+        if (use_tile3d(lv_[op->level].g)) { snprintf(buf, len, "evomg_tile3d<%s, %d, ", type_name<T>::get(), STRIP_RESIDUAL); return EVOMG_OK; }
         if (use_strip3d(lv_[op->level].g, false)) { snprintf(buf, len, "evomg_strip3d<%s, %d, 4, %s>", type_name<T>::get(), STRIP_RESIDUAL, strip_streams3d(lv_[op->level].g) ? "true" : "false"); return EVOMG_OK; }
         break;
       case EVOMG_OP_RICHARDSON: base = "evomg_richardson"; break;
@@ -695,7 +718,9 @@ template <typename T> class Impl : public ImplBase {
         T* x = fieldptr(L, op.dst);
         const T* f = fieldptr(L, op.src1);
         const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
-        if (cells > 1) {
+        if (cells == 2 && dim_ == 3 && op.block[2] == 1 && block_fast_ && use_tile3d(g) && tile_two_cell(lv, x, f, op)) {
+          advance(lv, L, op, x, lv.alt);
+        } else if (cells > 1) {
           T* y = lv.alt;
           const int bx = op.block[0], by = op.block[1], bz = dim_ == 3 ? op.block[2] : 1;
           const int inner = g.n - 2;
@@ -711,6 +736,11 @@ template <typename T> class Impl : public ImplBase {
           if (op.partitioning == EVOMG_PART_RED_BLACK) launch_strip<STRIP_RBGS>(g, lv.st, x, f, y, om, omm);
           else launch_strip<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
           if (!strip_bc_) apply_bc(L, y);                   // the strip kernels write the Robin columns themselves
+          advance(lv, L, op, x, y);
+        } else if (op.partitioning != EVOMG_PART_RED_BLACK && use_tile3d(g)) {
+          T* y = lv.alt;
+          ensure_faces(lv, x, y);
+          launch_tile3d<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
           advance(lv, L, op, x, y);
         } else if (use_strip3d(g, op.partitioning == EVOMG_PART_RED_BLACK)) {
           T* y = lv.alt;
@@ -1091,12 +1121,63 @@ template <typename T> class Impl : public ImplBase {
     if (strip_streams3d(g)) hipLaunchKernelGGL((evomg_strip3d_rbgs<T, TY, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
     else hipLaunchKernelGGL((evomg_strip3d_rbgs<T, TY, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
   }
+  // ---- 3D tiles with LDS-shared y halo (evomg_tile3d.h): Jacobi and residual ------------------------------------------
+  bool use_tile3d(const Geo& g) const {
+    if (dim_ != 3 || !strip_enabled_ || !tile3d_enabled_ || scalar_traits<T>::is_complex) return false;
+    return g.n >= (strip3d_min_n_ > 0 ? strip3d_min_n_ : 65);
+  }
+  // block-Jacobi with (2,1,1) or (1,2,1) tiles as a tile-kernel mode; false: not applicable (caller falls back)
+  bool tile_two_cell(Level<T>& lv, const T* x, const T* f, const evomg_op_t& op) {
+    if constexpr (scalar_traits<T>::is_complex) return false;
+    else {
+      const BlockPlan<T> pl = make_block_plan<T, 3>(lv.st, op.block[0], op.block[1], 1);
+      if (pl.skip[1][0]) return false;
+      const TwoCellPlan<T> two{pl.fac[1][0], pl.upper[0][1], pl.pivot[0], pl.pivot[1]};
+      T* y = lv.alt;
+      ensure_faces(lv, x, y);
+      const double om = op.omega, omm = 1.0 - op.omega;
+      if (op.block[0] == 2) launch_tile3d<TILE_BLOCK211>(lv.g, lv.st, x, f, y, om, omm, two);
+      else launch_tile3d<TILE_BLOCK121>(lv.g, lv.st, x, f, y, om, omm, two);
+      return true;
+    }
+  }
+  // the tiles write inner nodes only: y's boundary faces must equal x's (ping-pong twin, or one thin copy)
+  void ensure_faces(const Level<T>& lv, const T* x, T* y) {
+    if (mirror_enabled_ && prob_.bc_kind == EVOMG_BC_DIRICHLET && lv.alt_mirror == x) return;
+    const Geo& g = lv.g;
+    const dim3 fgrid((g.n + 63) / 64, (g.n + 3) / 4, 6);
+    hipLaunchKernelGGL((evomg_copy_faces<T, 3>), fgrid, node_block(), 0, stream_, g, x, y);
+  }
+  template <int MODE> void launch_tile3d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm,
+                                         TwoCellPlan<T> two = TwoCellPlan<T>{}) {
+    constexpr int TY = EVOMG_TILE3D_TY;
+    const int inner = g.n - 2;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    // eight waves per workgroup (y halo 34/32) where that still leaves a few thousand workgroups, else four (18/16)
+    int nw = tile3d_waves_ > 0 ? tile3d_waves_ : 8;
+    if (tile3d_waves_ == 0 && (long)strips * ((inner + 8 * TY - 1) / (8 * TY)) * ((inner + 15) / 16) < 1024) nw = 4;
+    const int ygroups = (inner + nw * TY - 1) / (nw * TY);
+    int planes = strip_planes_ > 0 ? strip_planes_ : 64;       // z halo: 2 planes per chunk
+    while (planes > 8 && (long)strips * ygroups * ((inner + planes - 1) / planes) < 2048) planes /= 2;
+    planes = (planes + 3) & ~3;
+    const int chunks = (inner + planes - 1) / planes;
+    const int blocks = strips * ygroups * chunks;
+    const dim3 grid(((blocks + 7) / 8) * 8);
+    const bool nt = strip_streams3d(g);
+    if constexpr (!scalar_traits<T>::is_complex) {
+#define EVOMG_TILE3D_LAUNCH(NW, NT) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two)
+      if (nw == 8) { if (nt) EVOMG_TILE3D_LAUNCH(8, true); else EVOMG_TILE3D_LAUNCH(8, false); }
+      else { if (nt) EVOMG_TILE3D_LAUNCH(4, true); else EVOMG_TILE3D_LAUNCH(4, false); }
+#undef EVOMG_TILE3D_LAUNCH
+    }
+  }
   bool strip_streams3d(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.plane * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
 
   // bc_out: the caller applies the boundary condition to r afterwards (the strip kernel then does it itself)
   void residual(int L, const Stencil<T>& st, const T* x, const T* f, T* r, bool bc_out = false) {
     const Geo& g = lv_[L].g;
     if (use_strip(g)) { launch_strip<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0, bc_out); return; }
+    if (use_tile3d(g)) { launch_tile3d<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
     if (use_strip3d(g, false)) { launch_strip3d<STRIP_RESIDUAL>(g, st, x, f, r, 0.0, 0.0); return; }
     if (dim_ == 2) hipLaunchKernelGGL((evomg_apply<T, 2, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
     else hipLaunchKernelGGL((evomg_apply<T, 3, true>), node_grid(g), node_block(), 0, stream_, g, st, x, f, r);
@@ -1266,7 +1347,7 @@ template <typename T> class Impl : public ImplBase {
     const Geo& g = lv_[op.level].g;
     const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
     const bool rb = op.partitioning == EVOMG_PART_RED_BLACK;
-    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || !rb;
+    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || !rb;       // (the 3D tiles are Jacobi: !rb)
   }
   int solve_mg(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
     const int L = prob_.max_level;
@@ -1515,6 +1596,8 @@ template <typename T> class Impl : public ImplBase {
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
   int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
   int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
+  bool tile3d_enabled_ = getenv("EVOMG_NO_TILE3D") == nullptr;
+  int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
 };
 

@@ -708,8 +708,10 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
       x[c] = xr[i];
       r_out[c] = r[i];
     }
-  if (w == 0 && t == 0) {
-    info[0] = it;
-    info[1] = alive ? 0 : 1;
+  // info[1] is sticky (only ever set here, cleared by the host before an evaluation): a later successful solve must not
+  // hide an earlier missed rendezvous, and any group may be the one that saw it
+  if (t == 0) {
+    if (w == 0) info[0] = it;
+    if (!alive) info[1] = 1;
   }
 }

@@ -39,8 +39,11 @@ def v_cycle_ops(min_level: int, max_level: int, pre: int, post: int, omega: floa
     return ops
 
 
-def reference_solver_ops(problem, hints: Optional[Dict[str, object]] = None) -> List[abi.Op]:
-    """Op program of the reference solver of `problem` (a problems.ProblemDescription)."""
+def reference_solver_ops(problem, hints: Optional[Dict[str, object]] = None, top_level: Optional[int] = None) -> List[abi.Op]:
+    """Op program of the reference solver of `problem` (a problems.ProblemDescription). `top_level` < max_level:
+    the same generated cycle entered at a coarser level, i.e. what the template's `gen_mgCycle@top_level` does when
+    an evolved cycle function calls it from the bottom of its level window (exastencils.py:894-896, multi-run
+    optimisation: optimization/program.py:811-813,898)."""
     h = dict(DEFAULT_HINTS.get(problem.name, {}))
     h.update(getattr(problem, "solver_hints", None) or {})
     h.update(hints or {})
@@ -48,6 +51,7 @@ def reference_solver_ops(problem, hints: Optional[Dict[str, object]] = None) -> 
         raise ValueError(f"no solver hints for problem {problem.name!r}")
     jacobi = str(h.get("solver_smoother_jacobiType", "false")).lower() == "true"
     coloured = str(h.get("solver_smoother_coloring", "red-black")).lower() in ("red-black", "rb", "2-way")
-    return v_cycle_ops(problem.min_level, problem.max_level, int(h.get("solver_smoother_numPre", 2)),
+    return v_cycle_ops(problem.min_level, problem.max_level if top_level is None else top_level,
+                       int(h.get("solver_smoother_numPre", 2)),
                        int(h.get("solver_smoother_numPost", 1)), float(h.get("solver_smoother_damping", 1.0)),
                        red_black=coloured and not jacobi)

@@ -20,10 +20,11 @@ def smooth(P, depth, cycle, spec):
     raise ValueError(kind)
 
 
-def v_cycle(P, depth, pre, post, cgc_index=18):
+def v_cycle(P, depth, pre, post, cgc_index=18, state=None):
     """`depth`+1 levels; pre/post: per level (finest first) list of smoother specs. Returns the state
-    (cycle expression, rhs)."""
-    state = P["u_and_f"]
+    (cycle expression, rhs). `state`: continue from the result of an earlier cycle (several coarse-grid corrections
+    in a row, as the grammar allows) instead of from the initial (u, f)."""
+    state = P["u_and_f"] if state is None else state
     cycle = P["residual_0"](state)
     for d in range(depth):
         for spec in pre[d]:
@@ -83,6 +84,10 @@ CASES = {
                             lambda P: v_cycle(P, 3, [[_blk(10, (2, 1))], [_blk(12, (2, 2)), _jac(9)], []],
                                               [[_blk(16, (1, 2)), _rb(20)], [], [_blk(5, (3, 2))]], cgc_index=17)),
     "poisson2d_tutorial": ("2D_FD_Poisson_fromL2", 5, 9, tutorial_cycle),
+    # two complete V(1,1) corrections per cycle (irregular shapes of this kind are what the grammar evolves)
+    "poisson2d_L7_double_v": ("2D_FD_Poisson_fromL2", 4, 7,
+                              lambda P: v_cycle(P, 3, [[_rb(20)]] * 3, [[_rb(20)]] * 3,
+                                                state=v_cycle(P, 3, [[_rb(18)]] * 3, [[_jac(14)]] * 3))),
     # 3D: block-Jacobi V(2,2) (C4 shape) and RB-GS
     "poisson3d_L4_v22_block": ("3D_FD_Poisson_fromL2", 2, 4,
                                lambda P: v_cycle(P, 2, [[_blk(10, (2, 1, 1))] * 2] * 2, [[_blk(10, (2, 1, 1))] * 2] * 2)),

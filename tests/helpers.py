@@ -34,6 +34,20 @@ def context_for(gen: ProgramGenerator, min_level, max_level):
                                         equations, gen.operators, fields, depth=max_level - min_level)
 
 
+def window_context(gen: ProgramGenerator, min_level, max_level):
+    """Production context of a level window below the problem's finest level, as the optimizer builds it for the later
+    runs of a multi-run optimisation (optimization/program.py:786-789,811-830: coarse approximations / right-hand sides,
+    `generate_primitive_set(..., max_level, depth=levels_per_run)`)."""
+    approximation = system.Approximation("x", [base.Approximation(f.name, g) for f, g in zip(gen.fields, gen.finest_grid)])
+    top = [eq for eq in gen.equations if eq.level == gen.max_level]
+    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, g) for eq, g in zip(top, gen.finest_grid)])
+    for _ in range(gen.max_level - max_level):
+        approximation = system.get_coarse_approximation(approximation, gen.coarsening_factor)
+        rhs = system.get_coarse_rhs(rhs, gen.coarsening_factor)
+    return productions.generate_context(approximation, rhs, gen.dimension, gen.coarsening_factor, max_level,
+                                        gen.equations, gen.operators, gen.fields, depth=max_level - min_level)
+
+
 def build_case(name, library=None, **kw):
     """(generator, expression, min_level, max_level) for a named case of cycles.CASES."""
     problem, min_level, max_level, builder = cycles.CASES[name]

@@ -63,3 +63,41 @@ def test_wavenumber_retargeting_changes_the_operator():
     assert a.init_res_norm == b.init_res_norm      # same right-hand side, zero initial guess
     assert not np.array_equal(h.get_field(hi, abi.F_CORR), np.zeros_like(h.get_field(hi, abi.F_CORR)))
     assert a.n_iterations != b.n_iterations or a.final_res_norm != b.final_res_norm
+
+
+def evolved_double_cycle_ops(lo, hi, k):
+    """The frozen "evolved" Helmholtz preconditioner of this repo (SURVEY 8d asks for one): TWO complete V(2,1) RB-GS
+    w = 0.6 corrections per application, built with the grammar's own productions (several coarse-grid corrections in a
+    row are ordinary members of the search space). It halves the outer iteration count of the hand-written cycle
+    (tools/helmholtz_multi_vcycle.py: 1825 -> 1211 at 257^2, k h = 0.625). Returns (generator, op program)."""
+    import cycles
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    from helpers import context_for
+    gen = ProgramGenerator(problem=problems.helmholtz_2d(lo, hi, k=k), library=object())
+    P = context_for(gen, lo, hi)
+    d = hi - lo
+    rb = [("rbgs", 10)]                      # linspace(0.1, 1.9, 37)[10] = 0.6
+    first = cycles.v_cycle(P, d, [rb * 2] * d, [rb] * d)
+    second = cycles.v_cycle(P, d, [rb * 2] * d, [rb] * d, state=first)
+    return gen, gen.generate_op_program(second[0], lo, hi)
+
+
+def test_evolved_double_cycle_fixture():
+    lo, hi = 3, 6
+    k = 0.625 * (1 << hi)
+    gen, ops = evolved_double_cycle_ops(lo, hi, k)
+    single = reference_vcycle_ops(lo, hi)
+    drop_self_copies = lambda seq: [(o.opcode, o.level, o.partitioning, o.omega) for o in seq if not (o.opcode == abi.OP_COPY and o.dst == o.src0)]
+    # statement for statement two hand-written cycles (prolongation weight: the grammar's 0.9999999999999999)
+    assert [t[:3] for t in drop_self_copies(ops)] == [t[:3] for t in drop_self_copies(single)] * 2
+    h = oracle.create(gen.problem)
+    a, b = h.evaluate(single, 1, 0, 0), h.evaluate(ops, 1, 0, 512)
+    assert a.status == b.status == abi.SOLVE_CONVERGED
+    assert b.n_iterations < 0.6 * a.n_iterations           # 161 -> 88 (BiCGStab counts are sensitive to the last bit)
+    u = h.get_field(hi, abi.F_CORR)
+    n = (1 << hi) + 1
+    hh = 1.0 / (n - 1)
+    f = gen.problem.right_hand_side(hi)
+    Au = (4.0 / hh ** 2 - k ** 2) * u[1:-1, 1:-1] - (u[1:-1, :-2] + u[1:-1, 2:] + u[:-2, 1:-1] + u[2:, 1:-1]) / hh ** 2
+    r = f[1:-1, 1:-1] - Au
+    assert np.sqrt(abs(np.sum(r * r))) / b.init_res_norm < 1e-6

@@ -65,8 +65,33 @@ def test_bad_candidates_return_sentinels_not_exceptions(native):
     # not lowerable -> (inf, inf, inf) like a failed code generation (exastencils.py:499-510)
     from evostencils_amd.ir import base
     assert gen.generate_and_evaluate(base.Addition(expression, expression), None, lo, hi, "") == (INF, INF, INF)
-    with pytest.raises(NotImplementedError):
-        gen.generate_and_evaluate(expression, None, lo, hi, "Function gen_mgCycle@7 {\n}\n")
+    # a solver_program this generator did not produce cannot be spliced: a failed candidate, not an exception
+    assert gen.generate_and_evaluate(expression, None, lo, hi, "Function gen_mgCycle@7 {\n}\n\n") == (INF, INF, INF)
+
+
+def test_level_windows_and_multi_run_solver_programs(native):
+    """SURVEY 8 row a7 on the GPU: a window over the top levels calls the template's generated cycle underneath; a
+    second run's candidate is evaluated underneath the first run's function handed back as `solver_program`
+    (optimization/program.py:811-898). Both against the oracle on the composed op program."""
+    from oracle import oracle
+    from helpers import window_context, generator_for
+    gen = generator_for("2D_FD_Poisson_fromL2", 4, 8, library=native.library())
+    gen.initialize_code_generation(4, 8)
+    rb = [("rbgs", 21)]
+    top, _ = cycles.v_cycle(window_context(gen, 6, 8), 2, [rb, [("jacobi", 12)]], [[("block", 14, (2, 1))], rb], cgc_index=17)
+    t, rho, its = gen.generate_and_evaluate(top, None, 6, 8, "", infinity=INF, evaluation_samples=1)
+    ref = oracle.create(gen.problem).evaluate(gen.generate_op_program(top, 6, 8), 1, 0, 128)
+    _, want_rho, want_its = ProgramGenerator.interpret_outcome(ref, INF)
+    assert its == want_its and rho == pytest.approx(want_rho, rel=1e-10) and rho < 0.5
+    solver_program = gen.generate_cycle_function(top, None, 6, 8, 8)
+    low, _ = cycles.v_cycle(window_context(gen, 4, 6), 2, [rb, rb], [[("rbgs", 20)], rb], cgc_index=19)
+    t, rho, its = gen.generate_and_evaluate(low, None, 4, 6, solver_program, infinity=INF, evaluation_samples=1)
+    ops = gen.generate_op_program(low, 4, 6, solver_program)
+    assert [o.level for o in ops if o.opcode == abi.OP_COARSE_SOLVE] == [4]
+    ref = oracle.create(gen.problem).evaluate(ops, 1, 0, 128)
+    _, want_rho, want_its = ProgramGenerator.interpret_outcome(ref, INF)
+    assert its == want_its and rho == pytest.approx(want_rho, rel=1e-10) and rho < 0.5
+    gen.close()
 
 
 def test_reinitialize_bumps_the_problem_size(native):
@@ -106,7 +131,7 @@ def test_helmholtz_wavenumber_sweep(native):
 
 def test_concurrent_3d_candidates_with_multi_workgroup_coarse_solver(native):
     """Throughput mode on 3D problems: each candidate's coarse solve on 33^3 is EIGHT co-resident workgroups that
-    rendezvous through global memory (evomg_cg_multi_wg3d). Four candidates in flight must neither dead-lock nor
+    rendezvous through global memory (evomg_cg_multi_wg3d). Six candidates in flight must neither dead-lock nor
     change any result (every handle has its own exchange area)."""
     from evostencils_amd import population
     lo, hi = 5, 6
@@ -128,7 +153,7 @@ def test_concurrent_3d_candidates_with_multi_workgroup_coarse_solver(native):
     solo = make()
     want = [evaluate(solo, s) for s in specs]
     solo.close()
-    workers = population.ConcurrentEvaluator(make, 4)
+    workers = population.ConcurrentEvaluator(make, 6)
     got = workers.map(evaluate, specs)
     workers.close()
     for (t0, rho0, its0), (t1, rho1, its1) in zip(want, got):
