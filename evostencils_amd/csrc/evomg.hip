@@ -313,8 +313,13 @@ template <typename T> class Impl : public ImplBase {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
-        if (cells == 1 && op->partitioning != EVOMG_PART_RED_BLACK && use_tile3d(lv_[op->level].g)) {
-          snprintf(buf, len, "evomg_tile3d<%s, %d, ", type_name<T>::get(), STRIP_JACOBI);
+        if (cells == 1 && use_tile3d(lv_[op->level].g) && (op->partitioning != EVOMG_PART_RED_BLACK || tile3d_rbgs_)) {
+          if (op->partitioning == EVOMG_PART_RED_BLACK) snprintf(buf, len, "evomg_tile3d_rbgs<%s, ", type_name<T>::get());
+          else snprintf(buf, len, "evomg_tile3d<%s, %d, ", type_name<T>::get(), STRIP_JACOBI);
+          return EVOMG_OK;
+        }
+        if (cells == 2 && dim_ == 3 && op->block[2] == 1 && block_fast_ && use_tile3d_blocks(lv_[op->level].g) && !scalar_traits<T>::is_complex) {
+          snprintf(buf, len, "evomg_tile3d<%s, %d, ", type_name<T>::get(), op->block[0] == 2 ? TILE_BLOCK211 : TILE_BLOCK121);
           return EVOMG_OK;
         }
         if (cells == 1 && use_strip3d(lv_[op->level].g, op->partitioning == EVOMG_PART_RED_BLACK)) {
@@ -718,7 +723,7 @@ template <typename T> class Impl : public ImplBase {
         T* x = fieldptr(L, op.dst);
         const T* f = fieldptr(L, op.src1);
         const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
-        if (cells == 2 && dim_ == 3 && op.block[2] == 1 && block_fast_ && use_tile3d(g) && tile_two_cell(lv, x, f, op)) {
+        if (cells == 2 && dim_ == 3 && op.block[2] == 1 && block_fast_ && use_tile3d_blocks(g) && tile_two_cell(lv, x, f, op)) {
           advance(lv, L, op, x, lv.alt);
         } else if (cells > 1) {
           T* y = lv.alt;
@@ -737,10 +742,11 @@ template <typename T> class Impl : public ImplBase {
           else launch_strip<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
           if (!strip_bc_) apply_bc(L, y);                   // the strip kernels write the Robin columns themselves
           advance(lv, L, op, x, y);
-        } else if (op.partitioning != EVOMG_PART_RED_BLACK && use_tile3d(g)) {
+        } else if (use_tile3d(g) && (op.partitioning != EVOMG_PART_RED_BLACK || tile3d_rbgs_)) {
           T* y = lv.alt;
           ensure_faces(lv, x, y);
-          launch_tile3d<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
+          if (op.partitioning == EVOMG_PART_RED_BLACK) launch_tile3d_rbgs(g, lv.st, x, f, y, om, omm);
+          else launch_tile3d<STRIP_JACOBI>(g, lv.st, x, f, y, om, omm);
           advance(lv, L, op, x, y);
         } else if (use_strip3d(g, op.partitioning == EVOMG_PART_RED_BLACK)) {
           T* y = lv.alt;
@@ -1124,8 +1130,12 @@ template <typename T> class Impl : public ImplBase {
   // ---- 3D tiles with LDS-shared y halo (evomg_tile3d.h): Jacobi and residual ------------------------------------------
   bool use_tile3d(const Geo& g) const {
     if (dim_ != 3 || !strip_enabled_ || !tile3d_enabled_ || scalar_traits<T>::is_complex) return false;
-    return g.n >= (strip3d_min_n_ > 0 ? strip3d_min_n_ : 65);
+    // measured (profiles/r02_pmc_3d.md): from 129^3 up the tiles match or beat every other 3D kernel of this library;
+    // below, a tile grid has too few workgroups and the thread-per-node kernels win on latency
+    return g.n >= (strip3d_min_n_ > 0 ? strip3d_min_n_ : 129);
   }
+  // the two-cell block modes pay from 257^3 (at 129^3 one thread per tile is 30 % faster)
+  bool use_tile3d_blocks(const Geo& g) const { return use_tile3d(g) && g.n >= (strip3d_min_n_ > 0 ? strip3d_min_n_ : 257); }
   // block-Jacobi with (2,1,1) or (1,2,1) tiles as a tile-kernel mode; false: not applicable (caller falls back)
   bool tile_two_cell(Level<T>& lv, const T* x, const T* f, const evomg_op_t& op) {
     if constexpr (scalar_traits<T>::is_complex) return false;
@@ -1157,18 +1167,38 @@ template <typename T> class Impl : public ImplBase {
     int nw = tile3d_waves_ > 0 ? tile3d_waves_ : 8;
     if (tile3d_waves_ == 0 && (long)strips * ((inner + 8 * TY - 1) / (8 * TY)) * ((inner + 15) / 16) < 1024) nw = 4;
     const int ygroups = (inner + nw * TY - 1) / (nw * TY);
-    int planes = strip_planes_ > 0 ? strip_planes_ : 64;       // z halo: 2 planes per chunk
-    while (planes > 8 && (long)strips * ygroups * ((inner + planes - 1) / planes) < 2048) planes /= 2;
+    // z halo: 2 planes per chunk. Measured at 513^3 (profiles/r02_pmc_3d.md): 16 planes (2560 workgroups) beat 32 and 64
+    int planes = strip_planes_ > 0 ? strip_planes_ : 16;
+    if (strip_planes_ <= 0) while (planes > 8 && (long)strips * ygroups * ((inner + planes - 1) / planes) < 2048) planes /= 2;
     planes = (planes + 3) & ~3;
     const int chunks = (inner + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
-    const bool nt = strip_streams3d(g);
+    const int nt = strip_streams3d(g) ? tile3d_nt_ : 0;
     if constexpr (!scalar_traits<T>::is_complex) {
-#define EVOMG_TILE3D_LAUNCH(NW, NT) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two)
-      if (nw == 8) { if (nt) EVOMG_TILE3D_LAUNCH(8, true); else EVOMG_TILE3D_LAUNCH(8, false); }
-      else { if (nt) EVOMG_TILE3D_LAUNCH(4, true); else EVOMG_TILE3D_LAUNCH(4, false); }
+#define EVOMG_TILE3D_LAUNCH(NW, NT) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_)
+#define EVOMG_TILE3D_NT(NW) if (nt & 1) EVOMG_TILE3D_LAUNCH(NW, 1); else EVOMG_TILE3D_LAUNCH(NW, 0);
+      if (nw == 8) { EVOMG_TILE3D_NT(8) } else { EVOMG_TILE3D_NT(4) }
+#undef EVOMG_TILE3D_NT
 #undef EVOMG_TILE3D_LAUNCH
+    }
+  }
+  void launch_tile3d_rbgs(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
+    constexpr int TY = EVOMG_TILE3D_TY;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    int nw = tile3d_waves_ > 0 ? tile3d_waves_ : 8;
+    if (tile3d_waves_ == 0 && (long)strips * ((g.n + 8 * TY - 3) / (8 * TY - 2)) * ((g.n + 15) / 16) < 1024) nw = 4;
+    const int stored = nw * TY - 2;                              // rows a workgroup finishes (the top one: one more)
+    const int ygroups = (g.n - 3 + stored - 1) / stored > 0 ? (g.n - 3 + stored - 1) / stored : 1;
+    int planes = strip_planes_ > 0 ? strip_planes_ : 64;       // z halo: 3 planes per chunk
+    if (strip_planes_ <= 0) while (planes > 8 && (long)strips * ygroups * ((g.n - 2 + planes - 1) / planes) < 2048) planes /= 2;
+    planes = (planes + 3) & ~3;
+    const int chunks = (g.n - 2 + planes - 1) / planes;
+    const int blocks = strips * ygroups * chunks;
+    const dim3 grid(((blocks + 7) / 8) * 8);
+    if constexpr (!scalar_traits<T>::is_complex) {
+      if (nw == 8) hipLaunchKernelGGL((evomg_tile3d_rbgs<T, 8, 0>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+      else hipLaunchKernelGGL((evomg_tile3d_rbgs<T, 4, 0>), grid, dim3(256), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
     }
   }
   bool strip_streams3d(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.plane * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
@@ -1347,7 +1377,7 @@ template <typename T> class Impl : public ImplBase {
     const Geo& g = lv_[op.level].g;
     const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
     const bool rb = op.partitioning == EVOMG_PART_RED_BLACK;
-    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || !rb;       // (the 3D tiles are Jacobi: !rb)
+    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || (rb && use_tile3d(g) && tile3d_rbgs_) || !rb;
   }
   int solve_mg(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
     const int L = prob_.max_level;
@@ -1597,6 +1627,9 @@ template <typename T> class Impl : public ImplBase {
   int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
   int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
   bool tile3d_enabled_ = getenv("EVOMG_NO_TILE3D") == nullptr;
+  bool tile3d_rbgs_ = getenv("EVOMG_NO_TILE3D_RBGS") == nullptr;
+  int tile3d_nt_ = getenv("EVOMG_TILE3D_NT") ? atoi(getenv("EVOMG_TILE3D_NT")) : 0;   // bit 0: non-temporal f loads (measured slower at 513^3: profiles/r02_pmc_3d.md)
+  int tile3d_order_ = getenv("EVOMG_TILE3D_ORDER") ? atoi(getenv("EVOMG_TILE3D_ORDER")) : 1;
   int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
 };

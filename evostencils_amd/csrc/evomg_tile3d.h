@@ -34,10 +34,10 @@ template <typename T> struct TwoCellPlan {
 };
 
 // grid: n_blocks (rounded up to a multiple of 8) workgroups of 64*NW threads; block -> (y group fastest, strip, z chunk)
-template <typename T, int MODE, int NW, bool NT_F>
+template <typename T, int MODE, int NW, int NT>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
-             double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl) {
+             double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl, int order) {
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == TILE_BLOCK211 || MODE == TILE_BLOCK121,
                 "3D tiles: Jacobi, residual, two-cell block-Jacobi");
   constexpr int TY = EVOMG_TILE3D_TY;
@@ -47,8 +47,10 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
   if (logical_block >= n_blocks) return;                   // whole workgroup: no barrier is skipped by a part of it
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int ygroup = logical_block % n_ygroups;
-  const int strip = (logical_block / n_ygroups) % n_strips;
+  // order 0: y group fastest (y neighbours adjacent in time); order 1: strip fastest — workgroups that run together then
+  // cover whole rows, i.e. one contiguous span of NW*4 rows per plane
+  const int ygroup = order ? (logical_block / n_strips) % n_ygroups : logical_block % n_ygroups;
+  const int strip = order ? logical_block % n_strips : (logical_block / n_ygroups) % n_strips;
   const int chunk = logical_block / (n_ygroups * n_strips);
   const int n = g.n;
   const long pitch = g.pitch, plane = g.plane;
@@ -64,11 +66,16 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
   // branch-free clamped loads (see evomg_strip2d): whatever an out-of-domain slot delivers only feeds non-inner nodes
   auto load_x = [&](int row, int pl) -> Pair<T> {
     const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);      // wave-uniform
-    return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+    if constexpr ((NT & 2) != 0) return load_pair_nt<T>(x + plane * p + pitch * r + c_clamped);
+    else return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+  };
+  auto store_y = [&](T* dst, const Pair<T>& v) {
+    if constexpr ((NT & 4) != 0) __builtin_nontemporal_store(evomg_f64x2{v.a, v.b}, reinterpret_cast<evomg_f64x2*>(dst));
+    else store_pair(dst, v);
   };
   auto load_f = [&](int row, int pl) -> Pair<T> {
     const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
-    if constexpr (NT_F) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
+    if constexpr ((NT & 1) != 0) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
     else return load_pair<T>(f + plane * p + pitch * r + c_clamped);
   };
   auto park = [&](int parity, const Pair<T>& first, const Pair<T>& last) {
@@ -151,13 +158,13 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
                     cell(fk[tp + 1].b, cB.a, eB, nB.b, below[tp + 1].b, above[tp + 1].b, true), cA.b, cB.b, o0, o1);
               if (inner_b) { oA.b = o0; oB.b = o1; }
               if (store_lane) {
-                store_pair(y + plane * k + pitch * rA + c0, oA);
-                store_pair(y + plane * k + pitch * (rA + 1) + c0, oB);
+                store_y(y + plane * k + pitch * rA + c0, oA);
+                store_y(y + plane * k + pitch * (rA + 1) + c0, oB);
               }
             } else if (rA == n - 2) {                            // the last inner row: a one-cell tile
               if (inner_a) oA.a = relax7(st, cA.a, wA, cA.b, sA.a, cB.a, below[tp].a, above[tp].a, fk[tp].a, om, omm);
               if (inner_b) oA.b = relax7(st, cA.b, cA.a, eA, sA.b, cB.b, below[tp].b, above[tp].b, fk[tp].b, om, omm);
-              if (store_lane) store_pair(y + plane * k + pitch * rA + c0, oA);
+              if (store_lane) store_y(y + plane * k + pitch * rA + c0, oA);
             }
           }
         } else {
@@ -192,7 +199,7 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
               if (inner_a) out.a = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa));
               if (inner_b) out.b = (c0 + 1 == n - 2) ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm)
                                                      : sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
-              store_pair(y + plane * k + pitch * row + c0, out);
+              store_y(y + plane * k + pitch * row + c0, out);
             }
           } else
           if (row <= n - 2 && store_lane) {                    // row: wave-uniform
@@ -201,11 +208,11 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             if constexpr (MODE == STRIP_JACOBI) {
               out.a = inner_a ? relax7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
               out.b = inner_b ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
-              store_pair(dst, out);
+              store_y(dst, out);
             } else {
               out.a = residual7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
               out.b = residual7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
-              if (inner_a && inner_b) store_pair(dst, out);
+              if (inner_a && inner_b) store_y(dst, out);
               else if (inner_a) dst[0] = out.a;
               else dst[1] = out.b;
             }
@@ -215,6 +222,169 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
         __syncthreads();
         hs = (w > 0) ? pick((k + 1) & 1, w - 1, 1) : gs;
         hn = (w < NW - 1) ? pick((k + 1) & 1, w + 1, 0) : gn;
+      }
+    }
+  }
+}
+
+// ---- 3D fused two-colour red-black Gauss-Seidel (K2) on LDS-sharing tiles, out of place -------------------------------
+// The lag scheme of evomg_strip3d_rbgs (step k: reds of plane k from old values, then blacks of plane k-1 from the new
+// reds of planes k-2, k-1, k) with the y direction shared inside a workgroup instead of recomputed per wave:
+//   * old x: as in evomg_tile3d, each wave parks the edge rows of plane k+1 one step before it becomes the centre plane;
+//   * new reds: after relaxing the reds of plane k a wave parks those of its first and last row (one value per lane:
+//     which element of a pair is red alternates with the row); the neighbours need them one step later, for the blacks
+//     of plane k. Both exchanges ride on the step's single barrier.
+//   * the workgroup relaxes reds on all its H = NW*4 rows but can finish blacks only where both neighbouring red rows
+//     exist: it stores rows R0+1 .. R0+H-2 and consecutive workgroups overlap by two rows (x: (H+2)/(H-2), f: H/(H-2):
+//     1.13 / 1.07 at NW = 8, against 2.0 / 1.5 per private 4-row tile). The topmost workgroup also finishes its last row:
+//     the row above it is the boundary, whose "reds" are just the old values.
+// Colour 0 = even index sum. c0, R0 (a multiple of H-2) and the first plane of a chunk are even, so which element of a
+// pair is red is static inside the twice-unrolled z loop. Inner nodes only are written (see evomg_tile3d).
+// Operation order = relax7 = relax_point: bit-identical to the two-pass form (evomg_rbgs_colour x 2) and to the oracle.
+template <typename T, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW)
+evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
+                  double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
+  constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
+  static_assert((H - 2) % 2 == 0 && TY % 2 == 0, "row parity must be static");
+  __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x: [plane parity][wave][first | last row][column]
+  __shared__ __attribute__((aligned(16))) T edge_r[2][NW][2][64];    // new reds: one value per lane
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (logical_block >= n_blocks) return;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = logical_block % n_strips;                 // strip fastest: concurrent workgroups cover whole rows
+  const int ygroup = (logical_block / n_strips) % n_ygroups;
+  const int chunk = logical_block / (n_ygroups * n_strips);
+  const int n = g.n;
+  const long pitch = g.pitch, plane = g.plane;
+  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int R0 = ygroup * (H - 2);                            // first red row of the workgroup (even)
+  const int row0 = R0 + w * TY;
+  const bool top_group = R0 + H - 1 >= n - 2;                 // the row above the workgroup is the boundary (or beyond)
+  const int z0 = 1 + chunk * planes_per_chunk;                // stored planes [z0, z1)
+  const int z1 = min(z0 + planes_per_chunk, n - 1);
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= 1 && lane <= 62 && col_ok && (inner_a || inner_b);
+  const int c_clamped = min(max(c0, 0), n - 1);
+  const T zero = scalar_traits<T>::zero();
+  auto load_x = [&](int row, int pl) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
+    return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+  };
+  auto load_f = [&](int row, int pl) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
+    if constexpr ((NT & 1) != 0) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
+    else return load_pair<T>(f + plane * p + pitch * r + c_clamped);
+  };
+  auto park_x = [&](int parity, const Pair<T>& first, const Pair<T>& last) {
+    *reinterpret_cast<Pair<T>*>(&edge_x[parity][w][0][2 * lane]) = first;
+    *reinterpret_cast<Pair<T>*>(&edge_x[parity][w][1][2 * lane]) = last;
+  };
+  auto pick_x = [&](int parity, int wave, int which) -> Pair<T> {
+    return *reinterpret_cast<const Pair<T>*>(&edge_x[parity][wave][which][2 * lane]);
+  };
+
+  const int ks = z0 - 1;                 // first plane whose reds are relaxed (even)
+  const int ke = z1 + 1;                 // one past the last
+  Pair<T> xb[TY], xc[TY], xa[TY], xq[TY];      // old x, planes k-1, k, k+1, k+2 (prefetch); own rows
+  Pair<T> fb[TY], fc[TY], fq[TY];              // f, planes k-1, k, k+1 (prefetch)
+  T r2[TY], r1[TY], rc[TY];                    // new reds of planes k-2, k-1, k
+  Pair<T> hs, hn, gs, gn;                      // old-x halo rows of the centre plane / of the next one (outermost waves)
+  Pair<T> hn_prev;                             // old-x row above the wave in plane k-1 (top group: the boundary row)
+  T rs1 = zero, rn1 = zero;                    // new reds of plane k-1 in the rows below / above the wave
+#pragma unroll
+  for (int t = 0; t < TY; ++t) {
+    xb[t] = load_x(row0 + t, ks - 1);
+    xc[t] = load_x(row0 + t, ks);
+    xa[t] = load_x(row0 + t, ks + 1);
+    fc[t] = load_f(row0 + t, ks);
+    fb[t] = Pair<T>{zero, zero};
+    r2[t] = zero;
+    r1[t] = zero;
+  }
+  hs = load_x(row0 - 1, ks);
+  hn = load_x(row0 + TY, ks);
+  hn_prev = hn;
+  park_x(ks & 1, xc[0], xc[TY - 1]);
+  __syncthreads();
+  if (w > 0) hs = pick_x(ks & 1, w - 1, 1);
+  if (w < NW - 1) hn = pick_x(ks & 1, w + 1, 0);
+
+  for (int kb = ks; kb < ke; kb += 2) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int k = kb + d;                                    // d == 0: k even, d == 1: k odd (ks is even)
+      if (k < ke) {
+#pragma unroll
+        for (int t = 0; t < TY; ++t) xq[t] = load_x(row0 + t, k + 2);
+#pragma unroll
+        for (int t = 0; t < TY; ++t) fq[t] = load_f(row0 + t, k + 1);
+        if (w == 0) gs = load_x(row0 - 1, k + 1);
+        if (w == NW - 1) gn = load_x(row0 + TY, k + 1);
+        park_x((k + 1) & 1, xa[0], xa[TY - 1]);
+        const bool plane_inner = k >= 1 && k <= n - 2;
+        // ---- reds of plane k, own rows ----
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          const int row = row0 + t;
+          const bool row_inner = plane_inner && row >= 1 && row <= n - 2;
+          const Pair<T> c = xc[t], s = (t == 0) ? hs : xc[t > 0 ? t - 1 : 0], nn = (t == TY - 1) ? hn : xc[t < TY - 1 ? t + 1 : t];
+          const Pair<T> dn = xb[t], up = xa[t];
+          // row0 even => row has the parity of t; k has the parity of d: a is red iff t + d is even
+          if (((t + d) & 1) == 0) {
+            const T we = from_left(c.b);
+            rc[t] = (row_inner && inner_a) ? relax7(st, c.a, we, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
+          } else {
+            const T ea = from_right(c.a);
+            rc[t] = (row_inner && inner_b) ? relax7(st, c.b, c.a, ea, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
+          }
+        }
+        edge_r[k & 1][w][0][lane] = rc[0];
+        edge_r[k & 1][w][1][lane] = rc[TY - 1];
+        // ---- blacks of plane k-1, own rows, from the new reds of planes k-2, k-1, k ----
+        const int kbk = k - 1;
+        const bool bplane_inner = kbk >= 1 && kbk <= n - 2;
+        const bool bplane_stored = kbk >= z0 && kbk < z1;
+        // the boundary row above the topmost workgroup never changes: its "new reds" are its old values (plane k-1)
+        const bool own_top = (w == NW - 1);
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          const int row = row0 + t;
+          const bool row_inner = bplane_inner && row >= 1 && row <= n - 2;
+          const Pair<T> old = xb[t];
+          const T red = r1[t];
+          // plane k-1 has the parity of d + 1: a is red iff t + d + 1 is even; the rows above / below hold their red in
+          // the OTHER element
+          const bool a_red = ((t + d + 1) & 1) == 0;
+          const T top_old = a_red ? hn_prev.b : hn_prev.a;      // red of the row above, were it a boundary row
+          const T rs = (t == 0) ? rs1 : r1[t > 0 ? t - 1 : 0];
+          const T rn = (t == TY - 1) ? ((own_top && top_group) ? top_old : rn1) : r1[t < TY - 1 ? t + 1 : t];
+          Pair<T> out;
+          if (a_red) {                                         // a red, b black
+            const T e = from_right(red);
+            out.a = red;
+            out.b = (row_inner && inner_b) ? relax7(st, old.b, red, e, rs, rn, r2[t], rc[t], fb[t].b, om, omm) : old.b;
+          } else {                                             // b red, a black
+            const T we = from_left(red);
+            out.a = (row_inner && inner_a) ? relax7(st, old.a, we, red, rs, rn, r2[t], rc[t], fb[t].a, om, omm) : old.a;
+            out.b = red;
+          }
+          const bool row_stored = row >= 1 && row <= n - 2 && row >= R0 + 1 && (row <= R0 + H - 2 || top_group);
+          if (store_lane && bplane_stored && row_stored) store_pair(y + plane * kbk + pitch * row + c0, out);
+        }
+        __syncthreads();
+        hn_prev = hn;                                          // halo of plane k: next step's plane k-1
+        hs = (w > 0) ? pick_x((k + 1) & 1, w - 1, 1) : gs;
+        hn = (w < NW - 1) ? pick_x((k + 1) & 1, w + 1, 0) : gn;
+        rs1 = (w > 0) ? edge_r[k & 1][w - 1][1][lane] : zero;
+        rn1 = (w < NW - 1) ? edge_r[k & 1][w + 1][0][lane] : zero;
+        // ---- advance one plane ----
+#pragma unroll
+        for (int t = 0; t < TY; ++t) { r2[t] = r1[t]; r1[t] = rc[t]; fb[t] = fc[t]; fc[t] = fq[t]; xb[t] = xc[t]; xc[t] = xa[t]; xa[t] = xq[t]; }
       }
     }
   }
