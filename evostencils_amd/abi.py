@@ -14,6 +14,7 @@ MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
 MAX_BLOCK_CELLS = 8
+MAX_UNKNOWNS = 2
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3
 SOLVE_CONVERGED, SOLVE_MAXITER, SOLVE_DIVERGED, SOLVE_WALL_LIMIT = 0, 1, 2, 3
@@ -49,7 +50,8 @@ class Problem(C.Structure):
         ("mg_stencil", (C64 * STENCIL_ENTRIES) * MAX_LEVELS),
         ("outer_stencil", C64 * STENCIL_ENTRIES),
         ("wavenumber", C.c_double),
-        ("jacobi_semantics", C.c_int32), ("reserved", C.c_int32),
+        ("jacobi_semantics", C.c_int32), ("n_unknowns", C.c_int32),
+        ("sys_stencil", (((C.c_double * 9) * MAX_UNKNOWNS) * MAX_UNKNOWNS) * MAX_LEVELS),
     ]
 
 
@@ -57,12 +59,12 @@ class Op(C.Structure):
     _fields_ = [
         ("opcode", C.c_int32), ("level", C.c_int32), ("dst", C.c_int32), ("src0", C.c_int32),
         ("src1", C.c_int32), ("partitioning", C.c_int32), ("block", C.c_int32 * MAX_DIM),
-        ("reserved", C.c_int32), ("omega", C.c_double),
+        ("unknowns", C.c_int32), ("omega", C.c_double),
     ]
 
     def key(self):
         return (self.opcode, self.level, self.dst, self.src0, self.src1, self.partitioning,
-                tuple(self.block), self.omega)
+                tuple(self.block), self.omega, self.unknowns)
 
     def __repr__(self):
         return (f"Op({OP_NAMES.get(self.opcode, self.opcode)}, L={self.level}, dst={self.dst}, "
@@ -83,8 +85,14 @@ class Bench(C.Structure):
                 ("launches", C.c_int32), ("reserved", C.c_int32)]
 
 
-def make_op(opcode, level, dst=0, src0=0, src1=0, partitioning=PART_SINGLE, block=(1, 1, 1), omega=1.0) -> Op:
+def field_of(slot: int, unknown: int = 0) -> int:
+    """Field id of `slot` (F_*) of the `unknown`-th unknown of a system of PDEs (EVOMG_FIELD in include/evomg.h)."""
+    return slot + F_COUNT * unknown
+
+
+def make_op(opcode, level, dst=0, src0=0, src1=0, partitioning=PART_SINGLE, block=(1, 1, 1), omega=1.0, unknowns=0) -> Op:
     op = Op()
+    op.unknowns = unknowns        # SMOOTH on a system: bit mask of the unknowns solved together (0 = scalar problem)
     op.opcode, op.level, op.dst, op.src0, op.src1 = opcode, level, dst, src0, src1
     op.partitioning = partitioning
     blk = tuple(block) + (1,) * (MAX_DIM - len(block))

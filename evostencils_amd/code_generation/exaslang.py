@@ -66,10 +66,32 @@ def _operator_terms(entry, level, field_exa):
     return _operator_product(entry, level, field_exa)
 
 
+def _system_local_equations(st: low.Statement, names: FieldNames, max_level: int):
+    """Systems of PDEs: for every unknown of the block (field order) and every block cell (i0 outermost) the line
+    `x_i@[c] => (sum_j A_ij x_j) == f_i@[c]` (ir/transformations.py:51-121: dictionary order = fields, then cells)."""
+    import sympy
+    level = st.level
+    prefix = "gen_error_" if level < max_level else ""
+    lines = []
+    for i in st.unknowns:
+        for idx in product(*[range(b) for b in st.block]):
+            expr = sympy.sympify(0)
+            for j, stencil in enumerate(st.system_stencils[i]):
+                for off, val in stencil.entries:
+                    pos = ", ".join(str(int(c) + int(o)) for c, o in zip(idx, off))
+                    expr = expr + val * sympy.Symbol(f"{prefix}{names.field_names[j]}@{level}@[{pos}]")
+            here = ", ".join(str(c) for c in idx)
+            lines.append((f"{prefix}{names.field_names[i]}@{level}@[{here}]", str(expr),
+                          f"{names.rhs_names[i]}@{level}@[{here}]"))
+    return lines
+
+
 def _local_equations(st: low.Statement, names: FieldNames, max_level: int):
     """One `unknown => (row of A) == rhs` line per block cell, i0 outermost
     (ir/transformations.py:51-121 + exastencils.py:608-633)."""
     import sympy
+    if st.unknowns:
+        return _system_local_equations(st, names, max_level)
     fname = names.field_names[st.dst.index]
     rhs_name = names.rhs_names[st.dst.index]
     level = st.level
@@ -99,6 +121,10 @@ def render_statement(st: low.Statement, names: FieldNames, max_level: int, dimen
     if k == "coarse_solve":
         return f"\t{st.cycle_name}@{st.level}()\n"
     if k == "residual":
+        if st.operator_row is not None:
+            terms = "".join(_operator_terms(entry, st.level, names.exa(fld))
+                            for entry, fld in zip(st.operator_row, st.row_fields))
+            return f"\t{names.exa(st.dst)} = {names.exa(st.rhs)}{terms}\n"
         return (f"\t{names.exa(st.dst)} = {names.exa(st.rhs)}"
                 f"{_operator_terms(st.operator_entry, st.level, names.exa(st.src))}\n")
     if k == "richardson":

@@ -183,8 +183,7 @@ class ProgramGenerator:
                 self._handle.close()
             window = self._problem.with_levels(min_level, max_level)
             self._handle = abi.Handle(self._lib(), window.to_c(params), self._device_id)
-            self._handle.set_initial_field(max_level, abi.F_SOL, window.initial_solution(max_level))
-            self._handle.set_initial_field(max_level, abi.F_RHS, window.right_hand_side(max_level))
+            window.upload_initial_fields(self._handle, max_level)
             self._handle_levels, self._handle_params, self._window = key, frozen, window
         elif self._handle_params != frozen:
             self._handle.set_operators(self._window.to_c(params))
@@ -308,6 +307,9 @@ class ProgramGenerator:
         for st in stmts:
             if st.kind not in ("smooth", "residual", "richardson"):
                 continue
+            if st.unknowns or st.operator_row is not None:
+                self._verify_system_operator(st)
+                continue
             # the operator terminals of the grammar are long-lived objects shared by all candidates: verify each
             # (object, level, PDE parameters) once; the cache keeps the object alive so that its id stays unique
             source = st.operator_entry if st.operator_entry is not None else st.operator_stencil
@@ -330,6 +332,34 @@ class ProgramGenerator:
                         f"operator {st.operator_name}@{st.level} differs from the problem's operator")
             if source is not None:
                 self._verified[key] = source
+
+    def _verify_system_operator(self, st):
+        """Systems of PDEs: the block operator the DAG carries, assembled entry by entry, IS the problem's."""
+        import numpy as np
+        if self._problem.system is None:
+            raise lowering.UnsupportedExpression("the candidate couples several unknowns but the problem has one")
+        key = ("system", st.level)
+        if self._verified.get(key):
+            return
+        expected = self._problem.system.assembled(st.level)
+        rows = st.system_stencils if st.unknowns else None
+        if rows is None:
+            i = st.dst.index
+            rows = {i: [e.generate_stencil() for e in st.operator_row]}
+            items = rows.items()
+        else:
+            items = enumerate(rows)
+        for i, row in items:
+            for j, stencil in enumerate(row):
+                got = np.zeros(9)
+                for off, val in stencil.entries:
+                    if tuple(off) not in problems.NINE_POINT_OFFSETS:
+                        raise lowering.UnsupportedExpression("system operators wider than 9 points are not supported")
+                    got[problems.NINE_POINT_OFFSETS.index(tuple(off))] += float(val)
+                if not np.array_equal(got, expected[i, j]):
+                    raise lowering.UnsupportedExpression(f"operator entry ({i}, {j})@{st.level} differs from the problem's")
+        if st.unknowns:
+            self._verified[key] = True
 
     # ---- THE call (exastencils.py:485-537) -----------------------------------------------------------
     def generate_and_evaluate(self, expression, storages, min_level: int, max_level: int, solver_program: str,

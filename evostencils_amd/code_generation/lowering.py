@@ -65,6 +65,11 @@ class Statement:
     operator_stencil: object = None  # constant stencil of the system operator (smoother equations)
     group: str = ""          # smoother: 'independent' | 'dependent' (exastencils.py:774-822)
     cycle_name: str = ""
+    # systems of PDEs (more than one unknown per node)
+    operator_row: Optional[list] = None    # residual / richardson: the row of operator entries, one per unknown
+    row_fields: Optional[list] = None      # ... and the field each entry applies to
+    unknowns: Tuple[int, ...] = ()         # smoother: the unknowns whose equations are solved together in one block
+    system_stencils: object = None         # smoother: [equation][unknown] -> constant stencil of the system operator
 
 
 class Lowering:
@@ -101,8 +106,8 @@ class Lowering:
         return cycle.relaxation_factor
 
     def _single_field(self, grids):
-        if len(grids) != 1:
-            raise UnsupportedExpression("systems of PDEs (more than one unknown) are not supported yet")
+        if len(grids) > 2:
+            raise UnsupportedExpression("systems with more than two unknowns are not supported")
 
     def _zero_if_needed(self, approximation, grids):
         if isa(approximation, "system", "ZeroApproximation"):
@@ -140,6 +145,8 @@ class Lowering:
             # x += w * (b - A x)
             self._preamble(corr.rhs, e.rhs, corr.approximation, e.approximation)
             self._zero_if_needed(e.approximation, grids)
+            if len(grids) != 1:
+                raise UnsupportedExpression("Richardson steps on systems of PDEs are not supported")
             for i, g in enumerate(grids):
                 entry = corr.operator.entries[i][i]
                 self.out.append(Statement("richardson", g.level, dst=self._sol(g.level, i),
@@ -176,6 +183,8 @@ class Lowering:
 
     def _smoother(self, cycle, smoothing_operator, system_operator, weight):
         grids = cycle.grid
+        if len(grids) > 1:
+            return self._system_smoother(cycle, smoothing_operator, system_operator, weight)
         g = grids[0]
         dim = g.dimension
         sys_entry = system_operator.entries[0][0]
@@ -207,6 +216,67 @@ class Lowering:
                                   operator_name=getattr(sys_entry, "name", ""), operator_level=g.level,
                                   operator_entry=sys_entry, operator_stencil=sys_stencil, group=group))
 
+    def _system_smoother(self, cycle, smoothing_operator, system_operator, weight):
+        """Smoothers on systems of PDEs (exastencils.py:769-822 with ir/transformations.py:51-145): the local
+        equations of unknown i at block cell c read  sum_j A_ij x_j = f_i  with the entries of the SMOOTHING operator
+        taken at their new values. Equations whose new unknowns occur in no other equation form a `solve locally`
+        block of their own (decoupled Jacobi: one block per unknown, in field order), all others share one block; the
+        element-wise diagonal always goes into one block (exastencils.py:775-777)."""
+        grids = cycle.grid
+        nf = len(grids)
+        g = grids[0]
+        dim = g.dimension
+        stencils = []
+        for i in range(nf):
+            row = []
+            for j in range(nf):
+                entry = system_operator.entries[i][j]
+                st = entry.generate_stencil() if hasattr(entry, "generate_stencil") else None
+                if st is not None and hasattr(st, "constant_stencils") and all(p == 1 for p in multiple.period_shape(st)):
+                    st = multiple.at(st, (0,) * dim)      # the reference's stencil algebra returns period-1 "multiple" stencils
+                if st is None or hasattr(st, "constant_stencils"):
+                    raise UnsupportedExpression("system operator entries must be constant-coefficient stencils")
+                row.append(st)
+            stencils.append(row)
+
+        def emit(unknowns, block, group):
+            self.out.append(Statement("smooth", g.level, dst=self._sol(g.level, unknowns[0]),
+                                      rhs=FieldRef(RHS, g.level, unknowns[0]), weight=weight,
+                                      partitioning=part.kind_of(cycle.partitioning), block=block, operator_level=g.level,
+                                      group=group, unknowns=tuple(unknowns), system_stencils=stencils))
+
+        if isa(smoothing_operator, "system", "Diagonal"):
+            for i in range(nf):
+                emit([i], (1,) * dim, "independent")
+        elif isa(smoothing_operator, "system", "ElementwiseDiagonal"):
+            emit(list(range(nf)), (1,) * dim, "dependent")
+        elif isa(smoothing_operator, "system", "Operator"):
+            shapes = []
+            for i in range(nf):
+                sm = smoothing_operator.entries[i][i].generate_stencil()
+                shapes.append(tuple(multiple.period_shape(sm)))
+                for j in range(nf):
+                    smj = smoothing_operator.entries[i][j].generate_stencil()
+                    if not multiple.is_block_diagonal_of(smj, stencils[i][j], shapes[i]):
+                        raise UnsupportedExpression("custom smoothing operator is not the block diagonal of the system operator")
+            if any(sh != shapes[0] for sh in shapes):
+                raise UnsupportedExpression("block smoothers with different block shapes per unknown are not supported")
+            block = shapes[0]
+            cells = 1
+            for b in block:
+                cells *= b
+            if cells == 1:
+                # new terms = the centre entries only: unknown i is coupled to unknown j only through a centre entry of A_ij
+                coupled = any(any(all(c == 0 for c in off) and val != 0 for off, val in stencils[i][j].entries)
+                              for i in range(nf) for j in range(nf) if i != j)
+                if not coupled:
+                    for i in range(nf):
+                        emit([i], block, "independent")
+                    return
+            emit(list(range(nf)), block, "dependent")
+        else:
+            raise UnsupportedExpression("Can not extract equations from smoothing operator")
+
     def _residual(self, e):
         self._preamble(e.rhs, e.rhs, e.approximation, e.approximation)
         grids = e.grid
@@ -214,10 +284,15 @@ class Lowering:
         self._zero_if_needed(e.approximation, grids)
         for i, g in enumerate(grids):
             entry = e.operator.entries[i][i]
-            self.out.append(Statement("residual", g.level, dst=FieldRef(RESIDUAL, g.level, i),
-                                      src=self._sol(g.level, i), rhs=FieldRef(RHS, g.level, i),
-                                      operator_entry=entry, operator_name=getattr(entry, "name", ""),
-                                      operator_level=g.level))
+            st = Statement("residual", g.level, dst=FieldRef(RESIDUAL, g.level, i),
+                           src=self._sol(g.level, i), rhs=FieldRef(RHS, g.level, i),
+                           operator_entry=entry, operator_name=getattr(entry, "name", ""),
+                           operator_level=g.level)
+            if len(grids) > 1:
+                # one `- (A_ij * x_j)` term per non-zero entry of the row (exastencils.py:837-852)
+                st.operator_row = list(e.operator.entries[i])
+                st.row_fields = [self._sol(g.level, j) for j in range(len(grids))]
+            self.out.append(st)
 
     def _multiplication(self, e):
         op1 = e.operand1

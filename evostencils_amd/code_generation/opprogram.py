@@ -10,9 +10,9 @@ _ROLE = {low.SOLUTION: abi.F_SOL, low.RHS: abi.F_RHS, low.RESIDUAL: abi.F_RES,
 
 
 def _f(ref: low.FieldRef) -> int:
-    if ref.index != 0:
-        raise low.UnsupportedExpression("systems of PDEs are not supported yet")
-    return _ROLE[ref.role]
+    if not 0 <= ref.index < abi.MAX_UNKNOWNS:
+        raise low.UnsupportedExpression("systems with more than two unknowns are not supported")
+    return abi.field_of(_ROLE[ref.role], ref.index)
 
 
 def _w(weight) -> float:
@@ -31,6 +31,9 @@ def encode(statements) -> List[abi.Op]:
             ops.append(abi.make_op(abi.OP_COPY, st.level, _f(st.dst), _f(st.src)))
         elif k == "coarse_solve":
             ops.append(abi.make_op(abi.OP_COARSE_SOLVE, st.level, abi.F_CORR, abi.F_CGS_RHS))
+        elif k == "residual" and st.operator_row is not None:
+            # row i of a system: reads every unknown (src0 = the solution slot of unknown 0), writes the residual of i
+            ops.append(abi.make_op(abi.OP_RESIDUAL, st.level, _f(st.dst), _f(st.row_fields[0]), _f(st.rhs)))
         elif k == "residual":
             _require_plain_operator(st)
             ops.append(abi.make_op(abi.OP_RESIDUAL, st.level, _f(st.dst), _f(st.src), _f(st.rhs)))
@@ -44,6 +47,13 @@ def encode(statements) -> List[abi.Op]:
             ops.append(abi.make_op(abi.OP_PROLONG_SET, st.level, _f(st.dst), _f(st.src)))
         elif k == "restrict":
             ops.append(abi.make_op(abi.OP_RESTRICT, st.level, _f(st.dst), _f(st.src)))
+        elif k == "smooth" and st.unknowns:
+            partitioning = abi.PART_RED_BLACK if st.partitioning == "red_black" else abi.PART_SINGLE
+            mask = 0
+            for u in st.unknowns:
+                mask |= 1 << u
+            ops.append(abi.make_op(abi.OP_SMOOTH, st.level, _f(st.dst), 0, _f(st.rhs), partitioning, st.block,
+                                   _w(st.weight), unknowns=mask))
         elif k == "smooth":
             _require_plain_operator(st)
             partitioning = abi.PART_RED_BLACK if st.partitioning == "red_black" else abi.PART_SINGLE

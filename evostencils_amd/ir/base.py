@@ -167,9 +167,15 @@ class BinaryExpression(Expression):
 class Addition(BinaryExpression):
     shape = property(lambda self: self._operand1.shape)
 
+    def generate_stencil(self):
+        return constant.add(self._operand1.generate_stencil(), self._operand2.generate_stencil())
+
 
 class Subtraction(BinaryExpression):
     shape = property(lambda self: self._operand1.shape)
+
+    def generate_stencil(self):
+        return constant.sub(self._operand1.generate_stencil(), self._operand2.generate_stencil())
 
 
 class Multiplication(BinaryExpression):
@@ -179,6 +185,11 @@ class Multiplication(BinaryExpression):
         super().__init__(operand1, operand2)
 
     shape = property(lambda self: (self._operand1.shape[0], self._operand2.shape[1]))
+
+    def generate_stencil(self):
+        """Operator product (only meaningful when both operands are operators: the row entries of a system of
+        PDEs, grammar/multigrid.py _term_to_ir)."""
+        return constant.mul(self._operand1.generate_stencil(), self._operand2.generate_stencil())
 
 
 class Scaling(Expression):
@@ -193,6 +204,9 @@ class Scaling(Expression):
 
     def mutate(self, f, *args):
         f(self._operand, *args)
+
+    def generate_stencil(self):
+        return constant.scale(self._factor, self._operand.generate_stencil())
 
 
 class InterGridOperator(Operator):

@@ -27,7 +27,5 @@ def create(problem_description, device_id=0, parameters=None, jacobi_semantics=N
     """Native solver instance with the problem's initial fields uploaded. `jacobi_semantics`: None = the
     descriptor's, else "textbook" | "exastencils-v1.1" (abi.JACOBI_SEMANTICS)."""
     h = abi.Handle(library(), problem_description.to_c(parameters, jacobi_semantics), device_id)
-    L = problem_description.max_level
-    h.set_initial_field(L, abi.F_SOL, problem_description.initial_solution(L))
-    h.set_initial_field(L, abi.F_RHS, problem_description.right_hand_side(L))
+    problem_description.upload_initial_fields(h)
     return h

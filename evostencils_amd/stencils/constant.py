@@ -60,6 +60,47 @@ def scale(factor, stencil: Optional[Stencil]) -> Optional[Stencil]:
     return Stencil([(o, factor * v) for o, v in stencil.entries], stencil.dimension)
 
 
+def combine(a: Optional[Stencil], b: Optional[Stencil], f) -> Optional[Stencil]:
+    """Entry-wise f(a, b) on the union of the offsets (reference: constant.py add / sub); offsets keep the order of
+    first appearance."""
+    if a is None or b is None:
+        return None
+    values, order = {}, []
+    for off, val in a.entries:
+        values[off] = val
+        order.append(off)
+    for off, val in b.entries:
+        if off in values:
+            values[off] = f(values[off], val)
+        else:
+            values[off] = f(0.0, val)
+            order.append(off)
+    return Stencil([(o, values[o]) for o in order], a.dimension)
+
+
+def add(a, b):
+    return combine(a, b, lambda x, y: x + y)
+
+
+def sub(a, b):
+    return combine(a, b, lambda x, y: x - y)
+
+
+def mul(a: Optional[Stencil], b: Optional[Stencil]) -> Optional[Stencil]:
+    """Stencil of the operator product a * b (offsets add, values multiply)."""
+    if a is None or b is None:
+        return None
+    values, order = {}, []
+    for oa, va in a.entries:
+        for ob, vb in b.entries:
+            off = tuple(x + y for x, y in zip(oa, ob))
+            if off not in values:
+                values[off] = 0.0
+                order.append(off)
+            values[off] = values[off] + va * vb
+    return Stencil([(o, values[o]) for o in order], a.dimension)
+
+
 def get_unit_stencil(grid) -> Stencil:
     return Stencil([((0,) * grid.dimension, 1.0)], grid.dimension)
 

@@ -30,6 +30,8 @@ extern "C" {
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
 #define EVOMG_MAX_BLOCK_CELLS 8   /* maximum_local_system_size default, optimization/program.py:107 */
+#define EVOMG_MAX_UNKNOWNS 2      /* systems of PDEs: unknowns per node (LinearElasticity: u, v) */
+#define EVOMG_SYS_STENCIL_ENTRIES 9 /* 2D compact stencil: centre, W, E, S, N, SW, SE, NW, NE */
 
 /* status codes (function return values) */
 enum {
@@ -115,7 +117,11 @@ typedef struct {
   /* Robin factor numerator data: wavenumber k (Helmholtz). */
   double wavenumber;
   int32_t jacobi_semantics;     /* EVOMG_JACOBI_*; 0 is rejected: the caller has to choose */
-  int32_t reserved;
+  /* Systems of PDEs (example_problems/LinearElasticity/2D_FD_LinearElasticity_fromL2.exa2:11-50; ir/system.py:32-135):
+   * n_unknowns > 1 fields per node, coupled by the block operator sys_stencil[level][equation][unknown][entry]
+   * (2D, real, Dirichlet; mg_stencil is ignored). n_unknowns <= 1: a scalar problem. */
+  int32_t n_unknowns;
+  double  sys_stencil[EVOMG_MAX_LEVELS][EVOMG_MAX_UNKNOWNS][EVOMG_MAX_UNKNOWNS][EVOMG_SYS_STENCIL_ENTRIES];
 } evomg_problem_t;
 
 /* field slots of one level (exastencils.py:14-26,295-316) */
@@ -127,6 +133,8 @@ enum {
   EVOMG_F_CGS_RHS = 4,  /* gen_rhs_u@min (exastencils.py:890-892) */
   EVOMG_F_COUNT = 5
 };
+/* field id of slot `slot` of the `unknown`-th unknown of a system (unknown 0 = the plain slot ids) */
+#define EVOMG_FIELD(slot, unknown) ((slot) + EVOMG_F_COUNT * (unknown))
 
 /* opcodes: one per ExaSlang statement kind the reference emits */
 enum {
@@ -151,7 +159,10 @@ typedef struct {
   int32_t src1;          /* EVOMG_F_* (right-hand side for SMOOTH/RESIDUAL/RICHARDSON) */
   int32_t partitioning;  /* EVOMG_PART_*; RED_BLACK => "color with {((i0+i1[+i2])%2), ...}" and in place */
   int32_t block[EVOMG_MAX_DIM]; /* block shape of the local solve, (1,1,1) = point smoother */
-  int32_t reserved;
+  int32_t unknowns;      /* SMOOTH on a system of PDEs: bit mask of the unknowns whose equations are solved together
+                            in one `solve locally` block (0b11 collective, 0b01 / 0b10 decoupled); 0 on scalar problems.
+                            On systems dst/src1 name the slots of the FIRST unknown of the mask, RESIDUAL's src0 the
+                            solution slot of unknown 0 (the row reads all unknowns) */
   double  omega;         /* relaxation factor */
 } evomg_op_t;
 

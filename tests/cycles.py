@@ -17,6 +17,13 @@ def smooth(P, depth, cycle, spec):
         return P[f"collective_jacobi_{depth}"](spec[1], P["red_black"], cycle)
     if kind == "block":
         return P[f"collective_block_jacobi_{depth}"](spec[1], (tuple(spec[2]),), cycle)
+    # systems of PDEs
+    if kind == "blocks":                       # one block shape per unknown
+        return P[f"collective_block_jacobi_{depth}"](spec[1], tuple(tuple(b) for b in spec[2]), cycle)
+    if kind == "decoupled":
+        return P[f"decoupled_jacobi_{depth}"](spec[1], P["single"], cycle)
+    if kind == "decoupled_rb":
+        return P[f"decoupled_jacobi_{depth}"](spec[1], P["red_black"], cycle)
     raise ValueError(kind)
 
 
@@ -63,6 +70,21 @@ def tutorial_cycle(P):
     return s
 
 
+def elasticity_mixed_cycle(P):
+    """Every smoother kind the grammar has for systems of PDEs, three levels: collective red-black, decoupled Jacobi,
+    collective block-Jacobi (2,1) on the coarser level, decoupled red-black."""
+    c = P["residual_0"](P["u_and_f"])
+    s = P["collective_jacobi_0"](14, P["red_black"], c)
+    s = P["decoupled_jacobi_0"](10, P["single"], P["residual_0"](s))
+    c = P["residual_0"](s)
+    c = P["coarsening_0"](P["A_1"], P["zero_1"], P["R_0"], c)
+    s = P["collective_block_jacobi_1"](12, ((2, 1), (2, 1)), c)
+    s = P["correct_with_coarse_grid_solver_1"](18, P["P_2"], P["CGS_2"], P["R_1"], P["residual_1"](s))
+    s = P["update_with_coarse_grid_correction_0"](18, P["P_1"], s)
+    s = P["decoupled_jacobi_0"](12, P["red_black"], P["residual_0"](s))
+    return s
+
+
 # name -> (problem, min_level, max_level, builder(P))
 def _jac(i): return ("jacobi", i)
 def _rb(i): return ("rbgs", i)
@@ -88,6 +110,14 @@ CASES = {
     "poisson2d_L7_double_v": ("2D_FD_Poisson_fromL2", 4, 7,
                               lambda P: v_cycle(P, 3, [[_rb(20)]] * 3, [[_rb(20)]] * 3,
                                                 state=v_cycle(P, 3, [[_rb(18)]] * 3, [[_jac(14)]] * 3))),
+    # systems of PDEs: linear elasticity, two unknowns, 9-point coupling
+    "elasticity2d_L6_mixed": ("2D_FD_LinearElasticity_fromL2", 4, 6, elasticity_mixed_cycle),
+    # the problem's own solver settings as a candidate: V(2,1), collective red-black w = 1.25 (exa3:10-23)
+    "elasticity2d_L6_v21_rb": ("2D_FD_LinearElasticity_fromL2", 3, 6,
+                               lambda P: v_cycle(P, 3, [[_rb(23)] * 2] * 3, [[_rb(23)]] * 3)),
+    "elasticity2d_L5_blocks": ("2D_FD_LinearElasticity_fromL2", 3, 5,
+                               lambda P: v_cycle(P, 2, [[("blocks", 12, ((2, 2), (2, 2)))], [("decoupled", 14), _jac(12)]],
+                                                 [[("blocks", 10, ((1, 2), (1, 2))), ("decoupled_rb", 18)], [_rb(20)]])),
     # 3D: block-Jacobi V(2,2) (C4 shape) and RB-GS
     "poisson3d_L4_v22_block": ("3D_FD_Poisson_fromL2", 2, 4,
                                lambda P: v_cycle(P, 2, [[_blk(10, (2, 1, 1))] * 2] * 2, [[_blk(10, (2, 1, 1))] * 2] * 2)),

@@ -68,23 +68,43 @@ def reference_context(problem, min_level, max_level):
 
     pd = our_problems.BY_NAME[problem](min_level, max_level)
     d = pd.dimension
-    fields = [sympy.Symbol(pd.field_name)]
     equations, operators = [], []
-    offs = our_problems._star_offsets(d)
-    for level in range(min_level, max_level + 1):
-        eq = mg.EquationInfo(pd.equation_name, level,
-                             f"( {pd.operator_name}@{level} * {pd.field_name}@{level} ) == {pd.rhs_name}@{level}")
-        eq._associated_field = fields[0]
-        equations.append(eq)
-        coeffs = pd.mg_stencil(level, pd.parameters)[:1 + 2 * d]
-        operators.append(mg.OperatorInfo(pd.operator_name, level,
-                                         constant.Stencil(list(zip(offs, [float(c.real) if isinstance(c, complex) else float(c) for c in coeffs])), d)))
-        fw = our_problems._fw_restriction_stencil(d)
-        pr = our_problems._linear_prolongation_stencil(d)
-        # ExaStencils declares the default inter-grid operators on every level; the reference asserts one
-        # restriction and one prolongation per field and level (grammar/multigrid.py:156-157)
-        operators.append(mg.OperatorInfo(pd.restriction_name, level, constant.Stencil(fw.entries, d), base.Restriction))
-        operators.append(mg.OperatorInfo(pd.prolongation_name, level, constant.Stencil(pr.entries, d), base.Prolongation))
+    fw = our_problems._fw_restriction_stencil(d)
+    pr = our_problems._linear_prolongation_stencil(d)
+    if pd.system is not None:
+        # a system of PDEs: the equation texts and named stencils of the problem description, handed to the REFERENCE's
+        # EquationInfo / OperatorInfo (what its parser extracts from ExaStencils' debug layer 3, parser.py:25-111)
+        spec = pd.system
+        fields = [sympy.Symbol(f) for f in spec.field_names]
+        for level in range(min_level, max_level + 1):
+            for i, text in enumerate(spec.equation_text(level)):
+                eq = mg.EquationInfo(spec.equation_names[i], level, text)
+                eq._associated_field = fields[i]
+                equations.append(eq)
+            for name, entries in spec.operator_stencils(level).items():
+                operators.append(mg.OperatorInfo(name, level, constant.Stencil(entries, d)))
+            for i, f in enumerate(fields):
+                r = mg.OperatorInfo(spec.restriction_names[i], level, constant.Stencil(fw.entries, d), base.Restriction)
+                r._associated_field = f
+                operators.append(r)
+                p_ = mg.OperatorInfo(spec.prolongation_names[i], level, constant.Stencil(pr.entries, d), base.Prolongation)
+                p_._associated_field = f
+                operators.append(p_)
+    else:
+        fields = [sympy.Symbol(pd.field_name)]
+        offs = our_problems._star_offsets(d)
+        for level in range(min_level, max_level + 1):
+            eq = mg.EquationInfo(pd.equation_name, level,
+                                 f"( {pd.operator_name}@{level} * {pd.field_name}@{level} ) == {pd.rhs_name}@{level}")
+            eq._associated_field = fields[0]
+            equations.append(eq)
+            coeffs = pd.mg_stencil(level, pd.parameters)[:1 + 2 * d]
+            operators.append(mg.OperatorInfo(pd.operator_name, level,
+                                             constant.Stencil(list(zip(offs, [float(c.real) if isinstance(c, complex) else float(c) for c in coeffs])), d)))
+            # ExaStencils declares the default inter-grid operators on every level; the reference asserts one
+            # restriction and one prolongation per field and level (grammar/multigrid.py:156-157)
+            operators.append(mg.OperatorInfo(pd.restriction_name, level, constant.Stencil(fw.entries, d), base.Restriction))
+            operators.append(mg.OperatorInfo(pd.prolongation_name, level, constant.Stencil(pr.entries, d), base.Prolongation))
 
     g = ProgramGenerator.__new__(ProgramGenerator)
     g._cycle_name = "gen_mgCycle"
@@ -92,13 +112,14 @@ def reference_context(problem, min_level, max_level):
     g._use_jacobi_prefix = True
     g._dimension = d
     g._equations, g._fields, g._operators = equations, fields, operators
-    g._coarsening_factor = [(2,) * d]
+    g._coarsening_factor = [(2,) * d for _ in fields]
     g._min_level, g._max_level = min_level, max_level
-    finest = [base.Grid((2 ** max_level,) * d, (1 / 2 ** max_level,) * d, max_level)]
+    finest = [base.Grid((2 ** max_level,) * d, (1 / 2 ** max_level,) * d, max_level) for _ in fields]
     storages = g.generate_storage(min_level, max_level, finest)
 
     approximation = system.Approximation("x", [base.Approximation(f.name, gr) for f, gr in zip(fields, finest)])
-    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, gr) for eq, gr in zip(equations[-1:], finest)])
+    top = [eq for eq in equations if eq.level == max_level]
+    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, gr) for eq, gr in zip(top, finest)])
     pset, _ = mg.generate_primitive_set(approximation, rhs, d, g._coarsening_factor, max_level, equations,
                                         operators, fields, maximum_local_system_size=8,
                                         depth=max_level - min_level)

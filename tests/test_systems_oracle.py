@@ -1,0 +1,164 @@
+"""SURVEY 8f N3 — systems of PDEs on the CPU oracle: the linear-elasticity problem of the reference
+(example_problems/LinearElasticity/2D_FD_LinearElasticity_fromL2.*), two unknowns coupled by 9-point stencils. Known
+answers: a manufactured discrete solution is recovered to round-off, local solves satisfy their equations exactly, the
+problem's own solver settings converge at the textbook rate, and the two `with jacobi` semantics behave as for scalar
+problems."""
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, problems, reference_solver
+from oracle import oracle
+
+import cycles
+from helpers import ops_for_case
+
+OFFS = problems.NINE_POINT_OFFSETS
+
+
+def apply_row(a, i, fields):
+    """Row i of the block operator on the inner nodes, numpy (independent of the oracle's loops)."""
+    n = fields[0].shape[0]
+    out = np.zeros((n - 2, n - 2))
+    for j, x in enumerate(fields):
+        for e, (ox, oy) in enumerate(OFFS):
+            out += a[i, j, e] * x[1 + oy:n - 1 + oy, 1 + ox:n - 1 + ox]
+    return out
+
+
+def manufactured(pd, level):
+    n = (1 << level) + 1
+    t = np.arange(n) / (n - 1)
+    X, Y = t[None, :], t[:, None]
+    w = [np.sin(2.0 * X) * np.cos(3.0 * Y) + X * Y, np.exp(X - 0.5 * Y) * (1.0 + X * X)]
+    a = pd.system.assembled(level)
+    f = []
+    for i in range(2):
+        fi = np.zeros((n, n))
+        fi[1:-1, 1:-1] = apply_row(a, i, w)
+        f.append(fi)
+    return w, f
+
+
+def system_v_cycle_ops(lo, hi, pre=2, post=1, omega=1.25, part=abi.PART_RED_BLACK, mask=0b11):
+    """The generated solver's cycle on a two-unknown system: collective point smoother, per-unknown transfers."""
+    F = abi.field_of
+    ops = []
+    sm = lambda L: abi.make_op(abi.OP_SMOOTH, L, F(abi.F_SOL), 0, F(abi.F_RHS), part, (1, 1, 1), omega, unknowns=mask)
+    for L in range(hi, lo, -1):
+        ops += [sm(L) for _ in range(pre)]
+        for u in range(2):
+            ops.append(abi.make_op(abi.OP_RESIDUAL, L, F(abi.F_RES, u), F(abi.F_SOL), F(abi.F_RHS, u)))
+        for u in range(2):
+            ops.append(abi.make_op(abi.OP_RESTRICT, L - 1, F(abi.F_RHS, u), F(abi.F_RES, u)))
+        if L - 1 > lo:
+            ops += [abi.make_op(abi.OP_SET_ZERO, L - 1, F(abi.F_SOL, u)) for u in range(2)]
+    for u in range(2):
+        ops.append(abi.make_op(abi.OP_COPY, lo, F(abi.F_CGS_RHS, u), F(abi.F_RHS, u)))
+        ops.append(abi.make_op(abi.OP_SET_ZERO, lo, F(abi.F_CORR, u)))
+    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, lo))
+    for L in range(lo + 1, hi + 1):
+        for u in range(2):
+            ops.append(abi.make_op(abi.OP_PROLONG_ADD, L, F(abi.F_SOL, u), F(abi.F_SOL, u), omega=1.0))
+        ops += [sm(L) for _ in range(post)]
+    return ops
+
+
+def test_manufactured_solution_is_recovered():
+    lo, hi = 3, 6
+    pd = problems.linear_elasticity_2d(lo, hi)
+    w, f = manufactured(pd, hi)
+    h = oracle.create(pd)
+    n = (1 << hi) + 1
+    for u in range(2):
+        x0 = np.where(problems._boundary_mask(n, 2), w[u], 0.0)
+        h.set_initial_field(hi, abi.field_of(abi.F_SOL, u), x0)
+        h.set_initial_field(hi, abi.field_of(abi.F_RHS, u), f[u])
+    out = h.evaluate(system_v_cycle_ops(lo, hi), 1, 0, 128)
+    assert out.status == abi.SOLVE_CONVERGED and out.conv_factor < 0.25
+    for u in range(2):
+        got = h.get_field(hi, abi.field_of(abi.F_SOL, u))
+        assert np.abs(got - w[u]).max() < 1e-9 * np.abs(w[u]).max()
+
+
+def test_the_problems_own_solver_settings_converge():
+    pd = problems.linear_elasticity_2d(3, 6)
+    ops = system_v_cycle_ops(3, 6)
+    out = oracle.create(pd).evaluate(ops, 1, 0, 128)
+    assert out.status == abi.SOLVE_CONVERGED and out.n_iterations < 20
+    # the same cycle through the grammar (goldens: tests/golden/elasticity2d_L6_v21_rb.exa3)
+    gen, gops = ops_for_case("elasticity2d_L6_v21_rb")
+    gout = oracle.create(pd).evaluate(gops, 1, 0, 128)
+    assert gout.n_iterations == out.n_iterations
+    assert gout.conv_factor == pytest.approx(out.conv_factor, rel=1e-3)
+
+
+@pytest.mark.parametrize("mask,block", [(0b11, (1, 1, 1)), (0b01, (1, 1, 1)), (0b10, (2, 1, 1)), (0b11, (2, 2, 1)),
+                                        (0b11, (1, 3, 1)), (0b11, (4, 1, 1)), (0b01, (3, 2, 1))])
+def test_local_solves_satisfy_their_equations(mask, block):
+    """After a block sweep with w = 1 (all tiles from the old state) every equation of a listed unknown holds exactly
+    when the tile's own unknowns take their new values and everything else the old ones."""
+    level = 4
+    pd = problems.linear_elasticity_2d(level - 1, level)
+    a = pd.system.assembled(level)
+    h = oracle.create(pd)
+    rng = np.random.default_rng(11)
+    n = (1 << level) + 1
+    x = [rng.standard_normal((n, n)) for _ in range(2)]
+    f = [1e6 * rng.standard_normal((n, n)) for _ in range(2)]
+    for u in range(2):
+        h.set_field(level, abi.field_of(abi.F_SOL, u), x[u])
+        h.set_field(level, abi.field_of(abi.F_RHS, u), f[u])
+    first = 0 if mask & 1 else 1
+    h.run_ops([abi.make_op(abi.OP_SMOOTH, level, abi.field_of(abi.F_SOL, first), 0, abi.field_of(abi.F_RHS, first),
+                           abi.PART_SINGLE, block, 1.0, unknowns=mask)])
+    y = [h.get_field(level, abi.field_of(abi.F_SOL, u)) for u in range(2)]
+    bx, by = block[0], block[1]
+    inner = n - 2
+    worst = 0.0
+    for ti in range((inner + bx - 1) // bx):
+        for tj in range((inner + by - 1) // by):
+            cells = [(1 + ti * bx + ci, 1 + tj * by + cj) for ci in range(bx) for cj in range(by)
+                     if 1 + ti * bx + ci <= n - 2 and 1 + tj * by + cj <= n - 2]
+            mixed = [xx.copy() for xx in x]
+            for u in range(2):
+                if (mask >> u) & 1:
+                    for (ca, cb) in cells:
+                        mixed[u][cb, ca] = y[u][cb, ca]
+            for u in range(2):
+                if (mask >> u) & 1:
+                    r = f[u][1:-1, 1:-1] - apply_row(a, u, mixed)
+                    for (ca, cb) in cells:
+                        worst = max(worst, abs(r[cb - 1, ca - 1]))
+    assert worst < 1e-6          # coefficients ~1e6, right-hand sides ~1e6
+    for u in range(2):
+        if not (mask >> u) & 1:
+            assert np.array_equal(y[u], x[u])
+
+
+def test_with_jacobi_semantics_on_systems():
+    level = 4
+    pd = problems.linear_elasticity_2d(level - 1, level)
+    rng = np.random.default_rng(3)
+    n = (1 << level) + 1
+    x = [rng.standard_normal((n, n)) for _ in range(2)]
+    f = [rng.standard_normal((n, n)) for _ in range(2)]
+    F = abi.field_of
+    for sem, changed in (("textbook", True), ("exastencils-v1.1", False)):
+        h = oracle.create(pd, jacobi_semantics=sem)
+        for u in range(2):
+            h.set_field(level, F(abi.F_SOL, u), x[u])
+            h.set_field(level, F(abi.F_RHS, u), f[u])
+        h.run_ops([abi.make_op(abi.OP_SMOOTH, level, F(abi.F_SOL), 0, F(abi.F_RHS), abi.PART_SINGLE, (2, 1, 1), 0.8, unknowns=0b11)])
+        assert (not np.array_equal(h.get_field(level, F(abi.F_SOL, 0)), x[0])) == changed
+        h.run_ops([abi.make_op(abi.OP_SMOOTH, level, F(abi.F_SOL), 0, F(abi.F_RHS), abi.PART_RED_BLACK, (1, 1, 1), 0.8, unknowns=0b11)])
+        assert not np.array_equal(h.get_field(level, F(abi.F_SOL, 1)), x[1])      # colour sweeps always take effect
+
+
+@pytest.mark.parametrize("name", ["elasticity2d_L6_mixed", "elasticity2d_L6_v21_rb", "elasticity2d_L5_blocks"])
+def test_golden_system_cases_run_on_the_oracle(name):
+    problem, lo, hi, _ = cycles.CASES[name]
+    gen, ops = ops_for_case(name)
+    for sem in ("textbook", "exastencils-v1.1"):
+        out = oracle.create(problems.BY_NAME[problem](lo, hi), jacobi_semantics=sem).evaluate(ops, 1, 0, 128)
+        assert out.status in (abi.SOLVE_CONVERGED, abi.SOLVE_MAXITER)
+        assert np.isfinite(out.final_res_norm) and out.final_res_norm < out.init_res_norm
