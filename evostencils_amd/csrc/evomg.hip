@@ -20,6 +20,7 @@
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
 #include "evomg_tile3d.h"
+#include "evomg_system.h"
 #ifndef EVOMG_FUSED_PF
 #define EVOMG_FUSED_PF 2   // prefetch depth of the fused sweeps (fewer waves per SIMD than the plain ones)
 #endif
@@ -1634,6 +1635,356 @@ template <typename T> class Impl : public ImplBase {
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
 };
 
+// ---- systems of PDEs (evomg_system.h): own storage and a plain interpreter, nothing shared with the tuned scalar path ----
+class SystemImpl : public ImplBase {
+ public:
+  SystemImpl(const evomg_problem_t& p, int device) : prob_(p), device_(device), nf_(p.n_unknowns) {}
+  ~SystemImpl() override {
+    (void)hipSetDevice(device_);
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      SLevel& lv = lv_[L];
+      for (auto* q : lv.f) if (q) (void)hipFree(q);
+      for (auto* q : lv.init) if (q) (void)hipFree(q);
+      for (auto* q : lv.alt) if (q) (void)hipFree(q);
+      for (auto* q : lv.tmp) if (q) (void)hipFree(q);
+    }
+    if (partials_) (void)hipFree(partials_);
+    if (dscalar_) (void)hipFree(dscalar_);
+    if (dinfo_) (void)hipFree(dinfo_);
+    if (hscalar_) (void)hipHostFree(hscalar_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+  int init() override {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device_ < 0 || device_ >= count) { snprintf(err, sizeof err, "device %d not available (%d devices)", device_, count); return EVOMG_ERR_DEVICE; }
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&partials_, sizeof(double) * kDotBlocks));
+    HIP_TRY(hipMalloc(&dscalar_, sizeof(double) * 8));
+    HIP_TRY(hipMalloc(&dinfo_, sizeof(int) * 4));
+    HIP_TRY(hipHostMalloc(&hscalar_, sizeof(double) * 8));
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      SLevel& lv = lv_[L];
+      const int n = (1 << L) + 1;
+      lv.g.n = n;
+      lv.g.pitch = ((n + 15) / 16) * 16;
+      lv.g.plane = 0;
+      lv.elems = (size_t)lv.g.pitch * n;
+      memcpy(lv.st.a, prob_.sys_stencil[L], sizeof lv.st.a);
+      for (int u = 0; u < nf_; ++u) {
+        for (int slot : {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES}) HIP_TRY(alloc_zero(&lv.f[EVOMG_FIELD(slot, u)], lv.elems));
+        if (L == prob_.max_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_FIELD(EVOMG_F_CORR, u)], lv.elems));
+        if (L == prob_.min_level) {
+          HIP_TRY(alloc_zero(&lv.f[EVOMG_FIELD(EVOMG_F_CGS_RHS, u)], lv.elems));
+          HIP_TRY(alloc_zero(&lv.tmp[2 * u], lv.elems));
+          HIP_TRY(alloc_zero(&lv.tmp[2 * u + 1], lv.elems));
+        }
+        HIP_TRY(alloc_zero(&lv.alt[u], lv.elems));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+  int set_initial_field(int level, int field, const double* host) override {
+    if (!level_ok(level) || !host) return invalid("set_initial_field: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    const int k = canon(level, field);
+    SLevel& lv = lv_[level];
+    if (k < 0 || !lv.f[k]) return invalid("set_initial_field: no such field on this level");
+    if (!lv.init[k]) HIP_TRY(alloc_zero(&lv.init[k], lv.elems));
+    HIP_TRY(upload(lv, lv.init[k], host));
+    HIP_TRY(hipMemcpyAsync(lv.f[k], lv.init[k], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+  int set_field(int level, int field, const double* host) override {
+    if (!level_ok(level) || !host) return invalid("set_field: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    double* d = fieldptr(level, field);
+    if (!d) return invalid("set_field: no such field on this level");
+    HIP_TRY(upload(lv_[level], d, host));
+    return EVOMG_OK;
+  }
+  int get_field(int level, int field, double* host) override {
+    if (!level_ok(level) || !host) return invalid("get_field: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    const double* d = fieldptr(level, field);
+    if (!d) return invalid("get_field: no such field on this level");
+    const SLevel& lv = lv_[level];
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(double), d, lv.g.pitch * sizeof(double), lv.g.n * sizeof(double), lv.g.n, hipMemcpyDeviceToHost));
+    return EVOMG_OK;
+  }
+  int set_operators(const evomg_problem_t*) override { return unsupported("set_operators: not available on systems of PDEs"); }
+  int run_ops(const evomg_op_t* ops, int n_ops) override {
+    HIP_TRY(hipSetDevice(device_));
+    int rc = validate(ops, n_ops);
+    if (rc != EVOMG_OK) return rc;
+    for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+  int norm(int level, int field, double* out) override {
+    if (!level_ok(level) || !out) return invalid("norm: bad level/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    const double* d = fieldptr(level, field);
+    if (!d) return invalid("norm: no such field on this level");
+    double v;
+    int rc = dot_to_host(level, d, &v);
+    if (rc != EVOMG_OK) return rc;
+    *out = sqrt(v);
+    return EVOMG_OK;
+  }
+  int evaluate(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) override {
+    HIP_TRY(hipSetDevice(device_));
+    if (!out || samples < 1 || n_ops < 0 || (!ops && n_ops > 0)) return invalid("evaluate: bad arguments");
+    memset(out, 0, sizeof *out);
+    int rc = validate(ops, n_ops);
+    if (rc != EVOMG_OK) return rc;
+    double tsum = 0.0;
+    int done = 0;
+    evomg_result_t r;
+    for (int smp = 0; smp < samples; ++smp) {
+      memset(&r, 0, sizeof r);
+      for (int L = prob_.min_level; L <= prob_.max_level; ++L)
+        for (int k = 0; k < kSlots; ++k) {
+          SLevel& lv = lv_[L];
+          if (!lv.f[k]) continue;
+          if (lv.init[k]) HIP_TRY(hipMemcpyAsync(lv.f[k], lv.init[k], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+          else HIP_TRY(hipMemsetAsync(lv.f[k], 0, lv.elems * sizeof(double), stream_));
+        }
+      HIP_TRY(hipStreamSynchronize(stream_));
+      int nh = 0;
+      const double t0 = wall_ms();
+      double res0 = 0.0;
+      if ((rc = residual_norm(&res0)) != EVOMG_OK) return rc;
+      if (hist && nh < cap) hist[nh] = res0;
+      ++nh;
+      double res = res0;
+      int it = 0, status = EVOMG_SOLVE_MAXITER;
+      if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+      else
+        for (it = 1; it <= prob_.max_iterations; ++it) {
+          for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+          if ((rc = residual_norm(&res)) != EVOMG_OK) return rc;
+          if (hist && nh < cap) hist[nh] = res;
+          ++nh;
+          if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+          if (res <= prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+          if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+        }
+      if (it > prob_.max_iterations) it = prob_.max_iterations;
+      r.time_ms = wall_ms() - t0;
+      r.n_iterations = (double)it;
+      r.init_res_norm = res0;
+      r.final_res_norm = res;
+      r.status = status;
+      r.n_history = (nh < cap || !hist) ? nh : cap;
+      r.conv_factor = (it > 0 && res0 > 0) ? pow(res / res0, 1.0 / (double)it) : 0.0;
+      tsum += r.time_ms;
+      ++done;
+      if (status != EVOMG_SOLVE_CONVERGED) break;
+    }
+    *out = r;
+    out->time_ms = tsum / (double)done;
+    return EVOMG_OK;
+  }
+  int bench_op(const evomg_op_t*, int, int, evomg_bench_t*) override { return unsupported("bench_op: not available on systems of PDEs"); }
+  int kernel_name(const evomg_op_t* op, char* buf, int len) override {
+    if (!op || !buf || len < 8) return invalid("kernel_name: bad arguments");
+    snprintf(buf, len, "%s", op->opcode == EVOMG_OP_SMOOTH ? "evomg_sys_smooth" : op->opcode == EVOMG_OP_RESIDUAL ? "evomg_sys_residual" :
+                             op->opcode == EVOMG_OP_COARSE_SOLVE ? "evomg_sys_cg" : "generic");
+    return EVOMG_OK;
+  }
+  int profile_begin(int, int) override { return EVOMG_OK; }
+  int profile_end(evomg_bench_t* out) override { if (out) memset(out, 0, sizeof *out); return EVOMG_OK; }
+
+ private:
+  static constexpr int kSlots = EVOMG_F_COUNT * EVOMG_MAX_UNKNOWNS;
+  struct SLevel {
+    Geo g{};
+    size_t elems = 0;
+    double* f[kSlots] = {};
+    double* init[kSlots] = {};
+    double* alt[EVOMG_MAX_UNKNOWNS] = {};
+    double* tmp[2 * EVOMG_MAX_UNKNOWNS] = {};
+    SysStencil st{};
+  };
+  hipError_t alloc_zero(double** p, size_t elems) {
+    hipError_t e = hipMalloc(p, elems * sizeof(double));
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(*p, 0, elems * sizeof(double), stream_);
+  }
+  hipError_t upload(const SLevel& lv, double* dst, const double* host) {
+    hipError_t e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess) return e;
+    return hipMemcpy2D(dst, lv.g.pitch * sizeof(double), host, lv.g.n * sizeof(double), lv.g.n * sizeof(double), lv.g.n, hipMemcpyHostToDevice);
+  }
+  bool level_ok(int L) const { return L >= prob_.min_level && L <= prob_.max_level; }
+  int canon(int level, int field) const {
+    if (field < 0 || field >= EVOMG_F_COUNT * nf_) return -1;
+    const int slot = field % EVOMG_F_COUNT, u = field / EVOMG_F_COUNT;
+    if (slot == EVOMG_F_CORR && level < prob_.max_level) return EVOMG_FIELD(EVOMG_F_SOL, u);
+    return field;
+  }
+  double* fieldptr(int level, int field) { const int k = canon(level, field); return k < 0 ? nullptr : lv_[level].f[k]; }
+  int invalid(const char* msg) { snprintf(err, sizeof err, "%s", msg); return EVOMG_ERR_INVALID; }
+  int unsupported(const char* msg) { snprintf(err, sizeof err, "%s", msg); return EVOMG_ERR_UNSUPPORTED; }
+  static dim3 blk() { return dim3(64, 4, 1); }
+  static dim3 grd(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1); }
+
+  // mirrors the oracle's sys_check_op
+  int validate(const evomg_op_t* ops, int n_ops) {
+    for (int i = 0; i < n_ops; ++i) {
+      const evomg_op_t& op = ops[i];
+      const int lo = prob_.min_level, hi = prob_.max_level;
+      int rc = EVOMG_ERR_INVALID;
+      bool ok = op.level >= lo && op.level <= hi && fieldptr(op.level, op.dst) != nullptr;
+      if (ok) switch (op.opcode) {
+        case EVOMG_OP_SMOOTH: {
+          const int mask = op.unknowns;
+          ok = fieldptr(op.level, op.src1) != nullptr && mask > 0 && mask < (1 << nf_) && op.block[0] >= 1 && op.block[1] >= 1;
+          if (!ok) break;
+          int k = 0, first = 0;
+          for (int u = 0; u < nf_; ++u) k += (mask >> u) & 1;
+          while (!((mask >> first) & 1)) ++first;
+          ok = k * op.block[0] * op.block[1] <= EVOMG_MAX_BLOCK_CELLS && op.dst / EVOMG_F_COUNT == first && op.src1 / EVOMG_F_COUNT == first &&
+               (op.partitioning == EVOMG_PART_SINGLE || op.partitioning == EVOMG_PART_RED_BLACK);
+          if (ok && op.partitioning == EVOMG_PART_RED_BLACK && op.block[0] * op.block[1] != 1) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
+          break;
+        }
+        case EVOMG_OP_RESIDUAL: ok = fieldptr(op.level, op.src0) && fieldptr(op.level, op.src1) && op.src0 / EVOMG_F_COUNT == 0; break;
+        case EVOMG_OP_RESTRICT: ok = op.level < hi && fieldptr(op.level + 1, op.src0); break;
+        case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: ok = op.level > lo && fieldptr(op.level - 1, op.src0); break;
+        case EVOMG_OP_SET_ZERO: break;
+        case EVOMG_OP_COPY: ok = fieldptr(op.level, op.src0) != nullptr; break;
+        case EVOMG_OP_COARSE_SOLVE: ok = op.level == lo; break;
+        case EVOMG_OP_RICHARDSON: ok = false; rc = EVOMG_ERR_UNSUPPORTED; break;
+        default: ok = false;
+      }
+      if (!ok) { snprintf(err, sizeof err, "op %d (opcode %d, level %d) rejected", i, op.opcode, op.level); return rc; }
+    }
+    return EVOMG_OK;
+  }
+
+  SysConstFields slot_fields(int level, int slot) {
+    SysConstFields x{};
+    for (int u = 0; u < nf_; ++u) x.p[u] = fieldptr(level, EVOMG_FIELD(slot, u));
+    return x;
+  }
+  int exec(const evomg_op_t& op) {
+    const int L = op.level;
+    SLevel& lv = lv_[L];
+    const Geo& g = lv.g;
+    switch (op.opcode) {
+      case EVOMG_OP_SMOOTH: {
+        const int mask = op.unknowns, bx = op.block[0], by = op.block[1], inner = g.n - 2;
+        const int sol_slot = canon(L, op.dst) % EVOMG_F_COUNT, rhs_slot = op.src1 % EVOMG_F_COUNT;
+        const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by;
+        const int passes = op.partitioning == EVOMG_PART_RED_BLACK ? 2 : 1;
+        const SysConstFields f = slot_fields(L, rhs_slot);
+        for (int pass = 0; pass < passes; ++pass) {
+          const SysConstFields x = slot_fields(L, sol_slot);
+          SysFields y{};
+          for (int u = 0; u < nf_; ++u) {
+            y.p[u] = lv.alt[u];
+            if ((mask >> u) & 1) HIP_TRY(hipMemcpyAsync(lv.alt[u], x.p[u], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+          }
+          hipLaunchKernelGGL(evomg_sys_smooth, grd(tx, ty), blk(), 0, stream_, g, lv.st, nf_, mask, bx, by, tx, ty,
+                             passes == 2 ? pass : -1, x, f, y, op.omega);
+          // a colour pass always takes effect; a `with jacobi` sweep only where the next slot is advanced (evomg.h)
+          const bool lost = passes == 1 && prob_.jacobi_semantics == EVOMG_JACOBI_EXASTENCILS_V11;
+          if (!lost)
+            for (int u = 0; u < nf_; ++u)
+              if ((mask >> u) & 1) std::swap(lv.f[canon(L, EVOMG_FIELD(sol_slot, u))], lv.alt[u]);
+        }
+        break;
+      }
+      case EVOMG_OP_RESIDUAL: {
+        const SysConstFields x = slot_fields(L, canon(L, op.src0) % EVOMG_F_COUNT);
+        hipLaunchKernelGGL(evomg_sys_residual, grd(g.n, g.n), blk(), 0, stream_, g, lv.st, nf_, op.dst / EVOMG_F_COUNT, x,
+                           (const double*)fieldptr(L, op.src1), fieldptr(L, op.dst));
+        break;
+      }
+      case EVOMG_OP_RESTRICT:
+        hipLaunchKernelGGL((evomg_restrict<double, 2>), grd(g.n, g.n), blk(), 0, stream_, g, lv_[L + 1].g, (const double*)fieldptr(L + 1, op.src0), fieldptr(L, op.dst));
+        break;
+      case EVOMG_OP_PROLONG_ADD:
+        hipLaunchKernelGGL((evomg_prolong<double, 2, true>), grd(g.n, g.n), blk(), 0, stream_, g, lv_[L - 1].g, (const double*)fieldptr(L - 1, op.src0), fieldptr(L, op.dst), op.omega);
+        break;
+      case EVOMG_OP_PROLONG_SET:
+        hipLaunchKernelGGL((evomg_prolong<double, 2, false>), grd(g.n, g.n), blk(), 0, stream_, g, lv_[L - 1].g, (const double*)fieldptr(L - 1, op.src0), fieldptr(L, op.dst), 1.0);
+        break;
+      case EVOMG_OP_SET_ZERO:
+        hipLaunchKernelGGL((evomg_zero_inner<double, 2>), grd(g.n, g.n), blk(), 0, stream_, g, fieldptr(L, op.dst), 0);
+        break;
+      case EVOMG_OP_COPY: {
+        double* d = fieldptr(L, op.dst);
+        const double* s2 = fieldptr(L, op.src0);
+        if (d != s2) HIP_TRY(hipMemcpyAsync(d, s2, lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        break;
+      }
+      case EVOMG_OP_COARSE_SOLVE: {
+        SysFields x{}, r{}, p{}, ap{};
+        SysConstFields b{};
+        for (int u = 0; u < nf_; ++u) {
+          x.p[u] = fieldptr(L, EVOMG_FIELD(EVOMG_F_CORR, u));
+          b.p[u] = fieldptr(L, EVOMG_FIELD(EVOMG_F_CGS_RHS, u));
+          r.p[u] = fieldptr(L, EVOMG_FIELD(EVOMG_F_RES, u));
+          p.p[u] = lv.tmp[2 * u];
+          ap.p[u] = lv.tmp[2 * u + 1];
+        }
+        hipLaunchKernelGGL(evomg_sys_cg, dim3(1), dim3(1024), 0, stream_, g, lv.st, nf_, x, b, r, p, ap, prob_.cgs_max_iterations,
+                           prob_.cgs_target_res_reduction, dinfo_);
+        break;
+      }
+      default: return invalid("exec: unknown opcode");
+    }
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }
+  int dot_to_host(int L, const double* a, double* out) {
+    const Geo& g = lv_[L].g;
+    const int m = g.n - 2;
+    const int blocks = m < kDotBlocks ? m : kDotBlocks;
+    hipLaunchKernelGGL((evomg_dot_partial<double, 2>), dim3(blocks), dim3(256), 0, stream_, g, a, a, partials_);
+    hipLaunchKernelGGL((evomg_dot_final<double>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dscalar_);
+    HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = hscalar_[0];
+    return EVOMG_OK;
+  }
+  // residual of every equation on the finest level + the combined norm sqrt(sum over all unknowns)
+  int residual_norm(double* out) {
+    const int L = prob_.max_level;
+    SLevel& lv = lv_[L];
+    const SysConstFields x = slot_fields(L, EVOMG_F_SOL);
+    double total = 0.0;
+    for (int u = 0; u < nf_; ++u) {
+      double* r = fieldptr(L, EVOMG_FIELD(EVOMG_F_RES, u));
+      hipLaunchKernelGGL(evomg_sys_residual, grd(lv.g.n, lv.g.n), blk(), 0, stream_, lv.g, lv.st, nf_, u, x,
+                         (const double*)fieldptr(L, EVOMG_FIELD(EVOMG_F_RHS, u)), r);
+      double d;
+      const int rc = dot_to_host(L, r, &d);
+      if (rc != EVOMG_OK) return rc;
+      total += d;
+    }
+    *out = sqrt(total);
+    return EVOMG_OK;
+  }
+
+  evomg_problem_t prob_;
+  int device_;
+  int nf_;
+  SLevel lv_[EVOMG_MAX_LEVELS];
+  hipStream_t stream_ = nullptr;
+  double* partials_ = nullptr;
+  double* dscalar_ = nullptr;
+  double* hscalar_ = nullptr;
+  int* dinfo_ = nullptr;
+};
+
 int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (!p) { snprintf(err, len, "null problem"); return EVOMG_ERR_INVALID; }
   if (p->abi_version != EVOMG_ABI_VERSION) { snprintf(err, len, "abi version %d != %d", p->abi_version, EVOMG_ABI_VERSION); return EVOMG_ERR_INVALID; }
@@ -1645,6 +1996,14 @@ int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) { snprintf(err, len, "PBiCGStab outer solver is 2D only"); return EVOMG_ERR_UNSUPPORTED; }
   if (p->max_iterations < 1 || p->cgs_max_iterations < 1) { snprintf(err, len, "iteration limits must be positive"); return EVOMG_ERR_INVALID; }
   if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) { snprintf(err, len, "jacobi_semantics must be EVOMG_JACOBI_TEXTBOOK or EVOMG_JACOBI_EXASTENCILS_V11"); return EVOMG_ERR_INVALID; }
+  if (p->n_unknowns > 1) {
+    if (p->n_unknowns > EVOMG_MAX_UNKNOWNS) { snprintf(err, len, "at most %d unknowns per node", EVOMG_MAX_UNKNOWNS); return EVOMG_ERR_UNSUPPORTED; }
+    if (p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 || p->bc_kind != EVOMG_BC_DIRICHLET ||
+        p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_CG) {
+      snprintf(err, len, "systems of PDEs: 2D real Dirichlet problems with the generated solver loop and CG only");
+      return EVOMG_ERR_UNSUPPORTED;
+    }
+  }
   return EVOMG_OK;
 }
 
@@ -1664,7 +2023,8 @@ int evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t**
   int rc = check_problem(problem, g_create_error, sizeof g_create_error);
   if (rc != EVOMG_OK) return rc;
   ImplBase* impl = nullptr;
-  if (problem->scalar_kind == EVOMG_COMPLEX_F64) impl = new Impl<cplx>(*problem, device_id);
+  if (problem->n_unknowns > 1) impl = new SystemImpl(*problem, device_id);
+  else if (problem->scalar_kind == EVOMG_COMPLEX_F64) impl = new Impl<cplx>(*problem, device_id);
   else impl = new Impl<double>(*problem, device_id);
   rc = impl->init();
   if (rc != EVOMG_OK) {

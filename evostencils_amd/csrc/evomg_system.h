@@ -1,0 +1,168 @@
+// evomg_system.h — systems of PDEs: several unknowns per node coupled by 9-point stencils; the linear
+// elasticity problem of the reference (example_problems/LinearElasticity/2D_FD_LinearElasticity_fromL2.*; IR:
+// evostencils/ir/system.py:32-135; lowering: code_generation/exastencils.py:769-873).
+//
+// First implementation: correct and complete for the op vocabulary the grammar produces on such problems, deliberately
+// plain in its kernels (thread per node / thread per tile, no fusion) — these problems run on the reference's own small
+// levels (4..8); the tuned strip / tile kernels of the scalar path are the model for a later round.
+// 2D, real, Dirichlet. Semantics and operation order = oracle/evomg_oracle_system.h (bit-identical pointwise kernels;
+// the coarse CG sums in the order that oracle restates).
+#pragma once
+#include "evomg_kernels.h"
+
+struct SysStencil {
+  double a[EVOMG_MAX_UNKNOWNS][EVOMG_MAX_UNKNOWNS][EVOMG_SYS_STENCIL_ENTRIES];
+};
+struct SysFields {
+  double* p[EVOMG_MAX_UNKNOWNS];
+};
+struct SysConstFields {
+  const double* p[EVOMG_MAX_UNKNOWNS];
+};
+
+__device__ __forceinline__ int sys_ox(int e) { return (e == 1 || e == 5 || e == 7) ? -1 : (e == 2 || e == 6 || e == 8) ? 1 : 0; }
+__device__ __forceinline__ int sys_oy(int e) { return (e == 3 || e == 5 || e == 6) ? -1 : (e == 4 || e == 7 || e == 8) ? 1 : 0; }
+
+// row i of the block operator at inner node (a, b): sum_j sum_e A[i][j][e] x_j(node + offset_e), j then e ascending
+__device__ __forceinline__ double sys_apply_row(const Geo& g, const SysStencil& st, int nf, int i, const SysConstFields& x, int a, int b) {
+  double s = 0.0;
+  for (int j = 0; j < nf; ++j)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) s = s + st.a[i][j][e] * x.p[j][(long)g.pitch * (b + sys_oy(e)) + a + sys_ox(e)];
+  return s;
+}
+
+// r_i = f_i - (A x)_i on inner nodes
+__global__ void __launch_bounds__(256) evomg_sys_residual(Geo g, SysStencil st, int nf, int i, SysConstFields x,
+                                                          const double* __restrict__ f, double* __restrict__ r) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+  if (a < 1 || b < 1 || a > g.n - 2 || b > g.n - 2) return;
+  const long c = (long)g.pitch * b + a;
+  r[c] = f[c] - sys_apply_row(g, st, nf, i, x, a, b);
+}
+// y_i = (A x)_i on inner nodes (CG)
+__global__ void __launch_bounds__(256) evomg_sys_apply(Geo g, SysStencil st, int nf, int i, SysConstFields x, double* __restrict__ y) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+  if (a < 1 || b < 1 || a > g.n - 2 || b > g.n - 2) return;
+  y[(long)g.pitch * b + a] = sys_apply_row(g, st, nf, i, x, a, b);
+}
+
+// One `solve locally` block per thread: the tile anchored at inner node (1 + ti*bx, 1 + tj*by), cut at the far boundary;
+// unknowns = (unknown of `mask`, cell), field order then cells with i0 outermost; every stencil entry that hits a listed
+// unknown goes into the local matrix, the rest to the right-hand side at its current value; Gaussian elimination without
+// pivoting, exactly-zero multipliers skipped; x <- (1-w) x + w x*. colour >= 0: only tiles whose anchor has that colour
+// (point blocks). Reads x, writes y (the caller made y a copy of x).
+__global__ void __launch_bounds__(256) evomg_sys_smooth(Geo g, SysStencil st, int nf, int mask, int bx, int by, int tx, int ty,
+                                                        int colour, SysConstFields x, SysConstFields f, SysFields y, double om) {
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x, tj = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ti >= tx || tj >= ty) return;
+  const int n = g.n;
+  const int a0 = 1 + ti * bx, b0 = 1 + tj * by;
+  if (colour >= 0 && ((a0 + b0) & 1) != colour) return;
+  const int wx = (a0 + bx <= n - 1) ? bx : n - 1 - a0, wy = (b0 + by <= n - 1) ? by : n - 1 - b0;
+  int eu[8], ea[8], eb[8], m = 0;
+  for (int u = 0; u < nf; ++u) {
+    if (!((mask >> u) & 1)) continue;
+    for (int ci = 0; ci < wx; ++ci)
+      for (int cj = 0; cj < wy; ++cj) { eu[m] = u; ea[m] = a0 + ci; eb[m] = b0 + cj; ++m; }
+  }
+  double M[8][8], r[8];
+  for (int p = 0; p < m; ++p) {
+    for (int q = 0; q < m; ++q) M[p][q] = 0.0;
+    const int i = eu[p];
+    double s = f.p[i][(long)g.pitch * eb[p] + ea[p]];
+    for (int j = 0; j < nf; ++j)
+      for (int e = 0; e < 9; ++e) {
+        const int ta = ea[p] + sys_ox(e), tb = eb[p] + sys_oy(e);
+        int hit = -1;
+        if ((mask >> j) & 1)
+          for (int q = 0; q < m; ++q)
+            if (eu[q] == j && ea[q] == ta && eb[q] == tb) hit = q;
+        if (hit >= 0) M[p][hit] = st.a[i][j][e];
+        else s = s - st.a[i][j][e] * x.p[j][(long)g.pitch * tb + ta];
+      }
+    r[p] = s;
+  }
+  for (int p = 0; p < m; ++p)
+    for (int q = p + 1; q < m; ++q) {
+      if (M[q][p] == 0.0) continue;
+      const double fac = M[q][p] / M[p][p];
+      for (int t = p + 1; t < m; ++t) M[q][t] = M[q][t] - fac * M[p][t];
+      r[q] = r[q] - fac * r[p];
+    }
+  for (int p = m - 1; p >= 0; --p) {
+    double s = r[p];
+    for (int t = p + 1; t < m; ++t) s = s - M[p][t] * r[t];
+    r[p] = s / M[p][p];
+  }
+  const double omm = 1.0 - om;
+  for (int p = 0; p < m; ++p) {
+    const long c = (long)g.pitch * eb[p] + ea[p];
+    y.p[eu[p]][c] = omm * x.p[eu[p]][c] + om * r[p];
+  }
+}
+
+// Coarse-grid CG on the stacked unknowns: ONE 1024-thread workgroup, vectors in global memory (L2-resident on the small
+// coarsest grids these problems have), thread t owns the stacked inner nodes t, t + 1024, ... (unknown-major, rows,
+// columns); dots: per-thread fma chain in that order, then the block_sum trees. Restated by the oracle (sys_dot).
+__global__ void __launch_bounds__(1024) evomg_sys_cg(Geo g, SysStencil st, int nf, SysFields x, SysConstFields b, SysFields r,
+                                                     SysFields p, SysFields ap, int maxit, double tol, int* __restrict__ info) {
+  __shared__ double red[17];
+  const int n = g.n, m = n - 2;
+  const long per = (long)m * m, total = per * nf;
+  const int t = threadIdx.x;
+  auto node = [&](long q, int& u, long& c, int& a, int& bb) {
+    u = (int)(q / per);
+    const long k = q % per;
+    a = 1 + (int)(k % m);
+    bb = 1 + (int)(k / m);
+    c = (long)g.pitch * bb + a;
+  };
+  SysConstFields xc, pc;
+  for (int u = 0; u < EVOMG_MAX_UNKNOWNS; ++u) { xc.p[u] = x.p[u]; pc.p[u] = p.p[u]; }
+  double loc = 0.0;
+  for (long q = t; q < total; q += 1024) {
+    int u, a, bb; long c;
+    node(q, u, c, a, bb);
+    const double v = b.p[u][c] - sys_apply_row(g, st, nf, u, xc, a, bb);
+    r.p[u][c] = v;
+    p.p[u][c] = v;
+    loc = __builtin_fma(v, v, loc);
+  }
+  double rr = block_sum(loc, red);
+  const double res0 = sqrt(rr);
+  int it = 0;
+  if (res0 != 0.0) {
+    for (; it < maxit; ++it) {
+      __syncthreads();                       // p complete (written by other threads' updates)
+      loc = 0.0;
+      for (long q = t; q < total; q += 1024) {
+        int u, a, bb; long c;
+        node(q, u, c, a, bb);
+        const double v = sys_apply_row(g, st, nf, u, pc, a, bb);
+        ap.p[u][c] = v;
+        loc = __builtin_fma(p.p[u][c], v, loc);
+      }
+      const double alpha = rr / block_sum(loc, red);
+      loc = 0.0;
+      for (long q = t; q < total; q += 1024) {
+        int u, a, bb; long c;
+        node(q, u, c, a, bb);
+        x.p[u][c] = __builtin_fma(alpha, p.p[u][c], x.p[u][c]);
+        const double v = __builtin_fma(-alpha, ap.p[u][c], r.p[u][c]);
+        r.p[u][c] = v;
+        loc = __builtin_fma(v, v, loc);
+      }
+      const double rrn = block_sum(loc, red);
+      if (!(sqrt(rrn) > tol * res0)) { ++it; break; }
+      const double beta = rrn / rr;
+      for (long q = t; q < total; q += 1024) {
+        int u, a, bb; long c;
+        node(q, u, c, a, bb);
+        p.p[u][c] = __builtin_fma(beta, p.p[u][c], r.p[u][c]);
+      }
+      rr = rrn;
+    }
+  }
+  if (t == 0) info[0] = it;
+}

@@ -1,0 +1,130 @@
+"""SURVEY 8f N3 on the GPU: the linear-elasticity system (two unknowns, 9-point coupling) through the C-ABI against the
+CPU oracle — every op kind bit for bit on random fields, the stacked coarse-grid CG, whole solves of the golden-string
+candidates in both `with jacobi` semantics, and a manufactured solution."""
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, problems
+from evostencils_amd.code_generation.hip import ProgramGenerator
+import cycles
+from helpers import build_case
+from test_systems_oracle import manufactured, system_v_cycle_ops
+
+pytestmark = pytest.mark.gpu
+F = abi.field_of
+
+
+@pytest.fixture(scope="module")
+def native():
+    from evostencils_amd import native as nat
+    nat.library()
+    return nat
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def load_random(handles, level, seed):
+    rng = np.random.default_rng(seed)
+    n = (1 << level) + 1
+    data = {}
+    for slot in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+        for u in range(2):
+            a = rng.standard_normal((n, n)) * (1e5 if slot == abi.F_RHS else 1.0)
+            data[(slot, u)] = a
+            for h in handles:
+                h.set_field(level, F(slot, u), a)
+    return data
+
+
+@pytest.mark.parametrize("level", [4, 6])
+def test_every_op_kind_is_bit_identical(native, oracle, level):
+    pd = problems.linear_elasticity_2d(level - 1, level)
+    hg, ho = native.create(pd), oracle.create(pd)
+    smooths = [(0b11, (1, 1, 1), abi.PART_SINGLE), (0b11, (1, 1, 1), abi.PART_RED_BLACK), (0b01, (1, 1, 1), abi.PART_SINGLE),
+               (0b10, (1, 1, 1), abi.PART_RED_BLACK), (0b11, (2, 1, 1), abi.PART_SINGLE), (0b11, (2, 2, 1), abi.PART_SINGLE),
+               (0b11, (1, 4, 1), abi.PART_SINGLE), (0b10, (3, 2, 1), abi.PART_SINGLE), (0b01, (1, 1, 1), abi.PART_RED_BLACK)]
+    for k, (mask, block, part) in enumerate(smooths):
+        load_random((hg, ho), level, 100 * level + k)
+        first = 0 if mask & 1 else 1
+        ops = [abi.make_op(abi.OP_SMOOTH, level, F(abi.F_SOL, first), 0, F(abi.F_RHS, first), part, block, 0.85, unknowns=mask)] * 2
+        ops += [abi.make_op(abi.OP_RESIDUAL, level, F(abi.F_RES, u), F(abi.F_SOL), F(abi.F_RHS, u)) for u in range(2)]
+        ops += [abi.make_op(abi.OP_RESTRICT, level - 1, F(abi.F_RHS, u), F(abi.F_RES, u)) for u in range(2)]
+        ops += [abi.make_op(abi.OP_SET_ZERO, level - 1, F(abi.F_SOL, u)) for u in range(2)]
+        ops += [abi.make_op(abi.OP_SMOOTH, level - 1, F(abi.F_SOL), 0, F(abi.F_RHS), abi.PART_RED_BLACK, (1, 1, 1), 1.25, unknowns=0b11)]
+        ops += [abi.make_op(abi.OP_PROLONG_ADD, level, F(abi.F_SOL, u), F(abi.F_SOL, u), omega=0.9) for u in range(2)]
+        ops += [abi.make_op(abi.OP_PROLONG_SET, level, F(abi.F_CORR, u), F(abi.F_SOL, u)) for u in range(2)]
+        hg.run_ops(ops)
+        ho.run_ops(ops)
+        for L, slots in ((level, (abi.F_SOL, abi.F_RES, abi.F_CORR)), (level - 1, (abi.F_SOL, abi.F_RHS))):
+            for slot in slots:
+                for u in range(2):
+                    assert np.array_equal(hg.get_field(L, F(slot, u)), ho.get_field(L, F(slot, u))), (mask, block, part, L, slot, u)
+    hg.close()
+    ho.close()
+
+
+@pytest.mark.parametrize("lo", [3, 4, 5])
+def test_stacked_coarse_cg(native, oracle, lo):
+    pd = problems.linear_elasticity_2d(lo, lo + 1)
+    hg, ho = native.create(pd), oracle.create(pd)
+    rng = np.random.default_rng(lo)
+    n = (1 << lo) + 1
+    ops = []
+    for u in range(2):
+        b = rng.standard_normal((n, n))
+        for h in (hg, ho):
+            h.set_field(lo, F(abi.F_CGS_RHS, u), b)
+        ops.append(abi.make_op(abi.OP_SET_ZERO, lo, F(abi.F_CORR, u)))
+    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, lo))
+    hg.run_ops(ops)
+    ho.run_ops(ops)
+    for u in range(2):
+        # one canonical summation order on both sides (oracle sys_dot restates the kernel's): the same bits
+        assert np.array_equal(hg.get_field(lo, F(abi.F_CORR, u)), ho.get_field(lo, F(abi.F_CORR, u)))
+    # and the system is actually solved: residual of the stacked system at 1e-12 of the right-hand side
+    res = [abi.make_op(abi.OP_RESIDUAL, lo, F(abi.F_RES, u), F(abi.F_CORR), F(abi.F_CGS_RHS, u)) for u in range(2)]
+    hg.run_ops(res)
+    r = np.sqrt(sum(hg.norm(lo, F(abi.F_RES, u)) ** 2 for u in range(2)))
+    b = np.sqrt(sum(hg.norm(lo, F(abi.F_CGS_RHS, u)) ** 2 for u in range(2)))
+    assert r <= 50 * pd.cgs_target_res_reduction * b
+
+
+@pytest.mark.parametrize("semantics", ["textbook", "exastencils-v1.1"])
+@pytest.mark.parametrize("name", ["elasticity2d_L6_mixed", "elasticity2d_L6_v21_rb", "elasticity2d_L5_blocks"])
+def test_whole_solves_through_the_program_generator(native, oracle, name, semantics):
+    gen, expression, lo, hi = build_case(name, library=native.library(), jacobi_semantics=semantics)
+    gen.initialize_code_generation(lo, hi)
+    t, rho, its = gen.generate_and_evaluate(expression, gen.generate_storage(lo, hi, gen.finest_grid), lo, hi, "", evaluation_samples=1)
+    ops = gen.generate_op_program(expression, lo, hi)
+    ho = oracle.create(gen.problem)
+    want = ho.evaluate(ops, 1, 0, 128)
+    got = gen._handle.evaluate(ops, 1, 0, 128)
+    _, want_rho, want_its = ProgramGenerator.interpret_outcome(want, 1e100)
+    assert its == want_its and rho == pytest.approx(want_rho, rel=1e-9) and t > 0
+    assert got.status == want.status and got.n_iterations == want.n_iterations
+    floor = want.history > 1e-9 * want.history[0]
+    assert np.max(np.abs(got.history - want.history)[floor] / want.history[floor]) <= 1e-10
+    for u in range(2):
+        a, b = gen._handle.get_field(hi, F(abi.F_SOL, u)), ho.get_field(hi, F(abi.F_SOL, u))
+        assert np.abs(a - b).max() <= 1e-10 * max(np.abs(b).max(), 1e-300)
+    gen.close()
+
+
+def test_manufactured_solution_on_the_gpu(native):
+    lo, hi = 4, 8
+    pd = problems.linear_elasticity_2d(lo, hi)
+    w, f = manufactured(pd, hi)
+    h = native.create(pd)
+    n = (1 << hi) + 1
+    for u in range(2):
+        h.set_initial_field(hi, F(abi.F_SOL, u), np.where(problems._boundary_mask(n, 2), w[u], 0.0))
+        h.set_initial_field(hi, F(abi.F_RHS, u), f[u])
+    out = h.evaluate(system_v_cycle_ops(lo, hi), 1, 0, 128)
+    assert out.status == abi.SOLVE_CONVERGED and out.conv_factor < 0.25
+    for u in range(2):
+        assert np.abs(h.get_field(hi, F(abi.F_SOL, u)) - w[u]).max() < 1e-8 * np.abs(w[u]).max()
+    h.close()
