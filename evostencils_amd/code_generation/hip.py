@@ -96,8 +96,17 @@ class ProgramGenerator:
             settings = problem_files.resolve_settings(problem_files.read_key_values(os.path.join(base_path, settings_path)))
             config = settings.get("configName")
             l2_path = os.path.join(base_path, settings.get("basePathPrefix", "."), settings.get("l2file", f"{config}.exa2"))
+            problem = None
             if os.path.exists(l2_path):
-                problem = problem_files.load_problem(base_path, settings_path, knowledge_path)
+                try:
+                    problem = problem_files.load_problem(base_path, settings_path, knowledge_path)
+                except problem_files.UnsupportedProblem:
+                    # outside the front end's subset (several unknowns, operator sums, Globals): the built-in
+                    # descriptor of the same configuration, if there is one
+                    if config not in problems.BY_NAME:
+                        raise
+            if problem is not None:
+                pass
             elif config in problems.BY_NAME:
                 problem = problems.BY_NAME[config](int(knowledge["minLevel"]), int(knowledge["maxLevel"]))
             else:

@@ -17,6 +17,34 @@ DEFAULT_HINTS = {
 }
 
 
+def system_v_cycle_ops(min_level: int, max_level: int, pre: int, post: int, omega: float, red_black: bool,
+                       n_unknowns: int) -> List[abi.Op]:
+    """The same cycle on a system of PDEs: collective point smoother (all unknowns of a node in one local solve), the
+    transfers and the residual once per unknown (the statement order the reference's lowering uses for systems,
+    exastencils.py:831-873)."""
+    one = (1, 1, 1)
+    part = abi.PART_RED_BLACK if red_black else abi.PART_SINGLE
+    F = abi.field_of
+    mask = (1 << n_unknowns) - 1
+    unknowns = range(n_unknowns)
+    smooth = lambda L: abi.make_op(abi.OP_SMOOTH, L, F(abi.F_SOL), 0, F(abi.F_RHS), part, one, omega, unknowns=mask)
+    ops = []
+    for L in range(max_level, min_level, -1):
+        ops += [smooth(L) for _ in range(pre)]
+        ops += [abi.make_op(abi.OP_RESIDUAL, L, F(abi.F_RES, u), F(abi.F_SOL), F(abi.F_RHS, u)) for u in unknowns]
+        ops += [abi.make_op(abi.OP_RESTRICT, L - 1, F(abi.F_RHS, u), F(abi.F_RES, u)) for u in unknowns]
+        if L - 1 > min_level:
+            ops += [abi.make_op(abi.OP_SET_ZERO, L - 1, F(abi.F_SOL, u)) for u in unknowns]
+    for u in unknowns:
+        ops.append(abi.make_op(abi.OP_COPY, min_level, F(abi.F_CGS_RHS, u), F(abi.F_RHS, u)))
+        ops.append(abi.make_op(abi.OP_SET_ZERO, min_level, F(abi.F_CORR, u)))
+    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, min_level))
+    for L in range(min_level + 1, max_level + 1):
+        ops += [abi.make_op(abi.OP_PROLONG_ADD, L, F(abi.F_SOL, u), F(abi.F_SOL, u), omega=1.0) for u in unknowns]
+        ops += [smooth(L) for _ in range(post)]
+    return ops
+
+
 def v_cycle_ops(min_level: int, max_level: int, pre: int, post: int, omega: float, red_black: bool = True) -> List[abi.Op]:
     """V(pre, post) point-smoother cycle over levels max..min with the coarse-grid solver on `min_level`; statement
     order as ExaStencils' generated gen_mgCycle: smooth, residual, restrict, zero the coarse error, recurse,
@@ -51,6 +79,11 @@ def reference_solver_ops(problem, hints: Optional[Dict[str, object]] = None, top
         raise ValueError(f"no solver hints for problem {problem.name!r}")
     jacobi = str(h.get("solver_smoother_jacobiType", "false")).lower() == "true"
     coloured = str(h.get("solver_smoother_coloring", "red-black")).lower() in ("red-black", "rb", "2-way")
+    if getattr(problem, "system", None) is not None:
+        return system_v_cycle_ops(problem.min_level, problem.max_level if top_level is None else top_level,
+                                  int(h.get("solver_smoother_numPre", 2)), int(h.get("solver_smoother_numPost", 1)),
+                                  float(h.get("solver_smoother_damping", 1.0)), coloured and not jacobi,
+                                  len(problem.system.field_names))
     return v_cycle_ops(problem.min_level, problem.max_level if top_level is None else top_level,
                        int(h.get("solver_smoother_numPre", 2)),
                        int(h.get("solver_smoother_numPost", 1)), float(h.get("solver_smoother_damping", 1.0)),

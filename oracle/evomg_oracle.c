@@ -10,11 +10,16 @@
  * on the problems example_problems/Poisson/{2D,3D}_FD_Poisson_fromL2.* and
  * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.*.
  *
- * PARITY UNPINNED: the arithmetic lives in ExaStencils v1.1 (github.com/lssfau/ExaStencils, tag v1.1,
- * README.md:19-21), a JVM code generator that is not under /root/reference and cannot run in this
- * pipeline (no java). The reference holds no numerical golden vectors for this path (no tests at all).
- * This oracle is therefore pinned only by (i) known-answer tests derived from the reference's problem
- * files (tests/test_oracle_known_answers.py) and (ii) the explicit algorithms spelled out in ExaSlang in
+ * PARITY PINNED against the one numerical result the reference records for this path: notebooks/tutorial.ipynb:3373
+ * ("convergence factor: 0.9212764170210773, number of iterations: 100.0" for the cycle at :3421-3470, 2D Poisson, levels
+ * 5..9). With jacobi_semantics = EVOMG_JACOBI_EXASTENCILS_V11 this oracle's residual history, read the way the reference
+ * reads its executable's stdout (6 significant digits per factor, three samples), gives exactly that value and count
+ * (tests/test_reference_recorded_run.py); so does the independent numpy restatement oracle/numpy_mg.py, and no other
+ * reading of SURVEY App. B does (oracle/appb_matrix.py -> oracle/APPB_MATRIX.md). ExaStencils itself (the JVM code generator
+ * that emits the reference's arithmetic: github.com/lssfau/ExaStencils, tag v1.1, README.md:19-21) is not under
+ * /root/reference and cannot run in this pipeline. What that one run cannot pin — Jacobi-type sweeps taking effect, 3D,
+ * Helmholtz, systems — rests on known-answer tests (tests/test_oracle_known_answers.py, test_helmholtz_oracle.py,
+ * test_systems_oracle.py) and on the algorithms spelled out in ExaSlang in
  * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3 (BiCGStab, V-cycle, norms).
  *
  * It consumes the same op program (include/evomg.h) as the HIP backend and exposes the same entry points

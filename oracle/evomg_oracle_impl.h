@@ -10,7 +10,7 @@
  * one ExaSlang statement kind that the reference's lowering emits
  * (evostencils/code_generation/exastencils.py:684-925). ExaStencils itself is not
  * in /root/reference (third-party, tag v1.1); semantics marked [EXTERNAL] follow
- * SURVEY.md Appendix B. PARITY WITH A REAL EXASTENCILS RUN IS UNPINNED.
+ * SURVEY.md Appendix B; the recorded run notebooks/tutorial.ipynb:3373 pins them (header of evomg_oracle.c).
  *
  * Arithmetic is written as explicit, fixed-order two-operand operations and is
  * compiled with -ffp-contract=off, so that the HIP kernels (same order, same flag)

@@ -83,6 +83,8 @@ def test_manufactured_solution_is_recovered():
 def test_the_problems_own_solver_settings_converge():
     pd = problems.linear_elasticity_2d(3, 6)
     ops = system_v_cycle_ops(3, 6)
+    # reference_solver.py derives the same program from the problem's `generate solver` settings (exa3:10-23)
+    assert [o.key() for o in reference_solver.reference_solver_ops(pd)] == [o.key() for o in ops]
     out = oracle.create(pd).evaluate(ops, 1, 0, 128)
     assert out.status == abi.SOLVE_CONVERGED and out.n_iterations < 20
     # the same cycle through the grammar (goldens: tests/golden/elasticity2d_L6_v21_rb.exa3)
@@ -133,6 +135,21 @@ def test_local_solves_satisfy_their_equations(mask, block):
     for u in range(2):
         if not (mask >> u) & 1:
             assert np.array_equal(y[u], x[u])
+
+
+def test_program_generator_reads_the_reference_problem_directory():
+    """The reference's LinearElasticity files lie outside the layer-2 front end's subset (two unknowns, operator sums,
+    Globals): the generator falls back to the built-in descriptor of the same configuration."""
+    import os
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    base = "/root/reference/example_problems"
+    if not os.path.isdir(base):
+        pytest.skip("reference checkout not present")
+    gen = ProgramGenerator("unused.jar", base, "LinearElasticity/2D_FD_LinearElasticity_fromL2.settings",
+                           "LinearElasticity/2D_FD_LinearElasticity_fromL2.knowledge", "lib/linux.platform", library=object())
+    assert gen.problem_name == "2D_FD_LinearElasticity_fromL2" and (gen.min_level, gen.max_level) == (4, 8)
+    assert [str(f) for f in gen.fields] == ["u", "v"] and len(gen.finest_grid) == 2
+    assert sorted({e.name for e in gen.equations}) == ["uEq", "vEq"]
 
 
 def test_with_jacobi_semantics_on_systems():
