@@ -1027,8 +1027,8 @@ template <typename T> class Impl : public ImplBase {
     if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
     return use_strip(lv_[sm.level].g);
   }
-  int ensure_norm_partials(int count) {
-    if ((size_t)count > norm_partials_cap_) {
+  int ensure_norm_partials(size_t count) {
+    if (count > norm_partials_cap_) {
       if (norm_partials_) (void)hipFree(norm_partials_);
       norm_partials_ = nullptr;
       HIP_TRY(hipMalloc(&norm_partials_, sizeof(T) * count));
@@ -1071,6 +1071,23 @@ template <typename T> class Impl : public ImplBase {
   // is canonical for 2D levels of at least 33 nodes (the oracle's FN(norm_strip2d)) and does NOT depend on
   // EVOMG_NO_STRIP or the tuning knobs.
   bool norm_fused(const Geo& g) const { return dim_ == 2 && g.n >= 33; }
+  // 3D from 129^3 up: residual + norm in ONE tile pass (evomg_tile3d<.., TILE_RESNORM>): canonical order of the solver
+  // loop's norm there, whatever kernels the ops themselves run on (oracle: FN(norm_tile3d))
+  bool norm_fused3d(const Geo& g) const { return dim_ == 3 && !scalar_traits<T>::is_complex && g.n >= 129 && prob_.bc_kind == EVOMG_BC_DIRICHLET; }
+  int residual_norm_launch3d(int L, const Stencil<T>& st, const T* x, const T* f, T* r, bool write_r) {
+    const Geo& g = lv_[L].g;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    const long count = (long)(g.n - 2) * (g.n - 2) * strips;
+    {
+      const int rc = ensure_norm_partials((size_t)count + kDotBlocks);
+      if (rc != EVOMG_OK) return rc;
+    }
+    if (write_r) launch_tile3d<TILE_RESNORM_W>(g, st, x, f, r, 0.0, 0.0, TwoCellPlan<T>{}, norm_partials_);
+    else launch_tile3d<TILE_RESNORM>(g, st, x, f, r, 0.0, 0.0, TwoCellPlan<T>{}, norm_partials_);
+    hipLaunchKernelGGL((evomg_sum_stage1<T>), dim3(kDotBlocks), dim3(256), 0, stream_, norm_partials_, count, norm_partials_ + count);
+    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_ + count, kDotBlocks, dscalar_);
+    return EVOMG_OK;
+  }
   int residual_norm_launch(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
     const Geo& g = lv_[L].g;
     const int strips = (g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS;
@@ -1160,7 +1177,7 @@ template <typename T> class Impl : public ImplBase {
     hipLaunchKernelGGL((evomg_copy_faces<T, 3>), fgrid, node_block(), 0, stream_, g, x, y);
   }
   template <int MODE> void launch_tile3d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm,
-                                         TwoCellPlan<T> two = TwoCellPlan<T>{}) {
+                                         TwoCellPlan<T> two = TwoCellPlan<T>{}, T* aux = nullptr) {
     constexpr int TY = EVOMG_TILE3D_TY;
     const int inner = g.n - 2;
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
@@ -1177,7 +1194,7 @@ template <typename T> class Impl : public ImplBase {
     const dim3 grid(((blocks + 7) / 8) * 8);
     const int nt = strip_streams3d(g) ? tile3d_nt_ : 0;
     if constexpr (!scalar_traits<T>::is_complex) {
-#define EVOMG_TILE3D_LAUNCH(NW, NT) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_)
+#define EVOMG_TILE3D_LAUNCH(NW, NT) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux)
 #define EVOMG_TILE3D_NT(NW) if (nt & 1) EVOMG_TILE3D_LAUNCH(NW, 1); else EVOMG_TILE3D_LAUNCH(NW, 0);
       if (nw == 8) { EVOMG_TILE3D_NT(8) } else { EVOMG_TILE3D_NT(4) }
 #undef EVOMG_TILE3D_NT
@@ -1387,11 +1404,17 @@ template <typename T> class Impl : public ImplBase {
     const double t0 = wall_ms();
     T d;
     if (!norm_event_) HIP_TRY(hipEventCreateWithFlags(&norm_event_, hipEventDisableTiming));
+    bool ahead = false, res_stale = false;
     // residual + norm of the current iterate: launched, the scalar copied back asynchronously, an event recorded
     auto residual_norm_launch_all = [&]() -> int {
       int rc = EVOMG_OK;
       if (norm_fused(lv.g)) rc = residual_norm_launch(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
-      else {
+      else if (norm_fused3d(lv.g)) {
+        // the residual field itself is written only if the cycle reads it before overwriting it
+        const bool dead = fuse_enabled_ && loop_residual_is_dead(ops, n_ops);
+        if (dead) res_stale = true;
+        rc = residual_norm_launch3d(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), !dead);
+      } else {
         residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
         dot_async(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), dscalar_);
       }
@@ -1430,7 +1453,6 @@ template <typename T> class Impl : public ImplBase {
       d = hscalar_[0];
       return EVOMG_OK;
     };
-    bool ahead = false, res_stale = false;
     int rc = residual_norm_launch_all();
     if (rc != EVOMG_OK) return rc;
     if ((rc = speculate(&ahead)) != EVOMG_OK) return rc;

@@ -28,7 +28,13 @@
 //            its neighbours by one DPP shift each way and replays the elimination of both tiles it takes part in;
 //   (1,2,1): tiles are the row pairs (row0, row0+1), (row0+2, row0+3) of a wave: no exchange at all.
 // The last inner column / row has no partner (2^L - 1 inner nodes): a one-cell tile, i.e. the point relaxation.
-enum { TILE_BLOCK211 = 4, TILE_BLOCK121 = 5 };
+enum { TILE_BLOCK211 = 4, TILE_BLOCK121 = 5, TILE_RESNORM = 6, TILE_RESNORM_W = 7 };
+// TILE_RESNORM(_W): the solver loop's residual + norm in one pass (K4 + K9): the squared residuals of every inner row
+// (strip s, row j, plane k) are summed over the wave — element a, then element b per lane, then the wave64 tree — into
+// aux[((k-1)*m + (j-1))*n_strips + s]; a second, fixed-order reduction over that array gives the norm. The order depends
+// on the strip width only (not on NW, chunking or workgroup order): it is the canonical summation order of the 3D solver
+// loop from 129^3 up and is restated by the oracle (FN(norm_tile3d)). _W also writes the residual field; without it the
+// pass moves 16 instead of 24 + 8 B/node (the loop's residual field is usually dead: the cycle recomputes it).
 template <typename T> struct TwoCellPlan {
   T fac, upper, pivot0, pivot1;      // BlockPlan: fac[1][0], upper[0][1], pivot[0], pivot[1]
 };
@@ -37,9 +43,11 @@ template <typename T> struct TwoCellPlan {
 template <typename T, int MODE, int NW, int NT>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
-             double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl, int order) {
-  static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == TILE_BLOCK211 || MODE == TILE_BLOCK121,
-                "3D tiles: Jacobi, residual, two-cell block-Jacobi");
+             double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl, int order,
+             T* __restrict__ aux) {
+  static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == TILE_BLOCK211 || MODE == TILE_BLOCK121 ||
+                    MODE == TILE_RESNORM || MODE == TILE_RESNORM_W,
+                "3D tiles: Jacobi, residual (+ norm), two-cell block-Jacobi");
   constexpr int TY = EVOMG_TILE3D_TY;
   __shared__ __attribute__((aligned(16))) T edge[2][NW][2][128];   // [plane parity][wave][first | last row][column]
   const int per_xcd = gridDim.x >> 3;
@@ -200,6 +208,25 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
               if (inner_b) out.b = (c0 + 1 == n - 2) ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm)
                                                      : sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
               store_y(y + plane * k + pitch * row + c0, out);
+            }
+          } else if constexpr (MODE == TILE_RESNORM || MODE == TILE_RESNORM_W) {
+            const bool valid = row <= n - 2 && store_lane;     // (row: wave-uniform)
+            const T ra = residual7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
+            const T rb = residual7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
+            T sq = scalar_traits<T>::zero();
+            if (valid && inner_a) sq = sc_add(sq, sc_mul(ra, ra));
+            if (valid && inner_b) sq = sc_add(sq, sc_mul(rb, rb));
+            sq = wave_sum(sq);                                  // whole wave
+            if (row <= n - 2) {
+              if (lane == 0) aux[((long)(k - 1) * (n - 2) + (row - 1)) * n_strips + strip] = sq;
+              if constexpr (MODE == TILE_RESNORM_W) {
+                if (valid) {
+                  T* dst = y + plane * k + pitch * row + c0;
+                  if (inner_a && inner_b) store_pair(dst, Pair<T>{ra, rb});
+                  else if (inner_a) dst[0] = ra;
+                  else dst[1] = rb;
+                }
+              }
             }
           } else
           if (row <= n - 2 && store_lane) {                    // row: wave-uniform
@@ -388,4 +415,15 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
       }
     }
   }
+}
+
+// first stage of the fixed-order reduction of a long array of partial sums: block b of gridDim.x, thread t adds the
+// elements b*256 + t, + gridDim.x*256, ...; then the block_sum trees; evomg_dot_final adds the block sums
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_sum_stage1(const T* __restrict__ p, long count, T* __restrict__ out) {
+  __shared__ T red[17];
+  T s = scalar_traits<T>::zero();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) s = sc_add(s, p[i]);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }

@@ -881,7 +881,59 @@ static double FN(norm_strip2d)(FN(ctx_t)* c, int level, const SC* r) {
   free(partial);
   return sc_norm_from_dot(FN(block_tree)(th));
 }
+/* Residual norm of the solver loop on 3D levels with at least 129 nodes per dimension: the device forms it in the
+ * residual pass itself (csrc/evomg_tile3d.h, TILE_RESNORM). Order: one partial sum per (plane k, row j, strip s of 124
+ * stored columns): lane l of the wave holds the column pair (c0, c0+1), c0 = 124 s - 2 + 2 l (lanes 0 and 63 are halo
+ * lanes), adds r(c0)^2 then r(c0+1)^2 (inner columns only), the 64 lane values go through the wave tree; the partials,
+ * indexed ((k-1) m + (j-1)) strips + s, are then summed by 1024 blocks of 256 threads striding over the array
+ * (evomg_sum_stage1) and the block sums like the partials of FN(dot). */
+#define TILE_STRIP_COLS 124
+static int FN(norm_is_fused3d)(FN(ctx_t)* c, int level) {
+  return c->dim == 3 && !SC_IS_COMPLEX && c->lv[level].n >= 129 && c->prob.bc_kind == EVOMG_BC_DIRICHLET;
+}
+static double FN(norm_tile3d)(FN(ctx_t)* c, int level, const SC* r) {
+  const int n = c->lv[level].n, m = n - 2;
+  const int strips = (n + TILE_STRIP_COLS - 1) / TILE_STRIP_COLS;
+  const long count = (long)m * m * strips;
+  SC* part = (SC*)malloc(sizeof(SC) * (size_t)count);
+#pragma omp parallel for schedule(static)
+  for (int k = 1; k <= m; ++k)
+    for (int j = 1; j <= m; ++j)
+      for (int s = 0; s < strips; ++s) {
+        SC lane[64];
+        for (int l = 0; l < 64; ++l) {
+          SC acc = sc_zero();
+          const int c0 = s * TILE_STRIP_COLS - 2 + 2 * l;
+          if (l >= 1 && l <= 62 && c0 >= 0 && c0 < n)
+            for (int e = 0; e < 2; ++e) {
+              const int i = c0 + e;
+              if (i < 1 || i > n - 2) continue;
+              const SC v = r[IDX3(n, i, j, k)];
+              acc = sc_add(acc, sc_mul(v, v));
+            }
+          lane[l] = acc;
+        }
+        part[((long)(k - 1) * m + (j - 1)) * strips + s] = FN(tree64)(lane);
+      }
+  SC block[DOT_BLOCKS];
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < DOT_BLOCKS; ++b) {
+    SC th[DOT_THREADS];
+    for (int t = 0; t < DOT_THREADS; ++t) {
+      SC acc = sc_zero();
+      for (long i = (long)b * DOT_THREADS + t; i < count; i += (long)DOT_BLOCKS * DOT_THREADS) acc = sc_add(acc, part[i]);
+      th[t] = acc;
+    }
+    block[b] = FN(block_tree)(th);
+  }
+  free(part);
+  SC th[DOT_THREADS];
+  for (int t = 0; t < DOT_THREADS; ++t) th[t] = sc_zero();
+  for (int i = 0; i < DOT_BLOCKS; ++i) th[i % DOT_THREADS] = sc_add(th[i % DOT_THREADS], block[i]);
+  return sc_norm_from_dot(FN(block_tree)(th));
+}
 static double FN(solver_res_norm)(FN(ctx_t)* c, int level, const SC* r) {
+  if (FN(norm_is_fused3d)(c, level)) return FN(norm_tile3d)(c, level, r);
   return FN(norm_is_fused)(c, level) ? FN(norm_strip2d)(c, level, r) : FN(norm)(c, level, r);
 }
 

@@ -126,3 +126,26 @@ def test_c3_helmholtz_2048_reference_cycle(native):
     again = h.evaluate(ops, 1, 600e3, 160)
     assert np.array_equal(again.history, out.history)
     print(f"C3: 150 outer iterations in {out.time_ms:.0f} ms ({out.time_ms / 150:.2f} ms per iteration = 2 MG cycles + 5 dots)")
+
+
+@pytest.mark.parametrize("smoother", ["block211", "rbgs"])
+def test_poisson3d_129_against_the_oracle(native, smoother):
+    """129^3 is the smallest grid on which the LDS-sharing tile kernels and the fused residual + norm pass of the solver
+    loop run by default: whole solves against the oracle (which restates the fused norm's summation order): same
+    iteration count, residual history to round-off, solution bit-identical."""
+    from oracle import oracle
+    lo, hi = 5, 7
+    pd = problems.poisson_3d(lo, hi)
+    if smoother == "rbgs":
+        sm = lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.15)
+    else:
+        sm = lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (2, 1, 1), 0.8)
+    ops = vcycle(lo, hi, 2, 2, sm)
+    hg, ho = native.create(pd), oracle.create(pd)
+    a, b = hg.evaluate(ops, 1, 0, 128), ho.evaluate(ops, 1, 0, 128)
+    assert a.status == b.status == abi.SOLVE_CONVERGED and a.n_iterations == b.n_iterations
+    assert np.max(np.abs(a.history - b.history) / b.history) <= 1e-12
+    assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+    assert np.array_equal(hg.get_field(hi, abi.F_RES), ho.get_field(hi, abi.F_RES))
+    hg.close()
+    ho.close()
