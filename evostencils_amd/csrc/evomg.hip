@@ -538,6 +538,12 @@ template <typename T> class Impl : public ImplBase {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
         continue;
       }
+      if (fusable_twice(ops, n_ops, i)) {
+        const int rc = exec_twice(ops[i]);
+        if (rc != EVOMG_OK) return rc;
+        ++i;
+        continue;
+      }
       if (fusable_smooth_residual_restrict(ops, n_ops, i, cyclic)) {
         const evomg_op_t &sm = ops[i], &rs = ops[i + 2];
         const int L = sm.level;
@@ -1201,6 +1207,60 @@ template <typename T> class Impl : public ImplBase {
 #undef EVOMG_TILE3D_LAUNCH
     }
   }
+  // two identical Jacobi-type sweeps in a row on one field (evomg_tile3d_twice): same geometry as the red-black tiles
+  template <int MODE> void launch_tile3d_twice(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm,
+                                               TwoCellPlan<T> two) {
+    constexpr int TY = EVOMG_TILE3D_TY;
+    constexpr int cols = (MODE == TILE_BLOCK211) ? 120 : EVOMG_STRIP_COLS;      // two halo lanes per side for the blocks
+    const int strips = (g.n + cols - 1) / cols;
+    const int nw = 8;
+    const int stored = nw * TY - 2;
+    const int ygroups = (g.n - 3 + stored - 1) / stored > 0 ? (g.n - 3 + stored - 1) / stored : 1;
+    int planes = strip_planes_ > 0 ? strip_planes_ : 16;
+    planes = (planes + 3) & ~3;
+    const int chunks = (g.n - 2 + planes - 1) / planes;
+    const int blocks = strips * ygroups * chunks;
+    const dim3 grid(((blocks + 7) / 8) * 8);
+    if constexpr (!scalar_traits<T>::is_complex)
+      hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two);
+  }
+  // SMOOTH, SMOOTH: the same Single-partitioned point or (2,1,1) block smoother twice in a row on the same field, on a 3D
+  // level the tiles serve (>= 257^3: below, two launches are as fast)
+  bool fusable_twice(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || !tile3d_twice_ || dim_ != 3 || scalar_traits<T>::is_complex || i + 1 >= n_ops) return false;
+    const evomg_op_t &a = ops[i], &b = ops[i + 1];
+    if (a.opcode != EVOMG_OP_SMOOTH || b.opcode != EVOMG_OP_SMOOTH || a.level != b.level) return false;
+    if (a.partitioning != EVOMG_PART_SINGLE || b.partitioning != EVOMG_PART_SINGLE || a.omega != b.omega) return false;
+    if (canon(a.level, a.dst) != canon(b.level, b.dst) || canon(a.level, a.src1) != canon(b.level, b.src1)) return false;
+    if (canon(a.level, a.src1) == canon(a.level, a.dst)) return false;
+    for (int d = 0; d < 3; ++d) if (a.block[d] != b.block[d]) return false;
+    const bool point = a.block[0] == 1 && a.block[1] == 1 && a.block[2] == 1;
+    const bool b211 = a.block[0] == 2 && a.block[1] == 1 && a.block[2] == 1 && block_fast_;
+    if (!point && !b211) return false;
+    if (prof_matches(a)) return false;
+    const Geo& g = lv_[a.level].g;
+    return use_tile3d_blocks(g);
+  }
+  int exec_twice(const evomg_op_t& sm) {
+    const int L = sm.level;
+    Level<T>& lv = lv_[L];
+    T* x = fieldptr(L, sm.dst);
+    const T* f = fieldptr(L, sm.src1);
+    T* y = lv.alt;
+    const double om = sm.omega, omm = 1.0 - sm.omega;
+    ensure_faces(lv, x, y);
+    if constexpr (!scalar_traits<T>::is_complex) {
+      if (sm.block[0] == 2) {
+        const BlockPlan<T> pl = make_block_plan<T, 3>(lv.st, 2, 1, 1);
+        launch_tile3d_twice<TILE_BLOCK211>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{pl.fac[1][0], pl.upper[0][1], pl.pivot[0], pl.pivot[1]});
+      } else {
+        launch_tile3d_twice<STRIP_JACOBI>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{});
+      }
+    }
+    advance(lv, L, sm, x, y);      // two sweeps, one pass: the result lives in the spare array -> ONE swap
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }
   void launch_tile3d_rbgs(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm) {
     constexpr int TY = EVOMG_TILE3D_TY;
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
@@ -1434,6 +1494,7 @@ template <typename T> class Impl : public ImplBase {
       // a sweep that fuses with the residual + restriction behind it is worth more than the overlap (and the fused
       // kernel writes the coarse right-hand side, which a speculative launch must not)
       if (fusable_smooth_residual_restrict(ops, n_ops, 0, true)) return EVOMG_OK;
+      if (fusable_twice(ops, n_ops, 0)) return EVOMG_OK;          // two sweeps in one pass beat the overlap
       const int l0 = ops[0].level;
       saved_alt = lv_[l0].alt;
       saved_mirror = lv_[l0].alt_mirror;
@@ -1651,6 +1712,7 @@ template <typename T> class Impl : public ImplBase {
   int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
   bool tile3d_enabled_ = getenv("EVOMG_NO_TILE3D") == nullptr;
   bool tile3d_rbgs_ = getenv("EVOMG_NO_TILE3D_RBGS") == nullptr;
+  bool tile3d_twice_ = getenv("EVOMG_NO_TILE3D_TWICE") == nullptr;
   int tile3d_nt_ = getenv("EVOMG_TILE3D_NT") ? atoi(getenv("EVOMG_TILE3D_NT")) : 0;   // bit 0: non-temporal f loads (measured slower at 513^3: profiles/r02_pmc_3d.md)
   int tile3d_order_ = getenv("EVOMG_TILE3D_ORDER") ? atoi(getenv("EVOMG_TILE3D_ORDER")) : 1;
   int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;

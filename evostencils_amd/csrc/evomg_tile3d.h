@@ -427,3 +427,168 @@ __global__ void __launch_bounds__(256) evomg_sum_stage1(const T* __restrict__ p,
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
+
+// ---- TWO consecutive Jacobi-type sweeps in one pass (temporal fusion) --------------------------------------------------
+// V(2,2)-type candidates relax the same field twice in a row with the same smoother (BASELINE config C4: block-Jacobi
+// (2,1,1) twice before and twice after the coarse-grid correction). The red-black kernel above is already a two-stage
+// pipeline along z; here both stages are full sweeps: at step k the wave forms y1 = S(x) on plane k from old values and
+// then y2 = S(y1) on plane k-1 from y1 on the planes k-2, k-1, k (registers) — y1 never reaches memory: x and f are read
+// once, y2 is written once, 24 instead of 48 B/node for the pair. y direction as in evomg_tile3d_rbgs: waves trade the
+// old-x edge rows of plane k+1 and the y1 edge rows of plane k through LDS on the step's single barrier; a workgroup
+// forms y1 on its 32 rows, finishes y2 on 30, consecutive workgroups overlap by two rows; the topmost workgroup finishes
+// its last row against the boundary row (y1 = x there). Sweep arithmetic = the one-sweep tile kernel's, applied twice:
+// bit-identical to two launches.
+template <typename T, int MODE, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW)
+evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
+                   double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl) {
+  static_assert(MODE == STRIP_JACOBI || MODE == TILE_BLOCK211, "two fused sweeps: point Jacobi and (2,1,1) blocks");
+  constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
+  __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x of the next centre plane
+  __shared__ __attribute__((aligned(16))) T edge_y[2][NW][2][128];   // y1 of the current centre plane
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (logical_block >= n_blocks) return;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = logical_block % n_strips;
+  const int ygroup = (logical_block / n_strips) % n_ygroups;
+  const int chunk = logical_block / (n_ygroups * n_strips);
+  const int n = g.n;
+  const long pitch = g.pitch, plane = g.plane;
+  // halo lanes per side: one for point Jacobi; two for the (2,1,1) blocks, whose tiles pair element b of a lane with
+  // element a of its right neighbour — the second sweep's tile at the strip's edge reads a first-sweep value that the
+  // outermost lane cannot form (its own tile partner lies outside the wave)
+  constexpr int HALO = (MODE == TILE_BLOCK211) ? 2 : 1;
+  constexpr int COLS = 128 - 4 * HALO;
+  const int c0 = strip * COLS - 2 * HALO + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int R0 = ygroup * (H - 2);
+  const int row0 = R0 + w * TY;
+  const bool top_group = R0 + H - 1 >= n - 2;
+  const int z0 = 1 + chunk * planes_per_chunk;                // stored planes [z0, z1)
+  const int z1 = min(z0 + planes_per_chunk, n - 1);
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= HALO && lane <= 63 - HALO && col_ok && (inner_a || inner_b);
+  const int c_clamped = min(max(c0, 0), n - 1);
+  const T zero = scalar_traits<T>::zero();
+  const Pair<T> zpair{zero, zero};
+  auto load_x = [&](int row, int pl_) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl_, 0), n - 1);
+    return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+  };
+  auto load_f = [&](int row, int pl_) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl_, 0), n - 1);
+    if constexpr ((NT & 1) != 0) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
+    else return load_pair<T>(f + plane * p + pitch * r + c_clamped);
+  };
+  auto park = [&](T (*edge)[NW][2][128], int parity, const Pair<T>& first, const Pair<T>& last) {
+    *reinterpret_cast<Pair<T>*>(&edge[parity][w][0][2 * lane]) = first;
+    *reinterpret_cast<Pair<T>*>(&edge[parity][w][1][2 * lane]) = last;
+  };
+  auto pick = [&](T (*edge)[NW][2][128], int parity, int wave, int which) -> Pair<T> {
+    return *reinterpret_cast<const Pair<T>*>(&edge[parity][wave][which][2 * lane]);
+  };
+  // one sweep at one row: centre pair c with its south / north / down / up pairs and right-hand side; non-inner nodes keep
+  // their value. Whole wave (DPP shifts inside).
+  auto sweep = [&](const Pair<T>& c, const Pair<T>& s, const Pair<T>& nn, const Pair<T>& dn, const Pair<T>& up,
+                   const Pair<T>& fk, bool node_rows_inner) -> Pair<T> {
+    Pair<T> out = c;
+    const T wa = from_left(c.b), eb = from_right(c.a);
+    if constexpr (MODE == STRIP_JACOBI) {
+      const T ra = relax7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a, om, omm);
+      const T rb = relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
+      if (node_rows_inner && inner_a) out.a = ra;
+      if (node_rows_inner && inner_b) out.b = rb;
+    } else {
+      T rb0 = fk.b;
+      rb0 = sc_sub(rb0, sc_mul(st.c[1], c.a));
+      rb0 = sc_sub(rb0, sc_mul(st.c[3], s.b));
+      rb0 = sc_sub(rb0, sc_mul(st.c[4], nn.b));
+      rb0 = sc_sub(rb0, sc_mul(st.c[5], dn.b));
+      rb0 = sc_sub(rb0, sc_mul(st.c[6], up.b));
+      T ra1 = fk.a;
+      ra1 = sc_sub(ra1, sc_mul(st.c[2], c.b));
+      ra1 = sc_sub(ra1, sc_mul(st.c[3], s.a));
+      ra1 = sc_sub(ra1, sc_mul(st.c[4], nn.a));
+      ra1 = sc_sub(ra1, sc_mul(st.c[5], dn.a));
+      ra1 = sc_sub(ra1, sc_mul(st.c[6], up.a));
+      const T r0_left = from_left(rb0), r1_right = from_right(ra1);
+      const T xa = sc_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), pl.pivot1);
+      const T x1 = sc_div(sc_sub(r1_right, sc_mul(pl.fac, rb0)), pl.pivot1);
+      const T xb = sc_div(sc_sub(rb0, sc_mul(pl.upper, x1)), pl.pivot0);
+      const T single = relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);   // last inner column: one-cell tile
+      if (node_rows_inner && inner_a) out.a = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa));
+      if (node_rows_inner && inner_b) out.b = (c0 + 1 == n - 2) ? single : sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
+    }
+    return out;
+  };
+
+  const int ks = z0 - 1;
+  const int ke = z1 + 1;
+  Pair<T> xb[TY], xc[TY], xa[TY], xq[TY];      // old x, planes k-1, k, k+1, k+2 (prefetch); own rows
+  Pair<T> fb[TY], fc[TY], fq[TY];              // f, planes k-1, k, k+1 (prefetch)
+  Pair<T> p2[TY], p1[TY], pc[TY];              // y1 on planes k-2, k-1, k
+  Pair<T> hs, hn, gs = zpair, gn = zpair;      // old-x halo rows of the centre plane / of the next one (outermost waves)
+  Pair<T> hn_prev;                             // old-x row above the wave in plane k-1 (top group: the boundary row)
+  Pair<T> ys1 = zpair, yn1 = zpair;            // y1 of plane k-1 in the rows below / above the wave
+#pragma unroll
+  for (int t = 0; t < TY; ++t) {
+    xb[t] = load_x(row0 + t, ks - 1);
+    xc[t] = load_x(row0 + t, ks);
+    xa[t] = load_x(row0 + t, ks + 1);
+    fc[t] = load_f(row0 + t, ks);
+    fb[t] = zpair;
+    p2[t] = zpair;
+    p1[t] = zpair;
+  }
+  hs = load_x(row0 - 1, ks);
+  hn = load_x(row0 + TY, ks);
+  hn_prev = hn;
+  park(edge_x, ks & 1, xc[0], xc[TY - 1]);
+  __syncthreads();
+  if (w > 0) hs = pick(edge_x, ks & 1, w - 1, 1);
+  if (w < NW - 1) hn = pick(edge_x, ks & 1, w + 1, 0);
+
+  for (int k = ks; k < ke; ++k) {
+#pragma unroll
+    for (int t = 0; t < TY; ++t) xq[t] = load_x(row0 + t, k + 2);
+#pragma unroll
+    for (int t = 0; t < TY; ++t) fq[t] = load_f(row0 + t, k + 1);
+    if (w == 0) gs = load_x(row0 - 1, k + 1);
+    if (w == NW - 1) gn = load_x(row0 + TY, k + 1);
+    park(edge_x, (k + 1) & 1, xa[0], xa[TY - 1]);
+    const bool plane_inner = k >= 1 && k <= n - 2;
+    // ---- first sweep: y1 on plane k, own rows ----
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      const int row = row0 + t;
+      const Pair<T> s = (t == 0) ? hs : xc[t > 0 ? t - 1 : 0], nn = (t == TY - 1) ? hn : xc[t < TY - 1 ? t + 1 : t];
+      pc[t] = sweep(xc[t], s, nn, xb[t], xa[t], fc[t], plane_inner && row >= 1 && row <= n - 2);
+    }
+    park(edge_y, k & 1, pc[0], pc[TY - 1]);
+    // ---- second sweep: y2 on plane k-1, own rows, from y1 on the planes k-2, k-1, k ----
+    const int kb2 = k - 1;
+    const bool bplane_inner = kb2 >= 1 && kb2 <= n - 2;
+    const bool bplane_stored = kb2 >= z0 && kb2 < z1;
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      const int row = row0 + t;
+      const Pair<T> s = (t == 0) ? ys1 : p1[t > 0 ? t - 1 : 0];
+      // the boundary row above the topmost workgroup: y1 = x there
+      const Pair<T> nn = (t == TY - 1) ? ((w == NW - 1 && top_group) ? hn_prev : yn1) : p1[t < TY - 1 ? t + 1 : t];
+      const Pair<T> out = sweep(p1[t], s, nn, p2[t], pc[t], fb[t], bplane_inner && row >= 1 && row <= n - 2);
+      const bool row_stored = row >= 1 && row <= n - 2 && row >= R0 + 1 && (row <= R0 + H - 2 || top_group);
+      if (store_lane && bplane_stored && row_stored) store_pair(y + plane * kb2 + pitch * row + c0, out);
+    }
+    __syncthreads();
+    hn_prev = hn;
+    hs = (w > 0) ? pick(edge_x, (k + 1) & 1, w - 1, 1) : gs;
+    hn = (w < NW - 1) ? pick(edge_x, (k + 1) & 1, w + 1, 0) : gn;
+    ys1 = (w > 0) ? pick(edge_y, k & 1, w - 1, 1) : zpair;
+    yn1 = (w < NW - 1) ? pick(edge_y, k & 1, w + 1, 0) : zpair;
+#pragma unroll
+    for (int t = 0; t < TY; ++t) { p2[t] = p1[t]; p1[t] = pc[t]; fb[t] = fc[t]; fc[t] = fq[t]; xb[t] = xc[t]; xc[t] = xa[t]; xa[t] = xq[t]; }
+  }
+}
