@@ -566,6 +566,14 @@ template <typename T> class Impl : public ImplBase {
         i += 2;
         continue;
       }
+      if (fusable_residual_restrict3d(ops, n_ops, i, cyclic)) {
+        const int L = ops[i].level;
+        launch_tile3d_residual_restrict(L, fieldptr(L, ops[i].src0), fieldptr(L, ops[i].src1), fieldptr(L - 1, ops[i + 1].dst));
+        apply_bc(L - 1, fieldptr(L - 1, ops[i + 1].dst));
+        HIP_TRY(hipGetLastError());
+        ++i;
+        continue;
+      }
       if (fusable_residual_restrict(ops, n_ops, i)) {
         const bool write_r = !(cyclic && residual_dead_after(ops, n_ops, i));
         const int L = ops[i].level;
@@ -1279,6 +1287,37 @@ template <typename T> class Impl : public ImplBase {
       else hipLaunchKernelGGL((evomg_tile3d_rbgs<T, 4, 0>), grid, dim3(256), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
     }
   }
+  // RESIDUAL@L, RESTRICT@(L-1) of that residual on a 3D level the tiles serve, the residual field dead afterwards
+  // (evomg_tile3d_residual_restrict never writes it)
+  bool fusable_residual_restrict3d(const evomg_op_t* ops, int n_ops, int i, bool cyclic) const {
+    if (!fuse_enabled_ || !tile3d_rr_ || dim_ != 3 || scalar_traits<T>::is_complex || !cyclic || i + 1 >= n_ops) return false;
+    const evomg_op_t &a = ops[i], &b = ops[i + 1];
+    if (a.opcode != EVOMG_OP_RESIDUAL || b.opcode != EVOMG_OP_RESTRICT) return false;
+    if (b.level != a.level - 1 || canon(a.level, b.src0) != canon(a.level, a.dst)) return false;
+    if (canon(a.level, a.dst) == canon(a.level, a.src0) || canon(a.level, a.dst) == canon(a.level, a.src1)) return false;
+    if (prob_.bc_kind != EVOMG_BC_DIRICHLET || !use_tile3d(lv_[a.level].g)) return false;
+    if ((a.opcode == prof_opcode_ && a.level == prof_level_) || (b.opcode == prof_opcode_ && b.level == prof_level_)) return false;
+    return residual_dead_after(ops, n_ops, i);
+  }
+  void launch_tile3d_residual_restrict(int L, const T* x, const T* f, T* coarse) {
+    constexpr int TY = EVOMG_TILE3D_TY;
+    const Geo& g = lv_[L].g;
+    const Geo& gc = lv_[L - 1].g;
+    const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+    const int rows_c = gc.n - 2;                                  // coarse rows / planes to produce
+    int nw = tile3d_waves_ > 0 ? tile3d_waves_ : 8;
+    if (tile3d_waves_ == 0 && (long)strips * ((rows_c + 14) / 15) * ((rows_c + 7) / 8) < 1024) nw = 4;
+    const int per_group = (nw * TY - 2) / 2;                      // coarse rows a workgroup finishes: 15 (7 with four waves)
+    const int ygroups = (rows_c + per_group - 1) / per_group;
+    int cplanes = strip_planes_ > 0 ? (strip_planes_ + 1) / 2 : 8;   // fine planes per chunk: 2 * cplanes + 1
+    const int chunks = (rows_c + cplanes - 1) / cplanes;
+    const int blocks = strips * ygroups * chunks;
+    const dim3 grid(((blocks + 7) / 8) * 8);
+    if constexpr (!scalar_traits<T>::is_complex) {
+      if (nw == 8) hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, 8, 0>), grid, dim3(512), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks);
+      else hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, 4, 0>), grid, dim3(256), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks);
+    }
+  }
   bool strip_streams3d(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.plane * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
 
   // bc_out: the caller applies the boundary condition to r afterwards (the strip kernel then does it itself)
@@ -1705,6 +1744,7 @@ template <typename T> class Impl : public ImplBase {
   bool use_reg_krylov_ = (getenv("EVOMG_NO_REG_KRYLOV") == nullptr);
   bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
+  bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;

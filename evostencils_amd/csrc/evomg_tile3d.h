@@ -592,3 +592,152 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
     for (int t = 0; t < TY; ++t) { p2[t] = p1[t]; p1[t] = pc[t]; fb[t] = fc[t]; fc[t] = fq[t]; xb[t] = xc[t]; xc[t] = xa[t]; xa[t] = xq[t]; }
   }
 }
+
+// ---- 3D residual + full-weighting restriction in one pass (K4 + K5) ---------------------------------------------------
+// coarse(I,J,K) = sum of the 27 fine residuals around (2I,2J,2K), weighted 1/8, 1/16, 1/32, 1/64 — without the residual
+// field ever reaching memory (24 B/node -> 16 B/node + the coarse field; the separate kernels move 24 + 8 + 1 B/node).
+// Geometry of the red-black tiles: a workgroup computes the residual on H = NW*4 rows x 128 columns and marches along z;
+//   * lane = column pair (c0 even, c0 + 1): the coarse column c0/2 sits on element a; its x neighbours are the lane's own
+//     b and the left lane's b (one DPP shift per row); lanes 1..62 produce coarse nodes (62 per strip);
+//   * coarse rows sit on the wave's local rows 0 and 2 (row0 is even): row 2 needs the wave's rows 1..3, row 0 needs the
+//     LAST residual row of the wave below — parked in LDS, riding on the step's single barrier; the workgroup's first row
+//     has no such neighbour, so it finishes the coarse rows at local rows 2, 4, .., H-2 and consecutive workgroups overlap
+//     by two rows, as the red-black tiles do;
+//   * planes: fine plane k = 2K is the centre plane of coarse plane K, the odd planes around it feed two coarse planes
+//     each. A chunk of C coarse planes computes the residual on 2C + 1 fine planes.
+// Summation order = evomg_restrict<T,3> (loop order dz, dy, dx; face / edge / corner sums carried across the three planes
+// in that order) on residuals computed by residual7 = evomg_apply: bit-identical to the two separate kernels.
+template <typename T, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW)
+evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
+                               T* __restrict__ coarse, int cplanes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
+  constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
+  static_assert(TY == 4 && (H - 2) % 2 == 0, "coarse rows on local rows 0 and 2 of every wave");
+  __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // x: [plane parity][wave][first | last row][column]
+  __shared__ __attribute__((aligned(16))) T edge_r[2][NW][128];      // residual: last row of the wave
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (logical_block >= n_blocks) return;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = logical_block % n_strips;                 // strip fastest: concurrent workgroups cover whole rows
+  const int ygroup = (logical_block / n_strips) % n_ygroups;
+  const int chunk = logical_block / (n_ygroups * n_strips);
+  const int n = g.n, nc = gc.n;
+  const long pitch = g.pitch, plane = g.plane;
+  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;      // even
+  const int R0 = ygroup * (H - 2);                            // even
+  const int row0 = R0 + w * TY;
+  const int K0 = 1 + chunk * cplanes_per_chunk;               // coarse planes [K0, K1)
+  const int K1 = min(K0 + cplanes_per_chunk, nc - 1);
+  const int ks = 2 * K0 - 1, ke = 2 * K1;                     // fine planes [ks, ke): odd first and last plane
+  const int c_clamped = min(max(c0, 0), n - 1);
+  const T zero = scalar_traits<T>::zero();
+  const Pair<T> zpair{zero, zero};
+  auto load_x = [&](int row, int pl_) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl_, 0), n - 1);
+    return load_pair<T>(x + plane * p + pitch * r + c_clamped);
+  };
+  auto load_f = [&](int row, int pl_) -> Pair<T> {
+    const int r = min(max(row, 0), n - 1), p = min(max(pl_, 0), n - 1);
+    if constexpr ((NT & 1) != 0) return load_pair_nt<T>(f + plane * p + pitch * r + c_clamped);
+    else return load_pair<T>(f + plane * p + pitch * r + c_clamped);
+  };
+  auto park_x = [&](int parity, const Pair<T>& first, const Pair<T>& last) {
+    *reinterpret_cast<Pair<T>*>(&edge_x[parity][w][0][2 * lane]) = first;
+    *reinterpret_cast<Pair<T>*>(&edge_x[parity][w][1][2 * lane]) = last;
+  };
+  auto pick_x = [&](int parity, int wave, int which) -> Pair<T> {
+    return *reinterpret_cast<const Pair<T>*>(&edge_x[parity][wave][which][2 * lane]);
+  };
+  // the two coarse nodes of this lane: column c0 / 2, rows (row0 + 0) / 2 and (row0 + 2) / 2
+  const int I = c0 >> 1;
+  const bool col_valid = lane >= 1 && lane <= 62 && I >= 1 && I <= nc - 2;
+  bool valid[2];
+  long cidx[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int J = (row0 + 2 * q) >> 1;
+    valid[q] = col_valid && J >= 1 && J <= nc - 2 && !(w == 0 && q == 0);
+    cidx[q] = (long)gc.pitch * min(max(J, 0), nc - 1) + min(max(I, 0), nc - 1);
+  }
+
+  Pair<T> xb[TY], xc[TY], xa[TY], xq[TY];      // x, planes k-1, k, k+1, k+2 (prefetch); own rows
+  Pair<T> fc[TY], fq[TY];                      // f, planes k, k+1 (prefetch)
+  Pair<T> hs, hn, gs = zpair, gn = zpair;      // x halo rows of the centre plane / of the next one (outermost waves)
+  T face[2], edg[2], cor[2], cen[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) face[q] = edg[q] = cor[q] = cen[q] = zero;
+#pragma unroll
+  for (int t = 0; t < TY; ++t) {
+    xb[t] = load_x(row0 + t, ks - 1);
+    xc[t] = load_x(row0 + t, ks);
+    xa[t] = load_x(row0 + t, ks + 1);
+    fc[t] = load_f(row0 + t, ks);
+  }
+  hs = load_x(row0 - 1, ks);
+  hn = load_x(row0 + TY, ks);
+  park_x(ks & 1, xc[0], xc[TY - 1]);
+  __syncthreads();
+  if (w > 0) hs = pick_x(ks & 1, w - 1, 1);
+  if (w < NW - 1) hn = pick_x(ks & 1, w + 1, 0);
+
+  for (int k = ks; k < ke; ++k) {
+#pragma unroll
+    for (int t = 0; t < TY; ++t) xq[t] = load_x(row0 + t, k + 2);
+#pragma unroll
+    for (int t = 0; t < TY; ++t) fq[t] = load_f(row0 + t, k + 1);
+    if (w == 0) gs = load_x(row0 - 1, k + 1);
+    if (w == NW - 1) gn = load_x(row0 + TY, k + 1);
+    park_x((k + 1) & 1, xa[0], xa[TY - 1]);
+    // ---- residual of plane k, own rows (whole wave: DPP shifts inside) ----
+    Pair<T> rk[TY];
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      const Pair<T> c = xc[t], s = (t == 0) ? hs : xc[t > 0 ? t - 1 : 0], nn = (t == TY - 1) ? hn : xc[t < TY - 1 ? t + 1 : t];
+      const T wa = from_left(c.b), eb = from_right(c.a);
+      rk[t].a = residual7(st, c.a, wa, c.b, s.a, nn.a, xb[t].a, xa[t].a, fc[t].a);
+      rk[t].b = residual7(st, c.b, c.a, eb, s.b, nn.b, xb[t].b, xa[t].b, fc[t].b);
+    }
+    *reinterpret_cast<Pair<T>*>(&edge_r[k & 1][w][2 * lane]) = rk[TY - 1];
+    __syncthreads();
+    hs = (w > 0) ? pick_x((k + 1) & 1, w - 1, 1) : gs;
+    hn = (w < NW - 1) ? pick_x((k + 1) & 1, w + 1, 0) : gn;
+    const Pair<T> rs = (w > 0) ? *reinterpret_cast<const Pair<T>*>(&edge_r[k & 1][w - 1][2 * lane]) : zpair;
+    // ---- the contributions of plane k to the coarse nodes ----
+    const T lbs = from_left(rs.b);
+    T lb[TY];
+#pragma unroll
+    for (int t = 0; t < TY; ++t) lb[t] = from_left(rk[t].b);
+    const bool odd = (k & 1) != 0;                           // uniform
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = 2 * q;
+      const Pair<T> south = (q == 0) ? rs : rk[1], mid = rk[j], north = rk[j + 1];
+      const T lsouth = (q == 0) ? lbs : lb[1], lmid = lb[j], lnorth = lb[j + 1];
+      const T C = mid.a, W = lmid, E = mid.b, S = south.a, N = north.a;
+      const T SW = lsouth, SE = south.b, NW_ = lnorth, NE = north.b;
+      if (odd) {
+        // upper plane of coarse plane (k-1)/2 ...
+        const T fa = sc_add(face[q], C);
+        const T ed = sc_add(sc_add(sc_add(sc_add(edg[q], S), W), E), N);
+        const T co = sc_add(sc_add(sc_add(sc_add(cor[q], SW), SE), NW_), NE);
+        T v = sc_rmul(0.125, cen[q]);
+        v = sc_add(v, sc_rmul(0.0625, fa));
+        v = sc_add(v, sc_rmul(0.03125, ed));
+        v = sc_add(v, sc_rmul(0.015625, co));
+        if (k > ks && valid[q]) coarse[(long)gc.plane * ((k - 1) >> 1) + cidx[q]] = v;
+        // ... and lower plane of coarse plane (k+1)/2
+        face[q] = sc_add(zero, C);
+        edg[q] = sc_add(sc_add(sc_add(sc_add(zero, S), W), E), N);
+        cor[q] = sc_add(sc_add(sc_add(sc_add(zero, SW), SE), NW_), NE);
+      } else {
+        face[q] = sc_add(sc_add(sc_add(sc_add(face[q], S), W), E), N);
+        edg[q] = sc_add(sc_add(sc_add(sc_add(edg[q], SW), SE), NW_), NE);
+        cen[q] = C;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TY; ++t) { fc[t] = fq[t]; xb[t] = xc[t]; xc[t] = xa[t]; xa[t] = xq[t]; }
+  }
+}

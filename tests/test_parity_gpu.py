@@ -421,6 +421,40 @@ def test_marching_tile_kernels_3d_match_generic_kernels(native, level, planes, w
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("smoother,pre,post,planes,waves", [("block211", 2, 2, 0, 0), ("jacobi", 2, 2, 8, 4), ("rbgs", 1, 1, 0, 8),
+                                                              ("block211", 1, 2, 12, 8)])
+def test_sweep_fusions_3d_do_not_change_a_bit(native, smoother, pre, post, planes, waves, monkeypatch):
+    """3D whole solves (129^3, three levels; the tiles forced onto 65^3 too) with the interpreter's fusions — two sweeps in
+    one pass (evomg_tile3d_twice), residual + restriction without the residual field (evomg_tile3d_residual_restrict),
+    residual + norm (TILE_RESNORM) — against the same solves with EVOMG_NO_FUSE: identical residual histories,
+    solutions, residuals and coarse right-hand sides."""
+    from test_full_size_gpu import vcycle
+    lo, hi = 5, 7
+    pd = problems.poisson_3d(lo, hi)
+    part, block, om = {"block211": (abi.PART_SINGLE, (2, 1, 1), 0.8), "jacobi": (abi.PART_SINGLE, (1, 1, 1), 0.8),
+                       "rbgs": (abi.PART_RED_BLACK, (1, 1, 1), 1.1)}[smoother]
+    ops = vcycle(lo, hi, pre, post, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, block, om))
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "33")
+    monkeypatch.setenv("EVOMG_STRIP_PLANES", str(planes))
+    monkeypatch.setenv("EVOMG_TILE3D_WAVES", str(waves))
+    results = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("EVOMG_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("EVOMG_NO_FUSE", raising=False)
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 128)
+        results.append((out, h.get_field(hi, abi.F_SOL), h.get_field(hi, abi.F_RES), h.get_field(hi - 1, abi.F_RHS),
+                        h.get_field(lo, abi.F_RHS)))
+        h.close()
+    (a, *fa), (b, *fb) = results
+    assert a.status == b.status and a.n_iterations == b.n_iterations and a.n_iterations > 3
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("smoother,pre,post", [("rbgs", 1, 1), ("rbgs", 2, 2), ("jacobi", 1, 2), ("rbgs", 0, 1), ("jacobi", 2, 0)])
 def test_sweep_fusions_do_not_change_a_bit(native, smoother, pre, post, monkeypatch):
     """Whole solves with every optimisation of the interpreter (residual+restriction, prolongation+smoother,

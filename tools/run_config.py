@@ -1,5 +1,5 @@
 """Developer tool: run one of the BASELINE.json configurations once on the GPU (for rocprofv3).
-usage: python tools/run_config.py c4|c2|c3|c5"""
+usage: python tools/run_config.py c4|c2|c3|c5|t9|t8"""
 import os, sys, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
@@ -17,6 +17,11 @@ elif cfg == "c2":
     ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
 elif cfg == "c5":
     lo, hi = 7, 11
+    pd = problems.poisson_2d(lo, hi)
+    ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
+elif cfg in ("t9", "t8"):
+    # the reference's own operating size (notebooks/tutorial.ipynb: levels 5..9 = 513^2, five levels)
+    lo, hi = (5, 9) if cfg == "t9" else (4, 8)
     pd = problems.poisson_2d(lo, hi)
     ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
 else:
