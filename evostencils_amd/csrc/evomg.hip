@@ -1224,7 +1224,7 @@ template <typename T> class Impl : public ImplBase {
     const int nw = 8;
     const int stored = nw * TY - 2;
     const int ygroups = (g.n - 3 + stored - 1) / stored > 0 ? (g.n - 3 + stored - 1) / stored : 1;
-    int planes = strip_planes_ > 0 ? strip_planes_ : 16;
+    int planes = strip_planes_ > 0 ? strip_planes_ : twice_planes_;
     planes = (planes + 3) & ~3;
     const int chunks = (g.n - 2 + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
@@ -1309,7 +1309,7 @@ template <typename T> class Impl : public ImplBase {
     if (tile3d_waves_ == 0 && (long)strips * ((rows_c + 14) / 15) * ((rows_c + 7) / 8) < 1024) nw = 4;
     const int per_group = (nw * TY - 2) / 2;                      // coarse rows a workgroup finishes: 15 (7 with four waves)
     const int ygroups = (rows_c + per_group - 1) / per_group;
-    int cplanes = strip_planes_ > 0 ? (strip_planes_ + 1) / 2 : 8;   // fine planes per chunk: 2 * cplanes + 1
+    int cplanes = strip_planes_ > 0 ? (strip_planes_ + 1) / 2 : rr_cplanes_;   // fine planes per chunk: 2 * cplanes + 1
     const int chunks = (rows_c + cplanes - 1) / cplanes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
@@ -1745,6 +1745,8 @@ template <typename T> class Impl : public ImplBase {
   bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
+  int twice_planes_ = getenv("EVOMG_TWICE_PLANES") ? atoi(getenv("EVOMG_TWICE_PLANES")) : 16;
+  int rr_cplanes_ = getenv("EVOMG_RR_CPLANES") ? atoi(getenv("EVOMG_RR_CPLANES")) : 8;
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : 33;
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;

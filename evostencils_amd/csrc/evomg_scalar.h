@@ -40,6 +40,30 @@ EVOMG_HD cplx sc_neg(cplx a) { return cplx{-a.re, -a.im}; }
 EVOMG_HD bool sc_iszero(cplx a) { return a.re == 0.0 && a.im == 0.0; }
 EVOMG_HD double sc_norm_from_dot(cplx d) { return sqrt(sqrt(d.re * d.re + d.im * d.im)); }
 
+// ---- quotients by a divisor that is constant over a kernel (stencil centre, block pivots) --------------------------------
+// The f64 division the compiler emits for a / b is
+//   s0 = div_scale(b), s1 = div_scale(a);  y = rcp(s0) refined by two Newton steps (four fma);
+//   m = s1 * y;  e = fma(-s0, m, s1);  q = div_fmas(e, y, m);  div_fixup(q, b, a)
+// (llvm AMDGPU LowerFDIV64). y depends on b only: const_div_make forms it once per kernel with those very operations, and
+// a quotient costs the remaining three — m, e, fma(e, y, m): the same roundings in the same order, so the same bits as
+// a / b whenever div_scale leaves its operands alone, i.e. for normal b and a with exponent(a) > -970 and
+// |exponent(a) - exponent(b)| < 768 (fields of a multigrid solve: yes; checked bit for bit by tools/check_const_div.hip).
+// Outside that range (and for a = -0, which comes out as +0) the result may differ from a / b in the last place.
+// Complex: plain sc_div.
+template <typename T> struct ConstDiv { T b, y; };
+__device__ __forceinline__ ConstDiv<double> const_div_make(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  return ConstDiv<double>{b, y};
+}
+__device__ __forceinline__ double const_div(double a, const ConstDiv<double>& d) {
+  const double m = a * d.y;
+  return __builtin_fma(__builtin_fma(-d.b, m, a), d.y, m);
+}
+__device__ __forceinline__ ConstDiv<cplx> const_div_make(cplx b) { return ConstDiv<cplx>{b, b}; }
+__device__ __forceinline__ cplx const_div(cplx a, const ConstDiv<cplx>& d) { return sc_div(a, d.b); }
+
 template <typename T> struct scalar_traits;
 template <> struct scalar_traits<double> {
   static EVOMG_HD double zero() { return 0.0; }

@@ -654,7 +654,7 @@ evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__
 // advancing a plane costs no register moves. No LDS, no barriers.
 // Operation order = relax_point / apply_stencil (evomg_kernels.h) = the oracle's FN(relax3) / FN(apply_st3).
 template <typename T>
-__device__ __forceinline__ T relax7(const Stencil<T>& st, T c, T w, T e, T s, T n, T d, T u, T f, double om, double omm) {
+__device__ __forceinline__ T relax7(const Stencil<T>& st, const ConstDiv<T>& cd, T c, T w, T e, T s, T n, T d, T u, T f, double om, double omm) {
   T r = f;
   r = sc_sub(r, sc_mul(st.c[1], w));
   r = sc_sub(r, sc_mul(st.c[2], e));
@@ -662,7 +662,7 @@ __device__ __forceinline__ T relax7(const Stencil<T>& st, T c, T w, T e, T s, T 
   r = sc_sub(r, sc_mul(st.c[4], n));
   r = sc_sub(r, sc_mul(st.c[5], d));
   r = sc_sub(r, sc_mul(st.c[6], u));
-  const T xs = sc_div(r, st.c[0]);
+  const T xs = const_div(r, cd);         // = r / st.c[0], bit for bit (evomg_scalar.h)
   return sc_add(sc_rmul(omm, c), sc_rmul(om, xs));
 }
 template <typename T>
@@ -689,6 +689,7 @@ evomg_strip3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
   const int lane = threadIdx.x & 63;
+  const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = (logical_block / n_ygroups) % n_strips;
   const int chunk = logical_block / (n_ygroups * n_strips);
@@ -750,8 +751,8 @@ evomg_strip3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             T* dst = y + plane * k + pitch * row + c0;
             Pair<T> out;
             if constexpr (MODE == STRIP_JACOBI) {
-              out.a = (row_inner && inner_a) ? relax7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
-              out.b = (row_inner && inner_b) ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
+              out.a = (row_inner && inner_a) ? relax7(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
+              out.b = (row_inner && inner_b) ? relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
               if (store_lane) store_pair(dst, out);
             } else {
               if (row_inner && store_lane) {
@@ -787,6 +788,7 @@ evomg_strip3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
   const int lane = threadIdx.x & 63;
+  const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = (logical_block / n_ygroups) % n_strips;
   const int chunk = logical_block / (n_ygroups * n_strips);
@@ -851,10 +853,10 @@ evomg_strip3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
           // row parity: y0 even => row = y0 - 1 + t has the parity of t + 1; k has the parity of d + 1
           if (((t + 1 + d + 1) & 1) == 0) {                    // a is red
             const T w = from_left(c.b);
-            rc[t] = (row_inner && inner_a) ? relax7(st, c.a, w, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
+            rc[t] = (row_inner && inner_a) ? relax7(st, cd0, c.a, w, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
           } else {                                             // b is red
             const T e = from_right(c.a);
-            rc[t] = (row_inner && inner_b) ? relax7(st, c.b, c.a, e, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
+            rc[t] = (row_inner && inner_b) ? relax7(st, cd0, c.b, c.a, e, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
           }
         }
         // ---- blacks of plane k-1, rows y0 .. y0+TY-1, from the new reds ----
@@ -871,12 +873,12 @@ evomg_strip3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
           // row = y0 + t has the parity of t; plane k-1 has the parity of d
           if (((t + d) & 1) == 0) {                            // a red, b black
             const T e = from_right(red);
-            const T bl = (row_inner && inner_b) ? relax7(st, old.b, red, e, r1[t], r1[t + 2], r2[t], rc[t + 1], fb[t].b, om, omm) : old.b;
+            const T bl = (row_inner && inner_b) ? relax7(st, cd0, old.b, red, e, r1[t], r1[t + 2], r2[t], rc[t + 1], fb[t].b, om, omm) : old.b;
             out.a = red;
             out.b = bl;
           } else {                                             // b red, a black
             const T w = from_left(red);
-            const T bl = (row_inner && inner_a) ? relax7(st, old.a, w, red, r1[t], r1[t + 2], r2[t], rc[t + 1], fb[t].a, om, omm) : old.a;
+            const T bl = (row_inner && inner_a) ? relax7(st, cd0, old.a, w, red, r1[t], r1[t + 2], r2[t], rc[t + 1], fb[t].a, om, omm) : old.a;
             out.a = bl;
             out.b = red;
           }

@@ -54,12 +54,15 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;                   // whole workgroup: no barrier is skipped by a part of it
   const int lane = threadIdx.x & 63;
+  const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
+  const ConstDiv<T> cdp0 = const_div_make(pl.pivot0), cdp1 = const_div_make(pl.pivot1);
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // order 0: y group fastest (y neighbours adjacent in time); order 1: strip fastest — workgroups that run together then
   // cover whole rows, i.e. one contiguous span of NW*4 rows per plane
   const int ygroup = order ? (logical_block / n_strips) % n_ygroups : logical_block % n_ygroups;
   const int strip = order ? logical_block % n_strips : (logical_block / n_ygroups) % n_strips;
   const int chunk = logical_block / (n_ygroups * n_strips);
+  const bool last_strip = strip == n_strips - 1;            // uniform
   const int n = g.n;
   const long pitch = g.pitch, plane = g.plane;
   const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
@@ -151,8 +154,8 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             };
             auto solve = [&](T r0, T r1, T x0, T x1, T& o0, T& o1) {
               r1 = sc_sub(r1, sc_mul(pl.fac, r0));
-              r1 = sc_div(r1, pl.pivot1);
-              r0 = sc_div(sc_sub(r0, sc_mul(pl.upper, r1)), pl.pivot0);
+              r1 = const_div(r1, cdp1);
+              r0 = const_div(sc_sub(r0, sc_mul(pl.upper, r1)), cdp0);
               o0 = sc_add(sc_rmul(omm, x0), sc_rmul(om, r0));
               o1 = sc_add(sc_rmul(omm, x1), sc_rmul(om, r1));
             };
@@ -170,8 +173,8 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
                 store_y(y + plane * k + pitch * (rA + 1) + c0, oB);
               }
             } else if (rA == n - 2) {                            // the last inner row: a one-cell tile
-              if (inner_a) oA.a = relax7(st, cA.a, wA, cA.b, sA.a, cB.a, below[tp].a, above[tp].a, fk[tp].a, om, omm);
-              if (inner_b) oA.b = relax7(st, cA.b, cA.a, eA, sA.b, cB.b, below[tp].b, above[tp].b, fk[tp].b, om, omm);
+              if (inner_a) oA.a = relax7(st, cd0, cA.a, wA, cA.b, sA.a, cB.a, below[tp].a, above[tp].a, fk[tp].a, om, omm);
+              if (inner_b) oA.b = relax7(st, cd0, cA.b, cA.a, eA, sA.b, cB.b, below[tp].b, above[tp].b, fk[tp].b, om, omm);
               if (store_lane) store_y(y + plane * k + pitch * rA + c0, oA);
             }
           }
@@ -196,17 +199,19 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             ra1 = sc_sub(ra1, sc_mul(st.c[4], nn.a));
             ra1 = sc_sub(ra1, sc_mul(st.c[5], dn.a));
             ra1 = sc_sub(ra1, sc_mul(st.c[6], up.a));
-            const T r0_left = from_left(rb0), r1_right = from_right(ra1);          // whole wave
+            const T r0_left = from_left(rb0);                                      // whole wave
             // tile (left b, a): a is the second unknown
-            const T xa = sc_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), pl.pivot1);
-            // tile (b, right a): b is the first unknown
-            const T x1 = sc_div(sc_sub(r1_right, sc_mul(pl.fac, rb0)), pl.pivot1);
-            const T xb = sc_div(sc_sub(rb0, sc_mul(pl.upper, x1)), pl.pivot0);
+            const T xa = const_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), cdp1);
+            // tile (b, right a): b is the first unknown; the second unknown of that tile is the right lane's xa
+            // (same operands, same operations: the value, not a recomputation of it, crosses the lanes)
+            const T x1 = from_right(xa);                                           // whole wave
+            const T xb = const_div(sc_sub(rb0, sc_mul(pl.upper, x1)), cdp0);
             if (row <= n - 2 && store_lane) {
               Pair<T> out = c;
               if (inner_a) out.a = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa));
-              if (inner_b) out.b = (c0 + 1 == n - 2) ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm)
-                                                     : sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
+              if (inner_b) out.b = sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
+              // the last inner column has no partner: a one-cell tile (only the last strip has such a lane)
+              if (last_strip && c0 + 1 == n - 2) out.b = relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm);
               store_y(y + plane * k + pitch * row + c0, out);
             }
           } else if constexpr (MODE == TILE_RESNORM || MODE == TILE_RESNORM_W) {
@@ -233,8 +238,8 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             T* dst = y + plane * k + pitch * row + c0;
             Pair<T> out;
             if constexpr (MODE == STRIP_JACOBI) {
-              out.a = inner_a ? relax7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
-              out.b = inner_b ? relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
+              out.a = inner_a ? relax7(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
+              out.b = inner_b ? relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
               store_y(dst, out);
             } else {
               out.a = residual7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
@@ -280,6 +285,7 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
   const int lane = threadIdx.x & 63;
+  const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = logical_block % n_strips;                 // strip fastest: concurrent workgroups cover whole rows
   const int ygroup = (logical_block / n_strips) % n_ygroups;
@@ -364,10 +370,10 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
           // row0 even => row has the parity of t; k has the parity of d: a is red iff t + d is even
           if (((t + d) & 1) == 0) {
             const T we = from_left(c.b);
-            rc[t] = (row_inner && inner_a) ? relax7(st, c.a, we, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
+            rc[t] = (row_inner && inner_a) ? relax7(st, cd0, c.a, we, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
           } else {
             const T ea = from_right(c.a);
-            rc[t] = (row_inner && inner_b) ? relax7(st, c.b, c.a, ea, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
+            rc[t] = (row_inner && inner_b) ? relax7(st, cd0, c.b, c.a, ea, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
           }
         }
         edge_r[k & 1][w][0][lane] = rc[0];
@@ -394,10 +400,10 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
           if (a_red) {                                         // a red, b black
             const T e = from_right(red);
             out.a = red;
-            out.b = (row_inner && inner_b) ? relax7(st, old.b, red, e, rs, rn, r2[t], rc[t], fb[t].b, om, omm) : old.b;
+            out.b = (row_inner && inner_b) ? relax7(st, cd0, old.b, red, e, rs, rn, r2[t], rc[t], fb[t].b, om, omm) : old.b;
           } else {                                             // b red, a black
             const T we = from_left(red);
-            out.a = (row_inner && inner_a) ? relax7(st, old.a, we, red, rs, rn, r2[t], rc[t], fb[t].a, om, omm) : old.a;
+            out.a = (row_inner && inner_a) ? relax7(st, cd0, old.a, we, red, rs, rn, r2[t], rc[t], fb[t].a, om, omm) : old.a;
             out.b = red;
           }
           const bool row_stored = row >= 1 && row <= n - 2 && row >= R0 + 1 && (row <= R0 + H - 2 || top_group);
@@ -450,6 +456,8 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
   const int lane = threadIdx.x & 63;
+  const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
+  const ConstDiv<T> cdp0 = const_div_make(pl.pivot0), cdp1 = const_div_make(pl.pivot1);
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = logical_block % n_strips;
   const int ygroup = (logical_block / n_strips) % n_ygroups;
@@ -459,6 +467,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   // halo lanes per side: one for point Jacobi; two for the (2,1,1) blocks, whose tiles pair element b of a lane with
   // element a of its right neighbour — the second sweep's tile at the strip's edge reads a first-sweep value that the
   // outermost lane cannot form (its own tile partner lies outside the wave)
+  const bool last_strip = strip == n_strips - 1;              // uniform
   constexpr int HALO = (MODE == TILE_BLOCK211) ? 2 : 1;
   constexpr int COLS = 128 - 4 * HALO;
   const int c0 = strip * COLS - 2 * HALO + 2 * lane;
@@ -497,8 +506,8 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
     Pair<T> out = c;
     const T wa = from_left(c.b), eb = from_right(c.a);
     if constexpr (MODE == STRIP_JACOBI) {
-      const T ra = relax7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a, om, omm);
-      const T rb = relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
+      const T ra = relax7(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a, om, omm);
+      const T rb = relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
       if (node_rows_inner && inner_a) out.a = ra;
       if (node_rows_inner && inner_b) out.b = rb;
     } else {
@@ -514,13 +523,14 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
       ra1 = sc_sub(ra1, sc_mul(st.c[4], nn.a));
       ra1 = sc_sub(ra1, sc_mul(st.c[5], dn.a));
       ra1 = sc_sub(ra1, sc_mul(st.c[6], up.a));
-      const T r0_left = from_left(rb0), r1_right = from_right(ra1);
-      const T xa = sc_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), pl.pivot1);
-      const T x1 = sc_div(sc_sub(r1_right, sc_mul(pl.fac, rb0)), pl.pivot1);
-      const T xb = sc_div(sc_sub(rb0, sc_mul(pl.upper, x1)), pl.pivot0);
-      const T single = relax7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);   // last inner column: one-cell tile
+      const T r0_left = from_left(rb0);
+      const T xa = const_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), cdp1);
+      const T x1 = from_right(xa);             // second unknown of the tile (b, right a) = the right lane's xa
+      const T xb = const_div(sc_sub(rb0, sc_mul(pl.upper, x1)), cdp0);
       if (node_rows_inner && inner_a) out.a = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa));
-      if (node_rows_inner && inner_b) out.b = (c0 + 1 == n - 2) ? single : sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
+      if (node_rows_inner && inner_b) out.b = sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
+      // last inner column: a one-cell tile (only the last strip has such a lane)
+      if (last_strip && node_rows_inner && c0 + 1 == n - 2) out.b = relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
     }
     return out;
   };
