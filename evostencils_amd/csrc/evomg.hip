@@ -120,6 +120,7 @@ template <typename T> class Impl : public ImplBase {
     }
     HIP_TRY(hipSetDevice(device_));
     HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || n_cu_ <= 0) n_cu_ = 256;
     HIP_TRY(hipEventCreate(&ev0_));
     HIP_TRY(hipEventCreate(&ev1_));
     HIP_TRY(hipMalloc(&partials_, sizeof(T) * kDotBlocks));
@@ -948,6 +949,25 @@ template <typename T> class Impl : public ImplBase {
   }
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
   bool strip_streams(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.pitch * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
+  // Chunk height of the 2D smoother strips. A block is four waves = four chunks and every block is resident at once, so a
+  // launch lasts as long as the compute unit that got the most blocks: ceil(blocks / CUs) * (rows + halo and prologue).
+  // Measured at 4097^2 (tools/sweep_rows.sh): 64 rows -> 553 blocks, three on some units and two on most, fused sweeps
+  // 91.2 us, plain 72.4 us; 48 rows -> 731 blocks, three on nearly every unit: 83.5 us / 67.4 us; 40: 84.4, 56: 87.5,
+  // 80: 88.2. `quantum`: rows must be a multiple of it (2: static row parity; EVOMG_NORM_ROWS: tail-norm chunks).
+  // Only heights that leave at least three blocks (twelve waves) per unit compete: below that a unit cannot keep enough
+  // loads in flight and the model no longer holds; if none does, the smallest height wins (as many waves as possible).
+  int balanced_rows(int n, int strips, int quantum, int lo, int hi) const {
+    long best_cost = -1;
+    int best = lo;
+    for (int r = lo; r <= hi; r += quantum) {
+      const long blocks = ((long)strips * ((n + r - 1) / r) + 3) / 4;
+      const long rounds = (blocks + n_cu_ - 1) / n_cu_;
+      if (rounds < 3) break;                                                      // blocks only shrink from here on
+      const long cost = rounds * (r + 4);
+      if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = r; }     // ties: the taller chunk (less halo)
+    }
+    return best;
+  }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
     // enough waves to fill 256 CUs several times over, but chunks tall enough to amortise the vertical halo
@@ -956,6 +976,7 @@ template <typename T> class Impl : public ImplBase {
     int rows = strip_rows_ > 0 ? strip_rows_ : (MODE == STRIP_RESIDUAL ? 16 : 64);
     while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
     rows = (rows + 1) & ~1;   // even chunk heights: the kernel relies on y0 being even (static row parity)
+    if (strip_rows_ <= 0 && balance_rows_ && MODE != STRIP_RESIDUAL) rows = balanced_rows(g.n, strips, 2, 8, 96);
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);   // multiple of 8: XCD remap in the kernel
@@ -991,6 +1012,8 @@ template <typename T> class Impl : public ImplBase {
     const int min_rows = TAIL ? EVOMG_NORM_ROWS : 8;
     while (rows > min_rows && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
     rows = TAIL ? ((rows + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : ((rows + 1) & ~1);
+    if (strip_rows_ <= 0 && balance_rows_) rows = TAIL ? balanced_rows(g.n, strips, EVOMG_NORM_ROWS, EVOMG_NORM_ROWS, 4 * EVOMG_NORM_ROWS)
+                                                        : balanced_rows(g.n, strips, 2, 8, 96);
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
     if (TAIL) {
@@ -1014,6 +1037,7 @@ template <typename T> class Impl : public ImplBase {
     int rows = strip_rows_ > 0 ? strip_rows_ : 64;
     while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
     rows = (rows + 1) & ~1;
+    if (strip_rows_ <= 0 && balance_rows_) rows = balanced_rows(g.n, strips, 2, 8, 96);
     const int chunks = (g.n + rows - 1) / rows;
     const int waves = strips * chunks;
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
@@ -1745,6 +1769,8 @@ template <typename T> class Impl : public ImplBase {
   bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
+  bool balance_rows_ = (getenv("EVOMG_NO_BALANCED_ROWS") == nullptr);
+  int n_cu_ = 256;
   int twice_planes_ = getenv("EVOMG_TWICE_PLANES") ? atoi(getenv("EVOMG_TWICE_PLANES")) : 16;
   int rr_cplanes_ = getenv("EVOMG_RR_CPLANES") ? atoi(getenv("EVOMG_RR_CPLANES")) : 8;
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
