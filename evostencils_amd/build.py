@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libevomg.so")
 SOURCES = ["evomg.hip"]
-HEADERS = ["evomg_scalar.h", "evomg_kernels.h", "evomg_krylov.h", "evomg_strip.h", "../../include/evomg.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/evomg.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -20,6 +20,7 @@
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
 #include "evomg_tile3d.h"
+#include "evomg_batch.h"
 #include "evomg_system.h"
 #ifndef EVOMG_FUSED_PF
 #define EVOMG_FUSED_PF 2   // prefetch depth of the fused sweeps (fewer waves per SIMD than the plain ones)
@@ -535,6 +536,12 @@ template <typename T> class Impl : public ImplBase {
   int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0, bool* tail_norm = nullptr) {
     if (tail_norm) *tail_norm = false;
     for (int i = first; i < n_ops; ++i) {
+      if (batchable(ops[i])) {              // small level: the op joins the list one workgroup runs in one launch
+        const int rc = exec_batched(ops[i]);
+        if (rc != EVOMG_OK) return rc;
+        continue;
+      }
+      flush_batch();
       if (elidable_zero(ops, n_ops, i)) {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
         continue;
@@ -640,6 +647,71 @@ template <typename T> class Impl : public ImplBase {
       }
       int rc = exec(ops[i]);
       if (rc != EVOMG_OK) return rc;
+    }
+    flush_batch();
+    return EVOMG_OK;
+  }
+
+  // ---- coarse-level op batches (evomg_batch.h) --------------------------------------------------------------------
+  bool batch_level(int L) const { return L >= 0 && L < EVOMG_BATCH_LEVELS && lv_[L].g.n <= batch_max_n_; }
+  bool batchable(const evomg_op_t& op) const {
+    if (!batch_enabled_ || dim_ != 2 || scalar_traits<T>::is_complex || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    if (prof_matches(op)) return false;
+    const int L = op.level;
+    switch (op.opcode) {
+      case EVOMG_OP_SMOOTH: return batch_level(L) && op.block[0] * op.block[1] == 1 && canon(L, op.src1) != canon(L, op.dst);
+      case EVOMG_OP_RESIDUAL: return batch_level(L) && canon(L, op.dst) != canon(L, op.src0) && canon(L, op.dst) != canon(L, op.src1);
+      case EVOMG_OP_RESTRICT: return batch_level(L) && batch_level(L + 1);
+      case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: return batch_level(L) && L - 1 >= prob_.min_level;
+      case EVOMG_OP_SET_ZERO: case EVOMG_OP_COPY: return batch_level(L);
+      default: return false;
+    }
+  }
+  void push_micro(int kind, int level, const void* a, const void* b, void* c, double om) {
+    if (batch_.n == EVOMG_BATCH_MAX) flush_batch();
+    batch_.op[batch_.n++] = MicroOp{kind, level, a, b, c, om};
+  }
+  void flush_batch() {
+    if (batch_.n == 0) return;
+    if constexpr (!scalar_traits<T>::is_complex) {
+      BatchLevels<T> lv;
+      memset(&lv, 0, sizeof lv);
+      for (int L = prob_.min_level; L <= prob_.max_level && L < EVOMG_BATCH_LEVELS; ++L) { lv.g[L] = lv_[L].g; lv.st[L] = lv_[L].st; }
+      hipLaunchKernelGGL((evomg_coarse_batch<T>), dim3(1), dim3(1024), 0, stream_, lv, batch_);
+    }
+    batch_.n = 0;
+  }
+  // the bookkeeping of exec_impl (ping-pong arrays, `with jacobi` slots), a micro-op instead of each launch
+  int exec_batched(const evomg_op_t& op) {
+    const int L = op.level;
+    Level<T>& lv = lv_[L];
+    switch (op.opcode) {
+      case EVOMG_OP_SMOOTH: {
+        T* x = fieldptr(L, op.dst);
+        const T* f = fieldptr(L, op.src1);
+        if (op.partitioning == EVOMG_PART_RED_BLACK) {
+          push_micro(MB_RBGS, L, x, f, nullptr, op.omega);          // two colour passes in place
+        } else {
+          T* y = lv.alt;
+          push_micro(MB_JACOBI, L, x, f, y, op.omega);              // writes all of y, boundary included
+          advance(lv, L, op, x, y);
+        }
+        break;
+      }
+      case EVOMG_OP_RESIDUAL: push_micro(MB_RESIDUAL, L, fieldptr(L, op.src0), fieldptr(L, op.src1), fieldptr(L, op.dst), 0.0); break;
+      case EVOMG_OP_RESTRICT: push_micro(MB_RESTRICT, L, fieldptr(L + 1, op.src0), nullptr, fieldptr(L, op.dst), 0.0); break;
+      case EVOMG_OP_PROLONG_ADD: push_micro(MB_PROLONG_ADD, L, fieldptr(L - 1, op.src0), nullptr, fieldptr(L, op.dst), op.omega); break;
+      case EVOMG_OP_PROLONG_SET: push_micro(MB_PROLONG_SET, L, fieldptr(L - 1, op.src0), nullptr, fieldptr(L, op.dst), 1.0); break;
+      case EVOMG_OP_SET_ZERO: push_micro(MB_ZERO, L, nullptr, nullptr, fieldptr(L, op.dst), 0.0); break;
+      case EVOMG_OP_COPY: {
+        T* d = fieldptr(L, op.dst);
+        const T* s = fieldptr(L, op.src0);
+        if (d != s) push_micro(MB_COPY, L, s, nullptr, d, 0.0);
+        bnd_zero_[L][canon(L, op.dst)] = bnd_zero_[L][canon(L, op.src0)];
+        lv.alt_mirror = nullptr;
+        break;
+      }
+      default: return invalid("exec_batched: unsupported opcode");
     }
     return EVOMG_OK;
   }
@@ -1770,6 +1842,11 @@ template <typename T> class Impl : public ImplBase {
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
   bool balance_rows_ = (getenv("EVOMG_NO_BALANCED_ROWS") == nullptr);
+  // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
+  // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
+  bool batch_enabled_ = (getenv("EVOMG_BATCH") != nullptr) && (getenv("EVOMG_NO_STRIP") == nullptr);
+  int batch_max_n_ = getenv("EVOMG_BATCH_MAX_N") ? atoi(getenv("EVOMG_BATCH_MAX_N")) : 129;
+  MicroBatch batch_ = {};
   int n_cu_ = 256;
   int twice_planes_ = getenv("EVOMG_TWICE_PLANES") ? atoi(getenv("EVOMG_TWICE_PLANES")) : 16;
   int rr_cplanes_ = getenv("EVOMG_RR_CPLANES") ? atoi(getenv("EVOMG_RR_CPLANES")) : 8;

@@ -455,6 +455,34 @@ def test_sweep_fusions_3d_do_not_change_a_bit(native, smoother, pre, post, plane
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("smoother,max_n", [("rbgs", 129), ("jacobi", 129), ("rbgs", 33)])
+def test_coarse_level_batches_do_not_change_a_bit(native, smoother, max_n, monkeypatch):
+    """EVOMG_BATCH=1: consecutive ops on levels up to max_n^2 run as micro-ops of ONE single-workgroup launch
+    (evomg_coarse_batch). Whole solves against the default interpreter: identical histories and fields."""
+    from test_full_size_gpu import vcycle
+    lo, hi = 4, 8
+    pd = problems.poisson_2d(lo, hi)
+    part, om = (abi.PART_RED_BLACK, 1.1) if smoother == "rbgs" else (abi.PART_SINGLE, 0.8)
+    ops = vcycle(lo, hi, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, (1, 1, 1), om))
+    results = []
+    for batched in (True, False):
+        if batched:
+            monkeypatch.setenv("EVOMG_BATCH", "1")
+            monkeypatch.setenv("EVOMG_BATCH_MAX_N", str(max_n))
+        else:
+            monkeypatch.delenv("EVOMG_BATCH", raising=False)
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 128)
+        results.append((out, h.get_field(hi, abi.F_SOL), h.get_field(hi - 2, abi.F_SOL), h.get_field(hi - 2, abi.F_RHS),
+                        h.get_field(lo, abi.F_RHS)))
+        h.close()
+    (a, *fa), (b, *fb) = results
+    assert a.status == b.status and a.n_iterations == b.n_iterations and a.n_iterations > 3
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("smoother,pre,post", [("rbgs", 1, 1), ("rbgs", 2, 2), ("jacobi", 1, 2), ("rbgs", 0, 1), ("jacobi", 2, 0)])
 def test_sweep_fusions_do_not_change_a_bit(native, smoother, pre, post, monkeypatch):
     """Whole solves with every optimisation of the interpreter (residual+restriction, prolongation+smoother,
