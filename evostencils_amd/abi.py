@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
@@ -21,7 +21,8 @@ SOLVE_CONVERGED, SOLVE_MAXITER, SOLVE_DIVERGED, SOLVE_WALL_LIMIT = 0, 1, 2, 3
 REAL_F64, COMPLEX_F64 = 0, 1
 BC_DIRICHLET, BC_HELMHOLTZ_ROBIN = 0, 1
 OUTER_MG_ITERATION, OUTER_PBICGSTAB = 0, 1
-CGS_CG, CGS_BICGSTAB = 0, 1
+CGS_CG, CGS_BICGSTAB, CGS_FAS_SMOOTHER = 0, 1, 2
+NONLINEAR_NONE, NONLINEAR_GAM_U_EXP_U = 0, 1
 # `with jacobi` slot handling (include/evomg.h EVOMG_JACOBI_*): TEXTBOOK = the sweep's result becomes the field;
 # EXASTENCILS_V11 = the next slot is never advanced, as in the reference's pipeline (notebooks/tutorial.ipynb:3373)
 JACOBI_TEXTBOOK, JACOBI_EXASTENCILS_V11 = 1, 2
@@ -29,11 +30,15 @@ JACOBI_SEMANTICS = {"textbook": JACOBI_TEXTBOOK, "exastencils-v1.1": JACOBI_EXAS
 F_SOL, F_RHS, F_RES, F_CORR, F_CGS_RHS, F_COUNT = 0, 1, 2, 3, 4, 5
 (OP_SMOOTH, OP_RESIDUAL, OP_RESTRICT, OP_PROLONG_ADD, OP_PROLONG_SET, OP_SET_ZERO, OP_COPY,
  OP_COARSE_SOLVE, OP_RICHARDSON) = range(1, 10)
+# non-linear FAS vocabulary (include/evomg.h; exastencils_FAS.py:99-319)
+(OP_FAS_SMOOTH, OP_FAS_RESIDUAL, OP_FAS_RESTRICT_SOLUTION, OP_FAS_COARSE_RHS, OP_FAS_CGS, OP_FAS_SUBTRACT) = range(16, 22)
 PART_SINGLE, PART_RED_BLACK = 0, 1
 
 OP_NAMES = {OP_SMOOTH: "SMOOTH", OP_RESIDUAL: "RESIDUAL", OP_RESTRICT: "RESTRICT",
             OP_PROLONG_ADD: "PROLONG_ADD", OP_PROLONG_SET: "PROLONG_SET", OP_SET_ZERO: "SET_ZERO",
-            OP_COPY: "COPY", OP_COARSE_SOLVE: "COARSE_SOLVE", OP_RICHARDSON: "RICHARDSON"}
+            OP_COPY: "COPY", OP_COARSE_SOLVE: "COARSE_SOLVE", OP_RICHARDSON: "RICHARDSON",
+            OP_FAS_SMOOTH: "FAS_SMOOTH", OP_FAS_RESIDUAL: "FAS_RESIDUAL", OP_FAS_RESTRICT_SOLUTION: "FAS_RESTRICT_SOLUTION",
+            OP_FAS_COARSE_RHS: "FAS_COARSE_RHS", OP_FAS_CGS: "FAS_CGS", OP_FAS_SUBTRACT: "FAS_SUBTRACT"}
 
 
 class C64(C.Structure):
@@ -52,6 +57,8 @@ class Problem(C.Structure):
         ("wavenumber", C.c_double),
         ("jacobi_semantics", C.c_int32), ("n_unknowns", C.c_int32),
         ("sys_stencil", (((C.c_double * 9) * MAX_UNKNOWNS) * MAX_UNKNOWNS) * MAX_LEVELS),
+        ("nonlinear_kind", C.c_int32), ("reserved0", C.c_int32), ("nonlinear_gamma", C.c_double),
+        ("fas_cgs_omega", C.c_double),
     ]
 
 

@@ -10,7 +10,8 @@ path optimization/program.py:904-933) can be evaluated into IR DAGs with ``compi
 Naming of primitives and terminals follows the reference so that its strings evaluate unchanged:
 ``residual_d``, ``collective_jacobi_d``, ``decoupled_jacobi_d``, ``collective_block_jacobi_d``,
 ``coarsening_d``, ``update_with_coarse_grid_correction_d``, ``correct_with_coarse_grid_solver_d``,
-terminals ``u_and_f``, ``zero_d``, ``A_d``, ``P_d``, ``R_d``, ``CGS_d``, ``single``, ``red_black``.
+terminals ``u_and_f``, ``zero_d``, ``A_d``, ``P_d``, ``R_d``, ``CGS_d``, ``single``, ``red_black``; with ``FAS=True``
+``jacobi_picard_d`` and ``jacobi_newton_d`` replace the linear smoothers.
 """
 import numpy as np
 
@@ -20,8 +21,10 @@ from evostencils_amd.ir import partitioning as part
 
 
 def _level_productions(ctx, depth, operator, coarse_operator, restriction, prolongation, coarse_grid_solver,
-                       relaxation_factors, coarsest):
-    """Adds the productions of one level (depth 0 = finest) to `ctx`."""
+                       relaxation_factors, coarsest, FAS=False):
+    """Adds the productions of one level (depth 0 = finest) to `ctx`. FAS: the non-linear full-approximation-scheme
+    variants (multigrid.py:275-345): the coarse right-hand side gets A_c (R u) added, the coarse result has R u
+    subtracted before it is prolongated, and the smoothers are the Picard / Newton point smoothers."""
 
     def residual(state):
         approximation, rhs = state
@@ -52,29 +55,56 @@ def _level_productions(ctx, depth, operator, coarse_operator, restriction, prolo
         return _smoothing(index, part.Single,
                           lambda op: smoother.generate_collective_block_jacobi(op, block_shape), cycle)
 
+    def _restrict(restriction_operator, cycle):
+        if not FAS:
+            return _apply(restriction_operator, cycle)
+        residual_c = base.mul(restriction_operator, cycle.correction)
+        residual_fas = base.mul(coarse_operator, base.Multiplication(restriction_operator, cycle.approximation))
+        cycle.correction = base.add(residual_c, residual_fas)
+        return cycle
+
+    def jacobi_picard(index, partitioning_, cycle):
+        return _smoothing(index, partitioning_, smoother.generate_jacobi_picard, cycle)
+
+    def jacobi_newton(index, partitioning_, n_newton_steps, cycle):
+        return _smoothing(index, partitioning_, lambda op: smoother.generate_jacobi_newton(op, n_newton_steps), cycle)
+
     def coarsening(coarse_op, coarse_approximation, restriction_operator, cycle):
-        _apply(restriction_operator, cycle)
+        _restrict(restriction_operator, cycle)
         new_cycle = base.Cycle(coarse_approximation, cycle.correction,
                                base.Residual(coarse_op, coarse_approximation, cycle.correction))
         new_cycle.predecessor = cycle
         return new_cycle
 
-    def update_with_coarse_grid_correction(index, prolongation_operator, state):
+    def update_with_coarse_grid_correction(index, prolongation_operator, state, restriction_operator=None):
         coarse_cycle = state[0]
         fine_cycle = coarse_cycle.predecessor
-        fine_cycle.correction = base.Multiplication(prolongation_operator, coarse_cycle)
+        if FAS:
+            restricted = base.mul(restriction_operator, fine_cycle.approximation)        # subtracted for FAS
+            fine_cycle.correction = base.mul(prolongation_operator, base.sub(coarse_cycle, restricted))
+        else:
+            fine_cycle.correction = base.Multiplication(prolongation_operator, coarse_cycle)
         return _update(index, part.Single, fine_cycle)
 
     def correct_with_coarse_grid_solver(index, prolongation_operator, cgs, restriction_operator, cycle):
-        _apply(restriction_operator, cycle)
-        _apply(cgs, cycle)
-        _apply(prolongation_operator, cycle)
+        _restrict(restriction_operator, cycle)
+        if FAS:
+            approximation_c = base.mul(cgs, cycle.correction)
+            restricted = base.mul(restriction_operator, cycle.approximation)
+            cycle.correction = base.mul(prolongation_operator, base.sub(approximation_c, restricted))
+        else:
+            _apply(cgs, cycle)
+            _apply(prolongation_operator, cycle)
         return _update(index, part.Single, cycle)
 
     ctx[f"residual_{depth}"] = residual
-    ctx[f"decoupled_jacobi_{depth}"] = decoupled_jacobi
-    ctx[f"collective_jacobi_{depth}"] = collective_jacobi
-    ctx[f"collective_block_jacobi_{depth}"] = collective_block_jacobi
+    if FAS:
+        ctx[f"jacobi_picard_{depth}"] = jacobi_picard
+        ctx[f"jacobi_newton_{depth}"] = jacobi_newton
+    else:
+        ctx[f"decoupled_jacobi_{depth}"] = decoupled_jacobi
+        ctx[f"collective_jacobi_{depth}"] = collective_jacobi
+        ctx[f"collective_block_jacobi_{depth}"] = collective_block_jacobi
     ctx[prolongation.name] = prolongation
     ctx[restriction.name] = restriction
     if not coarsest:
@@ -88,7 +118,7 @@ def _level_productions(ctx, depth, operator, coarse_operator, restriction, prolo
 
 
 def generate_context(approximation, rhs, dimension, coarsening_factors, max_level, equations, operators, fields,
-                     relaxation_factor_samples=37, depth=2):
+                     relaxation_factor_samples=37, depth=2, FAS=False):
     """Evaluation context for a `depth`+1-level hierarchy rooted at `max_level` (the counterpart of
     generate_primitive_set, multigrid.py:409-478). Level `max_level - depth` is the coarsest one, solved by
     the coarse-grid solver."""
@@ -106,7 +136,7 @@ def generate_context(approximation, rhs, dimension, coarsening_factors, max_leve
             equations, operators, fields, level - 1, d + 1, coarse_grid)
         cgs = base.CoarseGridSolver("Coarse-Grid Solver", coarse_operator, None)
         _level_productions(ctx, d, operator, coarse_operator, restriction, prolongation, cgs,
-                           relaxation_factors, coarsest=(d == depth - 1))
+                           relaxation_factors, coarsest=(d == depth - 1), FAS=FAS)
         fine_grid = coarse_grid
     return ctx
 

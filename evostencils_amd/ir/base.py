@@ -314,6 +314,14 @@ def get_coarse_operator(operator, coarse_grid):
     return Operator(operator.name, coarse_grid, operator.stencil_generator)
 
 
+def add(a, b):
+    return Addition(a, b)
+
+
+def sub(a, b):
+    return Subtraction(a, b)
+
+
 def mul(a, b):
     return Multiplication(a, b)
 

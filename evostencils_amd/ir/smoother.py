@@ -23,3 +23,14 @@ def generate_collective_block_jacobi(operator, block_sizes):
                                          base.ConstantStencilGenerator(blocked)))
         rows.append(new_row)
     return system.Operator(f"{operator.name}_block_diag", rows)
+
+
+def generate_jacobi_picard(operator):
+    """Non-linear FAS: point smoother that divides by the linear operator's diagonal only (smoother.py:41-42)."""
+    return system.ElementwiseDiagonal(operator)
+
+
+def generate_jacobi_newton(operator, n_newton_steps):
+    """Non-linear FAS: diagonal plus the derivative of the non-linear term, `n_newton_steps` local steps
+    (smoother.py:45-46)."""
+    return base.Addition(system.ElementwiseDiagonal(operator), system.Jacobian(operator, n_newton_steps))

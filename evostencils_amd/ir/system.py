@@ -75,6 +75,18 @@ class ElementwiseDiagonal(base.UnaryExpression):
         return "D"
 
 
+class Jacobian(base.UnaryExpression):
+    """Marker for the derivative of the non-linear term in a Newton-type point smoother; carries the number of local
+    Newton steps (reference: system.py:132-138)."""
+
+    def __init__(self, dummy_operator, n_newton_steps):
+        self.n_newton_steps = n_newton_steps
+        super().__init__(dummy_operator)
+
+    def __str__(self):
+        return f"J[{self.n_newton_steps}]"
+
+
 def get_coarse_grid(grid, coarsening_factors):
     return [base.get_coarse_grid(g, cf) for g, cf in zip(grid, coarsening_factors)]
 

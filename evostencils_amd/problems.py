@@ -135,6 +135,10 @@ class ProblemDescription:
     jacobi_semantics: int = abi.JACOBI_TEXTBOOK
     # systems of PDEs: more than one unknown per node (None for the scalar problems)
     system: Optional[SystemSpec] = None
+    # non-linear FAS problems: -Lap u + N(u) = f, abi.NONLINEAR_*; coarse solver = Newton-Jacobi sweeps
+    nonlinear_kind: int = abi.NONLINEAR_NONE
+    nonlinear_gamma: float = 0.0
+    fas_cgs_omega: float = 0.0
 
     def nodes(self, level):
         return (1 << level) + 1
@@ -189,6 +193,7 @@ class ProblemDescription:
         if jacobi_semantics is None:
             jacobi_semantics = self.jacobi_semantics
         p.jacobi_semantics = abi.JACOBI_SEMANTICS.get(jacobi_semantics, jacobi_semantics)
+        p.nonlinear_kind, p.nonlinear_gamma, p.fas_cgs_omega = self.nonlinear_kind, self.nonlinear_gamma, self.fas_cgs_omega
         return p
 
     # ---- what the reference's parser would extract (parser.py:25-111) -------------------------
@@ -396,6 +401,37 @@ def linear_elasticity_2d(min_level=4, max_level=8, lam=195.0, mu=130.0) -> Probl
                               solver_hints={"solver_smoother_numPre": 2, "solver_smoother_numPost": 1,
                                             "solver_smoother_damping": 1.25, "solver_smoother_coloring": "red-black",
                                             "solver_smoother_jacobiType": "false"})
+
+
+def fas_2d(template) -> ProblemDescription:
+    """-Laplace u + gam u e^u = f on (0,1)^2, u = 0 on the boundary, u0 = 0: the reference's non-linear FAS example
+    (example_problems/FAS_2D_Basic/FAS_2D_Basic_template.exa4). `template`: code_generation.fas.FASTemplate, i.e. what the
+    problem's .knowledge / _template.exa4 files say (levels, gam, right-hand side function, coarse solver, stopping rule)."""
+    def st(level, _params):
+        h = 1.0 / (1 << level)
+        c = 2.0 / (h * h) + 2.0 / (h * h)
+        o = -1.0 / (h * h)
+        return [c, o, o, o, o, 0.0, 0.0]
+
+    def u0(level):
+        n, _ = _coords(level, 2)
+        return np.zeros((n, n))
+
+    def rhs(level):
+        n, x = _coords(level, 2)
+        X, Y = x[None, :], x[:, None]
+        return np.asarray(template.rhs_function(X + 0.0 * Y, Y + 0.0 * X), dtype=np.float64)
+
+    if "exp" not in template.nonlinear_text or "gam" not in template.nonlinear_text:
+        raise ValueError(f"unsupported non-linear stencil: {template.nonlinear_text}")
+    return ProblemDescription("FAS_2D_Basic", 2, template.min_level, template.max_level, mg_stencil=st,
+                              initial_solution=u0, right_hand_side=rhs, cgs_kind=abi.CGS_FAS_SMOOTHER,
+                              max_iterations=template.max_iterations, cgs_max_iterations=template.cgs_sweeps,
+                              target_res_reduction=template.target_res_reduction,
+                              field_name="Solution", rhs_name="RHS", operator_name="Laplace",
+                              restriction_name="RestrictionNode", prolongation_name="CorrectionNode",
+                              nonlinear_kind=abi.NONLINEAR_GAM_U_EXP_U, nonlinear_gamma=template.gamma,
+                              fas_cgs_omega=template.cgs_omega)
 
 
 BY_NAME = {"2D_FD_LinearElasticity_fromL2": linear_elasticity_2d, "2D_FD_Poisson_fromL2": poisson_2d, "3D_FD_Poisson_fromL2": poisson_3d,

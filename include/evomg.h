@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EVOMG_ABI_VERSION 2
+#define EVOMG_ABI_VERSION 3
 #define EVOMG_MAX_LEVELS 24       /* levels are absolute: grid level L has 2^L+1 nodes per dimension */
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
@@ -70,7 +70,16 @@ enum {
 /* coarse-grid solver = gen_mgCycle@minLevel */
 enum {
   EVOMG_CGS_CG = 0,       /* solver_cgs = "CG" (Poisson/2D_FD_Poisson_fromL2.exa3:12-14) */
-  EVOMG_CGS_BICGSTAB = 1  /* explicit BiCGStab text, Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 */
+  EVOMG_CGS_BICGSTAB = 1, /* explicit BiCGStab text, Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 */
+  EVOMG_CGS_FAS_SMOOTHER = 2  /* non-linear FAS problems: cgs_max_iterations Newton-Jacobi sweeps with weight fas_cgs_omega
+                                 (`Function CGS@coarsest`: repeat 200 times Smoother, FAS_2D_Basic_template.exa4:56-61,63-71) */
+};
+
+/* Non-linear term N(u) of a FAS problem -Lap u + N(u) = f, SURVEY 8f N4 (exastencils_FAS.py; FAS_2D_Basic_template.exa4) */
+enum {
+  EVOMG_NONLINEAR_NONE = 0,
+  EVOMG_NONLINEAR_GAM_U_EXP_U = 1  /* `Stencil gamSten { [0,0] => gam * exp(Solution) }` applied to Solution:
+                                      N(u) = gam u e^u, N'(u) = gam (1 + u) e^u (template:27-29,69) */
 };
 
 /* What a `with jacobi` sweep — every smoother with Single partitioning, point or block
@@ -122,6 +131,13 @@ typedef struct {
    * (2D, real, Dirichlet; mg_stencil is ignored). n_unknowns <= 1: a scalar problem. */
   int32_t n_unknowns;
   double  sys_stencil[EVOMG_MAX_LEVELS][EVOMG_MAX_UNKNOWNS][EVOMG_MAX_UNKNOWNS][EVOMG_SYS_STENCIL_ENTRIES];
+  /* Non-linear FAS problems (ABI 3; 2D, real, homogeneous Dirichlet; linear part = mg_stencil): nonlinear_kind != 0 selects
+   * the FAS op vocabulary (EVOMG_OP_FAS_*) and the template's solver loop (repeat the cycle until the residual norm has
+   * dropped by target_res_reduction or max_iterations, FAS_2D_Basic_template.exa4:130-160). */
+  int32_t nonlinear_kind;       /* EVOMG_NONLINEAR_* */
+  int32_t reserved0;
+  double  nonlinear_gamma;      /* `Val gam : Real` */
+  double  fas_cgs_omega;        /* weight of the coarse-grid solver's Newton-Jacobi sweeps (template:66: 0.8) */
 } evomg_problem_t;
 
 /* field slots of one level (exastencils.py:14-26,295-316) */
@@ -146,7 +162,18 @@ enum {
   EVOMG_OP_SET_ZERO = 6,     /* dst@L = 0                                                 exastencils.py:709,756,836,892,895 */
   EVOMG_OP_COPY = 7,         /* dst@L = src0@L                                            exastencils.py:891,901 */
   EVOMG_OP_COARSE_SOLVE = 8, /* gen_mgCycle@min(): Krylov solve on gen_error/gen_rhs@min  exastencils.py:896 */
-  EVOMG_OP_RICHARDSON = 9    /* dst@L += w * (src1@L - A@L*dst@L)                         exastencils.py:710-726 */
+  EVOMG_OP_RICHARDSON = 9,   /* dst@L += w * (src1@L - A@L*dst@L)                         exastencils.py:710-726 */
+  /* Non-linear FAS vocabulary (exastencils_FAS.py:99-319). Fields are fixed by the statement kind: Solution = SOL,
+   * RHS, Residual = RES, Approximation = CORR (a separate array on EVERY level of a FAS problem). A(u) = L u + N(u). */
+  EVOMG_OP_FAS_SMOOTH = 16,            /* point smoother: u += w (f - A(u)) / (diag L [+ N'(u)]), block[0] local Newton
+                                          steps (0: Picard, divisor diag L only); PART_SINGLE: Jacobi through the next
+                                          slot + advance; PART_RED_BLACK: two colours in place        :209-268 */
+  EVOMG_OP_FAS_RESIDUAL = 17,          /* Residual@L = RHS@L - A(Solution@L)                          :158-180 */
+  EVOMG_OP_FAS_RESTRICT_SOLUTION = 18, /* Approximation@L = R * Solution@(L+1); Solution@L = Approximation@L  :121-136 */
+  EVOMG_OP_FAS_COARSE_RHS = 19,        /* RHS@L = R * Residual@(L+1) + (L@L Approximation@L + N-stencil(Solution@L) *
+                                          Approximation@L)                                           :138-156, grammar 287-293 */
+  EVOMG_OP_FAS_CGS = 20,               /* CGS@L ( ): cgs_max_iterations Newton-Jacobi sweeps           :195-207 */
+  EVOMG_OP_FAS_SUBTRACT = 21           /* Solution@L -= Approximation@L                               :182-193 */
 };
 
 enum { EVOMG_PART_SINGLE = 0, EVOMG_PART_RED_BLACK = 1 };  /* ir/partitioning.py:18,34 */

@@ -125,3 +125,47 @@ CASES = {
                            lambda P: v_cycle(P, 2, [[_rb(23)], [_blk(8, (2, 2, 1)), _jac(12)]],
                                              [[_jac(12), _rb(23)], [_blk(8, (1, 2, 2))]], cgc_index=19)),
 }
+
+
+# ---- non-linear FAS cycles (grammar/multigrid.py with FAS=True) ---------------------------------------
+def fas_smooth(P, depth, cycle, spec):
+    """spec: ('picard', idx, 'single'|'rb') | ('newton', idx, 'single'|'rb', n_newton_steps)"""
+    partitioning = P["red_black"] if spec[2] == "rb" else P["single"]
+    if spec[0] == "picard":
+        return P[f"jacobi_picard_{depth}"](spec[1], partitioning, cycle)
+    return P[f"jacobi_newton_{depth}"](spec[1], partitioning, spec[3], cycle)
+
+
+def fas_v_cycle(P, depth, pre, post, cgc_index=18):
+    """FAS V-cycle over depth+1 levels: pre/post = per level (finest first) lists of smoother specs."""
+    state = P["u_and_f"]
+    cycle = P["residual_0"](state)
+    for d in range(depth):
+        for spec in pre[d]:
+            state = fas_smooth(P, d, cycle, spec)
+            cycle = P[f"residual_{d}"](state)
+        if d < depth - 1:
+            cycle = P[f"coarsening_{d}"](P[f"A_{d + 1}"], P[f"zero_{d + 1}"], P[f"R_{d}"], cycle)
+        else:
+            state = P[f"correct_with_coarse_grid_solver_{d}"](cgc_index, P[f"P_{d + 1}"], P[f"CGS_{d + 1}"],
+                                                              P[f"R_{d}"], cycle)
+    for d in range(depth - 1, -1, -1):
+        if d < depth - 1:
+            state = P[f"update_with_coarse_grid_correction_{d}"](cgc_index, P[f"P_{d + 1}"], state, P[f"R_{d}"])
+        for spec in post[d]:
+            cycle = P[f"residual_{d}"](state)
+            state = fas_smooth(P, d, cycle, spec)
+    return state
+
+
+def _nw(i, p="single", n=1): return ("newton", i, p, n)
+def _pc(i, p="single"): return ("picard", i, p)
+
+
+# name -> (depth, builder); levels come from the problem's .knowledge file (tests/golden/problems/FAS_2D_Basic: 3..6)
+FAS_CASES = {
+    "fas2d_v11_newton": (3, lambda P: fas_v_cycle(P, 3, [[_nw(14)], [_nw(14)], [_nw(14)]], [[_nw(14)], [_nw(14)], [_nw(14)]])),
+    "fas2d_v21_mixed": (3, lambda P: fas_v_cycle(P, 3, [[_nw(14), _pc(12, "rb")], [_pc(14, "rb")], [_nw(16, "rb", 2)]],
+                                                 [[_nw(14, "rb")], [_pc(10)], [_nw(14, "single", 3)]], cgc_index=16)),
+    "fas2d_two_grid_picard": (1, lambda P: fas_v_cycle(P, 1, [[_pc(14, "rb"), _pc(14, "rb")]], [[_pc(14, "rb")]])),
+}

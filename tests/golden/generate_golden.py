@@ -126,6 +126,24 @@ def reference_context(problem, min_level, max_level):
     return pset.context, g, storages
 
 
+def fas_reference_context(depth):
+    """(context of the reference's FAS productions, the reference's ProgramGeneratorFAS) for this repository's own FAS
+    problem files (tests/golden/problems/FAS_2D_Basic). The reference class is constructed normally: its constructor
+    only reads the .knowledge file and the template (no JVM, exastencils_FAS.py:12-96)."""
+    from evostencils.ir import base, system
+    from evostencils.grammar import multigrid as mg
+    from evostencils.code_generation.exastencils_FAS import ProgramGeneratorFAS
+    g = ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
+                            "CorrectionNode", "Laplace", "gamSten", "gen_mgCycle", "CGS",
+                            build_path=os.path.join(HERE, "problems"))
+    approximation = system.Approximation("x", [base.Approximation(f.name, gr) for f, gr in zip(g.fields, g.finest_grid)])
+    top = [eq for eq in g.equations if eq.level == g.max_level]
+    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, gr) for eq, gr in zip(top, g.finest_grid)])
+    pset, _ = mg.generate_primitive_set(approximation, rhs, g.dimension, g.coarsening_factor, g.max_level, g.equations,
+                                        g.operators, g.fields, maximum_local_system_size=8, depth=depth, FAS=True)
+    return pset.context, g
+
+
 def extract_tutorial_cycle():
     with open(os.path.join(REFERENCE, "notebooks", "tutorial.ipynb")) as fh:
         nb = json.load(fh)
@@ -159,6 +177,16 @@ def main():
             fh.write(text)
         manifest[name] = {"problem": problem, "min_level": min_level, "max_level": max_level,
                           "file": f"{name}.exa3", "lines": text.count("\n")}
+        print(f"{name}: {text.count(chr(10))} lines")
+    # non-linear FAS backend (exastencils_FAS.py): layer-4 text of grammar-built cycles
+    for name, (depth, builder) in cycles.FAS_CASES.items():
+        ctx, gen = fas_reference_context(depth)
+        expression, _ = builder(ctx)
+        text = gen.generate_cycle_function(expression)
+        with open(os.path.join(HERE, f"{name}.exa4"), "w") as fh:
+            fh.write(text)
+        manifest[name] = {"problem": "FAS_2D_Basic (tests/golden/problems)", "depth": depth, "file": f"{name}.exa4",
+                          "lines": text.count("\n")}
         print(f"{name}: {text.count(chr(10))} lines")
     recorded = extract_tutorial_cycle()
     with open(os.path.join(HERE, "tutorial_recorded_cycle.exa3"), "w") as fh:

@@ -1,0 +1,76 @@
+"""Non-linear FAS backend, lowering half: the drop-in ProgramGeneratorFAS prints, for cycles built with the
+grammar's FAS productions, character for character the layer-4 text the reference's ProgramGeneratorFAS prints
+(goldens: tests/golden/fas2d_*.exa4, produced by tests/golden/generate_golden.py from the imported reference), and
+lowers the same walk to the flat FAS op program."""
+import os
+
+import pytest
+
+from evostencils_amd import abi
+from evostencils_amd.code_generation.fas import ProgramGeneratorFAS
+from evostencils_amd.grammar import productions
+from evostencils_amd.ir import base, system
+
+import cycles
+from helpers import GOLDEN
+
+
+def fas_generator(library=None):
+    return ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
+                               "CorrectionNode", "Laplace", "gamSten", "gen_mgCycle", "CGS",
+                               build_path=os.path.join(GOLDEN, "problems"), library=library)
+
+
+def fas_context(gen, depth):
+    approximation = system.Approximation("x", [base.Approximation(f.name, g) for f, g in zip(gen.fields, gen.finest_grid)])
+    top = [eq for eq in gen.equations if eq.level == gen.max_level]
+    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, g) for eq, g in zip(top, gen.finest_grid)])
+    return productions.generate_context(approximation, rhs, gen.dimension, gen.coarsening_factor, gen.max_level,
+                                        gen.equations, gen.operators, gen.fields, depth=depth, FAS=True)
+
+
+def test_template_is_read_from_the_problem_files():
+    gen = fas_generator()
+    t = gen.template
+    assert (gen.dimension, gen.min_level, gen.max_level) == (2, 3, 6) and gen.uses_FAS
+    assert (t.gamma, t.cgs_sweeps, t.cgs_omega, t.target_res_reduction, t.max_iterations) == (10.0, 200, 0.8, 1e-10, 300)
+    assert str(gen.sympy_jacobian) == "gam*(Solution + 1)*exp(Solution)"
+    pd = gen.problem_description()
+    c = pd.to_c()
+    assert c.nonlinear_kind == abi.NONLINEAR_GAM_U_EXP_U and c.cgs_kind == abi.CGS_FAS_SMOOTHER and c.nonlinear_gamma == 10.0
+
+
+@pytest.mark.parametrize("name", sorted(cycles.FAS_CASES))
+def test_layer4_text_equals_the_reference(name):
+    depth, builder = cycles.FAS_CASES[name]
+    gen = fas_generator()
+    expression, _ = builder(fas_context(gen, depth))
+    want = open(os.path.join(GOLDEN, f"{name}.exa4")).read()
+    assert gen.generate_cycle_function(expression) == want
+    # the per-level "right-hand side is up to date" flags end where they started: a second lowering prints the same
+    assert gen.generate_cycle_function(expression) == want
+
+
+def test_op_program_of_a_v_cycle():
+    depth, builder = cycles.FAS_CASES["fas2d_v11_newton"]
+    gen = fas_generator()
+    expression, _ = builder(fas_context(gen, depth))
+    ops = gen.generate_op_program(expression)
+    names = [(abi.OP_NAMES[o.opcode], o.level) for o in ops]
+    assert names[:5] == [("FAS_SMOOTH", 6), ("FAS_RESIDUAL", 6), ("FAS_RESTRICT_SOLUTION", 5), ("FAS_COARSE_RHS", 5), ("FAS_SMOOTH", 5)]
+    assert ("FAS_CGS", 3) in names and names.count(("FAS_SUBTRACT", 3)) == 1
+    assert [n for n in names if n[0] == "PROLONG_ADD"] == [("PROLONG_ADD", 4), ("PROLONG_ADD", 5), ("PROLONG_ADD", 6)]
+    assert names[-1] == ("FAS_SMOOTH", 6)
+    sm = ops[0]
+    assert sm.partitioning == abi.PART_SINGLE and sm.block[0] == 1 and abs(sm.omega - 0.8) < 1e-12
+    mixed = gen.generate_op_program(cycles.FAS_CASES["fas2d_v21_mixed"][1](fas_context(gen, 3))[0])
+    newton_steps = sorted({(o.level, o.block[0], o.partitioning) for o in mixed if o.opcode == abi.OP_FAS_SMOOTH})
+    assert (4, 2, abi.PART_RED_BLACK) in newton_steps and (6, 0, abi.PART_RED_BLACK) in newton_steps and (4, 3, abi.PART_SINGLE) in newton_steps
+
+
+def test_result_is_derived_from_the_printed_residuals():
+    gen = fas_generator()
+    # Solve prints with 4 / 3 / 2 / 1 significant digits by magnitude and nothing at or below 1e-12 (template)
+    assert gen._printed(123.456789) == 123.5 and gen._printed(5.4321e-10) == 5.43e-10 and gen._printed(3e-13) is None
+    t, c, n = gen.interpret_history([100.0, 1.0, 0.010004, 1e-13], 7.0)
+    assert (t, n) == (7.0, 3) and c == (0.01 / 100.0) ** (1.0 / 3.0)
