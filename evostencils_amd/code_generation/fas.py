@@ -134,11 +134,11 @@ def read_template(build_path, knowledge_file, template_file, nonlinear_stencil):
 class ProgramGeneratorFAS:
     """Same constructor arguments, attributes and methods as the reference class (exastencils_FAS.py:11-96,
     396-445); `library` / `device_id` select the HIP backend (no ExaStencils run, `exastencils_compiler` and
-    `platform_file` are accepted and ignored)."""
+    `platform_file` are accepted and ignored); `levels` = (min, max) overrides the .knowledge file's level range."""
 
     def __init__(self, problem_name, solution, rhs, residual, FASApproximation, restriction, prolongation, op_linear,
                  op_nonlinear, fct_name_mgcycle, fct_cgs, fct_smoother=None, mpi_rank=0, platform_file=None,
-                 build_path=None, exastencils_compiler=None, library=None, device_id=None):
+                 build_path=None, exastencils_compiler=None, library=None, device_id=None, levels=None):
         self.problem_name = problem_name
         self.platform_file, self.build_path, self.exastencils_compiler = platform_file, build_path, exastencils_compiler
         self.knowledge_file = os.path.join(problem_name, f"{problem_name}.knowledge")
@@ -151,6 +151,9 @@ class ProgramGeneratorFAS:
         if op_nonlinear is None:
             raise UnsupportedFASExpression("a FAS problem without a non-linear stencil is the linear backend's job")
         self.template = read_template(build_path, self.knowledge_file, self.exa_file_template, op_nonlinear)
+        if levels is not None:          # not in the reference: another level range than the .knowledge file's (tests, benchmarks)
+            import dataclasses
+            self.template = dataclasses.replace(self.template, min_level=levels[0], max_level=levels[1])
         self.dimension, self.min_level, self.max_level = self.template.dimension, self.template.min_level, self.template.max_level
         # derivative of the non-linear term as sympy prints it (parser.extract_nonlinear_term, parser.py:146-169)
         expr = re.sub("<[^>]+>", "", self.template.nonlinear_text)

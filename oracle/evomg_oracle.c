@@ -110,8 +110,13 @@ static inline double csc_norm_from_dot(cplx d) { return sqrt(sqrt(d.re * d.re + 
 /* ===================== systems of PDEs (real, 2D) ===================== */
 #include "evomg_oracle_system.h"
 
+/* ===================== non-linear FAS problems (real, 2D) ===================== */
+#include "evomg_oracle_fas.h"
+
 /* ===================== C entry points (same shapes as evomg_*) ===================== */
 typedef struct {
+  int is_fas;
+  fas_ctx_t* fas;
   int is_system;
   sys_ctx_t* s;
   int is_complex;
@@ -123,6 +128,7 @@ static char g_err[256];
 
 const char* oracle_last_error(const oracle_handle_t* h) {
   if (!h) return g_err;
+  if (h->is_fas) return h->fas->err;
   if (h->is_system) return h->s->err;
   return h->is_complex ? h->c->err : h->r->err;
 }
@@ -139,6 +145,14 @@ static int check_problem(const evomg_problem_t* p) {
   if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) {
     snprintf(g_err, sizeof g_err, "jacobi_semantics must be chosen"); return EVOMG_ERR_INVALID;
   }
+  if (p->nonlinear_kind != EVOMG_NONLINEAR_NONE) {
+    if (p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
+        p->bc_kind != EVOMG_BC_DIRICHLET || p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER ||
+        p->n_unknowns > 1) {
+      snprintf(g_err, sizeof g_err, "non-linear FAS: 2D real Dirichlet scalar problems, N(u) = gam u exp(u), smoother as coarse solver");
+      return EVOMG_ERR_UNSUPPORTED;
+    }
+  } else if (p->cgs_kind == EVOMG_CGS_FAS_SMOOTHER) return EVOMG_ERR_INVALID;
   if (p->n_unknowns > 1) {
     if (p->n_unknowns > EVOMG_MAX_UNKNOWNS) { snprintf(g_err, sizeof g_err, "too many unknowns"); return EVOMG_ERR_UNSUPPORTED; }
     if (p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 || p->bc_kind != EVOMG_BC_DIRICHLET ||
@@ -155,9 +169,10 @@ int oracle_create(const evomg_problem_t* p, int device_id, oracle_handle_t** out
   int rc = check_problem(p);
   if (rc != EVOMG_OK) return rc;
   oracle_handle_t* h = (oracle_handle_t*)calloc(1, sizeof *h);
-  h->is_system = p->n_unknowns > 1;
+  h->is_fas = p->nonlinear_kind != EVOMG_NONLINEAR_NONE;
+  h->is_system = !h->is_fas && p->n_unknowns > 1;
   h->is_complex = (p->scalar_kind == EVOMG_COMPLEX_F64);
-  rc = h->is_system ? sys_create(p, &h->s) : h->is_complex ? create_c(p, &h->c) : create_r(p, &h->r);
+  rc = h->is_fas ? fas_create(p, &h->fas) : h->is_system ? sys_create(p, &h->s) : h->is_complex ? create_c(p, &h->c) : create_r(p, &h->r);
   if (rc != EVOMG_OK) { free(h); return rc; }
   *out = h;
   return EVOMG_OK;
@@ -165,7 +180,8 @@ int oracle_create(const evomg_problem_t* p, int device_id, oracle_handle_t** out
 
 void oracle_destroy(oracle_handle_t* h) {
   if (!h) return;
-  if (h->is_system) sys_destroy(h->s);
+  if (h->is_fas) fas_destroy(h->fas);
+  else if (h->is_system) sys_destroy(h->s);
   else if (h->is_complex) destroy_c(h->c); else destroy_r(h->r);
   free(h);
 }
@@ -175,6 +191,15 @@ int oracle_abi_version(void) { return EVOMG_ABI_VERSION; }
 #define LEVEL_OK(P, L) ((L) >= (P).min_level && (L) <= (P).max_level)
 
 int oracle_set_initial_field(oracle_handle_t* h, int level, int field, const double* host) {
+  if (h && h->is_fas && host) {
+    fas_ctx_t* c = h->fas;
+    if (!LEVEL_OK(c->prob, level) || !fas_field(c, level, field)) return EVOMG_ERR_INVALID;
+    fas_level_t* lv = &c->lv[level];
+    if (!lv->init[field]) lv->init[field] = (double*)calloc(lv->count, sizeof(double));
+    memcpy(lv->init[field], host, lv->count * sizeof(double));
+    memcpy(lv->f[field], host, lv->count * sizeof(double));
+    return EVOMG_OK;
+  }
   if (h && h->is_system && host) {
     sys_ctx_t* c = h->s;
     if (!LEVEL_OK(c->prob, level)) return EVOMG_ERR_INVALID;
@@ -208,6 +233,11 @@ int oracle_set_initial_field(oracle_handle_t* h, int level, int field, const dou
 }
 
 int oracle_set_field(oracle_handle_t* h, int level, int field, const double* host) {
+  if (h && h->is_fas && host) {
+    if (!LEVEL_OK(h->fas->prob, level) || !fas_field(h->fas, level, field)) return EVOMG_ERR_INVALID;
+    memcpy(fas_field(h->fas, level, field), host, h->fas->lv[level].count * sizeof(double));
+    return EVOMG_OK;
+  }
   if (h && h->is_system && host) {
     if (!LEVEL_OK(h->s->prob, level)) return EVOMG_ERR_INVALID;
     double* p = sys_field(h->s, level, field);
@@ -231,6 +261,11 @@ int oracle_set_field(oracle_handle_t* h, int level, int field, const double* hos
 }
 
 int oracle_get_field(oracle_handle_t* h, int level, int field, double* host) {
+  if (h && h->is_fas && host) {
+    if (!LEVEL_OK(h->fas->prob, level) || !fas_field(h->fas, level, field)) return EVOMG_ERR_INVALID;
+    memcpy(host, fas_field(h->fas, level, field), h->fas->lv[level].count * sizeof(double));
+    return EVOMG_OK;
+  }
   if (h && h->is_system && host) {
     if (!LEVEL_OK(h->s->prob, level)) return EVOMG_ERR_INVALID;
     const double* p = sys_field(h->s, level, field);
@@ -255,7 +290,7 @@ int oracle_get_field(oracle_handle_t* h, int level, int field, double* host) {
 
 int oracle_set_operators(oracle_handle_t* h, const evomg_problem_t* p) {
   if (!h || !p) return EVOMG_ERR_INVALID;
-  if (h->is_system) return EVOMG_ERR_UNSUPPORTED;
+  if (h->is_system || h->is_fas) return EVOMG_ERR_UNSUPPORTED;
   if (h->is_complex) {
     ctx_t_c* c = h->c;
     if (p->min_level != c->prob.min_level || p->max_level != c->prob.max_level) return EVOMG_ERR_INVALID;
@@ -277,11 +312,17 @@ int oracle_set_operators(oracle_handle_t* h, const evomg_problem_t* p) {
 
 int oracle_run_ops(oracle_handle_t* h, const evomg_op_t* ops, int n_ops) {
   if (!h || (!ops && n_ops > 0) || n_ops < 0) return EVOMG_ERR_INVALID;
+  if (h->is_fas) return fas_run_ops(h->fas, ops, n_ops);
   if (h->is_system) return sys_run_ops(h->s, ops, n_ops);
   return h->is_complex ? run_ops_c(h->c, ops, n_ops) : run_ops_r(h->r, ops, n_ops);
 }
 
 int oracle_norm(oracle_handle_t* h, int level, int field, double* out) {
+  if (h && h->is_fas && out) {
+    if (!LEVEL_OK(h->fas->prob, level) || !fas_field(h->fas, level, field)) return EVOMG_ERR_INVALID;
+    *out = fas_norm(h->fas, level, fas_field(h->fas, level, field));
+    return EVOMG_OK;
+  }
   if (h && h->is_system && out) {
     if (!LEVEL_OK(h->s->prob, level)) return EVOMG_ERR_INVALID;
     const double* p = sys_field(h->s, level, field);
@@ -312,6 +353,7 @@ int oracle_evaluate(oracle_handle_t* h, const evomg_op_t* ops, int n_ops, int ev
                     double wall_limit_ms, evomg_result_t* out, double* res_history, int history_capacity) {
   if (!h || !out || (!ops && n_ops > 0) || n_ops < 0 || evaluation_samples < 1) return EVOMG_ERR_INVALID;
   memset(out, 0, sizeof *out);
+  if (h->is_fas) return fas_evaluate(h->fas, ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity);
   if (h->is_system) return sys_evaluate(h->s, ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity);
   /* validate once */
   for (int i = 0; i < n_ops; ++i) {

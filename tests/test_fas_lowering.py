@@ -15,10 +15,10 @@ import cycles
 from helpers import GOLDEN
 
 
-def fas_generator(library=None):
+def fas_generator(library=None, levels=None):
     return ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
                                "CorrectionNode", "Laplace", "gamSten", "gen_mgCycle", "CGS",
-                               build_path=os.path.join(GOLDEN, "problems"), library=library)
+                               build_path=os.path.join(GOLDEN, "problems"), library=library, levels=levels)
 
 
 def fas_context(gen, depth):

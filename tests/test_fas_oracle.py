@@ -1,0 +1,126 @@
+"""Non-linear FAS backend, oracle half. The arithmetic of the FAS statements has no recorded reference
+output to be pinned against ("parity unpinned", oracle/evomg_oracle_fas.h); what these tests hold instead are known
+answers: the manufactured solution of -Lap u + gam u e^u = f is recovered to O(h^2), the FAS V-cycle converges at a
+level-independent rate, the coarse-grid solver alone solves the coarsest problem, and every statement kind does what its
+layer-4 text says on random fields (numpy restatement)."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from evostencils_amd import abi
+from oracle import oracle
+
+import cycles
+from test_fas_lowering import fas_context, fas_generator
+
+
+def fas_problem(min_level, max_level):
+    gen = fas_generator(levels=(min_level, max_level))
+    return gen, gen.problem_description(), gen.template
+
+
+def ops_for(min_level, max_level, smoother=None):
+    """FAS op program of a V(1,1) cycle (Newton-Jacobi, one local step, w = 0.8 unless `smoother` says otherwise) on a
+    level range of the test problem."""
+    gen = fas_generator(levels=(min_level, max_level))
+    depth = max_level - min_level
+    sm = [[smoother or cycles._nw(14)] for _ in range(depth)]
+    expression, _ = cycles.fas_v_cycle(fas_context(gen, depth), depth, sm, sm)
+    return gen.generate_op_program(expression)
+
+
+def exact_solution(t, level):
+    n = (1 << level) + 1
+    x = np.linspace(0.0, 1.0, n)
+    return np.asarray(t.solution_function(x[None, :] + 0 * x[:, None], x[:, None] + 0 * x[None, :]), dtype=np.float64)
+
+
+@pytest.mark.parametrize("max_level", [5, 6, 7])
+def test_fas_v_cycle_recovers_the_manufactured_solution(max_level):
+    _, pd, t = fas_problem(3, max_level)
+    h = oracle.create(pd)
+    out = h.evaluate(ops_for(3, max_level), 1, 0, 400)
+    assert out.status == abi.SOLVE_CONVERGED and 3 <= out.n_iterations <= 40
+    assert out.history[-1] < 1e-10 * out.history[0]
+    err = np.abs(h.get_field(max_level, abi.F_SOL) - exact_solution(t, max_level)).max()
+    hh = 1.0 / (1 << max_level)
+    assert err < 0.3 * hh * hh * (np.pi ** 2), err             # second-order discretisation error
+    rates = out.history[1:] / out.history[:-1]
+    assert rates[2:].max() < 0.6                                 # V(1,1) Newton-Jacobi, w = 0.8
+    h.close()
+
+
+def test_convergence_rate_does_not_depend_on_the_level():
+    its = []
+    for max_level in (5, 6, 7):
+        _, pd, _ = fas_problem(3, max_level)
+        h = oracle.create(pd)
+        its.append(h.evaluate(ops_for(3, max_level), 1, 0, 400).n_iterations)
+        h.close()
+    assert max(its) - min(its) <= 2, its
+
+
+def test_statements_follow_their_text_on_random_fields():
+    """numpy restatement of each statement kind (the layer-4 text, left to right) against the oracle."""
+    _, pd, t = fas_problem(3, 5)
+    h = oracle.create(pd)
+    rng = np.random.default_rng(5)
+    L = 5
+    n = (1 << L) + 1
+    hh = 1.0 / (1 << L)
+    gam = t.gamma
+
+    def inner(a):
+        b = np.zeros_like(a)
+        b[1:-1, 1:-1] = a[1:-1, 1:-1]
+        return b
+
+    u, f = inner(0.3 * rng.standard_normal((n, n))), rng.standard_normal((n, n))
+    c0, o = 4.0 / hh ** 2, -1.0 / hh ** 2
+
+    def A(x, s):
+        a = c0 * x[1:-1, 1:-1] + o * x[1:-1, :-2] + o * x[1:-1, 2:] + o * x[:-2, 1:-1] + o * x[2:, 1:-1]
+        return a + (gam * np.exp(s[1:-1, 1:-1])) * x[1:-1, 1:-1]
+
+    h.set_field(L, abi.F_SOL, u)
+    h.set_field(L, abi.F_RHS, f)
+    h.run_ops([abi.make_op(abi.OP_FAS_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS)])
+    assert np.allclose(h.get_field(L, abi.F_RES)[1:-1, 1:-1], f[1:-1, 1:-1] - A(u, u), rtol=1e-13, atol=1e-9)
+    # one Jacobi sweep: Picard and Newton
+    for newton in (0, 1):
+        h.set_field(L, abi.F_SOL, u)
+        h.run_ops([abi.make_op(abi.OP_FAS_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (newton, 1, 1), 0.7)])
+        den = c0 + (gam * (u[1:-1, 1:-1] + 1.0) * np.exp(u[1:-1, 1:-1]) if newton else 0.0)
+        want = u[1:-1, 1:-1] + 0.7 * ((f[1:-1, 1:-1] - A(u, u)) / den)
+        assert np.allclose(h.get_field(L, abi.F_SOL)[1:-1, 1:-1], want, rtol=1e-13, atol=1e-13)
+    # FAS transfers
+    h.set_field(L, abi.F_SOL, u)
+    r = inner(rng.standard_normal((n, n)))
+    h.set_field(L, abi.F_RES, r)
+    h.run_ops([abi.make_op(abi.OP_FAS_RESTRICT_SOLUTION, L - 1, abi.F_CORR, abi.F_SOL),
+               abi.make_op(abi.OP_FAS_COARSE_RHS, L - 1, abi.F_RHS, abi.F_RES)])
+
+    def fw(a):
+        return (0.25 * a[2:-2:2, 2:-2:2] + 0.125 * (a[2:-2:2, 1:-3:2] + a[2:-2:2, 3:-1:2] + a[1:-3:2, 2:-2:2] + a[3:-1:2, 2:-2:2])
+                + 0.0625 * (a[1:-3:2, 1:-3:2] + a[1:-3:2, 3:-1:2] + a[3:-1:2, 1:-3:2] + a[3:-1:2, 3:-1:2]))
+
+    uc = h.get_field(L - 1, abi.F_CORR)
+    assert np.allclose(uc[1:-1, 1:-1], fw(u), rtol=1e-13, atol=1e-14) and np.array_equal(uc, h.get_field(L - 1, abi.F_SOL))
+    hc = 2 * hh
+    c0c, oc = 4.0 / hc ** 2, -1.0 / hc ** 2
+    Ac = (c0c * uc[1:-1, 1:-1] + oc * (uc[1:-1, :-2] + uc[1:-1, 2:] + uc[:-2, 1:-1] + uc[2:, 1:-1])
+          + gam * np.exp(uc[1:-1, 1:-1]) * uc[1:-1, 1:-1])
+    assert np.allclose(h.get_field(L - 1, abi.F_RHS)[1:-1, 1:-1], fw(r) + Ac, rtol=1e-12, atol=1e-9)
+    h.run_ops([abi.make_op(abi.OP_FAS_SUBTRACT, L - 1, abi.F_SOL, abi.F_CORR)])
+    assert np.abs(h.get_field(L - 1, abi.F_SOL)).max() == 0.0
+    h.close()
+
+
+def test_coarse_grid_solver_solves_the_coarsest_problem():
+    _, pd, t = fas_problem(3, 3)
+    h = oracle.create(pd)
+    h.run_ops([abi.make_op(abi.OP_FAS_CGS, 3, abi.F_SOL, 0, abi.F_RHS), abi.make_op(abi.OP_FAS_RESIDUAL, 3, abi.F_RES, abi.F_SOL, abi.F_RHS)])
+    assert h.norm(3, abi.F_RES) < 1e-6 * h.norm(3, abi.F_RHS)
+    h.close()
