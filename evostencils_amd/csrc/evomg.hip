@@ -22,6 +22,7 @@
 #include "evomg_tile3d.h"
 #include "evomg_batch.h"
 #include "evomg_system.h"
+#include "evomg_fas.h"
 #ifndef EVOMG_FUSED_PF
 #define EVOMG_FUSED_PF 2   // prefetch depth of the fused sweeps (fewer waves per SIMD than the plain ones)
 #endif
@@ -2214,6 +2215,277 @@ class SystemImpl : public ImplBase {
   int* dinfo_ = nullptr;
 };
 
+// ---- non-linear FAS problems (evomg_fas.h): own storage and a plain interpreter, like the systems of PDEs -----------------
+class FASImpl : public ImplBase {
+ public:
+  FASImpl(const evomg_problem_t& p, int device) : prob_(p), device_(device) {}
+  ~FASImpl() override {
+    (void)hipSetDevice(device_);
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      FLevel& lv = lv_[L];
+      for (auto* q : lv.f) if (q) (void)hipFree(q);
+      for (auto* q : lv.init) if (q) (void)hipFree(q);
+      if (lv.next) (void)hipFree(lv.next);
+    }
+    if (partials_) (void)hipFree(partials_);
+    if (dscalar_) (void)hipFree(dscalar_);
+    if (hscalar_) (void)hipHostFree(hscalar_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+  int init() override {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device_ < 0 || device_ >= count) { snprintf(err, sizeof err, "device %d not available (%d devices)", device_, count); return EVOMG_ERR_DEVICE; }
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&partials_, sizeof(double) * kDotBlocks));
+    HIP_TRY(hipMalloc(&dscalar_, sizeof(double) * 8));
+    HIP_TRY(hipHostMalloc(&hscalar_, sizeof(double) * 8));
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      FLevel& lv = lv_[L];
+      const int n = (1 << L) + 1;
+      lv.g.n = n;
+      lv.g.pitch = ((n + 15) / 16) * 16;
+      lv.g.plane = 0;
+      lv.elems = (size_t)lv.g.pitch * n;
+      for (int e = 0; e < EVOMG_STENCIL_ENTRIES; ++e) lv.st.c[e] = prob_.mg_stencil[L][e].re;
+      for (int k = 0; k < kFields; ++k) HIP_TRY(alloc_zero(&lv.f[k], lv.elems));     // Solution, RHS, Residual, Approximation
+      HIP_TRY(alloc_zero(&lv.next, lv.elems));                                          // Solution<next>
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+  int set_initial_field(int level, int field, const double* host) override {
+    if (!level_ok(level) || !host || !fieldptr(level, field)) return invalid("set_initial_field: bad level/field/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    FLevel& lv = lv_[level];
+    if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
+    HIP_TRY(upload(lv, lv.init[field], host));
+    HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+  int set_field(int level, int field, const double* host) override {
+    if (!level_ok(level) || !host || !fieldptr(level, field)) return invalid("set_field: bad level/field/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(upload(lv_[level], fieldptr(level, field), host));
+    return EVOMG_OK;
+  }
+  int get_field(int level, int field, double* host) override {
+    if (!level_ok(level) || !host || !fieldptr(level, field)) return invalid("get_field: bad level/field/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    const FLevel& lv = lv_[level];
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(double), fieldptr(level, field), lv.g.pitch * sizeof(double), lv.g.n * sizeof(double), lv.g.n, hipMemcpyDeviceToHost));
+    return EVOMG_OK;
+  }
+  int set_operators(const evomg_problem_t*) override { return unsupported("set_operators: not available on FAS problems"); }
+  int run_ops(const evomg_op_t* ops, int n_ops) override {
+    HIP_TRY(hipSetDevice(device_));
+    int rc = validate(ops, n_ops);
+    if (rc != EVOMG_OK) return rc;
+    for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+  int norm(int level, int field, double* out) override {
+    if (!level_ok(level) || !out || !fieldptr(level, field)) return invalid("norm: bad level/field/pointer");
+    HIP_TRY(hipSetDevice(device_));
+    double v;
+    int rc = dot_to_host(level, fieldptr(level, field), &v);
+    if (rc != EVOMG_OK) return rc;
+    *out = sqrt(v);
+    return EVOMG_OK;
+  }
+  // the template's Solve (FAS_2D_Basic_template.exa4:130-160): UpResidual, norm; repeat the cycle until the norm has dropped
+  // below target * initial or max_iterations cycles have run
+  int evaluate(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) override {
+    HIP_TRY(hipSetDevice(device_));
+    if (!out || samples < 1 || n_ops < 0 || (!ops && n_ops > 0)) return invalid("evaluate: bad arguments");
+    memset(out, 0, sizeof *out);
+    int rc = validate(ops, n_ops);
+    if (rc != EVOMG_OK) return rc;
+    const int L = prob_.max_level;
+    double tsum = 0.0;
+    int done = 0;
+    evomg_result_t r;
+    for (int smp = 0; smp < samples; ++smp) {
+      memset(&r, 0, sizeof r);
+      for (int l = prob_.min_level; l <= prob_.max_level; ++l) {
+        FLevel& lv = lv_[l];
+        for (int k = 0; k < kFields; ++k) {
+          if (lv.init[k]) HIP_TRY(hipMemcpyAsync(lv.f[k], lv.init[k], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+          else HIP_TRY(hipMemsetAsync(lv.f[k], 0, lv.elems * sizeof(double), stream_));
+        }
+        HIP_TRY(hipMemsetAsync(lv.next, 0, lv.elems * sizeof(double), stream_));
+      }
+      HIP_TRY(hipStreamSynchronize(stream_));
+      int nh = 0;
+      const double t0 = wall_ms();
+      double res0 = 0.0;
+      if ((rc = residual_norm(L, &res0)) != EVOMG_OK) return rc;
+      if (hist && nh < cap) hist[nh] = res0;
+      ++nh;
+      double res = res0;
+      int it = 0, status = EVOMG_SOLVE_MAXITER;
+      if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+      else
+        for (it = 1; it <= prob_.max_iterations; ++it) {
+          for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+          if ((rc = residual_norm(L, &res)) != EVOMG_OK) return rc;
+          if (hist && nh < cap) hist[nh] = res;
+          ++nh;
+          if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+          if (res < prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+          if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+        }
+      if (it > prob_.max_iterations) it = prob_.max_iterations;
+      r.time_ms = wall_ms() - t0;
+      r.n_iterations = (double)it;
+      r.init_res_norm = res0;
+      r.final_res_norm = res;
+      r.status = status;
+      r.n_history = (nh < cap || !hist) ? nh : cap;
+      r.conv_factor = (it > 0 && res0 > 0) ? pow(res / res0, 1.0 / (double)it) : 0.0;
+      tsum += r.time_ms;
+      ++done;
+      if (status != EVOMG_SOLVE_CONVERGED) break;
+    }
+    *out = r;
+    out->time_ms = tsum / (double)done;
+    return EVOMG_OK;
+  }
+  int bench_op(const evomg_op_t*, int, int, evomg_bench_t*) override { return unsupported("bench_op: not available on FAS problems"); }
+  int kernel_name(const evomg_op_t* op, char* buf, int len) override {
+    if (!op || !buf || len < 8) return invalid("kernel_name: bad arguments");
+    snprintf(buf, len, "%s", op->opcode == EVOMG_OP_FAS_SMOOTH || op->opcode == EVOMG_OP_FAS_CGS ? "evomg_fas_smooth" :
+                             op->opcode == EVOMG_OP_FAS_RESIDUAL ? "evomg_fas_residual" : "generic");
+    return EVOMG_OK;
+  }
+  int profile_begin(int, int) override { return EVOMG_OK; }
+  int profile_end(evomg_bench_t* out) override { if (out) memset(out, 0, sizeof *out); return EVOMG_OK; }
+
+ private:
+  static constexpr int kFields = 4;      // EVOMG_F_SOL, _RHS, _RES, _CORR (= Approximation, a separate array on every level)
+  struct FLevel {
+    Geo g{};
+    size_t elems = 0;
+    double* f[kFields] = {};
+    double* init[kFields] = {};
+    double* next = nullptr;
+    Stencil<double> st{};
+  };
+  hipError_t alloc_zero(double** p, size_t elems) {
+    hipError_t e = hipMalloc(p, elems * sizeof(double));
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(*p, 0, elems * sizeof(double), stream_);
+  }
+  hipError_t upload(const FLevel& lv, double* dst, const double* host) {
+    hipError_t e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess) return e;
+    return hipMemcpy2D(dst, lv.g.pitch * sizeof(double), host, lv.g.n * sizeof(double), lv.g.n * sizeof(double), lv.g.n, hipMemcpyHostToDevice);
+  }
+  bool level_ok(int L) const { return L >= prob_.min_level && L <= prob_.max_level; }
+  double* fieldptr(int level, int field) { return (field < 0 || field >= kFields) ? nullptr : lv_[level].f[field]; }
+  int invalid(const char* msg) { snprintf(err, sizeof err, "%s", msg); return EVOMG_ERR_INVALID; }
+  int unsupported(const char* msg) { snprintf(err, sizeof err, "%s", msg); return EVOMG_ERR_UNSUPPORTED; }
+  static dim3 blk() { return dim3(64, 4, 1); }
+  static dim3 grd(int n) { return dim3((n + 63) / 64, (n + 3) / 4, 1); }
+
+  // mirrors the oracle's fas_check_op
+  int validate(const evomg_op_t* ops, int n_ops) {
+    for (int i = 0; i < n_ops; ++i) {
+      const evomg_op_t& op = ops[i];
+      const int lo = prob_.min_level, hi = prob_.max_level, L = op.level;
+      int rc = EVOMG_ERR_INVALID;
+      bool ok = L >= lo && L <= hi;
+      if (ok) switch (op.opcode) {
+        case EVOMG_OP_FAS_SMOOTH:
+          ok = op.block[0] >= 0 && op.block[0] <= 16 && (op.partitioning == EVOMG_PART_SINGLE || op.partitioning == EVOMG_PART_RED_BLACK);
+          break;
+        case EVOMG_OP_FAS_RESIDUAL: case EVOMG_OP_FAS_SUBTRACT: case EVOMG_OP_FAS_CGS: break;
+        case EVOMG_OP_FAS_RESTRICT_SOLUTION: case EVOMG_OP_FAS_COARSE_RHS: ok = L < hi; break;
+        case EVOMG_OP_PROLONG_ADD: ok = L > lo && op.dst == EVOMG_F_SOL && op.src0 == EVOMG_F_SOL; break;
+        default: ok = false; rc = EVOMG_ERR_UNSUPPORTED;
+      }
+      if (!ok) { snprintf(err, sizeof err, "op %d (opcode %d, level %d) rejected", i, op.opcode, op.level); return rc; }
+    }
+    return EVOMG_OK;
+  }
+  void smooth(int L, double om, bool red_black, int n_newton) {
+    FLevel& lv = lv_[L];
+    const double gam = prob_.nonlinear_gamma;
+    double* x = lv.f[EVOMG_F_SOL];
+    const double* f = lv.f[EVOMG_F_RHS];
+    if (red_black) {
+      for (int colour = 0; colour < 2; ++colour)
+        hipLaunchKernelGGL(evomg_fas_smooth, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.st, gam, (const double*)x, f, x, om, n_newton > 0 ? 1 : 0, n_newton, colour);
+      return;
+    }
+    hipLaunchKernelGGL(evomg_fas_smooth, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.st, gam, (const double*)x, f, lv.next, om, n_newton > 0 ? 1 : 0, n_newton, -1);
+    std::swap(lv.f[EVOMG_F_SOL], lv.next);        // advance Solution
+  }
+  int exec(const evomg_op_t& op) {
+    const int L = op.level;
+    FLevel& lv = lv_[L];
+    const double gam = prob_.nonlinear_gamma;
+    switch (op.opcode) {
+      case EVOMG_OP_FAS_SMOOTH: smooth(L, op.omega, op.partitioning == EVOMG_PART_RED_BLACK, op.block[0]); break;
+      case EVOMG_OP_FAS_RESIDUAL:
+        hipLaunchKernelGGL(evomg_fas_residual, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.st, gam, (const double*)lv.f[EVOMG_F_SOL], (const double*)lv.f[EVOMG_F_RHS], lv.f[EVOMG_F_RES]);
+        break;
+      case EVOMG_OP_FAS_RESTRICT_SOLUTION:
+        hipLaunchKernelGGL(evomg_fas_restrict_solution, grd(lv.g.n), blk(), 0, stream_, lv.g, lv_[L + 1].g, (const double*)lv_[L + 1].f[EVOMG_F_SOL], lv.f[EVOMG_F_CORR], lv.f[EVOMG_F_SOL]);
+        break;
+      case EVOMG_OP_FAS_COARSE_RHS:
+        hipLaunchKernelGGL(evomg_fas_coarse_rhs, grd(lv.g.n), blk(), 0, stream_, lv.g, lv_[L + 1].g, lv.st, gam, (const double*)lv_[L + 1].f[EVOMG_F_RES],
+                           (const double*)lv.f[EVOMG_F_CORR], (const double*)lv.f[EVOMG_F_SOL], lv.f[EVOMG_F_RHS]);
+        break;
+      case EVOMG_OP_FAS_SUBTRACT:
+        hipLaunchKernelGGL(evomg_fas_subtract, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.f[EVOMG_F_SOL], (const double*)lv.f[EVOMG_F_CORR]);
+        break;
+      case EVOMG_OP_FAS_CGS:
+        for (int s = 0; s < prob_.cgs_max_iterations; ++s) smooth(L, prob_.fas_cgs_omega, false, 1);
+        break;
+      case EVOMG_OP_PROLONG_ADD:
+        hipLaunchKernelGGL((evomg_prolong<double, 2, true>), grd(lv.g.n), blk(), 0, stream_, lv.g, lv_[L - 1].g, (const double*)lv_[L - 1].f[EVOMG_F_SOL], lv.f[EVOMG_F_SOL], op.omega);
+        break;
+      default: return invalid("exec: unknown opcode");
+    }
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }
+  int dot_to_host(int L, const double* a, double* out) {
+    const Geo& g = lv_[L].g;
+    const int m = g.n - 2;
+    const int blocks = m < kDotBlocks ? m : kDotBlocks;
+    hipLaunchKernelGGL((evomg_dot_partial<double, 2>), dim3(blocks), dim3(256), 0, stream_, g, a, a, partials_);
+    hipLaunchKernelGGL((evomg_dot_final<double>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dscalar_);
+    HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = hscalar_[0];
+    return EVOMG_OK;
+  }
+  int residual_norm(int L, double* out) {      // UpResidual@finest ; NormResidual_0@finest
+    FLevel& lv = lv_[L];
+    hipLaunchKernelGGL(evomg_fas_residual, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.st, prob_.nonlinear_gamma, (const double*)lv.f[EVOMG_F_SOL],
+                       (const double*)lv.f[EVOMG_F_RHS], lv.f[EVOMG_F_RES]);
+    double d;
+    const int rc = dot_to_host(L, lv.f[EVOMG_F_RES], &d);
+    if (rc != EVOMG_OK) return rc;
+    *out = sqrt(d);
+    return EVOMG_OK;
+  }
+
+  evomg_problem_t prob_;
+  int device_;
+  FLevel lv_[EVOMG_MAX_LEVELS];
+  hipStream_t stream_ = nullptr;
+  double* partials_ = nullptr;
+  double* dscalar_ = nullptr;
+  double* hscalar_ = nullptr;
+};
+
 int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (!p) { snprintf(err, len, "null problem"); return EVOMG_ERR_INVALID; }
   if (p->abi_version != EVOMG_ABI_VERSION) { snprintf(err, len, "abi version %d != %d", p->abi_version, EVOMG_ABI_VERSION); return EVOMG_ERR_INVALID; }
@@ -2225,6 +2497,14 @@ int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) { snprintf(err, len, "PBiCGStab outer solver is 2D only"); return EVOMG_ERR_UNSUPPORTED; }
   if (p->max_iterations < 1 || p->cgs_max_iterations < 1) { snprintf(err, len, "iteration limits must be positive"); return EVOMG_ERR_INVALID; }
   if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) { snprintf(err, len, "jacobi_semantics must be EVOMG_JACOBI_TEXTBOOK or EVOMG_JACOBI_EXASTENCILS_V11"); return EVOMG_ERR_INVALID; }
+  if (p->nonlinear_kind != EVOMG_NONLINEAR_NONE) {
+    if (p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
+        p->bc_kind != EVOMG_BC_DIRICHLET || p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER ||
+        p->n_unknowns > 1) {
+      snprintf(err, len, "non-linear FAS: 2D real Dirichlet scalar problems, N(u) = gam u exp(u), smoother as coarse solver");
+      return EVOMG_ERR_UNSUPPORTED;
+    }
+  } else if (p->cgs_kind == EVOMG_CGS_FAS_SMOOTHER) { snprintf(err, len, "EVOMG_CGS_FAS_SMOOTHER needs a non-linear problem"); return EVOMG_ERR_INVALID; }
   if (p->n_unknowns > 1) {
     if (p->n_unknowns > EVOMG_MAX_UNKNOWNS) { snprintf(err, len, "at most %d unknowns per node", EVOMG_MAX_UNKNOWNS); return EVOMG_ERR_UNSUPPORTED; }
     if (p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 || p->bc_kind != EVOMG_BC_DIRICHLET ||
@@ -2252,7 +2532,8 @@ int evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t**
   int rc = check_problem(problem, g_create_error, sizeof g_create_error);
   if (rc != EVOMG_OK) return rc;
   ImplBase* impl = nullptr;
-  if (problem->n_unknowns > 1) impl = new SystemImpl(*problem, device_id);
+  if (problem->nonlinear_kind != EVOMG_NONLINEAR_NONE) impl = new FASImpl(*problem, device_id);
+  else if (problem->n_unknowns > 1) impl = new SystemImpl(*problem, device_id);
   else if (problem->scalar_kind == EVOMG_COMPLEX_F64) impl = new Impl<cplx>(*problem, device_id);
   else impl = new Impl<double>(*problem, device_id);
   rc = impl->init();
