@@ -2445,7 +2445,14 @@ class FASImpl : public ImplBase {
         hipLaunchKernelGGL(evomg_fas_subtract, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.f[EVOMG_F_SOL], (const double*)lv.f[EVOMG_F_CORR]);
         break;
       case EVOMG_OP_FAS_CGS:
-        for (int s = 0; s < prob_.cgs_max_iterations; ++s) smooth(L, prob_.fas_cgs_omega, false, 1);
+        if (lv.g.n <= 65 && fas_cgs_one_launch_) {
+          // all sweeps in one single-workgroup launch (evomg_fas.h); an odd count leaves the result in the other slot
+          hipLaunchKernelGGL(evomg_fas_cgs, dim3(1), dim3(1024), 0, stream_, lv.g, lv.st, gam, lv.f[EVOMG_F_SOL], lv.next,
+                             (const double*)lv.f[EVOMG_F_RHS], prob_.fas_cgs_omega, prob_.cgs_max_iterations);
+          if (prob_.cgs_max_iterations & 1) std::swap(lv.f[EVOMG_F_SOL], lv.next);
+        } else {
+          for (int s = 0; s < prob_.cgs_max_iterations; ++s) smooth(L, prob_.fas_cgs_omega, false, 1);
+        }
         break;
       case EVOMG_OP_PROLONG_ADD:
         hipLaunchKernelGGL((evomg_prolong<double, 2, true>), grd(lv.g.n), blk(), 0, stream_, lv.g, lv_[L - 1].g, (const double*)lv_[L - 1].f[EVOMG_F_SOL], lv.f[EVOMG_F_SOL], op.omega);
@@ -2479,6 +2486,7 @@ class FASImpl : public ImplBase {
 
   evomg_problem_t prob_;
   int device_;
+  bool fas_cgs_one_launch_ = getenv("EVOMG_NO_FAS_CGS_KERNEL") == nullptr;
   FLevel lv_[EVOMG_MAX_LEVELS];
   hipStream_t stream_ = nullptr;
   double* partials_ = nullptr;

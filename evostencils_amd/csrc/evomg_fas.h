@@ -83,3 +83,25 @@ __global__ void __launch_bounds__(256) evomg_fas_subtract(Geo g, double* __restr
   const long c = gidx<2>(g, i, j, 0);
   sol[c] = sol[c] - approx[c];
 }
+
+// CGS@coarsest: `sweeps` Newton-Jacobi sweeps (one local step, weight om) in ONE launch of ONE 1024-thread workgroup when
+// the level has at most 65^2 nodes: a sweep there is a few thousand nodes, 200 launches of it are 200 x 5 us of launch
+// floor for 200 x ~1 us of work. Thread t owns the inner nodes t, t + 1024, ...; a barrier between sweeps; the two slots
+// alternate. Same per-node formula as evomg_fas_smooth (fas_relax): bit-identical to the launch-per-sweep form.
+// After an even number of sweeps the result is in `a`, after an odd number in `b` (the host swaps accordingly).
+__global__ void __launch_bounds__(1024) evomg_fas_cgs(Geo g, Stencil<double> st, double gam, double* a, double* b, const double* f,
+                                                      double om, int sweeps) {
+  const int m = g.n - 2;
+  const int total = m * m;
+  double* x = a;
+  double* y = b;
+  for (int s = 0; s < sweeps; ++s) {
+    for (int q = threadIdx.x; q < total; q += 1024) {
+      const int i = 1 + q % m, j = 1 + q / m;
+      const long c = gidx<2>(g, i, j, 0);
+      y[c] = fas_relax(st, gam, x, f, g, c, om, 1, 1);
+    }
+    __syncthreads();
+    double* t = x; x = y; y = t;
+  }
+}

@@ -1,5 +1,5 @@
 """Developer tool: run one of the BASELINE.json configurations once on the GPU (for rocprofv3).
-usage: python tools/run_config.py c4|c2|c3|c5|t9|t8"""
+usage: python tools/run_config.py c4|c2|c3|c5|t9|t8|fas"""
 import os, sys, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
@@ -19,6 +19,14 @@ elif cfg == "c5":
     lo, hi = 7, 11
     pd = problems.poisson_2d(lo, hi)
     ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
+elif cfg == "fas":
+    # the reference's non-linear FAS example at its own level range (6..10), V(1,1) Newton-Jacobi
+    import cycles
+    from test_fas_lowering import fas_context, fas_generator
+    gen = fas_generator(levels=(6, 10))
+    sm = [[cycles._nw(14)] for _ in range(4)]
+    ops = gen.generate_op_program(cycles.fas_v_cycle(fas_context(gen, 4), 4, sm, sm)[0])
+    pd, lo, hi = gen.problem_description(), 6, 10
 elif cfg in ("t9", "t8"):
     # the reference's own operating size (notebooks/tutorial.ipynb: levels 5..9 = 513^2, five levels)
     lo, hi = (5, 9) if cfg == "t9" else (4, 8)
