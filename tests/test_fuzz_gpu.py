@@ -1,0 +1,130 @@
+"""Randomised op programs, HIP backend vs CPU oracle through the C-ABI: sequences the hand-written tests do not spell out
+(any order of smoothers, transfers, residuals, zeroing, copies and coarse solves on any level), on grids where the strip /
+tile kernels and the interpreter's peephole fusions are active. Everything the ops write is compared BIT FOR BIT after
+`run_ops`; as the body of the solver loop (cyclic: fusions with dead residual fields, tail norm, speculation) the residual
+histories agree to 1e-10 and the solutions bit for bit."""
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, problems
+
+pytestmark = pytest.mark.gpu
+
+OMEGAS = [0.5, 0.6, 0.8, 0.9999999999999999, 1.0, 1.15]
+
+
+@pytest.fixture(scope="module")
+def native():
+    from evostencils_amd import native as nat
+    nat.library()
+    return nat
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def random_program(rng, dim, lo, hi, length):
+    blocks2 = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (2, 2, 1), (3, 1, 1)]
+    blocks3 = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (1, 1, 2), (2, 2, 1), (2, 2, 2)]
+    ops = [abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS)]          # the coarse solver's right-hand side exists
+    for _ in range(length):
+        L = int(rng.integers(lo, hi + 1))
+        kind = rng.choice(["smooth", "smooth", "smooth", "residual", "restrict", "prolong_add", "prolong_set", "zero", "copy", "coarse",
+                           "smooth_res_restrict", "prolong_smooth"])
+        om = float(rng.choice(OMEGAS))
+        part = abi.PART_RED_BLACK if rng.random() < 0.5 else abi.PART_SINGLE
+        block = (1, 1, 1) if part == abi.PART_RED_BLACK or rng.random() < 0.5 else (blocks2 if dim == 2 else blocks3)[int(rng.integers(0, 5))]
+        smooth = abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, block, om)
+        if kind == "smooth":
+            ops.append(smooth)
+        elif kind == "residual":
+            ops.append(abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS))
+        elif kind == "restrict" and L < hi:
+            ops.append(abi.make_op(abi.OP_RESTRICT, L, abi.F_RHS, abi.F_RES if rng.random() < 0.7 else abi.F_SOL))
+        elif kind == "prolong_add" and L > lo:
+            ops.append(abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=om))
+        elif kind == "prolong_set" and L > lo:
+            ops.append(abi.make_op(abi.OP_PROLONG_SET, L, abi.F_RES, abi.F_SOL))
+        elif kind == "zero" and L < hi:
+            ops.append(abi.make_op(abi.OP_SET_ZERO, L, abi.F_SOL))
+        elif kind == "copy":
+            ops.append(abi.make_op(abi.OP_COPY, L, abi.F_RES, abi.F_RHS))
+        elif kind == "coarse":
+            ops += [abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS), abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR),
+                    abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+        elif kind == "smooth_res_restrict" and L > lo:       # the shapes the peepholes look for
+            ops += [smooth, abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS), abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES)]
+        elif kind == "prolong_smooth" and L > lo:
+            ops += [abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=om), smooth]
+    return ops
+
+
+def load_random(hg, ho, pd, rng):
+    for L in range(pd.min_level, pd.max_level + 1):
+        shape = hg.field_shape(L)
+        for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+            a = rng.standard_normal(shape)
+            hg.set_field(L, f, a)
+            ho.set_field(L, f, a)
+
+
+# (dim, lo, hi, seed): small grids with forced strips / tiles, and grids with several strips, y groups and z chunks
+FUZZ = ([(2, 3, 7, s) for s in range(8)] + [(3, 2, 5, s) for s in range(8)] + [(2, 5, 9, s) for s in range(8, 12)]
+        + [(3, 3, 6, s) for s in range(8, 11)] + [(3, 4, 7, 11), (2, 6, 10, 12)])
+
+
+@pytest.mark.parametrize("dim,lo,hi,seed", FUZZ)
+def test_random_programs_are_bit_exact(native, oracle, dim, lo, hi, seed, monkeypatch):
+    # strips / tiles and their fusions from 17^2 / 9^3 up, odd chunk sizes
+    monkeypatch.setenv("EVOMG_STRIP_MIN_N", "17")
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "9")
+    monkeypatch.setenv("EVOMG_STRIP_ROWS", str([0, 10, 16, 22][seed % 4]))
+    monkeypatch.setenv("EVOMG_STRIP_PLANES", str([0, 4, 8, 12][seed % 4]))
+    pd = problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi)
+    rng = np.random.default_rng(1000 * dim + seed)
+    hg, ho = native.create(pd), oracle.create(pd)
+    ops = random_program(rng, dim, lo, hi, 24 if hi - lo <= 4 else 30)
+    load_random(hg, ho, pd, rng)
+    hg.run_ops(ops)
+    ho.run_ops(ops)
+    for L in range(lo, hi + 1):
+        for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+            got, want = hg.get_field(L, f), ho.get_field(L, f)
+            assert np.array_equal(got, want, equal_nan=True), (dim, seed, L, f, np.nanmax(np.abs(got - want)))
+    hg.close()
+    ho.close()
+
+
+CYCLES = ([(2, 3, 7, s) for s in range(6)] + [(3, 2, 5, s) for s in range(6)] + [(2, 5, 9, 6), (2, 5, 9, 7), (3, 3, 6, 8), (3, 4, 7, 9)])
+
+
+@pytest.mark.parametrize("dim,lo,hi,seed", CYCLES)
+def test_random_cycles_in_the_solver_loop(native, oracle, dim, lo, hi, seed, monkeypatch):
+    """A random V-shaped cycle (random smoothers and sweep counts per level, random weights) as the body of the solver
+    loop: the cyclic-only fusions (dead residual fields, norm tails, speculation) against the oracle."""
+    import dataclasses
+    from test_full_size_gpu import vcycle
+    monkeypatch.setenv("EVOMG_STRIP_MIN_N", "17")
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "9")
+    monkeypatch.setenv("EVOMG_STRIP_PLANES", str([0, 4, 8][seed % 3]))
+    rng = np.random.default_rng(77 * dim + seed)
+    pd = dataclasses.replace(problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi), max_iterations=6)
+    blocks = [(1, 1, 1), (2, 1, 1), (1, 2, 1)]
+
+    def smoother(L):
+        part = abi.PART_RED_BLACK if rng.random() < 0.5 else abi.PART_SINGLE
+        block = (1, 1, 1) if part == abi.PART_RED_BLACK else blocks[int(rng.integers(0, 3))]
+        return abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, block, float(rng.choice(OMEGAS[:4])))
+
+    per_level = {L: smoother(L) for L in range(lo, hi + 1)}
+    ops = vcycle(lo, hi, int(rng.integers(0, 3)), int(rng.integers(1, 3)), lambda L: per_level[L])
+    hg, ho = native.create(pd), oracle.create(pd)
+    got, want = hg.evaluate(ops, 1, 0, 32), ho.evaluate(ops, 1, 0, 32)
+    assert got.status == want.status and got.n_iterations == want.n_iterations
+    assert np.max(np.abs(got.history - want.history) / want.history) <= 1e-10
+    assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+    hg.close()
+    ho.close()
