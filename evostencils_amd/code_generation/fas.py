@@ -220,8 +220,13 @@ class ProgramGeneratorFAS:
         red_black = getattr(partitioning, "__name__", type(partitioning).__name__) == "RedBlack"
         solution = self._n("solution", level)
         if self.fct_smoother is not None:
+            # a smoother function of the template instead of generated statements (exastencils_FAS.py:266-267); the
+            # template's `Smoother` is the Newton-Jacobi sweep of the coarse-grid solver: one local step, its weight
             self._emit(f"{self.fct_smoother}@{level} (  )")
-            self._ops_ok = False
+            if self.fct_smoother == "Smoother":
+                self._op(abi.OP_FAS_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (1, 1, 1), self.template.cgs_omega)
+            else:
+                self._ops_ok = False
             return
         operator = expression.operand1.operand
         numerator = f"( {self._n('rhs', level)} - {self._operator_of(solution, level)} )"

@@ -74,3 +74,17 @@ def test_result_is_derived_from_the_printed_residuals():
     assert gen._printed(123.456789) == 123.5 and gen._printed(5.4321e-10) == 5.43e-10 and gen._printed(3e-13) is None
     t, c, n = gen.interpret_history([100.0, 1.0, 0.010004, 1e-13], 7.0)
     assert (t, n) == (7.0, 3) and c == (0.01 / 100.0) ** (1.0 / 3.0)
+
+
+def test_predefined_smoother_function():
+    """`fct_smoother`: every smoothing step becomes a call of the template's smoother function (exastencils_FAS.py:266-267),
+    whatever smoother the DAG names; in the op program that is the template's Newton-Jacobi sweep."""
+    gen = ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode", "CorrectionNode",
+                              "Laplace", "gamSten", "gen_mgCycle", "CGS", fct_smoother="Smoother",
+                              build_path=os.path.join(GOLDEN, "problems"))
+    expression, _ = cycles.FAS_CASES["fas2d_two_grid_picard"][1](fas_context(gen, 1))
+    text = gen.generate_cycle_function(expression)
+    assert text.count("Smoother@6 (  )") == 3 and "color with" not in text
+    ops = gen.generate_op_program(expression)
+    sm = [o for o in ops if o.opcode == abi.OP_FAS_SMOOTH]
+    assert len(sm) == 3 and all(o.partitioning == abi.PART_SINGLE and o.block[0] == 1 and o.omega == 0.8 for o in sm)
