@@ -191,3 +191,33 @@ class ConcurrentEvaluator:
         self._pool.shutdown(wait=True)
         for g in self.generators:
             g.close()
+
+
+def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[object, int], Tuple[float, float, float]],
+                                  n_candidates: int, local_rank: int = 0):
+    """`evaluate_population` with this rank's share evaluated by the workers of a ConcurrentEvaluator — several
+    candidates in flight on the rank's GPU (own generator, stream and fields each) — instead of one after the other.
+    fn(generator, i) -> (time_ms, rho, iterations). Same split (`i % world == rank`), same single collective, same
+    result table on every rank; a worker that breaks is recorded with the sentinel triple and its first exception is
+    re-raised after the collective, as in the sequential form."""
+    rank, world = world_info()
+    mine_idx = shard_indices(n_candidates, rank, world)
+
+    def guarded(generator, i):
+        try:
+            return fn(generator, i)
+        except Exception as exc:        # noqa: BLE001 — re-raised once the collective is done
+            return exc
+
+    failure = None
+    mine = []
+    for i, r in zip(mine_idx, evaluator.map(guarded, mine_idx)):
+        if isinstance(r, Exception):
+            failure = failure if failure is not None else r
+            r = (FAILED, FAILED, FAILED)
+        t_ms, rho, its = r
+        mine.append((i, float(rho), float(t_ms), float(its)))
+    rows = allgather_fitness(mine, n_candidates, world, local_rank)
+    if failure is not None:
+        raise failure
+    return rows

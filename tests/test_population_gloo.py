@@ -124,3 +124,68 @@ def test_single_process_is_identity():
     assert [r[0] for r in rows] == [0, 1, 2]
     rows, mine = population.evaluate_population_dynamic(_fake_fitness, 3)
     assert [r[0] for r in rows] == [0, 1, 2] and mine == [0, 1, 2]
+
+
+class _FakeGenerator:
+    """Stand-in for a ProgramGenerator worker of the ConcurrentEvaluator: counts what it evaluated."""
+
+    def __init__(self):
+        self.seen = []
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def _in_flight_worker(rank, world, port, n_candidates, queue):
+    import time
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        workers = population.ConcurrentEvaluator(_FakeGenerator, 3)
+
+        def fn(generator, i):
+            time.sleep(0.01)
+            generator.seen.append(i)
+            if i == 5 and rank == 1:
+                raise RuntimeError("device lost")         # one broken candidate must not block the collective
+            return _fake_fitness(i)
+
+        error = None
+        try:
+            rows = population.evaluate_population_in_flight(workers, fn, n_candidates)
+        except RuntimeError as exc:
+            error, rows = str(exc), None
+        seen = sorted(i for g in workers.generators for i in g.seen)
+        used = sum(1 for g in workers.generators if g.seen)
+        workers.close()
+        queue.put((rank, rows, seen, used, error, all(g.closed for g in workers.generators)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_in_flight_evaluation_keeps_the_split_and_the_collective():
+    world, n_candidates = 2, 12
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_in_flight_worker, args=(r, world, port, n_candidates, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, rows, seen, used, error, closed = queue.get(timeout=120)
+        results[rank] = (rows, seen, used, error, closed)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == [0, 2, 4, 6, 8, 10] and results[1][1] == [1, 3, 5, 7, 9, 11]     # the static split
+    assert results[0][2] > 1 and results[1][2] > 1                                          # several workers took part
+    assert results[0][4] and results[1][4]
+    # rank 0 gets the full table, the broken candidate with the sentinel; rank 1 re-raises AFTER the collective
+    rows0 = results[0][0]
+    assert results[0][3] is None and [r[0] for r in rows0] == list(range(n_candidates))
+    assert rows0[5][1] == population.FAILED and rows0[4] == (4, 0.1 + 0.004, 14.0, 6.0)
+    assert results[1][0] is None and "device lost" in results[1][3]
