@@ -101,8 +101,7 @@ class ProgramGenerator:
                 try:
                     problem = problem_files.load_problem(base_path, settings_path, knowledge_path)
                 except problem_files.UnsupportedProblem:
-                    # outside the front end's subset (several unknowns, operator sums, Globals): the built-in
-                    # descriptor of the same configuration, if there is one
+                    # outside the front end's subset: the built-in descriptor of the same configuration, if there is one
                     if config not in problems.BY_NAME:
                         raise
             if problem is not None:

@@ -229,6 +229,9 @@ class Layer2:
     boundaries: Dict[str, List[Tuple[str, Expression]]] = field(default_factory=dict)  # name -> [(levels, expr)]
     operators: Dict[str, List[Tuple[Tuple[int, ...], Expression]]] = field(default_factory=dict)
     equations: Dict[str, Tuple[str, str, str]] = field(default_factory=dict)           # name -> (op, field, rhs)
+    # systems of PDEs: name -> (left-hand side text, rhs field) of equations that are not `Op * field == rhs`
+    general_equations: Dict[str, Tuple[str, str]] = field(default_factory=dict)
+    globals_: Dict[str, Expression] = field(default_factory=dict)                      # `Globals { Expr name = value }`
 
 
 _NUM = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?"
@@ -236,6 +239,7 @@ _NUM = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?"
 
 def parse_layer2(text: str) -> Layer2:
     out = Layer2()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)             # block comments (LinearElasticity/...exa2:38-43)
     src = "\n".join(_strip_comment(l) for l in text.splitlines())
     # blocks first: Operator ... from Stencil { ... } and Equation ... { ... }
     def take_blocks(pattern, handler, s):
@@ -265,13 +269,27 @@ def parse_layer2(text: str) -> Layer2:
         out.operators[m.group(1)] = entries
 
     def on_equation(m, body):
-        if m.group(1) in ("Globals", "Function", "Solve"):
+        if m.group(1) == "Globals":
+            for line in body.splitlines():
+                line = line.strip()
+                if not line:
+                    continue
+                g = re.match(r"(?:Expr|Val|Var)\s+(\w+)\s*(?::\s*\w+\s*)?=\s*(.+)$", line)
+                if not g:
+                    raise UnsupportedProblem(f"Globals entry not understood: {line!r}")
+                out.globals_[g.group(1)] = Expression(g.group(2))
+            return
+        if m.group(1) in ("Function", "Solve"):
             raise UnsupportedProblem(f"layer-2 `{m.group(1)} {{...}}` block is not understood")
-        e = re.match(r"\s*(\w+)\s*\*\s*(\w+)\s*==\s*(\w+)\s*$", " ".join(body.split()))
-        if not e:
-            raise UnsupportedProblem(f"equation {m.group(1)!r}: only `Op * field == rhs_field` is supported, got "
-                                     f"{' '.join(body.split())!r}")
-        out.equations[m.group(1)] = (e.group(1), e.group(2), e.group(3))
+        flat = " ".join(body.split())
+        e = re.match(r"\s*(\w+)\s*\*\s*(\w+)\s*==\s*(\w+)\s*$", flat)
+        if e:
+            out.equations[m.group(1)] = (e.group(1), e.group(2), e.group(3))
+            return
+        g = re.match(r"(.+)==\s*(\w+)\s*$", flat)
+        if not g:
+            raise UnsupportedProblem(f"equation {m.group(1)!r}: `<linear expression> == rhs_field` expected, got {flat!r}")
+        out.general_equations[m.group(1)] = (g.group(1).strip(), g.group(2))
 
     src = take_blocks(r"(?:\bOperator\s+)?\b(\w+)\s+from\s+Stencil\s*\{", on_stencil, src)
     src = take_blocks(r"(?:\bEquation\s+)?\b(\w+)\s*\{", on_equation, src)
@@ -301,12 +319,17 @@ def parse_layer2(text: str) -> Layer2:
 # ---- layer-3 solver hints ------------------------------------------------------------------------------------------
 def parse_solver_hints(text: str) -> Dict[str, str]:
     """`generate solver for u in solEq with { key = value ... }` (Poisson/2D_FD_Poisson_fromL2.exa3:1-15)."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     src = "\n".join(_strip_comment(l) for l in text.splitlines())
-    m = re.search(r"generate\s+solver\s+for\s+(\w+)\s+in\s+(\w+)\s+with\s*\{([^}]*)\}", src)
+    m = re.search(r"generate\s+solver\s+for\s+((?:\w+\s+in\s+\w+)(?:\s+and\s+\w+\s+in\s+\w+)*)\s+with\s*\{([^}]*)\}", src)
     if not m:
         return {}
-    hints = {"field": m.group(1), "equation": m.group(2)}
-    for line in m.group(3).splitlines():
+    pairs = re.findall(r"(\w+)\s+in\s+(\w+)", m.group(1))
+    hints = {"field": pairs[0][0], "equation": pairs[0][1]}
+    if len(pairs) > 1:          # a system of PDEs: unknown i belongs to equation i (LinearElasticity/...exa3:1)
+        hints["fields"] = ",".join(f for f, _ in pairs)
+        hints["equations"] = ",".join(e for _, e in pairs)
+    for line in m.group(2).splitlines():
         if "=" in line:
             k, v = line.split("=", 1)
             hints[k.strip()] = v.strip().strip('"')
@@ -349,9 +372,10 @@ def describe(l2: Layer2, name: str, dimension: int, min_level: int, max_level: i
         raise UnsupportedProblem(f"domain has {len(l2.lower)} dimensions, knowledge says {dimension}")
     if dimension not in (2, 3):
         raise UnsupportedProblem("only 2D and 3D problems are supported")
+    if l2.general_equations or len(l2.equations) > 1:
+        return describe_system(l2, name, dimension, min_level, max_level, hints)
     if len(l2.equations) != 1:
-        raise UnsupportedProblem(f"exactly one equation is supported (systems of PDEs are not), found "
-                                 f"{sorted(l2.equations)}")
+        raise UnsupportedProblem(f"no equation found in the layer-2 file")
     (eq_name, (op_name, field_name, rhs_name)), = l2.equations.items()
     if hints.get("equation", eq_name) != eq_name or hints.get("field", field_name) != field_name:
         raise UnsupportedProblem("the generated solver targets another field/equation than the layer-2 file defines")
@@ -439,6 +463,134 @@ def describe(l2: Layer2, name: str, dimension: int, min_level: int, max_level: i
         field_name=field_name, rhs_name=rhs_name, operator_name=op_name, equation_name=eq_name,
         restriction_name=f"gen_restrictionForRes_{field_name}", prolongation_name=f"gen_prolongationForSol_{field_name}",
         mg_stencil=stencil, initial_solution=initial_solution, right_hand_side=right_hand_side,
+        domain_lower=tuple(lower) + (0.0,) * (3 - dimension), domain_upper=tuple(upper) + (1.0,) * (3 - dimension),
+        solver_hints={k: v for k, v in hints.items() if k.startswith("solver_")})
+
+
+def describe_system(l2: Layer2, name: str, dimension: int, min_level: int, max_level: int,
+                    hints: Optional[Dict[str, str]] = None) -> problems.ProblemDescription:
+    """Systems of PDEs (LinearElasticity/2D_FD_LinearElasticity_fromL2.exa2): several `Real on Node` unknowns,
+    equations whose left-hand sides are linear combinations `coefficient * Stencil * field` with coefficients built from
+    numbers and `Globals`, named stencils with constant coefficients in vf_gridWidth_* (any offsets of the 3 x 3
+    neighbourhood). Which unknown belongs to which equation comes from the layer-3 `generate solver for u in uEq and v in
+    vEq` line, else from the order of declaration."""
+    hints = hints or {}
+    if dimension != 2:
+        raise UnsupportedProblem("systems of PDEs are supported in 2D only")
+    equations = dict(l2.general_equations)
+    for eq_name, (op, fld, rhs) in l2.equations.items():
+        equations[eq_name] = (f"{op} * {fld}", rhs)
+    if "fields" in hints:
+        field_names, equation_names = hints["fields"].split(","), hints["equations"].split(",")
+    else:
+        equation_names = list(equations)
+        rhs_fields = {rhs for _, rhs in equations.values()}
+        field_names = [f for f in l2.fields if f not in rhs_fields][:len(equation_names)]
+    if sorted(equation_names) != sorted(equations) or len(field_names) != len(equation_names):
+        raise UnsupportedProblem(f"equations {sorted(equations)} do not match the solver's {equation_names}")
+    if len(field_names) > abi.MAX_UNKNOWNS:
+        raise UnsupportedProblem(f"at most {abi.MAX_UNKNOWNS} unknowns per node are supported, found {field_names}")
+    rhs_names = [equations[e][1] for e in equation_names]
+    for f in field_names + rhs_names:
+        if f not in l2.fields:
+            raise UnsupportedProblem(f"field {f!r} is not declared")
+        kind, where, _ = l2.fields[f]
+        if kind != "Real" or where != "Node":
+            raise UnsupportedProblem(f"field {f!r}: only `Real on Node` is supported, got `{kind} on {where}`")
+    lower, upper = l2.lower, l2.upper
+    allowed = {"PI"} | {f"vf_gridWidth_{a}" for a in _AXES[:dimension]}
+    for op_name, entries in l2.operators.items():
+        for offset, expr in entries:
+            if len(offset) != dimension or any(abs(c) > 1 for c in offset):
+                raise UnsupportedProblem(f"operator {op_name!r}: offset {list(offset)} is outside the 3 x 3 neighbourhood")
+            if not expr.names() <= allowed:
+                raise UnsupportedProblem(f"operator {op_name!r}: only constant coefficients in vf_gridWidth_* are supported, "
+                                         f"found {sorted(expr.names() - allowed)}")
+    global_values = {}
+    for g, expr in l2.globals_.items():
+        if not expr.names() <= {"PI"}:
+            raise UnsupportedProblem(f"global {g!r}: only numeric expressions are supported")
+        global_values[g] = float(expr.evaluate({"PI": np.pi}))
+
+    def widths(level):
+        return [(upper[d] - lower[d]) / (1 << level) for d in range(dimension)]
+
+    def operator_stencils(level):
+        env = {"PI": np.pi}
+        for d, h in enumerate(widths(level)):
+            env[f"vf_gridWidth_{_AXES[d]}"] = h
+        return {op: [(tuple(off), float(e.evaluate(env))) for off, e in entries] for op, entries in l2.operators.items()}
+
+    def equation_text(level):
+        """The equation with globals numeric and level tags on stencils and fields, every token blank-separated (what
+        grammar.multigrid.EquationInfo parses; the reference gets this text from ExaStencils' debug layer 3)."""
+        texts = []
+        for eq in equation_names:
+            lhs, rhs = equations[eq]
+
+            def token(m):
+                w = m.group(0)
+                if w in l2.operators or w in l2.fields:
+                    return f"{w}@{level}"
+                if w in global_values:
+                    return repr(global_values[w])
+                raise UnsupportedProblem(f"equation {eq!r}: unknown symbol {w!r}")
+            spaced = re.sub(r"([()*+\-/])", r" \1 ", lhs)
+            body = " ".join(re.sub(r"[A-Za-z_]\w*", token, spaced).split())
+            texts.append(f"( {body} ) == {rhs}@{level}")
+        return texts
+
+    def position_env(level):
+        n = (1 << level) + 1
+        env = {"PI": np.pi}
+        for d, h in enumerate(widths(level)):
+            shape = [1] * dimension
+            shape[dimension - 1 - d] = n
+            x = (lower[d] + np.arange(n, dtype=np.float64) * h).reshape(shape)
+            for prefix in ("vf_nodePos_", "vf_boundaryPos_", "vf_boundaryCoord_", "vf_nodePosition_"):
+                env[prefix + _AXES[d]] = x
+            env[f"vf_gridWidth_{_AXES[d]}"] = h
+        env.update(global_values)
+        return n, env
+
+    def on_grid(expr, level):
+        n, env = position_env(level)
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(expr.evaluate(env), dtype=np.float64), (n,) * dimension))
+
+    def initial_solution(level):
+        n = (1 << level) + 1
+        out = []
+        for f in field_names:
+            u = on_grid(l2.fields[f][2], level).copy()
+            chosen = None
+            for levels, expr in l2.boundaries.get(f, []):
+                if _applies(levels, level, min(min_level, level), level):
+                    chosen = expr
+            if chosen is not None:
+                mask = problems._boundary_mask(n, dimension)
+                u[mask] = on_grid(chosen, level)[mask]
+            out.append(u)
+        return out
+
+    def right_hand_side(level):
+        return [on_grid(l2.fields[r][2], level) for r in rhs_names]
+
+    cgs = hints.get("solver_cgs", "CG")
+    if cgs != "CG":
+        raise UnsupportedProblem(f"systems of PDEs: coarse-grid solver {cgs!r} is not supported")
+    spec = problems.SystemSpec(list(field_names), rhs_names, list(equation_names), equation_text, operator_stencils,
+                               [f"gen_restrictionForRes_{f}" for f in field_names],
+                               [f"gen_prolongationForSol_{f}" for f in field_names], initial_solution, right_hand_side)
+    try:
+        spec.assembled(max_level)      # every term must be a scaled named stencil applied to an unknown
+    except (ValueError, KeyError, StopIteration) as exc:
+        raise UnsupportedProblem(f"system of PDEs: {exc}") from exc
+    return problems.ProblemDescription(
+        name, dimension, min_level, max_level, system=spec, parameters=dict(global_values),
+        max_iterations=int(hints.get("solver_maxNumIts", 100)),
+        cgs_max_iterations=int(hints.get("solver_cgs_maxNumIts", 1000)),
+        target_res_reduction=float(hints.get("solver_targetResReduction", 1e-12)),
+        cgs_target_res_reduction=float(hints.get("solver_cgs_targetResReduction", 1e-12)),
         domain_lower=tuple(lower) + (0.0,) * (3 - dimension), domain_upper=tuple(upper) + (1.0,) * (3 - dimension),
         solver_hints={k: v for k, v in hints.items() if k.startswith("solver_")})
 

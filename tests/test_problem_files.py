@@ -139,10 +139,10 @@ def test_3d_fixture_is_solved_exactly():
 @pytest.mark.parametrize("edit, message", [
     (lambda s: s.replace("[ 1,  0] => -0.1", "[ 1,  1] => -0.1"), "outside the star stencil"),
     (lambda s: s.replace("with Real on Node", "with Real on Cell", 1), "only `Real on Node`"),
-    (lambda s: s.replace("Diffusion * v == load", "Diffusion * v + v == load"), "is supported"),
+    (lambda s: s.replace("Diffusion * v == load", "Diffusion * v + v == load"), "not a scaled stencil"),
     (lambda s: s.replace("-0.1 / ( vf_gridWidth_x ** 2 )", "-0.1 * vf_nodePos_x / ( vf_gridWidth_x ** 2 )", 1), "constant coefficients"),
-    (lambda s: s + "\nEquation second {\n  Diffusion * v == load\n}\n", "exactly one equation"),
-    (lambda s: s + "\nGlobals { Var k : Real = 1.0 }\n", "not understood"),
+    (lambda s: s + "\nEquation second {\n  Diffusion * v == load\n}\n", "do not match"),
+    (lambda s: s + "\nGlobals {\n  k is 1.0\n}\n", "Globals entry not understood"),
 ])
 def test_unsupported_constructs_are_named(edit, message):
     with open(os.path.join(FIXTURES, "Diffusion", "2D_FD_AnisotropicDiffusion.exa2")) as fh:
@@ -177,3 +177,55 @@ def test_reference_poisson_files_reproduce_the_builtin_descriptors(name, builtin
     L = b.max_level
     assert np.array_equal(p.initial_solution(L), b.initial_solution(L))
     assert np.array_equal(p.right_hand_side(L), b.right_hand_side(L))
+
+
+# ---- systems of PDEs from problem files (SURVEY 8f N2 x N3) -----------------------------------------------------------
+def test_system_descriptor_from_files():
+    """Two unknowns, equations as sums of scaled named stencils with `Globals` in the coefficients, a four-corner cross
+    derivative, the unknown order taken from the layer-3 `generate solver for ux in momentumX and uy in momentumY`."""
+    p = pf.load_problem(FIXTURES, "Elasticity/2D_FD_Elasticity.settings", "Elasticity/2D_FD_Elasticity.knowledge")
+    spec = p.system
+    assert (p.name, p.dimension, p.min_level, p.max_level) == ("2D_FD_Elasticity", 2, 3, 6)
+    assert spec.field_names == ["ux", "uy"] and spec.rhs_names == ["fx", "fy"] and spec.equation_names == ["momentumX", "momentumY"]
+    assert p.parameters == {"firstLame": 1.5, "shear": 1.0}
+    assert (p.max_iterations, p.cgs_max_iterations, p.target_res_reduction) == (80, 800, 1e-11)
+    a = spec.assembled(5)                          # [equation][unknown][centre, W, E, S, N, SW, SE, NW, NE], h = 1/32
+    s = 1024.0
+    assert np.allclose(a[0, 0], [-2 * 3.5 * s - 2 * s, 3.5 * s, 3.5 * s, s, s, 0, 0, 0, 0])
+    assert np.allclose(a[1, 1], [-2 * s - 2 * 3.5 * s, s, s, 3.5 * s, 3.5 * s, 0, 0, 0, 0])
+    assert np.allclose(a[0, 1], [0, 0, 0, 0, 0, 2.5 * 0.25 * s, -2.5 * 0.25 * s, -2.5 * 0.25 * s, 2.5 * 0.25 * s])
+    assert np.array_equal(a[0, 1], a[1, 0])
+    u0 = spec.initial_solution(4)
+    x = np.arange(17) / 16.0
+    assert np.all(u0[0] == 0.0) and np.all(u0[1][1:-1, 1:-1] == 0.0)
+    assert np.allclose(u0[1][-1, :], 0.25 * x * (1 - x)) and np.all(u0[1][0, :] == 0.0)
+    f = spec.right_hand_side(4)
+    assert np.all(f[0] == 0.0) and np.allclose(f[1], 1.5e-3 * np.sin(np.pi * x)[None, :] * np.ones((17, 1)))
+    c = p.to_c()
+    assert c.n_unknowns == 2 and c.sys_stencil[5][0][1][5] == a[0, 1, 5]
+
+
+def test_program_generator_on_a_system_directory():
+    gen = ProgramGenerator("unused.jar", FIXTURES, "Elasticity/2D_FD_Elasticity.settings", "Elasticity/2D_FD_Elasticity.knowledge")
+    assert [str(f) for f in gen.fields] == ["ux", "uy"] and (gen.min_level, gen.max_level) == (3, 6)
+    ctx = context_for(gen, 3, 6)
+    expression, _ = cycles.v_cycle(ctx, 3, [[("rbgs", 18)]] * 3, [[("decoupled", 14)]] * 3)
+    text = gen.generate_cycle_function(expression, gen.generate_storage(3, 6, gen.finest_grid), 3, 6, 6)
+    assert "gen_residual_ux@6 = fx@6 - " in text.replace("(", "").replace(")", "") or "gen_residual_ux@6" in text
+    ops = gen.generate_op_program(expression, 3, 6)
+    assert any(o.opcode == abi.OP_SMOOTH and o.unknowns == 3 for o in ops) and any(o.opcode == abi.OP_SMOOTH and o.unknowns in (1, 2) for o in ops)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not present")
+def test_reference_elasticity_files_reproduce_the_builtin_descriptor():
+    p = pf.load_problem(REFERENCE, "LinearElasticity/2D_FD_LinearElasticity_fromL2.settings",
+                        "LinearElasticity/2D_FD_LinearElasticity_fromL2.knowledge")
+    b = problems.linear_elasticity_2d()
+    assert (p.name, p.min_level, p.max_level, p.parameters) == (b.name, b.min_level, b.max_level, b.parameters)
+    for attr in ("field_names", "rhs_names", "equation_names", "restriction_names", "prolongation_names"):
+        assert getattr(p.system, attr) == getattr(b.system, attr), attr
+    for level in range(b.min_level, b.max_level + 1):
+        assert np.array_equal(p.system.assembled(level), b.system.assembled(level))
+    L = b.max_level
+    for x, y in zip(p.system.initial_solution(L) + p.system.right_hand_side(L), b.system.initial_solution(L) + b.system.right_hand_side(L)):
+        assert np.array_equal(x, y)

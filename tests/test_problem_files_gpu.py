@@ -22,6 +22,9 @@ CASES = {
     "diffusion2d_block": ("Diffusion/2D_FD_AnisotropicDiffusion", [("block", 16, (1, 4))], 3, 6),
     "harmonic3d": ("Harmonic/3D_FD_Harmonic", [("rbgs", 18)], 2, 5),
     "harmonic3d_block": ("Harmonic/3D_FD_Harmonic", [("block", 12, (2, 1, 1)), ("jacobi", 12)], 2, 4),
+    # a system of two PDEs read from files (`Globals`, equations as sums of scaled stencils, four-corner cross derivative)
+    "elasticity2d": ("Elasticity/2D_FD_Elasticity", [("rbgs", 18)], 3, 6),
+    "elasticity2d_decoupled": ("Elasticity/2D_FD_Elasticity", [("decoupled", 14), ("blocks", 14, ((2, 1), (2, 1)))], 3, 5),
 }
 
 
