@@ -380,7 +380,7 @@ class ProgramGeneratorFAS:
 
     def problem_description(self):
         from evostencils_amd import problems
-        return problems.fas_2d(self.template)
+        return problems.fas_2d(self.template, self.problem_name)
 
     @staticmethod
     def _printed(value):

@@ -403,7 +403,7 @@ def linear_elasticity_2d(min_level=4, max_level=8, lam=195.0, mu=130.0) -> Probl
                                             "solver_smoother_jacobiType": "false"})
 
 
-def fas_2d(template) -> ProblemDescription:
+def fas_2d(template, name="FAS_2D_Basic") -> ProblemDescription:
     """-Laplace u + gam u e^u = f on (0,1)^2, u = 0 on the boundary, u0 = 0: the reference's non-linear FAS example
     (example_problems/FAS_2D_Basic/FAS_2D_Basic_template.exa4). `template`: code_generation.fas.FASTemplate, i.e. what the
     problem's .knowledge / _template.exa4 files say (levels, gam, right-hand side function, coarse solver, stopping rule)."""
@@ -424,7 +424,7 @@ def fas_2d(template) -> ProblemDescription:
 
     if "exp" not in template.nonlinear_text or "gam" not in template.nonlinear_text:
         raise ValueError(f"unsupported non-linear stencil: {template.nonlinear_text}")
-    return ProblemDescription("FAS_2D_Basic", 2, template.min_level, template.max_level, mg_stencil=st,
+    return ProblemDescription(name, 2, template.min_level, template.max_level, mg_stencil=st,
                               initial_solution=u0, right_hand_side=rhs, cgs_kind=abi.CGS_FAS_SMOOTHER,
                               max_iterations=template.max_iterations, cgs_max_iterations=template.cgs_sweeps,
                               target_res_reduction=template.target_res_reduction,

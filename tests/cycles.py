@@ -162,7 +162,7 @@ def _nw(i, p="single", n=1): return ("newton", i, p, n)
 def _pc(i, p="single"): return ("picard", i, p)
 
 
-# name -> (depth, builder); levels come from the problem's .knowledge file (tests/golden/problems/FAS_2D_Basic: 3..6)
+# name -> (depth, builder); levels come from the problem's .knowledge file (tests/golden/problems/FAS_2D_Exponential: 3..6)
 FAS_CASES = {
     "fas2d_v11_newton": (3, lambda P: fas_v_cycle(P, 3, [[_nw(14)], [_nw(14)], [_nw(14)]], [[_nw(14)], [_nw(14)], [_nw(14)]])),
     "fas2d_v21_mixed": (3, lambda P: fas_v_cycle(P, 3, [[_nw(14), _pc(12, "rb")], [_pc(14, "rb")], [_nw(16, "rb", 2)]],

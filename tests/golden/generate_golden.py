@@ -128,12 +128,12 @@ def reference_context(problem, min_level, max_level):
 
 def fas_reference_context(depth):
     """(context of the reference's FAS productions, the reference's ProgramGeneratorFAS) for this repository's own FAS
-    problem files (tests/golden/problems/FAS_2D_Basic). The reference class is constructed normally: its constructor
+    problem files (tests/golden/problems/FAS_2D_Exponential). The reference class is constructed normally: its constructor
     only reads the .knowledge file and the template (no JVM, exastencils_FAS.py:12-96)."""
     from evostencils.ir import base, system
     from evostencils.grammar import multigrid as mg
     from evostencils.code_generation.exastencils_FAS import ProgramGeneratorFAS
-    g = ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
+    g = ProgramGeneratorFAS("FAS_2D_Exponential", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
                             "CorrectionNode", "Laplace", "gamSten", "gen_mgCycle", "CGS",
                             build_path=os.path.join(HERE, "problems"))
     approximation = system.Approximation("x", [base.Approximation(f.name, gr) for f, gr in zip(g.fields, g.finest_grid)])
@@ -185,7 +185,7 @@ def main():
         text = gen.generate_cycle_function(expression)
         with open(os.path.join(HERE, f"{name}.exa4"), "w") as fh:
             fh.write(text)
-        manifest[name] = {"problem": "FAS_2D_Basic (tests/golden/problems)", "depth": depth, "file": f"{name}.exa4",
+        manifest[name] = {"problem": "FAS_2D_Exponential (tests/golden/problems)", "depth": depth, "file": f"{name}.exa4",
                           "lines": text.count("\n")}
         print(f"{name}: {text.count(chr(10))} lines")
     recorded = extract_tutorial_cycle()

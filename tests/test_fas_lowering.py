@@ -16,7 +16,7 @@ from helpers import GOLDEN
 
 
 def fas_generator(library=None, levels=None):
-    return ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
+    return ProgramGeneratorFAS("FAS_2D_Exponential", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
                                "CorrectionNode", "Laplace", "gamSten", "gen_mgCycle", "CGS",
                                build_path=os.path.join(GOLDEN, "problems"), library=library, levels=levels)
 
@@ -79,7 +79,7 @@ def test_result_is_derived_from_the_printed_residuals():
 def test_predefined_smoother_function():
     """`fct_smoother`: every smoothing step becomes a call of the template's smoother function (exastencils_FAS.py:266-267),
     whatever smoother the DAG names; in the op program that is the template's Newton-Jacobi sweep."""
-    gen = ProgramGeneratorFAS("FAS_2D_Basic", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode", "CorrectionNode",
+    gen = ProgramGeneratorFAS("FAS_2D_Exponential", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode", "CorrectionNode",
                               "Laplace", "gamSten", "gen_mgCycle", "CGS", fct_smoother="Smoother",
                               build_path=os.path.join(GOLDEN, "problems"))
     expression, _ = cycles.FAS_CASES["fas2d_two_grid_picard"][1](fas_context(gen, 1))
