@@ -188,6 +188,16 @@ def main():
         manifest[name] = {"problem": "FAS_2D_Exponential (tests/golden/problems)", "depth": depth, "file": f"{name}.exa4",
                           "lines": text.count("\n")}
         print(f"{name}: {text.count(chr(10))} lines")
+    # a RECORDED output of the reference's FAS generator (an earlier version of it): the cycle function appended to
+    # example_problems/FAS_2D_Basic/FAS_2D_Basic.exa4 behind the marker "//generated by EvoStencils" — data, like the
+    # tutorial's recorded cycle
+    with open(os.path.join(REFERENCE, "example_problems", "FAS_2D_Basic", "FAS_2D_Basic.exa4")) as fh:
+        text = fh.read()
+    recorded_fas = text[text.index("Function gen_mgCycle@5", text.index("//generated by EvoStencils")):].rstrip() + "\n"
+    with open(os.path.join(HERE, "fas_recorded_cycle.exa4"), "w") as fh:
+        fh.write(recorded_fas)
+    manifest["fas_recorded_cycle"] = {"source": "example_problems/FAS_2D_Basic/FAS_2D_Basic.exa4:213-270 (generated cycle recorded in the file)",
+                                      "file": "fas_recorded_cycle.exa4"}
     recorded = extract_tutorial_cycle()
     with open(os.path.join(HERE, "tutorial_recorded_cycle.exa3"), "w") as fh:
         fh.write(recorded)

@@ -88,3 +88,36 @@ def test_predefined_smoother_function():
     ops = gen.generate_op_program(expression)
     sm = [o for o in ops if o.opcode == abi.OP_FAS_SMOOTH]
     assert len(sm) == 3 and all(o.partitioning == abi.PART_SINGLE and o.block[0] == 1 and o.omega == 0.8 for o in sm)
+
+
+def _normalised(text):
+    """Statement sequence of a cycle function with the two spellings that changed between the generator version that
+    wrote the recorded cycle and the current one removed: the outer parentheses of the residual's right-hand side and the
+    relaxation factor in front of a prolongated correction (the recorded cycle has none, i.e. 1)."""
+    import re
+    out = []
+    for line in text.splitlines():
+        line = " ".join(line.split())
+        line = re.sub(r"^(Residual@\d+ = )\( (RHS@\d+ - \( .* \)) \)$", r"\1\2", line)
+        line = re.sub(r"\+= \( [0-9.]+ \* (\( CorrectionNode@\d+ \* Solution@\d+ \)) \)$", r"+= \1", line)
+        if line:
+            out.append(line)
+    return out
+
+
+def test_recorded_reference_cycle_is_reproduced():
+    """example_problems/FAS_2D_Basic/FAS_2D_Basic.exa4:213-270 holds a cycle function the reference's generator once
+    wrote (V(2,2), three levels 3..5, the template's `Smoother` as smoother): the same DAG built with the FAS productions
+    lowers to the same statement sequence."""
+    gen = ProgramGeneratorFAS("FAS_2D_Exponential", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode", "CorrectionNode",
+                              "Laplace", "gamSten", "gen_mgCycle", "CGS", fct_smoother="Smoother",
+                              build_path=os.path.join(GOLDEN, "problems"), levels=(3, 5))
+    two = [[cycles._nw(18), cycles._nw(18)], [cycles._nw(18), cycles._nw(18)]]
+    expression, _ = cycles.fas_v_cycle(fas_context(gen, 2), 2, two, two)
+    recorded = open(os.path.join(GOLDEN, "fas_recorded_cycle.exa4")).read()
+    assert _normalised(gen.generate_cycle_function(expression)) == _normalised(recorded)
+    ops = gen.generate_op_program(expression)
+    assert [abi.OP_NAMES[o.opcode] for o in ops] == (
+        ["FAS_SMOOTH"] * 2 + ["FAS_RESIDUAL", "FAS_RESTRICT_SOLUTION", "FAS_COARSE_RHS"] + ["FAS_SMOOTH"] * 2
+        + ["FAS_RESIDUAL", "FAS_RESTRICT_SOLUTION", "FAS_COARSE_RHS", "FAS_CGS", "FAS_SUBTRACT", "PROLONG_ADD"] + ["FAS_SMOOTH"] * 2
+        + ["FAS_SUBTRACT", "PROLONG_ADD"] + ["FAS_SMOOTH"] * 2)
