@@ -21,6 +21,7 @@
 #include "evomg_strip.h"
 #include "evomg_tile3d.h"
 #include "evomg_batch.h"
+#include "evomg_strip_block.h"
 #include "evomg_system.h"
 #include "evomg_fas.h"
 #ifndef EVOMG_FUSED_PF
@@ -315,6 +316,11 @@ template <typename T> class Impl : public ImplBase {
         base = cells > 1 ? (block_fast_ ? "evomg_block_jacobi_fast" : "evomg_block_jacobi") : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
         if (cells == 1 && use_strip(lv_[op->level].g)) {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
+          return EVOMG_OK;
+        }
+        if (cells > 1 && dim_ == 2 && !scalar_traits<T>::is_complex && strip_block_ && use_strip(lv_[op->level].g) && op->block[0] <= 2 &&
+            op->block[1] <= 2 && prob_.bc_kind == EVOMG_BC_DIRICHLET) {
+          snprintf(buf, len, "evomg_strip2d_block<%d, %d, %s>", op->block[0], op->block[1], strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
         if (cells == 1 && use_tile3d(lv_[op->level].g) && (op->partitioning != EVOMG_PART_RED_BLACK || tile3d_rbgs_)) {
@@ -945,10 +951,20 @@ template <typename T> class Impl : public ImplBase {
       hipLaunchKernelGGL((evomg_block_jacobi<T, DIM>), tgrid, blk, 0, stream_, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz, 0, -1);
       return;
     }
-    launch_block_fast<DIM>(cells, tgrid, blk, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
     const int inner = g.n - 2;
     const int b[3] = {bx, by, bz};
     const int t[3] = {tx, ty, tz};
+    bool strip_blocks = false;
+    if constexpr (DIM == 2 && !scalar_traits<T>::is_complex) {
+      // (2,1), (1,2), (2,2) tiles on the strip layout (evomg_strip_block.h): full tiles only, the cut ones below
+      if (strip_block_ && use_strip(g) && bx <= 2 && by <= 2 && prob_.bc_kind == EVOMG_BC_DIRICHLET &&
+          !make_block_plan<T, 2>(st, 1, 2, 1).skip[1][0] && !make_block_plan<T, 2>(st, 2, 1, 1).skip[1][0]) {
+        launch_strip_block(g, st, x, f, y, om, omm, bx, by);
+        strip_blocks = true;
+      }
+    }
+    if (strip_blocks) return;                      // the strip kernel's extra waves solve the cut tiles
+    launch_block_fast<DIM>(cells, tgrid, blk, g, st, x, f, y, om, omm, bx, by, bz, tx, ty, tz);
     // two-cell shapes: the fast kernel relaxes the single leftover node of a cut tile itself
     if (bx * by * (DIM == 3 ? bz : 1) == 2) return;
     for (int d = 0; d < DIM; ++d) {
@@ -963,6 +979,35 @@ template <typename T> class Impl : public ImplBase {
     }
   }
 
+  void launch_strip_block(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, int bx, int by) {
+    if constexpr (!scalar_traits<T>::is_complex) {
+      const BlockPlan<T> pl = make_block_plan<T, 2>(st, bx, by, 1);
+      const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+      int rows = strip_rows_ > 0 ? ((strip_rows_ + 1) & ~1) : 64;
+      if (strip_rows_ <= 0) {
+        while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
+        if (balance_rows_) rows = balanced_rows(g.n, strips, 2, 8, 96);
+      }
+      const int chunks = (g.n - 2 + rows - 1) / rows;
+      const int waves = strips * chunks;
+      // two-cell shapes: extra waves behind the strip waves relax the partner-less last column / row, 64 nodes each
+      // (2,2): one thread per cut tile of the last column and row + the corner node
+      const int extra = (bx * by == 2) ? (g.n - 2 + 63) / 64 : (2 * ((g.n - 2) / 2) + 1 + 63) / 64;
+      const BlockPlan<T> pc = make_block_plan<T, 2>(st, 1, 2, 1), pr = make_block_plan<T, 2>(st, 2, 1, 1);
+      const TwoCell2D cut_col{pc.fac[1][0], pc.upper[0][1], pc.pivot[0], pc.pivot[1]}, cut_row{pr.fac[1][0], pr.upper[0][1], pr.pivot[0], pr.pivot[1]};
+      const dim3 grid((((waves + extra + 3) / 4 + 7) / 8) * 8), block(256);
+      const bool nt = strip_streams(g);
+#define EVOMG_SB(BX, BY)                                                                                                              \
+      if (bx == BX && by == BY) {                                                                                                      \
+        if (nt) hipLaunchKernelGGL((evomg_strip2d_block<BX, BY, true>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, rows, strips, waves, cut_col, cut_row);  \
+        else hipLaunchKernelGGL((evomg_strip2d_block<BX, BY, false>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, rows, strips, waves, cut_col, cut_row);    \
+      }
+      EVOMG_SB(2, 1)
+      EVOMG_SB(1, 2)
+      EVOMG_SB(2, 2)
+#undef EVOMG_SB
+    }
+  }
   // full tiles: replay of the host-side tile factorisation, one instantiation per number of cells
   template <int DIM> void launch_block_fast(int cells, dim3 grid, dim3 block, const Geo& g, const Stencil<T>& st, const T* x,
                                             const T* f, T* y, double om, double omm, int bx, int by, int bz, int tx, int ty, int tz) {
@@ -1845,6 +1890,7 @@ template <typename T> class Impl : public ImplBase {
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
   bool balance_rows_ = (getenv("EVOMG_NO_BALANCED_ROWS") == nullptr);
+  bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
   bool batch_enabled_ = (getenv("EVOMG_BATCH") != nullptr) && (getenv("EVOMG_NO_STRIP") == nullptr);
