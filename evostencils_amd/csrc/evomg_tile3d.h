@@ -40,8 +40,14 @@ template <typename T> struct TwoCellPlan {
 };
 
 // grid: n_blocks (rounded up to a multiple of 8) workgroups of 64*NW threads; block -> (y group fastest, strip, z chunk)
+#ifndef EVOMG_TILE3D_WPE
+#define EVOMG_TILE3D_WPE 0
+#endif
 template <typename T, int MODE, int NW, int NT>
 __global__ void __launch_bounds__(64 * NW)
+#if EVOMG_TILE3D_WPE > 0
+__attribute__((amdgpu_waves_per_eu(EVOMG_TILE3D_WPE, EVOMG_TILE3D_WPE)))
+#endif
 evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
              double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl, int order,
              T* __restrict__ aux) {
