@@ -40,6 +40,8 @@ template <typename T> struct TwoCellPlan {
 };
 
 // grid: n_blocks (rounded up to a multiple of 8) workgroups of 64*NW threads; block -> (y group fastest, strip, z chunk)
+// build knob for A/B only: -DEVOMG_TILE3D_WPE=4 forces 128 VGPRs (two workgroups per compute unit, 36-132 B of scratch per
+// thread) — measured slower at 513^3 (Jacobi 666 -> 739 us), hence off
 #ifndef EVOMG_TILE3D_WPE
 #define EVOMG_TILE3D_WPE 0
 #endif
