@@ -318,9 +318,8 @@ template <typename T> class Impl : public ImplBase {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
-        if (cells > 1 && dim_ == 2 && !scalar_traits<T>::is_complex && strip_block_ && use_strip(lv_[op->level].g) && op->block[0] <= 2 &&
-            op->block[1] <= 2 && prob_.bc_kind == EVOMG_BC_DIRICHLET) {
-          snprintf(buf, len, "evomg_strip2d_block<%d, %d, %s>", op->block[0], op->block[1], strip_streams(lv_[op->level].g) ? "true" : "false");
+        if (cells > 1 && dim_ == 2 && strip_block_ && use_strip(lv_[op->level].g) && op->block[0] <= 2 && op->block[1] <= 2) {
+          snprintf(buf, len, "evomg_strip2d_block<%s, %d, %d, %s>", type_name<T>::get(), op->block[0], op->block[1], strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
         if (cells == 1 && use_tile3d(lv_[op->level].g) && (op->partitioning != EVOMG_PART_RED_BLACK || tile3d_rbgs_)) {
@@ -955,9 +954,9 @@ template <typename T> class Impl : public ImplBase {
     const int b[3] = {bx, by, bz};
     const int t[3] = {tx, ty, tz};
     bool strip_blocks = false;
-    if constexpr (DIM == 2 && !scalar_traits<T>::is_complex) {
-      // (2,1), (1,2), (2,2) tiles on the strip layout (evomg_strip_block.h): full tiles only, the cut ones below
-      if (strip_block_ && use_strip(g) && bx <= 2 && by <= 2 && prob_.bc_kind == EVOMG_BC_DIRICHLET &&
+    if constexpr (DIM == 2) {
+      // (2,1), (1,2), (2,2) tiles on the strip layout (evomg_strip_block.h), cut tiles included
+      if (strip_block_ && use_strip(g) && bx <= 2 && by <= 2 &&
           !make_block_plan<T, 2>(st, 1, 2, 1).skip[1][0] && !make_block_plan<T, 2>(st, 2, 1, 1).skip[1][0]) {
         launch_strip_block(g, st, x, f, y, om, omm, bx, by);
         strip_blocks = true;
@@ -980,7 +979,7 @@ template <typename T> class Impl : public ImplBase {
   }
 
   void launch_strip_block(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, int bx, int by) {
-    if constexpr (!scalar_traits<T>::is_complex) {
+    {
       const BlockPlan<T> pl = make_block_plan<T, 2>(st, bx, by, 1);
       const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
       int rows = strip_rows_ > 0 ? ((strip_rows_ + 1) & ~1) : 64;
@@ -994,13 +993,13 @@ template <typename T> class Impl : public ImplBase {
       // (2,2): one thread per cut tile of the last column and row + the corner node
       const int extra = (bx * by == 2) ? (g.n - 2 + 63) / 64 : (2 * ((g.n - 2) / 2) + 1 + 63) / 64;
       const BlockPlan<T> pc = make_block_plan<T, 2>(st, 1, 2, 1), pr = make_block_plan<T, 2>(st, 2, 1, 1);
-      const TwoCell2D cut_col{pc.fac[1][0], pc.upper[0][1], pc.pivot[0], pc.pivot[1]}, cut_row{pr.fac[1][0], pr.upper[0][1], pr.pivot[0], pr.pivot[1]};
+      const TwoCell2D<T> cut_col{pc.fac[1][0], pc.upper[0][1], pc.pivot[0], pc.pivot[1]}, cut_row{pr.fac[1][0], pr.upper[0][1], pr.pivot[0], pr.pivot[1]};
       const dim3 grid((((waves + extra + 3) / 4 + 7) / 8) * 8), block(256);
       const bool nt = strip_streams(g);
 #define EVOMG_SB(BX, BY)                                                                                                              \
       if (bx == BX && by == BY) {                                                                                                      \
-        if (nt) hipLaunchKernelGGL((evomg_strip2d_block<BX, BY, true>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, rows, strips, waves, cut_col, cut_row);  \
-        else hipLaunchKernelGGL((evomg_strip2d_block<BX, BY, false>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, rows, strips, waves, cut_col, cut_row);    \
+        if (nt) hipLaunchKernelGGL((evomg_strip2d_block<T, BX, BY, true>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, rows, strips, waves, cut_col, cut_row);  \
+        else hipLaunchKernelGGL((evomg_strip2d_block<T, BX, BY, false>), grid, block, 0, stream_, g, st, pl, x, f, y, om, omm, rows, strips, waves, cut_col, cut_row);    \
       }
       EVOMG_SB(2, 1)
       EVOMG_SB(1, 2)

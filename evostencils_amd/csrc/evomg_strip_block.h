@@ -14,24 +14,24 @@
 // Tiles cut by the far boundary (2^L - 1 inner nodes per dimension: the last column and the last row have no partner): of a
 // two-cell shape a single node is left, of a (2,2) tile a (1,2) tile (last column), a (2,1) tile (last row) or a single node
 // (corner): extra waves of the same launch solve those, one thread each, as the generic kernel does for cut tiles.
-// Quotients by the pivots: const_div (evomg_scalar.h). Bit-identical to evomg_block_jacobi_fast and the oracle.
+// Quotients by the pivots: const_div (evomg_scalar.h). Real and complex fields (the Robin columns of a Helmholtz field are
+// re-applied by the caller after the sweep, as for every block smoother). Bit-identical to evomg_block_jacobi_fast and the oracle.
 // grid: ceil(strips * chunks / 4) blocks of 256 threads (4 independent waves), rows_per_chunk even.
 #pragma once
 #include "evomg_strip.h"
 
 // elimination of a two-cell tile (BlockPlan of a (2,1) or (1,2) shape): fac[1][0], upper[0][1], pivot[0], pivot[1]
-struct TwoCell2D {
-  double fac, upper, pivot0, pivot1;
+template <typename T> struct TwoCell2D {
+  T fac, upper, pivot0, pivot1;
 };
 
 // cut_col / cut_row: the eliminations of the (1,2) / (2,1) systems a (2,2) tile leaves at the far boundary
-template <int BX, int BY, bool NT_F>
+template <typename T, int BX, int BY, bool NT_F>
 __global__ void __launch_bounds__(256)
-evomg_strip2d_block(Geo g, Stencil<double> st, BlockPlan<double> pl, const double* __restrict__ x, const double* __restrict__ f,
-                    double* __restrict__ y, double om, double omm, int rows_per_chunk, int n_strips, int n_waves,
-                    TwoCell2D cut_col, TwoCell2D cut_row) {
+evomg_strip2d_block(Geo g, Stencil<T> st, BlockPlan<T> pl, const T* __restrict__ x, const T* __restrict__ f,
+                    T* __restrict__ y, double om, double omm, int rows_per_chunk, int n_strips, int n_waves,
+                    TwoCell2D<T> cut_col, TwoCell2D<T> cut_row) {
   static_assert((BX == 1 || BX == 2) && (BY == 1 || BY == 2) && BX * BY > 1, "two- and four-cell tiles");
-  typedef double T;
   constexpr int M = BX * BY;
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -53,7 +53,7 @@ evomg_strip2d_block(Geo g, Stencil<double> st, BlockPlan<double> pl, const doubl
       const int m2 = g.n - 2, half = m2 / 2;                    // m2 is odd: `half` full pairs + the partner-less line
       const int idx = (wave - n_waves) * 64 + lane;
       const long p = g.pitch;
-      auto finish = [&](long c0_, long c1_, T r0, T r1, const TwoCell2D& tc) {
+      auto finish = [&](long c0_, long c1_, T r0, T r1, const TwoCell2D<T>& tc) {
         r1 = sc_sub(r1, sc_mul(tc.fac, r0));
         r1 = sc_div(r1, tc.pivot1);
         r0 = sc_div(sc_sub(r0, sc_mul(tc.upper, r1)), tc.pivot0);
