@@ -552,6 +552,12 @@ template <typename T> class Impl : public ImplBase {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
         continue;
       }
+      if (fusable_prolong_twice(ops, n_ops, i)) {
+        const int rc = exec_twice(ops[i + 1], &ops[i]);
+        if (rc != EVOMG_OK) return rc;
+        i += 2;
+        continue;
+      }
       if (fusable_twice(ops, n_ops, i)) {
         const int rc = exec_twice(ops[i]);
         if (rc != EVOMG_OK) return rc;
@@ -1360,7 +1366,7 @@ template <typename T> class Impl : public ImplBase {
   }
   // two identical Jacobi-type sweeps in a row on one field (evomg_tile3d_twice): same geometry as the red-black tiles
   template <int MODE> void launch_tile3d_twice(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm,
-                                               TwoCellPlan<T> two) {
+                                               TwoCellPlan<T> two, const T* coarse = nullptr, const Geo* gc = nullptr, double om_p = 0.0) {
     constexpr int TY = EVOMG_TILE3D_TY;
     constexpr int cols = (MODE == TILE_BLOCK211) ? 120 : EVOMG_STRIP_COLS;      // two halo lanes per side for the blocks
     const int strips = (g.n + cols - 1) / cols;
@@ -1372,8 +1378,21 @@ template <typename T> class Impl : public ImplBase {
     const int chunks = (g.n - 2 + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
-    if constexpr (!scalar_traits<T>::is_complex)
-      hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two);
+    if constexpr (!scalar_traits<T>::is_complex) {
+      if (coarse) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, true>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two,
+                                     TwiceProlong<T>{coarse, *gc, om_p});
+      else hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, false>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two,
+                              TwiceProlong<T>{nullptr, g, 0.0});
+    }
+  }
+  // PROLONG_ADD@L, SMOOTH, SMOOTH: the coarse-grid correction folded into the double sweep's loads (evomg_tile3d_twice<PRO>)
+  bool fusable_prolong_twice(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!tile3d_pro_ || i + 2 >= n_ops || ops[i].opcode != EVOMG_OP_PROLONG_ADD || !fusable_twice(ops, n_ops, i + 1)) return false;
+    const evomg_op_t &pr = ops[i], &sm = ops[i + 1];
+    if (pr.level != sm.level || pr.level <= prob_.min_level || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    if (canon(pr.level, pr.dst) != canon(sm.level, sm.dst)) return false;
+    if (prof_matches(pr)) return false;
+    return canon(pr.level - 1, pr.src0) >= 0 && lv_[pr.level - 1].f[canon(pr.level - 1, pr.src0)] != nullptr;
   }
   // SMOOTH, SMOOTH: the same Single-partitioned point or (2,1,1) block smoother twice in a row on the same field, on a 3D
   // level the tiles serve (>= 257^3: below, two launches are as fast)
@@ -1392,7 +1411,7 @@ template <typename T> class Impl : public ImplBase {
     const Geo& g = lv_[a.level].g;
     return use_tile3d_blocks(g);
   }
-  int exec_twice(const evomg_op_t& sm) {
+  int exec_twice(const evomg_op_t& sm, const evomg_op_t* pr = nullptr) {
     const int L = sm.level;
     Level<T>& lv = lv_[L];
     T* x = fieldptr(L, sm.dst);
@@ -1403,9 +1422,13 @@ template <typename T> class Impl : public ImplBase {
     if constexpr (!scalar_traits<T>::is_complex) {
       if (sm.block[0] == 2) {
         const BlockPlan<T> pl = make_block_plan<T, 3>(lv.st, 2, 1, 1);
-        launch_tile3d_twice<TILE_BLOCK211>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{pl.fac[1][0], pl.upper[0][1], pl.pivot[0], pl.pivot[1]});
+        const T* cz = pr ? fieldptr(L - 1, pr->src0) : nullptr;
+        launch_tile3d_twice<TILE_BLOCK211>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{pl.fac[1][0], pl.upper[0][1], pl.pivot[0], pl.pivot[1]},
+                                           cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g, pr ? pr->omega : 0.0);
       } else {
-        launch_tile3d_twice<STRIP_JACOBI>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{});
+        const T* cz = pr ? fieldptr(L - 1, pr->src0) : nullptr;
+        launch_tile3d_twice<STRIP_JACOBI>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{}, cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g,
+                                          pr ? pr->omega : 0.0);
       }
     }
     advance(lv, L, sm, x, y);      // two sweeps, one pass: the result lives in the spare array -> ONE swap
@@ -1906,6 +1929,7 @@ template <typename T> class Impl : public ImplBase {
   bool tile3d_enabled_ = getenv("EVOMG_NO_TILE3D") == nullptr;
   bool tile3d_rbgs_ = getenv("EVOMG_NO_TILE3D_RBGS") == nullptr;
   bool tile3d_twice_ = getenv("EVOMG_NO_TILE3D_TWICE") == nullptr;
+  bool tile3d_pro_ = getenv("EVOMG_NO_TILE3D_PRO") == nullptr;
   int tile3d_nt_ = getenv("EVOMG_TILE3D_NT") ? atoi(getenv("EVOMG_TILE3D_NT")) : 0;   // bit 0: non-temporal f loads (measured slower at 513^3: profiles/r02_pmc_3d.md)
   int tile3d_order_ = getenv("EVOMG_TILE3D_ORDER") ? atoi(getenv("EVOMG_TILE3D_ORDER")) : 1;
   int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;

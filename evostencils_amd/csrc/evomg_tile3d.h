@@ -452,10 +452,24 @@ __global__ void __launch_bounds__(256) evomg_sum_stage1(const T* __restrict__ p,
 // forms y1 on its 32 rows, finishes y2 on 30, consecutive workgroups overlap by two rows; the topmost workgroup finishes
 // its last row against the boundary row (y1 = x there). Sweep arithmetic = the one-sweep tile kernel's, applied twice:
 // bit-identical to two launches.
-template <typename T, int MODE, int NW, int NT>
+// PRO (round 2): the sweeps' input is x + om_p * P(coarse) instead of x — the PROLONG_ADD that precedes the post-smoothing
+// sweeps of a V-cycle — formed on the fly exactly as evomg_prolong_cell3d forms it (sums from zero in dz, dy, dx order,
+// one scaling, then x + om_p * v on inner nodes): the corrected field is never written nor read back (a 1.1 GB
+// read-modify-write pass at 513^3 less). Every row of x the kernel loads is corrected before anything uses it:
+//   * own rows and the outermost waves' halo rows of plane k+2 at the END of step k (they were loaded at its start), from
+//     the four coarse rows (row0/2 - 1 .. row0/2 + 2) x two coarse planes the step loaded beside them (eight 16-byte
+//     loads per lane, L1/L2 hits: the coarse field is 1/8 of the fine one);
+//   * the prologue's three planes with loads of their own.
+template <typename T> struct TwiceProlong {
+  const T* coarse;
+  Geo gc;
+  double om;
+};
+template <typename T, int MODE, int NW, int NT, bool PRO = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
-                   double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl) {
+                   double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl,
+                   TwiceProlong<T> pro) {
   static_assert(MODE == STRIP_JACOBI || MODE == TILE_BLOCK211, "two fused sweeps: point Jacobi and (2,1,1) blocks");
   constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
   __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x of the next centre plane
@@ -507,6 +521,41 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   auto pick = [&](T (*edge)[NW][2][128], int parity, int wave, int which) -> Pair<T> {
     return *reinterpret_cast<const Pair<T>*>(&edge[parity][wave][which][2 * lane]);
   };
+  // ---- PRO: trilinear prolongation of the coarse correction onto a loaded row ----
+  const int nc = PRO ? pro.gc.n : 1;
+  const int Ic = min(max(c0 >> 1, 0), nc - 1);               // coarse column of element a; b lies between Ic and Ic + 1
+  auto coarse_line = [&](int J, int K) -> Pair<T> {           // e[K][J][Ic], e[K][J][Ic + 1] (8-byte aligned 16-byte load)
+    const int jj = min(max(J, 0), nc - 1), kk = min(max(K, 0), nc - 1);
+    return load_pair<T>(pro.coarse + pro.gc.plane * kk + (long)pro.gc.pitch * jj + Ic);
+  };
+  // x + om_p * P(e) at (row, pl_): l00 = coarse row J = row/2 of coarse plane K = pl_/2, l01 = row J+1, l10 / l11 = plane K+1
+  auto corrected = [&](const Pair<T>& raw, int row, int pl_, const Pair<T>& l00, const Pair<T>& l01, const Pair<T>& l10,
+                       const Pair<T>& l11) -> Pair<T> {
+    const bool in = row >= 1 && row <= n - 2 && pl_ >= 1 && pl_ <= n - 2;          // uniform
+    const bool oy = (row & 1) != 0, oz = (pl_ & 1) != 0;                           // uniform
+    T s0 = sc_add(zero, l00.a), s1 = sc_add(sc_add(zero, l00.a), l00.b);
+    if (oy) { s0 = sc_add(s0, l01.a); s1 = sc_add(sc_add(s1, l01.a), l01.b); }
+    if (oz) {
+      s0 = sc_add(s0, l10.a); s1 = sc_add(sc_add(s1, l10.a), l10.b);
+      if (oy) { s0 = sc_add(s0, l11.a); s1 = sc_add(sc_add(s1, l11.a), l11.b); }
+    }
+    const double w0 = (oy && oz) ? 0.25 : (oy || oz) ? 0.5 : 1.0;
+    const T v0 = sc_rmul(w0, s0), v1 = sc_rmul(0.5 * w0, s1);
+    Pair<T> out = raw;
+    if (in && inner_a) out.a = sc_add(raw.a, sc_rmul(pro.om, v0));
+    if (in && inner_b) out.b = sc_add(raw.b, sc_rmul(pro.om, v1));
+    return out;
+  };
+  // a row loaded and corrected with coarse loads of its own (prologue)
+  auto load_x_pro = [&](int row, int pl_) -> Pair<T> {
+    const Pair<T> raw = load_x(row, pl_);
+    if constexpr (!PRO) return raw;
+    else {
+      const int r = min(max(row, 0), n - 1), p_ = min(max(pl_, 0), n - 1);
+      const int J = r >> 1, K = p_ >> 1;
+      return corrected(raw, row, pl_, coarse_line(J, K), coarse_line(J + 1, K), coarse_line(J, K + 1), coarse_line(J + 1, K + 1));
+    }
+  };
   // one sweep at one row: centre pair c with its south / north / down / up pairs and right-hand side; non-inner nodes keep
   // their value. Whole wave (DPP shifts inside).
   auto sweep = [&](const Pair<T>& c, const Pair<T>& s, const Pair<T>& nn, const Pair<T>& dn, const Pair<T>& up,
@@ -553,17 +602,25 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   Pair<T> ys1 = zpair, yn1 = zpair;            // y1 of plane k-1 in the rows below / above the wave
 #pragma unroll
   for (int t = 0; t < TY; ++t) {
-    xb[t] = load_x(row0 + t, ks - 1);
-    xc[t] = load_x(row0 + t, ks);
-    xa[t] = load_x(row0 + t, ks + 1);
+    xb[t] = load_x_pro(row0 + t, ks - 1);
+    xc[t] = load_x_pro(row0 + t, ks);
+    xa[t] = load_x_pro(row0 + t, ks + 1);
     fc[t] = load_f(row0 + t, ks);
     fb[t] = zpair;
     p2[t] = zpair;
     p1[t] = zpair;
   }
-  hs = load_x(row0 - 1, ks);
-  hn = load_x(row0 + TY, ks);
+  hs = load_x_pro(row0 - 1, ks);
+  hn = load_x_pro(row0 + TY, ks);
   hn_prev = hn;
+  // PRO: the outermost waves' halo rows are fetched one plane further ahead (beside xq, so that the step's coarse rows serve
+  // them too); gs / gn enter the loop holding plane ks + 1
+  Pair<T> gqs = zpair, gqn = zpair;
+  Pair<T> cl[2][4];                            // coarse rows row0/2 - 1 .. row0/2 + 2 of the coarse planes (k+2)/2, (k+2)/2 + 1
+  if constexpr (PRO) {
+    if (w == 0) gs = load_x_pro(row0 - 1, ks + 1);
+    if (w == NW - 1) gn = load_x_pro(row0 + TY, ks + 1);
+  }
   park(edge_x, ks & 1, xc[0], xc[TY - 1]);
   __syncthreads();
   if (w > 0) hs = pick(edge_x, ks & 1, w - 1, 1);
@@ -574,8 +631,18 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
     for (int t = 0; t < TY; ++t) xq[t] = load_x(row0 + t, k + 2);
 #pragma unroll
     for (int t = 0; t < TY; ++t) fq[t] = load_f(row0 + t, k + 1);
-    if (w == 0) gs = load_x(row0 - 1, k + 1);
-    if (w == NW - 1) gn = load_x(row0 + TY, k + 1);
+    if constexpr (PRO) {
+      if (w == 0) gqs = load_x(row0 - 1, k + 2);
+      if (w == NW - 1) gqn = load_x(row0 + TY, k + 2);
+      const int Jb = (row0 >> 1) - 1, Kq = min(max(k + 2, 0), n - 1) >> 1;
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int jl = 0; jl < 4; ++jl) cl[dz][jl] = coarse_line(Jb + jl, Kq + dz);
+    } else {
+      if (w == 0) gs = load_x(row0 - 1, k + 1);
+      if (w == NW - 1) gn = load_x(row0 + TY, k + 1);
+    }
     park(edge_x, (k + 1) & 1, xa[0], xa[TY - 1]);
     const bool plane_inner = k >= 1 && k <= n - 2;
     // ---- first sweep: y1 on plane k, own rows ----
@@ -606,6 +673,17 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
     hn = (w < NW - 1) ? pick(edge_x, (k + 1) & 1, w + 1, 0) : gn;
     ys1 = (w > 0) ? pick(edge_y, k & 1, w - 1, 1) : zpair;
     yn1 = (w < NW - 1) ? pick(edge_y, k & 1, w + 1, 0) : zpair;
+    if constexpr (PRO) {
+      // plane k+2 arrives: correct its rows before they become `xa`. Row row0 + t (row0 even): coarse row index
+      // jl = 1 + floor(t / 2) of the four loaded, the next one as well when t is odd
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        const int jl = 1 + (t >> 1);
+        xq[t] = corrected(xq[t], row0 + t, k + 2, cl[0][jl], cl[0][jl + 1 < 4 ? jl + 1 : 3], cl[1][jl], cl[1][jl + 1 < 4 ? jl + 1 : 3]);
+      }
+      if (w == 0) gs = corrected(gqs, row0 - 1, k + 2, cl[0][0], cl[0][1], cl[1][0], cl[1][1]);          // row0 - 1: odd
+      if (w == NW - 1) gn = corrected(gqn, row0 + TY, k + 2, cl[0][3], cl[0][3], cl[1][3], cl[1][3]);     // row0 + 4: even
+    }
 #pragma unroll
     for (int t = 0; t < TY; ++t) { p2[t] = p1[t]; p1[t] = pc[t]; fb[t] = fc[t]; fc[t] = fq[t]; xb[t] = xc[t]; xc[t] = xa[t]; xa[t] = xq[t]; }
   }
