@@ -635,10 +635,15 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
       if (w == 0) gqs = load_x(row0 - 1, k + 2);
       if (w == NW - 1) gqn = load_x(row0 + TY, k + 2);
       const int Jb = (row0 >> 1) - 1, Kq = min(max(k + 2, 0), n - 1) >> 1;
+      // the upper coarse plane only for odd fine planes, the row below the workgroup only for its first wave (uniform)
+      const bool odd_plane = ((k + 2) & 1) != 0;
 #pragma unroll
       for (int dz = 0; dz < 2; ++dz)
+        if (dz == 0 || odd_plane) {
+          if (w == 0) cl[dz][0] = coarse_line(Jb, Kq + dz);
 #pragma unroll
-        for (int jl = 0; jl < 4; ++jl) cl[dz][jl] = coarse_line(Jb + jl, Kq + dz);
+          for (int jl = 1; jl < 4; ++jl) cl[dz][jl] = coarse_line(Jb + jl, Kq + dz);
+        }
     } else {
       if (w == 0) gs = load_x(row0 - 1, k + 1);
       if (w == NW - 1) gn = load_x(row0 + TY, k + 1);
