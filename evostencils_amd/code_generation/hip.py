@@ -346,8 +346,18 @@ class ProgramGenerator:
         import numpy as np
         if self._problem.system is None:
             raise lowering.UnsupportedExpression("the candidate couples several unknowns but the problem has one")
-        key = ("system", st.level)
-        if self._verified.get(key):
+        # as on the scalar path: one comparison per (operator object, level, PDE parameters); the cache keeps the object
+        # alive so that its id stays unique. Smoothers carry the whole block operator, residual / Richardson statements
+        # one row of entry objects — both are grammar terminals shared by all candidates
+        params = tuple(sorted((k, complex(v)) for k, v in self._problem.parameters.items()))
+        if st.unknowns:
+            source = st.operator_source
+            key = ("system", id(source), st.level, params)
+        else:
+            source = tuple(st.operator_row)
+            key = ("system-row", st.dst.index, tuple(id(e) for e in source), st.level, params)
+        cached = self._verified.get(key)
+        if source is not None and cached is not None and (cached is source or cached == source):
             return
         expected = self._problem.system.assembled(st.level)
         rows = st.system_stencils if st.unknowns else None
@@ -366,8 +376,8 @@ class ProgramGenerator:
                     got[problems.NINE_POINT_OFFSETS.index(tuple(off))] += float(val)
                 if not np.array_equal(got, expected[i, j]):
                     raise lowering.UnsupportedExpression(f"operator entry ({i}, {j})@{st.level} differs from the problem's")
-        if st.unknowns:
-            self._verified[key] = True
+        if source is not None:
+            self._verified[key] = source
 
     # ---- THE call (exastencils.py:485-537) -----------------------------------------------------------
     def generate_and_evaluate(self, expression, storages, min_level: int, max_level: int, solver_program: str,

@@ -70,6 +70,7 @@ class Statement:
     row_fields: Optional[list] = None      # ... and the field each entry applies to
     unknowns: Tuple[int, ...] = ()         # smoother: the unknowns whose equations are solved together in one block
     system_stencils: object = None         # smoother: [equation][unknown] -> constant stencil of the system operator
+    operator_source: object = None         # system smoother: the (long-lived) system operator object the stencils came from
 
 
 class Lowering:
@@ -243,7 +244,8 @@ class Lowering:
             self.out.append(Statement("smooth", g.level, dst=self._sol(g.level, unknowns[0]),
                                       rhs=FieldRef(RHS, g.level, unknowns[0]), weight=weight,
                                       partitioning=part.kind_of(cycle.partitioning), block=block, operator_level=g.level,
-                                      group=group, unknowns=tuple(unknowns), system_stencils=stencils))
+                                      group=group, unknowns=tuple(unknowns), system_stencils=stencils,
+                                      operator_source=system_operator))
 
         if isa(smoothing_operator, "system", "Diagonal"):
             for i in range(nf):

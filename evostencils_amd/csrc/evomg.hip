@@ -1407,7 +1407,11 @@ template <typename T> class Impl : public ImplBase {
     const bool point = a.block[0] == 1 && a.block[1] == 1 && a.block[2] == 1;
     const bool b211 = a.block[0] == 2 && a.block[1] == 1 && a.block[2] == 1 && block_fast_;
     if (!point && !b211) return false;
-    if (prof_matches(a)) return false;
+    // `with jacobi` sweeps whose slot is never advanced: each one is launched on its own and its output discarded (the
+    // contract of EVOMG_JACOBI_EXASTENCILS_V11: the sweep runs and costs its time); a double sweep would also swallow a
+    // prolongation folded into it, because its only output is the discarded array
+    if (jacobi_lost(a) || jacobi_lost(b)) return false;
+    if (prof_matches(a) || prof_matches(b)) return false;
     const Geo& g = lv_[a.level].g;
     return use_tile3d_blocks(g);
   }

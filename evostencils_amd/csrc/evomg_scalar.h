@@ -48,7 +48,13 @@ EVOMG_HD double sc_norm_from_dot(cplx d) { return sqrt(sqrt(d.re * d.re + d.im *
 // a quotient costs the remaining three — m, e, fma(e, y, m): the same roundings in the same order, so the same bits as
 // a / b whenever div_scale leaves its operands alone, i.e. for normal b and a with exponent(a) > -970 and
 // |exponent(a) - exponent(b)| < 768 (fields of a multigrid solve: yes; checked bit for bit by tools/check_const_div.hip).
-// Outside that range (and for a = -0, which comes out as +0) the result may differ from a / b in the last place.
+// Outside that range (and for a = -0, which comes out as +0) the result may differ from a / b in the last place, and a
+// non-finite numerator gives NaN where a / b gives inf. Neither is reachable with a result that matters: the solver loops
+// stop at the first residual norm that is inf or NaN (status DIVERGED, same test on both sides), the norm — a sum of
+// squares — is inf from |r| ~ 1e154 on, and the divisors here are 4/h^2 ... 6/h^2 and block pivots of that size, so a
+// numerator would have to grow from below 1e154 past 2^768 * b ~ 1e237 within ONE cycle to be rescaled; a field that has
+// already overflowed makes the norm non-finite either way (inf on the CPU, NaN here) and ends the solve at the same
+// iteration with the same status. tests/test_parity_gpu.py::test_diverging_candidate_3d_tiles pins that.
 // Complex: plain sc_div.
 template <typename T> struct ConstDiv { T b, y; };
 __device__ __forceinline__ ConstDiv<double> const_div_make(double b) {

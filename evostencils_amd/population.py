@@ -54,21 +54,38 @@ def gather_fitness(local: Sequence[Tuple[float, float, float]], world: int, loca
     return list(local)
 
 
+class RemoteEvaluationFailure(RuntimeError):
+    """Raised on the HEALTHY ranks of a generation in which another rank's evaluator broke: the gathered table holds
+    sentinel rows that are not fitness values, so no rank may continue with it."""
+
+
+_FLAG_OK, _FLAG_FAILED = -1.0, -2.0
+
+
 def allgather_fitness(indexed: Sequence[Tuple[int, float, float, float]], n_total: int, world: int,
-                      local_rank: int = 0):
+                      local_rank: int = 0, failed: bool = False):
     """All ranks obtain the fitness of all candidates: rows (index, rho, time_ms, iterations), padded to
-    the largest shard. Counterpart of `allgather([(i, fitness)])` (program.py:536)."""
+    the largest shard. Counterpart of `allgather([(i, fitness)])` (program.py:536). The same collective carries one
+    flag row per rank (`failed`: this rank's evaluator broke); if any rank set it, every OTHER rank raises
+    RemoteEvaluationFailure after the collective (the failing rank re-raises its own exception)."""
     if world <= 1:
         return sorted(indexed)
     import torch
     dist = _dist()
     per = (n_total + world - 1) // world
-    t = torch.full((per, 4), -1.0, dtype=torch.float64, device=_device(local_rank))
+    t = torch.full((per + 1, 4), _FLAG_OK, dtype=torch.float64)
     if indexed:
         t[:len(indexed)] = torch.tensor(list(indexed), dtype=torch.float64)
+    if failed:
+        t[per, 0] = _FLAG_FAILED
+    t = t.to(_device(local_rank))
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
-    rows = [tuple(r) for chunk in out for r in chunk.cpu().tolist() if r[0] >= 0]
+    chunks = [chunk.cpu().tolist() for chunk in out]
+    sick = [r for r, chunk in enumerate(chunks) if chunk[per][0] == _FLAG_FAILED]
+    if sick and not failed:
+        raise RemoteEvaluationFailure("evaluator failed on rank(s) %s: this generation's fitness table is invalid" % sick)
+    rows = [tuple(r) for chunk in chunks for r in chunk[:per] if r[0] >= 0]
     return sorted((int(r[0]), r[1], r[2], r[3]) for r in rows)
 
 
@@ -83,9 +100,11 @@ def evaluate_population(evaluate: Callable[[int], Tuple[float, float, float]], n
     for i in shard_indices(n_candidates, rank, world):
         t_ms, rho, its, failure = _guarded(evaluate, i, failure)
         mine.append((i, float(rho), float(t_ms), float(its)))
-    rows = allgather_fitness(mine, n_candidates, world, local_rank)
-    if failure is not None:
-        raise failure
+    try:
+        rows = allgather_fitness(mine, n_candidates, world, local_rank, failed=failure is not None)
+    finally:
+        if failure is not None:
+            raise failure
     return rows
 
 
@@ -95,7 +114,10 @@ FAILED = 1e100      # the reference's `infinity` sentinel (optimization/program.
 def _guarded(evaluate, i, failure):
     """A rank whose evaluator breaks (device error, ...) must still reach the generation's collective, or every other
     rank blocks in it forever: the candidate is recorded with the sentinel triple, the first exception is kept and
-    re-raised on this rank AFTER the collective."""
+    re-raised on this rank AFTER the collective. After a failure the rank evaluates nothing more (its remaining
+    candidates get the sentinel without a call: a broken device fails every call at once)."""
+    if failure is not None:
+        return FAILED, FAILED, FAILED, failure
     try:
         t_ms, rho, its = evaluate(i)
         return t_ms, rho, its, failure
@@ -122,6 +144,10 @@ def evaluate_population_dynamic(evaluate: Callable[[int], Tuple[float, float, fl
     rendezvous store (host side, tens of microseconds against solves of tens of milliseconds), and per generation
     one all-reduce of the [n_candidates x 4] fitness table (each row is written by exactly one rank, the others
     contribute zeros, so the sum is exact).
+    A rank whose evaluator breaks stops drawing at once (a sick rank fails instantly and would otherwise drain the
+    queue, turning candidates the healthy ranks could have evaluated into sentinels); the candidate it held gets the
+    sentinel row, the extra last row of the table counts failed ranks, and EVERY rank raises after the collective —
+    the failing one its own exception, the others RemoteEvaluationFailure.
     Returns (rows, evaluated_here): rows = [(i, rho, time_ms, iterations)] for all candidates on every rank."""
     rank, world = world_info()
     if world <= 1:
@@ -135,21 +161,26 @@ def evaluate_population_dynamic(evaluate: Callable[[int], Tuple[float, float, fl
     store = store if store is not None else _work_queue_store()
     key = "evomg/work_queue/%d" % _queue_generation[0]     # same sequence of calls on every rank -> same key
     _queue_generation[0] += 1
-    table = torch.zeros((n_candidates, 4), dtype=torch.float64)
+    table = torch.zeros((n_candidates + 1, 4), dtype=torch.float64)
     mine = []
     failure = None
-    while True:
+    while failure is None:
         i = store.add(key, 1) - 1
         if i >= n_candidates:
             break
         t_ms, rho, its, failure = _guarded(evaluate, i, failure)
         table[i] = torch.tensor([1.0, float(rho), float(t_ms), float(its)], dtype=torch.float64)
         mine.append(i)
+    if failure is not None:
+        table[n_candidates, 0] = 1.0
     table = table.to(_device(local_rank))
     dist.all_reduce(table, op=dist.ReduceOp.SUM)
     rows = table.cpu().tolist()
+    n_failed = rows.pop()[0]
     if failure is not None:
         raise failure
+    if n_failed:
+        raise RemoteEvaluationFailure("evaluator failed on %d other rank(s): this generation's fitness table is invalid" % int(n_failed))
     missing = [i for i, r in enumerate(rows) if r[0] != 1.0]
     if missing:
         raise RuntimeError("work queue: candidates %s were evaluated %s" % (missing[:8], "not exactly once"))
@@ -217,7 +248,9 @@ def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[
             r = (FAILED, FAILED, FAILED)
         t_ms, rho, its = r
         mine.append((i, float(rho), float(t_ms), float(its)))
-    rows = allgather_fitness(mine, n_candidates, world, local_rank)
-    if failure is not None:
-        raise failure
+    try:
+        rows = allgather_fitness(mine, n_candidates, world, local_rank, failed=failure is not None)
+    finally:
+        if failure is not None:
+            raise failure
     return rows

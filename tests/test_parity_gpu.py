@@ -513,3 +513,68 @@ def test_sweep_fusions_do_not_change_a_bit(native, smoother, pre, post, monkeypa
     assert np.array_equal(a.history, b.history)
     for x, y in zip(fa, fb):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("post", ["jacobi", "block211"])
+def test_lost_jacobi_sweeps_3d_keep_the_coarse_grid_correction(native, oracle, post, monkeypatch):
+    """EVOMG_JACOBI_EXASTENCILS_V11 on the 3D tiles (forced on from 33^3): PROLONG_ADD followed by two Single-partitioned
+    sweeps must not become one double sweep — its only output is the array the semantics discard, and the correction
+    folded into its loads would be discarded with it. RB-GS pre-smoothing keeps the cycle convergent; the two lost
+    post-sweeps are launched and change nothing. GPU vs oracle (same semantics): identical iteration counts, histories
+    within 1e-10, solution bit-identical; and identical to the same solve with EVOMG_NO_FUSE."""
+    import dataclasses
+    lo, hi = 4, 6
+    pd = dataclasses.replace(problems.poisson_3d(lo, hi), jacobi_semantics=abi.JACOBI_EXASTENCILS_V11)
+    block = (2, 1, 1) if post == "block211" else (1, 1, 1)
+    rb = lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0)
+    lost = lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, block, 0.8)
+    ops = []
+    for L in range(hi, lo, -1):
+        ops += [rb(L), rb(L), abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS),
+                abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES)]
+        if L - 1 > lo:
+            ops.append(abi.make_op(abi.OP_SET_ZERO, L - 1, abi.F_SOL))
+    ops += [abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS), abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR),
+            abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+    for L in range(lo + 1, hi + 1):
+        ops += [abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=1.0), lost(L), lost(L)]
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "33")
+    ho = oracle.create(pd)
+    oo = ho.evaluate(ops, 1, 0, 128)
+    assert oo.status == abi.SOLVE_CONVERGED and oo.n_iterations > 3      # the correction arrived: the cycle converges
+    results = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("EVOMG_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("EVOMG_NO_FUSE", raising=False)
+        hg = native.create(pd)
+        og = hg.evaluate(ops, 1, 0, 128)
+        compare_solves(og, oo)
+        results.append((og.history, hg.get_field(hi, abi.F_SOL)))
+        assert np.array_equal(results[-1][1], ho.get_field(hi, abi.F_SOL))
+        hg.close()
+    assert np.array_equal(results[0][0], results[1][0])
+
+
+@pytest.mark.parametrize("smoother", ["jacobi", "block211"])
+def test_diverging_candidate_3d_tiles(native, oracle, smoother, monkeypatch):
+    """A diverging candidate (over-relaxed Jacobi / (2,1,1) block sweeps, omega = 1.9, textbook semantics) on the 3D tile
+    kernels, whose quotients go through const_div (csrc/evomg_scalar.h): the residual norm overflows at the same
+    iteration on both sides, both report DIVERGED, and every finite entry of the two histories agrees to 1e-10."""
+    from test_full_size_gpu import vcycle
+    lo, hi = 4, 6
+    pd = problems.poisson_3d(lo, hi)
+    block = (2, 1, 1) if smoother == "block211" else (1, 1, 1)
+    ops = vcycle(lo, hi, 2, 2, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, block, 1.9))
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "33")
+    hg, ho = make_pair(native, oracle, pd)
+    og = hg.evaluate(ops, 1, 0, 128)
+    oo = ho.evaluate(ops, 1, 0, 128)
+    assert oo.status == abi.SOLVE_DIVERGED and og.status == abi.SOLVE_DIVERGED
+    assert og.n_iterations == oo.n_iterations and len(og.history) == len(oo.history)
+    finite = np.isfinite(oo.history)
+    assert np.array_equal(finite, np.isfinite(og.history)) and finite.sum() >= 3
+    rel = np.abs(og.history[finite] - oo.history[finite]) / oo.history[finite]
+    assert rel.max() <= REL_TOL
+    hg.close()

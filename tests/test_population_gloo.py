@@ -184,8 +184,55 @@ def test_in_flight_evaluation_keeps_the_split_and_the_collective():
     assert results[0][1] == [0, 2, 4, 6, 8, 10] and results[1][1] == [1, 3, 5, 7, 9, 11]     # the static split
     assert results[0][2] > 1 and results[1][2] > 1                                          # several workers took part
     assert results[0][4] and results[1][4]
-    # rank 0 gets the full table, the broken candidate with the sentinel; rank 1 re-raises AFTER the collective
-    rows0 = results[0][0]
-    assert results[0][3] is None and [r[0] for r in rows0] == list(range(n_candidates))
-    assert rows0[5][1] == population.FAILED and rows0[4] == (4, 0.1 + 0.004, 14.0, 6.0)
+    # both ranks reach and leave the collective; rank 1 re-raises its own exception AFTER it, rank 0 learns from the
+    # flag row that the table holds sentinels and raises too: nobody continues with a poisoned fitness table
     assert results[1][0] is None and "device lost" in results[1][3]
+    assert results[0][0] is None and "rank(s) [1]" in results[0][3]
+
+
+def _dynamic_failure_worker(rank, world, port, n_candidates, queue):
+    import time
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def evaluate(i):
+            calls.append(i)
+            if rank == 1:
+                raise RuntimeError("device lost")     # fails instantly, every time: a sick rank
+            time.sleep(0.02)
+            return _fake_fitness(i)
+
+        dist.barrier()
+        try:
+            population.evaluate_population_dynamic(evaluate, n_candidates)
+            error = None
+        except RuntimeError as exc:
+            error = "%s: %s" % (type(exc).__name__, exc)
+        queue.put((rank, calls, error))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dynamic_queue_sick_rank_stops_drawing_and_every_rank_raises():
+    """a rank whose evaluator fails instantly must not drain the shared queue; all ranks raise."""
+    world, n_candidates = 2, 24
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dynamic_failure_worker, args=(r, world, port, n_candidates, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, calls, error = queue.get(timeout=120)
+        results[rank] = (calls, error)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(results[1][0]) == 1 and "device lost" in results[1][1]            # one draw, then it stopped
+    assert len(results[0][0]) == n_candidates - 1                                 # the healthy rank evaluated the rest
+    assert results[0][1].startswith("RemoteEvaluationFailure")
