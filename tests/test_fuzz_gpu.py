@@ -33,7 +33,7 @@ def random_program(rng, dim, lo, hi, length):
     for _ in range(length):
         L = int(rng.integers(lo, hi + 1))
         kind = rng.choice(["smooth", "smooth", "smooth", "residual", "restrict", "prolong_add", "prolong_set", "zero", "copy", "coarse",
-                           "smooth_res_restrict", "prolong_smooth"])
+                           "smooth_res_restrict", "prolong_smooth", "smooth_twice", "prolong_smooth_twice"])
         om = float(rng.choice(OMEGAS))
         part = abi.PART_RED_BLACK if rng.random() < 0.5 else abi.PART_SINGLE
         block = (1, 1, 1) if part == abi.PART_RED_BLACK or rng.random() < 0.5 else (blocks2 if dim == 2 else blocks3)[int(rng.integers(0, 5))]
@@ -59,6 +59,10 @@ def random_program(rng, dim, lo, hi, length):
             ops += [smooth, abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS), abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES)]
         elif kind == "prolong_smooth" and L > lo:
             ops += [abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=om), smooth]
+        elif kind == "smooth_twice":                          # temporal fusion of two identical sweeps (3D tiles)
+            ops += [smooth, smooth]
+        elif kind == "prolong_smooth_twice" and L > lo:
+            ops += [abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=om), smooth, smooth]
     return ops
 
 
@@ -76,14 +80,24 @@ FUZZ = ([(2, 3, 7, s) for s in range(8)] + [(3, 2, 5, s) for s in range(8)] + [(
         + [(3, 3, 6, s) for s in range(8, 11)] + [(3, 4, 7, 11), (2, 6, 10, 12)])
 
 
-@pytest.mark.parametrize("dim,lo,hi,seed", FUZZ)
-def test_random_programs_are_bit_exact(native, oracle, dim, lo, hi, seed, monkeypatch):
+def with_semantics(pd, semantics):
+    import dataclasses
+    return dataclasses.replace(pd, jacobi_semantics=abi.JACOBI_SEMANTICS[semantics])
+
+
+# the reference pipeline's `with jacobi` semantics (EVOMG_JACOBI_EXASTENCILS_V11: Single-partitioned sweeps are launched
+# and their result discarded) is the drop-in class's default: every fusion has to leave such sweeps alone
+FUZZ_V11 = [(d, lo, hi, s, "exastencils-v1.1") for d, lo, hi, s in FUZZ if s % 2 == 0 or s >= 8]
+
+
+@pytest.mark.parametrize("dim,lo,hi,seed,semantics", [f + ("textbook",) for f in FUZZ] + FUZZ_V11)
+def test_random_programs_are_bit_exact(native, oracle, dim, lo, hi, seed, semantics, monkeypatch):
     # strips / tiles and their fusions from 17^2 / 9^3 up, odd chunk sizes
     monkeypatch.setenv("EVOMG_STRIP_MIN_N", "17")
     monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "9")
     monkeypatch.setenv("EVOMG_STRIP_ROWS", str([0, 10, 16, 22][seed % 4]))
     monkeypatch.setenv("EVOMG_STRIP_PLANES", str([0, 4, 8, 12][seed % 4]))
-    pd = problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi)
+    pd = with_semantics(problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi), semantics)
     rng = np.random.default_rng(1000 * dim + seed)
     hg, ho = native.create(pd), oracle.create(pd)
     ops = random_program(rng, dim, lo, hi, 24 if hi - lo <= 4 else 30)
@@ -101,8 +115,8 @@ def test_random_programs_are_bit_exact(native, oracle, dim, lo, hi, seed, monkey
 CYCLES = ([(2, 3, 7, s) for s in range(6)] + [(3, 2, 5, s) for s in range(6)] + [(2, 5, 9, 6), (2, 5, 9, 7), (3, 3, 6, 8), (3, 4, 7, 9)])
 
 
-@pytest.mark.parametrize("dim,lo,hi,seed", CYCLES)
-def test_random_cycles_in_the_solver_loop(native, oracle, dim, lo, hi, seed, monkeypatch):
+@pytest.mark.parametrize("dim,lo,hi,seed,semantics", [c + ("textbook",) for c in CYCLES] + [c + ("exastencils-v1.1",) for c in CYCLES])
+def test_random_cycles_in_the_solver_loop(native, oracle, dim, lo, hi, seed, semantics, monkeypatch):
     """A random V-shaped cycle (random smoothers and sweep counts per level, random weights) as the body of the solver
     loop: the cyclic-only fusions (dead residual fields, norm tails, speculation) against the oracle."""
     import dataclasses
@@ -111,7 +125,8 @@ def test_random_cycles_in_the_solver_loop(native, oracle, dim, lo, hi, seed, mon
     monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "9")
     monkeypatch.setenv("EVOMG_STRIP_PLANES", str([0, 4, 8][seed % 3]))
     rng = np.random.default_rng(77 * dim + seed)
-    pd = dataclasses.replace(problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi), max_iterations=6)
+    pd = dataclasses.replace(problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi), max_iterations=6,
+                             jacobi_semantics=abi.JACOBI_SEMANTICS[semantics])
     blocks = [(1, 1, 1), (2, 1, 1), (1, 2, 1)]
 
     def smoother(L):
@@ -124,7 +139,9 @@ def test_random_cycles_in_the_solver_loop(native, oracle, dim, lo, hi, seed, mon
     hg, ho = native.create(pd), oracle.create(pd)
     got, want = hg.evaluate(ops, 1, 0, 32), ho.evaluate(ops, 1, 0, 32)
     assert got.status == want.status and got.n_iterations == want.n_iterations
-    assert np.max(np.abs(got.history - want.history) / want.history) <= 1e-10
+    finite = np.isfinite(want.history)                  # a cycle whose only smoothers are lost sweeps may diverge
+    assert np.array_equal(finite, np.isfinite(got.history))
+    assert np.max(np.abs(got.history[finite] - want.history[finite]) / want.history[finite]) <= 1e-10
     assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
     hg.close()
     ho.close()
