@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
@@ -66,12 +66,12 @@ class Op(C.Structure):
     _fields_ = [
         ("opcode", C.c_int32), ("level", C.c_int32), ("dst", C.c_int32), ("src0", C.c_int32),
         ("src1", C.c_int32), ("partitioning", C.c_int32), ("block", C.c_int32 * MAX_DIM),
-        ("unknowns", C.c_int32), ("omega", C.c_double),
+        ("unknowns", C.c_int32), ("block_other", C.c_int32 * MAX_DIM), ("reserved", C.c_int32), ("omega", C.c_double),
     ]
 
     def key(self):
         return (self.opcode, self.level, self.dst, self.src0, self.src1, self.partitioning,
-                tuple(self.block), self.omega, self.unknowns)
+                tuple(self.block), self.omega, self.unknowns, tuple(self.block_other))
 
     def __repr__(self):
         return (f"Op({OP_NAMES.get(self.opcode, self.opcode)}, L={self.level}, dst={self.dst}, "
@@ -97,8 +97,13 @@ def field_of(slot: int, unknown: int = 0) -> int:
     return slot + F_COUNT * unknown
 
 
-def make_op(opcode, level, dst=0, src0=0, src1=0, partitioning=PART_SINGLE, block=(1, 1, 1), omega=1.0, unknowns=0) -> Op:
+def make_op(opcode, level, dst=0, src0=0, src1=0, partitioning=PART_SINGLE, block=(1, 1, 1), omega=1.0, unknowns=0,
+            block_other=None) -> Op:
     op = Op()
+    if block_other is not None:   # system smoother: the second unknown's block shape where it differs from `block`
+        other = tuple(block_other) + (1,) * (MAX_DIM - len(block_other))
+        for i in range(MAX_DIM):
+            op.block_other[i] = int(other[i])
     op.unknowns = unknowns        # SMOOTH on a system: bit mask of the unknowns solved together (0 = scalar problem)
     op.opcode, op.level, op.dst, op.src0, op.src1 = opcode, level, dst, src0, src1
     op.partitioning = partitioning

@@ -73,8 +73,8 @@ def _system_local_equations(st: low.Statement, names: FieldNames, max_level: int
     level = st.level
     prefix = "gen_error_" if level < max_level else ""
     lines = []
-    for i in st.unknowns:
-        for idx in product(*[range(b) for b in st.block]):
+    for k, i in enumerate(st.unknowns):
+        for idx in product(*[range(b) for b in (st.blocks[k] if st.blocks else st.block)]):
             expr = sympy.sympify(0)
             for j, stencil in enumerate(st.system_stencils[i]):
                 for off, val in stencil.entries:

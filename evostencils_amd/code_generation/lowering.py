@@ -10,6 +10,7 @@ Dispatch is on (module-tail, class-name) pairs taken from the MRO, so DAGs built
 reference's own ``evostencils.ir`` classes are accepted as well as ``evostencils_amd.ir`` ones.
 """
 from dataclasses import dataclass, field
+from itertools import product
 from typing import List, Optional, Tuple
 
 from evostencils_amd.ir import partitioning as part
@@ -71,6 +72,7 @@ class Statement:
     unknowns: Tuple[int, ...] = ()         # smoother: the unknowns whose equations are solved together in one block
     system_stencils: object = None         # smoother: [equation][unknown] -> constant stencil of the system operator
     operator_source: object = None         # system smoother: the (long-lived) system operator object the stencils came from
+    blocks: Optional[tuple] = None         # system block smoother whose block shape differs per unknown: one shape per entry of `unknowns`
 
 
 class Lowering:
@@ -240,12 +242,12 @@ class Lowering:
                 row.append(st)
             stencils.append(row)
 
-        def emit(unknowns, block, group):
+        def emit(unknowns, block, group, blocks=None):
             self.out.append(Statement("smooth", g.level, dst=self._sol(g.level, unknowns[0]),
                                       rhs=FieldRef(RHS, g.level, unknowns[0]), weight=weight,
                                       partitioning=part.kind_of(cycle.partitioning), block=block, operator_level=g.level,
                                       group=group, unknowns=tuple(unknowns), system_stencils=stencils,
-                                      operator_source=system_operator))
+                                      operator_source=system_operator, blocks=blocks))
 
         if isa(smoothing_operator, "system", "Diagonal"):
             for i in range(nf):
@@ -262,7 +264,7 @@ class Lowering:
                     if not multiple.is_block_diagonal_of(smj, stencils[i][j], shapes[i]):
                         raise UnsupportedExpression("custom smoothing operator is not the block diagonal of the system operator")
             if any(sh != shapes[0] for sh in shapes):
-                raise UnsupportedExpression("block smoothers with different block shapes per unknown are not supported")
+                return self._mixed_shape_blocks(smoothing_operator, shapes, nf, dim, emit)
             block = shapes[0]
             cells = 1
             for b in block:
@@ -278,6 +280,43 @@ class Lowering:
             emit(list(range(nf)), block, "dependent")
         else:
             raise UnsupportedExpression("Can not extract equations from smoothing operator")
+
+    @staticmethod
+    def _mixed_shape_blocks(smoothing_operator, shapes, nf, dim, emit):
+        """Collective block smoother whose block shape differs per unknown (most BlockShape terminals of a system,
+        grammar/multigrid.py:388-407). The reference forms one equation per (unknown i, cell of ITS block shape); the
+        entries of the smoothing operator M_ij = block_diagonal(A_ij, shape_i) are that equation's new values
+        (ir/transformations.py:51-121). An equation none of whose new values occurs among another equation's is
+        "independent" and becomes a `solve locally` statement of its own, printed FIRST; all other equations share one
+        statement (find_independent_equation_sets :124-145, exastencils.py:774-822)."""
+        equations = []                       # (unknown, cell, new values as {(unknown, position)})
+        for i in range(nf):
+            for cell in product(*[range(b) for b in shapes[i]]):
+                new = set()
+                for j in range(nf):
+                    smj = smoothing_operator.entries[i][j].generate_stencil()
+                    for off, val in multiple.at(smj, cell).entries:
+                        if val != 0:
+                            new.add((j, tuple(int(c) + int(o) for c, o in zip(cell, off))))
+                equations.append((i, cell, new))
+        independent, dependent = [], []
+        for k, (i, cell, new) in enumerate(equations):
+            alone = all(not (new & other) for m, (_, _, other) in enumerate(equations) if m != k)
+            (independent if alone else dependent).append((i, cell))
+        for i, cell in independent:
+            # one unknown, one cell: a point sweep over that unknown (its block has one cell, or its cells would share
+            # new values through the 5-point part of A_ii)
+            if any(c != 0 for c in cell) or any(b != 1 for b in shapes[i]):
+                raise UnsupportedExpression("independent equation away from the block's first cell")
+            emit([i], (1,) * dim, "independent")
+        if dependent:
+            unknowns = sorted({i for i, _ in dependent})
+            for i in unknowns:
+                cells = [c for k, c in dependent if k == i]
+                if cells != list(product(*[range(b) for b in shapes[i]])):
+                    raise UnsupportedExpression("block with independent and dependent cells")
+            blocks = tuple(tuple(shapes[i]) for i in unknowns)
+            emit(unknowns, blocks[0], "dependent", blocks=blocks if any(b != blocks[0] for b in blocks) else None)
 
     def _residual(self, e):
         self._preamble(e.rhs, e.rhs, e.approximation, e.approximation)

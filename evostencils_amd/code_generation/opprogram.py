@@ -52,8 +52,9 @@ def encode(statements) -> List[abi.Op]:
             mask = 0
             for u in st.unknowns:
                 mask |= 1 << u
+            other = st.blocks[1] if st.blocks and len(st.blocks) > 1 and st.blocks[1] != st.blocks[0] else None
             ops.append(abi.make_op(abi.OP_SMOOTH, st.level, _f(st.dst), 0, _f(st.rhs), partitioning, st.block,
-                                   _w(st.weight), unknowns=mask))
+                                   _w(st.weight), unknowns=mask, block_other=other))
         elif k == "smooth":
             _require_plain_operator(st)
             partitioning = abi.PART_RED_BLACK if st.partitioning == "red_black" else abi.PART_SINGLE

@@ -2154,9 +2154,12 @@ class SystemImpl : public ImplBase {
           int k = 0, first = 0;
           for (int u = 0; u < nf_; ++u) k += (mask >> u) & 1;
           while (!((mask >> first) & 1)) ++first;
-          ok = k * op.block[0] * op.block[1] <= EVOMG_MAX_BLOCK_CELLS && op.dst / EVOMG_F_COUNT == first && op.src1 / EVOMG_F_COUNT == first &&
+          const bool other = op.block_other[0] != 0 || op.block_other[1] != 0;       // second unknown: its own block shape
+          if (other && (k != 2 || op.block_other[0] < 1 || op.block_other[1] < 1)) { ok = false; break; }
+          const int cells = op.block[0] * op.block[1] + (k == 2 ? (other ? op.block_other[0] * op.block_other[1] : op.block[0] * op.block[1]) : 0);
+          ok = cells <= EVOMG_MAX_BLOCK_CELLS && op.dst / EVOMG_F_COUNT == first && op.src1 / EVOMG_F_COUNT == first &&
                (op.partitioning == EVOMG_PART_SINGLE || op.partitioning == EVOMG_PART_RED_BLACK);
-          if (ok && op.partitioning == EVOMG_PART_RED_BLACK && op.block[0] * op.block[1] != 1) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
+          if (ok && op.partitioning == EVOMG_PART_RED_BLACK && cells != k) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
           break;
         }
         case EVOMG_OP_RESIDUAL: ok = fieldptr(op.level, op.src0) && fieldptr(op.level, op.src1) && op.src0 / EVOMG_F_COUNT == 0; break;
@@ -2184,7 +2187,18 @@ class SystemImpl : public ImplBase {
     const Geo& g = lv.g;
     switch (op.opcode) {
       case EVOMG_OP_SMOOTH: {
-        const int mask = op.unknowns, bx = op.block[0], by = op.block[1], inner = g.n - 2;
+        const int mask = op.unknowns, inner = g.n - 2;
+        // per-unknown block shapes: the first unknown of the mask has `block`, the second `block_other` where that is set
+        SysShapes sh{};
+        int bx = 1, by = 1, seen = 0;
+        for (int u = 0; u < nf_; ++u) {
+          if (!((mask >> u) & 1)) { sh.bx[u] = sh.by[u] = 0; continue; }
+          const bool second = seen++ > 0 && op.block_other[0] > 0;
+          sh.bx[u] = second ? op.block_other[0] : op.block[0];
+          sh.by[u] = second ? op.block_other[1] : op.block[1];
+          bx = sh.bx[u] > bx ? sh.bx[u] : bx;
+          by = sh.by[u] > by ? sh.by[u] : by;
+        }
         const int sol_slot = canon(L, op.dst) % EVOMG_F_COUNT, rhs_slot = op.src1 % EVOMG_F_COUNT;
         const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by;
         const int passes = op.partitioning == EVOMG_PART_RED_BLACK ? 2 : 1;
@@ -2196,7 +2210,7 @@ class SystemImpl : public ImplBase {
             y.p[u] = lv.alt[u];
             if ((mask >> u) & 1) HIP_TRY(hipMemcpyAsync(lv.alt[u], x.p[u], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
           }
-          hipLaunchKernelGGL(evomg_sys_smooth, grd(tx, ty), blk(), 0, stream_, g, lv.st, nf_, mask, bx, by, tx, ty,
+          hipLaunchKernelGGL(evomg_sys_smooth, grd(tx, ty), blk(), 0, stream_, g, lv.st, nf_, mask, sh, bx, by, tx, ty,
                              passes == 2 ? pass : -1, x, f, y, op.omega);
           // a colour pass always takes effect; a `with jacobi` sweep only where the next slot is advanced (evomg.h)
           const bool lost = passes == 1 && prob_.jacobi_semantics == EVOMG_JACOBI_EXASTENCILS_V11;

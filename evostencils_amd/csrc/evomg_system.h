@@ -48,21 +48,27 @@ __global__ void __launch_bounds__(256) evomg_sys_apply(Geo g, SysStencil st, int
 }
 
 // One `solve locally` block per thread: the tile anchored at inner node (1 + ti*bx, 1 + tj*by), cut at the far boundary;
-// unknowns = (unknown of `mask`, cell), field order then cells with i0 outermost; every stencil entry that hits a listed
-// unknown goes into the local matrix, the rest to the right-hand side at its current value; Gaussian elimination without
-// pivoting, exactly-zero multipliers skipped; x <- (1-w) x + w x*. colour >= 0: only tiles whose anchor has that colour
-// (point blocks). Reads x, writes y (the caller made y a copy of x).
-__global__ void __launch_bounds__(256) evomg_sys_smooth(Geo g, SysStencil st, int nf, int mask, int bx, int by, int tx, int ty,
+// (bx, by) = the componentwise maximum of the listed unknowns' block shapes sh (they may differ per unknown, evomg.h:
+// block / block_other): tiles repeat with the bounding box of the statement's unknowns, and a node of the box that no
+// listed (unknown, cell) names keeps its value. Unknowns = (unknown of `mask`, cell of ITS shape), field order then
+// cells with i0 outermost; every stencil entry that hits a listed unknown goes into the local matrix, the rest to the
+// right-hand side at its current value; Gaussian elimination without pivoting, exactly-zero multipliers skipped;
+// x <- (1-w) x + w x*. colour >= 0: only tiles whose anchor has that colour (point blocks). Reads x, writes y (the
+// caller made y a copy of x).
+struct SysShapes {
+  int bx[EVOMG_MAX_UNKNOWNS], by[EVOMG_MAX_UNKNOWNS];
+};
+__global__ void __launch_bounds__(256) evomg_sys_smooth(Geo g, SysStencil st, int nf, int mask, SysShapes sh, int bx, int by, int tx, int ty,
                                                         int colour, SysConstFields x, SysConstFields f, SysFields y, double om) {
   const int ti = blockIdx.x * blockDim.x + threadIdx.x, tj = blockIdx.y * blockDim.y + threadIdx.y;
   if (ti >= tx || tj >= ty) return;
   const int n = g.n;
   const int a0 = 1 + ti * bx, b0 = 1 + tj * by;
   if (colour >= 0 && ((a0 + b0) & 1) != colour) return;
-  const int wx = (a0 + bx <= n - 1) ? bx : n - 1 - a0, wy = (b0 + by <= n - 1) ? by : n - 1 - b0;
   int eu[8], ea[8], eb[8], m = 0;
   for (int u = 0; u < nf; ++u) {
     if (!((mask >> u) & 1)) continue;
+    const int wx = (a0 + sh.bx[u] <= n - 1) ? sh.bx[u] : n - 1 - a0, wy = (b0 + sh.by[u] <= n - 1) ? sh.by[u] : n - 1 - b0;
     for (int ci = 0; ci < wx; ++ci)
       for (int cj = 0; cj < wy; ++cj) { eu[m] = u; ea[m] = a0 + ci; eb[m] = b0 + cj; ++m; }
   }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EVOMG_ABI_VERSION 3
+#define EVOMG_ABI_VERSION 4
 #define EVOMG_MAX_LEVELS 24       /* levels are absolute: grid level L has 2^L+1 nodes per dimension */
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
@@ -190,6 +190,12 @@ typedef struct {
                             in one `solve locally` block (0b11 collective, 0b01 / 0b10 decoupled); 0 on scalar problems.
                             On systems dst/src1 name the slots of the FIRST unknown of the mask, RESIDUAL's src0 the
                             solution slot of unknown 0 (the row reads all unknowns) */
+  int32_t block_other[EVOMG_MAX_DIM]; /* ABI 4, SMOOTH on a system whose mask names two unknowns: block shape of the SECOND
+                            unknown's cells when it differs from the first's (`block`); all zero = the same shape. The
+                            grammar registers one BlockShape terminal per combination of per-unknown shapes
+                            (grammar/multigrid.py:388-407), so most collective block smoothers of a system look like this.
+                            Tiles repeat with the componentwise maximum of the two shapes */
+  int32_t reserved;
   double  omega;         /* relaxation factor */
 } evomg_op_t;
 

@@ -113,11 +113,14 @@ static void sys_residual(sys_ctx_t* c, int level, int i, double* const* x, const
 /* ---- one `solve locally` block on the tile anchored at (a0, b0) with extents (wx, wy): unknown e = (unknown u of
  * the mask, cell (ci, cj)), field order, then cells with i0 outermost. x: current values; out[e]: relaxed values. ---- */
 static void sys_local_solve(const sys_level_t* lv, int nf, int mask, double* const* x, double* const* f, int a0, int b0,
-                            int wx, int wy, double om, double* out) {
+                            const int (*shape)[2], double om, double* out) {
   const int n = lv->n;
   int eu[8], ea[8], eb[8], m = 0;
   for (int u = 0; u < nf; ++u) {
     if (!((mask >> u) & 1)) continue;
+    /* the cells of unknown u: its own block shape (exastencils.py:778-822 prints one equation per (unknown, cell of the
+     * unknown's block), ir/transformations.py:51-121), cut at the far boundary */
+    const int wx = (a0 + shape[u][0] <= n - 1) ? shape[u][0] : n - 1 - a0, wy = (b0 + shape[u][1] <= n - 1) ? shape[u][1] : n - 1 - b0;
     for (int ci = 0; ci < wx; ++ci)
       for (int cj = 0; cj < wy; ++cj) { eu[m] = u; ea[m] = a0 + ci; eb[m] = b0 + cj; ++m; }
   }
@@ -159,7 +162,20 @@ static void sys_local_solve(const sys_level_t* lv, int nf, int mask, double* con
 static int sys_smooth(sys_ctx_t* c, const evomg_op_t* op) {
   sys_level_t* lv = &c->lv[op->level];
   const int n = lv->n, nf = c->nf, mask = op->unknowns, inner = n - 2;
-  const int bx = op->block[0], by = op->block[1];
+  /* block shape per unknown of the mask: `block` for the first, `block_other` (where set) for the second; tiles repeat with
+   * the bounding box of the statement's unknowns [EXTERNAL: the loop ExaStencils generates around a `solve locally`
+   * is not visible from the reference; with equal shapes this is the IR's non-overlapping tiling, stencils/multiple.py:204-217] */
+  int shape[SYS_NF][2];
+  int bx = 1, by = 1, seen = 0;
+  for (int u = 0; u < nf; ++u) {
+    shape[u][0] = shape[u][1] = 0;
+    if (!((mask >> u) & 1)) continue;
+    const int second = seen++ > 0 && op->block_other[0] > 0;
+    shape[u][0] = second ? op->block_other[0] : op->block[0];
+    shape[u][1] = second ? op->block_other[1] : op->block[1];
+    if (shape[u][0] > bx) bx = shape[u][0];
+    if (shape[u][1] > by) by = shape[u][1];
+  }
   const int sol_slot = sys_canon(c, op->level, op->dst) % EVOMG_F_COUNT;
   const int rhs_slot = op->src1 % EVOMG_F_COUNT;
   double* x[SYS_NF];
@@ -178,12 +194,12 @@ static int sys_smooth(sys_ctx_t* c, const evomg_op_t* op) {
       for (int ti = 0; ti < tx; ++ti) {
         const int a0 = 1 + ti * bx, b0 = 1 + tj * by;
         if (passes == 2 && ((a0 + b0) & 1) != pass) continue;
-        const int wx = (a0 + bx <= n - 1) ? bx : n - 1 - a0, wy = (b0 + by <= n - 1) ? by : n - 1 - b0;
         double out[8];
-        sys_local_solve(lv, nf, mask, x, f, a0, b0, wx, wy, op->omega, out);
+        sys_local_solve(lv, nf, mask, x, f, a0, b0, (const int (*)[2])shape, op->omega, out);
         int p = 0;
         for (int u = 0; u < nf; ++u) {
           if (!((mask >> u) & 1)) continue;
+          const int wx = (a0 + shape[u][0] <= n - 1) ? shape[u][0] : n - 1 - a0, wy = (b0 + shape[u][1] <= n - 1) ? shape[u][1] : n - 1 - b0;
           for (int ci = 0; ci < wx; ++ci)
             for (int cj = 0; cj < wy; ++cj) lv->alt[u][IDX2(n, a0 + ci, b0 + cj)] = out[p++];
         }
@@ -315,8 +331,11 @@ static int sys_check_op(sys_ctx_t* c, const evomg_op_t* op) {
       if (op->block[0] < 1 || op->block[1] < 1) return EVOMG_ERR_INVALID;
       int k = 0;
       for (int u = 0; u < c->nf; ++u) k += (mask >> u) & 1;
-      if (k * op->block[0] * op->block[1] > EVOMG_MAX_BLOCK_CELLS) return EVOMG_ERR_INVALID;
-      if (op->partitioning == EVOMG_PART_RED_BLACK && op->block[0] * op->block[1] != 1) return EVOMG_ERR_UNSUPPORTED;
+      const int other = op->block_other[0] != 0 || op->block_other[1] != 0;
+      if (other && (k != 2 || op->block_other[0] < 1 || op->block_other[1] < 1)) return EVOMG_ERR_INVALID;
+      const int cells = op->block[0] * op->block[1] + (k == 2 ? (other ? op->block_other[0] * op->block_other[1] : op->block[0] * op->block[1]) : 0);
+      if (cells > EVOMG_MAX_BLOCK_CELLS) return EVOMG_ERR_INVALID;
+      if (op->partitioning == EVOMG_PART_RED_BLACK && cells != k) return EVOMG_ERR_UNSUPPORTED;
       if (op->partitioning != EVOMG_PART_SINGLE && op->partitioning != EVOMG_PART_RED_BLACK) return EVOMG_ERR_INVALID;
       /* dst / src1 name the slots of the first unknown of the mask */
       int first = 0;

@@ -118,7 +118,11 @@ CASES = {
     "elasticity2d_L5_blocks": ("2D_FD_LinearElasticity_fromL2", 3, 5,
                                lambda P: v_cycle(P, 2, [[("blocks", 12, ((2, 2), (2, 2)))], [("decoupled", 14), _jac(12)]],
                                                  [[("blocks", 10, ((1, 2), (1, 2))), ("decoupled_rb", 18)], [_rb(20)]])),
-    # 3D: block-Jacobi V(2,2) (C4 shape) and RB-GS
+    # collective block smoothers whose block shape differs per unknown — most of the BlockShape terminals the grammar
+    # registers for a two-unknown problem (grammar/multigrid.py:388-407: itertools.product over the unknowns' shapes)
+    "elasticity2d_L5_mixed_shapes": ("2D_FD_LinearElasticity_fromL2", 3, 5,
+                                     lambda P: v_cycle(P, 2, [[("blocks", 12, ((2, 1), (1, 1))), _rb(20)], [("blocks", 14, ((2, 2), (2, 1)))]],
+                                                       [[("blocks", 10, ((1, 1), (1, 2))), _rb(20)], [("blocks", 9, ((3, 1), (1, 3))), _rb(18)]])),
     "poisson3d_L4_v22_block": ("3D_FD_Poisson_fromL2", 2, 4,
                                lambda P: v_cycle(P, 2, [[_blk(10, (2, 1, 1))] * 2] * 2, [[_blk(10, (2, 1, 1))] * 2] * 2)),
     "poisson3d_L4_mixed": ("3D_FD_Poisson_fromL2", 2, 4,

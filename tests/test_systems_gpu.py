@@ -46,11 +46,17 @@ def test_every_op_kind_is_bit_identical(native, oracle, level):
     hg, ho = native.create(pd), oracle.create(pd)
     smooths = [(0b11, (1, 1, 1), abi.PART_SINGLE), (0b11, (1, 1, 1), abi.PART_RED_BLACK), (0b01, (1, 1, 1), abi.PART_SINGLE),
                (0b10, (1, 1, 1), abi.PART_RED_BLACK), (0b11, (2, 1, 1), abi.PART_SINGLE), (0b11, (2, 2, 1), abi.PART_SINGLE),
-               (0b11, (1, 4, 1), abi.PART_SINGLE), (0b10, (3, 2, 1), abi.PART_SINGLE), (0b01, (1, 1, 1), abi.PART_RED_BLACK)]
+               (0b11, (1, 4, 1), abi.PART_SINGLE), (0b10, (3, 2, 1), abi.PART_SINGLE), (0b01, (1, 1, 1), abi.PART_RED_BLACK),
+               # one block shape per unknown (block / block_other)
+               (0b11, ((2, 1, 1), (1, 1, 1)), abi.PART_SINGLE), (0b11, ((1, 1, 1), (1, 2, 1)), abi.PART_SINGLE),
+               (0b11, ((2, 2, 1), (2, 1, 1)), abi.PART_SINGLE), (0b11, ((3, 1, 1), (1, 3, 1)), abi.PART_SINGLE),
+               (0b11, ((1, 4, 1), (2, 2, 1)), abi.PART_SINGLE)]
     for k, (mask, block, part) in enumerate(smooths):
         load_random((hg, ho), level, 100 * level + k)
         first = 0 if mask & 1 else 1
-        ops = [abi.make_op(abi.OP_SMOOTH, level, F(abi.F_SOL, first), 0, F(abi.F_RHS, first), part, block, 0.85, unknowns=mask)] * 2
+        block, other = (block, None) if isinstance(block[0], int) else block
+        ops = [abi.make_op(abi.OP_SMOOTH, level, F(abi.F_SOL, first), 0, F(abi.F_RHS, first), part, block, 0.85, unknowns=mask,
+                           block_other=other)] * 2
         ops += [abi.make_op(abi.OP_RESIDUAL, level, F(abi.F_RES, u), F(abi.F_SOL), F(abi.F_RHS, u)) for u in range(2)]
         ops += [abi.make_op(abi.OP_RESTRICT, level - 1, F(abi.F_RHS, u), F(abi.F_RES, u)) for u in range(2)]
         ops += [abi.make_op(abi.OP_SET_ZERO, level - 1, F(abi.F_SOL, u)) for u in range(2)]
@@ -94,7 +100,7 @@ def test_stacked_coarse_cg(native, oracle, lo):
 
 
 @pytest.mark.parametrize("semantics", ["textbook", "exastencils-v1.1"])
-@pytest.mark.parametrize("name", ["elasticity2d_L6_mixed", "elasticity2d_L6_v21_rb", "elasticity2d_L5_blocks"])
+@pytest.mark.parametrize("name", ["elasticity2d_L6_mixed", "elasticity2d_L6_v21_rb", "elasticity2d_L5_blocks", "elasticity2d_L5_mixed_shapes"])
 def test_whole_solves_through_the_program_generator(native, oracle, name, semantics):
     gen, expression, lo, hi = build_case(name, library=native.library(), jacobi_semantics=semantics)
     gen.initialize_code_generation(lo, hi)

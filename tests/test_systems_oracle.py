@@ -137,6 +137,49 @@ def test_local_solves_satisfy_their_equations(mask, block):
             assert np.array_equal(y[u], x[u])
 
 
+@pytest.mark.parametrize("shapes", [((2, 1), (1, 1)), ((1, 1), (1, 2)), ((2, 2), (2, 1)), ((3, 1), (1, 3)), ((1, 4), (2, 2))])
+def test_mixed_shape_local_solves_satisfy_their_equations(shapes):
+    """Collective block smoothers whose block shape differs per unknown (evomg_op_t.block / block_other): tiles repeat
+    with the bounding box of the two shapes; after a sweep with w = 1 every equation of a listed (unknown, cell) holds
+    exactly when the tile's listed unknowns take their new values and everything else the old ones, and nodes of the
+    box that no listed cell names keep their values."""
+    level = 4
+    pd = problems.linear_elasticity_2d(level - 1, level)
+    a = pd.system.assembled(level)
+    h = oracle.create(pd)
+    rng = np.random.default_rng(12)
+    n = (1 << level) + 1
+    x = [rng.standard_normal((n, n)) for _ in range(2)]
+    f = [1e6 * rng.standard_normal((n, n)) for _ in range(2)]
+    for u in range(2):
+        h.set_field(level, abi.field_of(abi.F_SOL, u), x[u])
+        h.set_field(level, abi.field_of(abi.F_RHS, u), f[u])
+    h.run_ops([abi.make_op(abi.OP_SMOOTH, level, abi.field_of(abi.F_SOL), 0, abi.field_of(abi.F_RHS), abi.PART_SINGLE,
+                           shapes[0], 1.0, unknowns=0b11, block_other=shapes[1])])
+    y = [h.get_field(level, abi.field_of(abi.F_SOL, u)) for u in range(2)]
+    bx, by = max(s[0] for s in shapes), max(s[1] for s in shapes)
+    inner = n - 2
+    worst = 0.0
+    touched = [np.zeros((n, n), bool) for _ in range(2)]
+    for ti in range((inner + bx - 1) // bx):
+        for tj in range((inner + by - 1) // by):
+            cells = [[(1 + ti * bx + ci, 1 + tj * by + cj) for ci in range(shapes[u][0]) for cj in range(shapes[u][1])
+                      if 1 + ti * bx + ci <= n - 2 and 1 + tj * by + cj <= n - 2] for u in range(2)]
+            mixed = [xx.copy() for xx in x]
+            for u in range(2):
+                for (ca, cb) in cells[u]:
+                    mixed[u][cb, ca] = y[u][cb, ca]
+                    touched[u][cb, ca] = True
+            for u in range(2):
+                r = f[u][1:-1, 1:-1] - apply_row(a, u, mixed)
+                for (ca, cb) in cells[u]:
+                    worst = max(worst, abs(r[cb - 1, ca - 1]))
+    assert worst < 1e-6
+    for u in range(2):
+        assert np.array_equal(y[u][~touched[u]], x[u][~touched[u]])
+        assert not np.array_equal(y[u][touched[u]], x[u][touched[u]])
+
+
 def test_program_generator_reads_the_reference_problem_directory():
     """The reference's LinearElasticity files lie outside the layer-2 front end's subset (two unknowns, operator sums,
     Globals): the generator falls back to the built-in descriptor of the same configuration."""
@@ -171,7 +214,7 @@ def test_with_jacobi_semantics_on_systems():
         assert not np.array_equal(h.get_field(level, F(abi.F_SOL, 1)), x[1])      # colour sweeps always take effect
 
 
-@pytest.mark.parametrize("name", ["elasticity2d_L6_mixed", "elasticity2d_L6_v21_rb", "elasticity2d_L5_blocks"])
+@pytest.mark.parametrize("name", ["elasticity2d_L6_mixed", "elasticity2d_L6_v21_rb", "elasticity2d_L5_blocks", "elasticity2d_L5_mixed_shapes"])
 def test_golden_system_cases_run_on_the_oracle(name):
     problem, lo, hi, _ = cycles.CASES[name]
     gen, ops = ops_for_case(name)
