@@ -1073,7 +1073,13 @@ template <typename T> class Impl : public ImplBase {
     return use_strip(lv_[z.level].g);
   }
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
-  bool strip_streams(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.pitch * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
+  // Non-temporal placement of the 2D strip kernels (template flag NT_XY): on a level whose three arrays (x, y, f) exceed
+  // the 256 MiB Infinity Cache while f alone fits with room to spare (<= 192 MiB), x loads and y stores carry the hint and
+  // f stays cacheable. When not even f fits (8193^2), no hint at all is fastest (profiles/r03_nt_placement.md).
+  bool strip_streams(const Geo& g) const {
+    const double field = (double)g.pitch * g.n * sizeof(T);
+    return strip_nt_ && 3.0 * field > 256.0 * 1024 * 1024 && field <= 192.0 * 1024 * 1024;
+  }
   // Chunk height of the 2D smoother strips. A block is four waves = four chunks and every block is resident at once, so a
   // launch lasts as long as the compute unit that got the most blocks: ceil(blocks / CUs) * (rows + halo and prologue).
   // Measured at 4097^2 (tools/sweep_rows.sh): 64 rows -> 553 blocks, three on some units and two on most, fused sweeps

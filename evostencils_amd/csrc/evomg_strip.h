@@ -54,12 +54,27 @@ template <> __device__ __forceinline__ Pair<cplx> load_pair_nt<cplx>(const cplx*
   const evomg_f64x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const evomg_f64x2*>(p) + 1);
   return Pair<cplx>{cplx{v0.x, v0.y}, cplx{v1.x, v1.y}};
 }
-__device__ __forceinline__ void store_pair(double* __restrict__ p, const Pair<double>& v) {
-  *reinterpret_cast<double2*>(p) = make_double2(v.a, v.b);
+template <bool NT = false> __device__ __forceinline__ void store_pair(double* __restrict__ p, const Pair<double>& v) {
+  if constexpr (NT) {
+    evomg_f64x2 t;
+    t.x = v.a;
+    t.y = v.b;
+    __builtin_nontemporal_store(t, reinterpret_cast<evomg_f64x2*>(p));
+  } else {
+    *reinterpret_cast<double2*>(p) = make_double2(v.a, v.b);
+  }
 }
-__device__ __forceinline__ void store_pair(cplx* __restrict__ p, const Pair<cplx>& v) {
-  reinterpret_cast<double2*>(p)[0] = make_double2(v.a.re, v.a.im);
-  reinterpret_cast<double2*>(p)[1] = make_double2(v.b.re, v.b.im);
+template <bool NT = false> __device__ __forceinline__ void store_pair(cplx* __restrict__ p, const Pair<cplx>& v) {
+  if constexpr (NT) {
+    evomg_f64x2 t0, t1;
+    t0.x = v.a.re; t0.y = v.a.im;
+    t1.x = v.b.re; t1.y = v.b.im;
+    __builtin_nontemporal_store(t0, reinterpret_cast<evomg_f64x2*>(p));
+    __builtin_nontemporal_store(t1, reinterpret_cast<evomg_f64x2*>(p) + 1);
+  } else {
+    reinterpret_cast<double2*>(p)[0] = make_double2(v.a.re, v.a.im);
+    reinterpret_cast<double2*>(p)[1] = make_double2(v.b.re, v.b.im);
+  }
 }
 
 // same operation order as relax_point / apply_stencil (evomg_kernels.h) and the oracle's FN(relax2)/FN(apply_st2)
@@ -112,7 +127,7 @@ template <typename T> struct ProlongIn {
 // TAIL_RESTRICT (smoother modes): the sweep is followed by RESIDUAL + RESTRICT of a residual nobody else reads. Same
 // finalised-row window, one more halo row per side; the residual rows feed a three-row residual window from which
 // every second step emits one row of the coarse right-hand side exactly as evomg_strip_residual_restrict does.
-template <typename T, int MODE, int PF, bool NT_F, bool PRO = false, bool TAIL_NORM = false, bool TAIL_RESTRICT = false,
+template <typename T, int MODE, int PF, bool NT_XY, bool PRO = false, bool TAIL_NORM = false, bool TAIL_RESTRICT = false,
           bool XZERO = false>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
@@ -156,14 +171,17 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   auto load_row = [&](const T* __restrict__ base, int row) -> Pair<T> {
     if constexpr (XZERO) return zpair;
     const int r = min(max(row, 0), n - 1);                  // wave-uniform
-    return load_pair<T>(base + pitch * r + c_clamped);
+    if constexpr (NT_XY) return load_pair_nt<T>(base + pitch * r + c_clamped);
+    else return load_pair<T>(base + pitch * r + c_clamped);
   };
-  // right-hand side: read exactly once per sweep -> optional non-temporal (streaming) load so that it does not
-  // evict x / y from the 256 MiB Infinity Cache between back-to-back sweeps
+  // NT_XY (levels whose x, y and f together exceed the 256 MiB Infinity Cache while f alone fits): x is loaded and y
+  // stored with the non-temporal hint, the right-hand side with plain loads — f is the one array every sweep of the level
+  // reads again, x and y are streamed through once, so f stays resident across the coarse part of the cycle instead of
+  // being evicted by them. Measured inside C2 solves (profiles/r03_nt_placement.md): fused sweeps 84-91 -> 76.5 us; the
+  // round-1/2 placement (hint on f, kept x / y of back-to-back ping-pong sweeps resident) was the wrong one in a cycle
   auto load_row_f = [&](const T* __restrict__ base, int row) -> Pair<T> {
     const int r = min(max(row, 0), n - 1);
-    if constexpr (NT_F) return load_pair_nt<T>(base + pitch * r + c_clamped);
-    else return load_pair<T>(base + pitch * r + c_clamped);
+    return load_pair<T>(base + pitch * r + c_clamped);
   };
 
   // Helmholtz Robin boundary (K8) applied to what the sweep produced: x_b = x_in / (1 - i k h) in the first and the
@@ -346,7 +364,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm, pro.inv_c0) : xc.a;
             out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm, pro.inv_c0) : xc.b;
             if (row_inner) robin_fix(out);
-            if (store_lane && j >= y0 && j < y1) store_pair(y + pitch * j + c0, out);
+            if (store_lane && j >= y0 && j < y1) store_pair<NT_XY>(y + pitch * j + c0, out);
             if constexpr (TAIL) {
               tail(out, j - 1, ((parity + 1) & 1) != 0, fprev);  // row j is final now: residual of row j - 1
               fprev = fc;
@@ -408,7 +426,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             out.b = rm1;
           }
           if (brow_inner) robin_fix(out);
-          if (store_lane && jb >= y0 && jb < y1) store_pair(y + pitch * jb + c0, out);
+          if (store_lane && jb >= y0 && jb < y1) store_pair<NT_XY>(y + pitch * jb + c0, out);
           if constexpr (TAIL) {
             tail(out, jb - 1, (parity & 1) != 0, fprev);         // row j - 1 is final now: residual of row j - 2
             fprev = fm;
@@ -448,7 +466,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
 // row). Consecutive lanes write consecutive coarse nodes. The residual field itself is written only if WRITE_R
 // (it is skipped when the op program never reads it again before overwriting it): 16 + 8/4 instead of 24 + 10 B/node.
 // Same operation order as evomg_apply<.., true> followed by evomg_restrict => bit-identical coarse right-hand side.
-template <typename T, bool WRITE_R, bool NT_F>
+template <typename T, bool WRITE_R, bool NT_XY>
 __global__ void __launch_bounds__(256)
 evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
                               T* __restrict__ res, T* __restrict__ coarse, int rows_per_chunk, int n_strips, int n_waves,
@@ -473,14 +491,15 @@ evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict_
   const int I = c0 >> 1;                                     // coarse column of element a
   const bool coarse_col_inner = I >= 1 && I <= nc - 2;
   const int c_clamped = min(max(c0, 0), n - 1);
+  // NT_XY: as in evomg_strip2d — x streamed with the non-temporal hint, the right-hand side kept cacheable
   auto load_row = [&](const T* __restrict__ base, int row) -> Pair<T> {
     const int r = min(max(row, 0), n - 1);
-    return load_pair<T>(base + pitch * r + c_clamped);
+    if constexpr (NT_XY) return load_pair_nt<T>(base + pitch * r + c_clamped);
+    else return load_pair<T>(base + pitch * r + c_clamped);
   };
   auto load_row_f = [&](const T* __restrict__ base, int row) -> Pair<T> {
     const int r = min(max(row, 0), n - 1);
-    if constexpr (NT_F) return load_pair_nt<T>(base + pitch * r + c_clamped);
-    else return load_pair<T>(base + pitch * r + c_clamped);
+    return load_pair<T>(base + pitch * r + c_clamped);
   };
   constexpr int PF = 2;
   const int js = y0 - 1;            // first residual row needed (south neighbour row of the chunk's first coarse row)

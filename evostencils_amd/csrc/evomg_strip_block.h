@@ -26,7 +26,7 @@ template <typename T> struct TwoCell2D {
 };
 
 // cut_col / cut_row: the eliminations of the (1,2) / (2,1) systems a (2,2) tile leaves at the far boundary
-template <typename T, int BX, int BY, bool NT_F>
+template <typename T, int BX, int BY, bool NT_XY>
 __global__ void __launch_bounds__(256)
 evomg_strip2d_block(Geo g, Stencil<T> st, BlockPlan<T> pl, const T* __restrict__ x, const T* __restrict__ f,
                     T* __restrict__ y, double om, double omm, int rows_per_chunk, int n_strips, int n_waves,
@@ -104,14 +104,15 @@ evomg_strip2d_block(Geo g, Stencil<T> st, BlockPlan<T> pl, const T* __restrict__
   ConstDiv<T> cdp[M];
 #pragma unroll
   for (int p = 0; p < M; ++p) cdp[p] = const_div_make(pl.pivot[p]);
+  // NT_XY: as in evomg_strip2d — x and y streamed with the non-temporal hint, the right-hand side kept cacheable
   auto load_x = [&](int row) -> Pair<T> {
     const int r = min(max(row, 0), n - 1);
-    return load_pair<T>(x + pitch * r + c_clamped);
+    if constexpr (NT_XY) return load_pair_nt<T>(x + pitch * r + c_clamped);
+    else return load_pair<T>(x + pitch * r + c_clamped);
   };
   auto load_f = [&](int row) -> Pair<T> {
     const int r = min(max(row, 0), n - 1);
-    if constexpr (NT_F) return load_pair_nt<T>(f + pitch * r + c_clamped);
-    else return load_pair<T>(f + pitch * r + c_clamped);
+    return load_pair<T>(f + pitch * r + c_clamped);
   };
   // the replay of make_block_plan's elimination on one tile's right-hand sides (cells: i0 outermost), in place
   auto solve = [&](T (&r)[M]) {
@@ -194,7 +195,7 @@ evomg_strip2d_block(Geo g, Stencil<T> st, BlockPlan<T> pl, const T* __restrict__
         const T va = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa[cj]));
         const T vb = sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb[cj]));
         const bool wa_ = rows_full && a_full, wb_ = rows_full && b_full;
-        if (wa_ && wb_) store_pair(dst, Pair<T>{va, vb});
+        if (wa_ && wb_) store_pair<NT_XY>(dst, Pair<T>{va, vb});
         else if (wa_) dst[0] = va;
         else if (wb_) dst[1] = vb;
       }

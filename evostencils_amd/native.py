@@ -4,7 +4,8 @@ import os
 
 from evostencils_amd import abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libevomg.so")
+# EVOMG_LIB: another build of the same library (A/B experiments of tools/, e.g. a -D variant); the default is the in-tree one
+LIB_PATH = os.environ.get("EVOMG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libevomg.so")
 _library = None
 
 
