@@ -527,6 +527,23 @@ template <typename T> class Impl : public ImplBase {
     }
     return true;   // nothing else touches it: the same pair overwrites it in the next pass
   }
+  // COPY gen_rhs@min = ..., SET_ZERO gen_error@min, COARSE_SOLVE@min (what every cycle emits around gen_mgCycle@min,
+  // exastencils.py:890-896) on a grid the one-wave CG serves: ONE launch instead of three
+  bool fusable_copy_zero_solve(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || !use_reg_krylov_ || i + 2 >= n_ops || dim_ != 2 || scalar_traits<T>::is_complex) return false;
+    if (prob_.cgs_kind != EVOMG_CGS_CG || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
+    const evomg_op_t &cp = ops[i], &z = ops[i + 1], &cs = ops[i + 2];
+    const int L = prob_.min_level;
+    if (cp.opcode != EVOMG_OP_COPY || z.opcode != EVOMG_OP_SET_ZERO || cs.opcode != EVOMG_OP_COARSE_SOLVE) return false;
+    if (cp.level != L || z.level != L || cs.level != L) return false;
+    if (canon(L, cp.dst) != EVOMG_F_CGS_RHS || canon(L, cp.src0) == EVOMG_F_CGS_RHS) return false;
+    if (canon(L, z.dst) != canon(L, EVOMG_F_CORR) || canon(L, cp.src0) == canon(L, EVOMG_F_CORR) || canon(L, cp.src0) == EVOMG_F_RES) return false;
+    if (prof_matches(cp) || prof_matches(z) || prof_matches(cs)) return false;
+    // "x = 0, so r = b" needs the boundary values of x to be zero as well (SET_ZERO leaves them alone); true for every
+    // error field of a cycle, not for a field a test filled with random numbers
+    if (!bnd_zero_[L][canon(L, EVOMG_F_CORR)]) return false;
+    return krylov_own<2>(lv_[L].g.n, true).wave != 0;
+  }
   bool fusable_residual_restrict(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || i + 1 >= n_ops) return false;
     const evomg_op_t &a = ops[i], &b = ops[i + 1];
@@ -550,6 +567,12 @@ template <typename T> class Impl : public ImplBase {
       flush_batch();
       if (elidable_zero(ops, n_ops, i)) {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
+        continue;
+      }
+      if (fusable_copy_zero_solve(ops, n_ops, i)) {
+        const int rc = coarse_solve(&ops[i]);
+        if (rc != EVOMG_OK) return rc;
+        i += 2;
         continue;
       }
       if (fusable_prolong_twice(ops, n_ops, i)) {
@@ -1078,7 +1101,7 @@ template <typename T> class Impl : public ImplBase {
   // f stays cacheable. When not even f fits (8193^2), no hint at all is fastest (profiles/r03_nt_placement.md).
   bool strip_streams(const Geo& g) const {
     const double field = (double)g.pitch * g.n * sizeof(T);
-    return strip_nt_ && 3.0 * field > 256.0 * 1024 * 1024 && field <= 192.0 * 1024 * 1024;
+    return strip_nt_ && 3.0 * field > nt_lo_mib_ * 1024 * 1024 && field <= nt_hi_mib_ * 1024 * 1024;
   }
   // Chunk height of the 2D smoother strips. A block is four waves = four chunks and every block is resident at once, so a
   // launch lasts as long as the compute unit that got the most blocks: ceil(blocks / CUs) * (rows + halo and prologue).
@@ -1516,19 +1539,37 @@ template <typename T> class Impl : public ImplBase {
     else hipLaunchKernelGGL((evomg_axpy<T, 3>), node_grid(g), node_block(), 0, stream_, g, z, x, a, y);
   }
 
-  int coarse_solve() {
+  // copy_op: the COPY `gen_rhs = ...` and the SET_ZERO of the solution that precede the solve are folded into its launch
+  // (fusable_copy_zero_solve): the kernel reads its right-hand side from the copy's source, writes the copy itself and
+  // starts from x = 0 without reading x
+  int coarse_solve(const evomg_op_t* copy_op = nullptr) {
     const int L = prob_.min_level;
     Level<T>& lv = lv_[L];
     T* x = fieldptr(L, EVOMG_F_CORR);
     const T* b = fieldptr(L, EVOMG_F_CGS_RHS);
     T* r = fieldptr(L, EVOMG_F_RES);
+    if (copy_op) {
+      if constexpr (!scalar_traits<T>::is_complex) {
+        const T* src = fieldptr(L, copy_op->src0);
+        T* cgs = fieldptr(L, EVOMG_F_CGS_RHS);
+        hipLaunchKernelGGL((evomg_cg_wave2d<T, true>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, src, r, cgs, prob_.cgs_max_iterations,
+                           prob_.cgs_target_res_reduction, dinfo_);
+        bnd_zero_[L][canon(L, copy_op->dst)] = bnd_zero_[L][canon(L, copy_op->src0)];     // the COPY's bookkeeping
+        lv.alt_mirror = nullptr;
+        apply_bc(L, x);
+        HIP_TRY(hipGetLastError());
+        return EVOMG_OK;
+      }
+      return invalid("coarse_solve: folded copy on a complex problem");
+    }
     T* w[kTmpVectors];
     const int need = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? 6 : 2;
     for (int i = 0; i < need; ++i) {
       int rc = tmpvec(L, i, &w[i]);
       if (rc != EVOMG_OK) return rc;
     }
-    const int lanes = (dim_ == 2 ? krylov_own<2>(lv.g.n) : krylov_own<3>(lv.g.n)).lanes;
+    const bool real_cg = prob_.cgs_kind != EVOMG_CGS_BICGSTAB && !scalar_traits<T>::is_complex;   // ownership of the real-valued CG
+    const int lanes = (dim_ == 2 ? krylov_own<2>(lv.g.n, real_cg) : krylov_own<3>(lv.g.n, real_cg)).lanes;
     const dim3 one(1), thr(lanes);
     if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
       const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
@@ -1609,6 +1650,14 @@ template <typename T> class Impl : public ImplBase {
     if (!use_reg_krylov_) return EVOMG_OK;
     const KrylovOwn own = krylov_own<DIM>(lv.g.n, !scalar_traits<T>::is_complex);
     if (DIM == 2) {
+      if (own.wave) {             // up to 33^2: the whole solve in one wave
+        if constexpr (!scalar_traits<T>::is_complex) {
+          hipLaunchKernelGGL((evomg_cg_wave2d<T, false>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, (T*)nullptr,
+                             prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+          *launched = true;
+        }
+        return EVOMG_OK;
+      }
       if (!own.tile || own.lanes != 512) return EVOMG_OK;
       // 512 threads = 8 waves = 8 bands; up to 65^2: one column per lane, 129^2: a column pair per lane
       if (!own.pair) {
@@ -1944,6 +1993,8 @@ template <typename T> class Impl : public ImplBase {
   int tile3d_order_ = getenv("EVOMG_TILE3D_ORDER") ? atoi(getenv("EVOMG_TILE3D_ORDER")) : 1;
   int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
+  double nt_lo_mib_ = getenv("EVOMG_NT_LO_MIB") ? atof(getenv("EVOMG_NT_LO_MIB")) : 256.0;   // 3 fields above this: stream x, y
+  double nt_hi_mib_ = getenv("EVOMG_NT_HI_MIB") ? atof(getenv("EVOMG_NT_HI_MIB")) : 192.0;   // ... unless one field exceeds this
 };
 
 // ---- systems of PDEs (evomg_system.h): own storage and a plain interpreter, nothing shared with the tuned scalar path ----

@@ -526,6 +526,15 @@ __device__ __forceinline__ double lanes_plus32(double v) {
   const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return __hiloint2double((int)b[1], (int)a[1]);
 }
+// value held by the lane 32 away (lane l <-> lane l ^ 32): one v_permlane32_swap per 32-bit half serves both directions
+__device__ __forceinline__ double lanes_swap32(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const bool upper = (threadIdx.x & 32) != 0;
+  return __hiloint2double((int)(upper ? b[0] : b[1]), (int)(upper ? a[0] : a[1]));
+}
+__device__ __forceinline__ cplx lanes_swap32(cplx v) { return cplx{lanes_swap32(v.re), lanes_swap32(v.im)}; }
 __device__ __forceinline__ double lanes_plus16(double v) {
   const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
   const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);

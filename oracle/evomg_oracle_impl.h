@@ -451,7 +451,7 @@ static double FN(norm)(FN(ctx_t)* c, int level, const SC* a) { return sc_norm_fr
  *       slots of the device kernels. Pointwise multigrid kernels elsewhere stay unfused. */
 #define KRYLOV_LANES 1024
 typedef struct {
-  int tile, pair, column, m, cb, bands, R, slots, lanes;
+  int tile, pair, column, m, cb, bands, R, slots, lanes, wave;
   long total;
 } FN(own_t);
 /* for_cg: the pair tiles are used by the real-valued CG only (BiCGStab and complex solvers: one column per lane) */
@@ -471,11 +471,21 @@ static FN(own_t) FN(own_make)(FN(ctx_t)* c, int level, int for_cg) {
   /* 3D "column" ownership when m*m <= 1024: thread t owns the z-column (t % m, t / m), iz ascending */
   o.column = (c->dim == 3 && (long)o.m * o.m <= o.lanes);
   o.slots = o.pair ? 2 * o.R : o.tile ? o.R : o.column ? o.m : (int)((o.total + o.lanes - 1) / o.lanes);
+  /* "wave" ownership, real-valued CG on 2D grids up to 33^2 (csrc/evomg_krylov.h: evomg_cg_wave2d): ONE wave64, lane l =
+   * (half h = l >> 5, column l & 31) owns the rows 16 h .. 16 h + 15 of its column, rows ascending; the reduction is the
+   * wave64 tree alone */
+  o.wave = (c->dim == 2 && for_cg && !SC_IS_COMPLEX && o.m <= 31);
+  if (o.wave) { o.tile = 0; o.pair = 0; o.lanes = 64; o.bands = 2; o.R = 16; o.slots = 16; }
   return o;
 }
 /* dense index of slot i of thread t, or (size_t)-1 if the slot is empty */
 static size_t FN(own_node)(FN(ctx_t)* c, int level, const FN(own_t)* o, int t, int i) {
   const int n = c->lv[level].n, m = o->m;
+  if (o->wave) {
+    const int h = t >> 5, ix = t & 31, iy = h * o->R + i;
+    if (t >= 64 || ix >= m || i >= o->R || iy >= m) return (size_t)-1;
+    return IDX2(n, ix + 1, iy + 1);
+  }
   if (o->pair) {
     const int w = t >> 6, l = t & 63;
     if (w >= o->bands || 2 * l >= m) return (size_t)-1;

@@ -288,6 +288,46 @@ def test_rejects_malformed_programs(native):
     assert rc == abi.ERR_INVALID   # gen_rhs_u exists on the coarsest level only
 
 
+@pytest.mark.parametrize("lo", [1, 2, 3, 4, 5])
+def test_one_wave_cg_and_its_folded_copy_and_zero(native, oracle, lo, monkeypatch):
+    """2D grids up to 33^2: the whole CG in one wave (evomg_cg_wave2d), and `gen_rhs = RHS; gen_error = 0; gen_mgCycle@min()`
+    as ONE launch (the kernel copies the right-hand side and starts from x = 0 without reading x) — against the three
+    separate ops, the global-memory kernel and the oracle: solution, residual and the copied right-hand side bit for bit.
+    With a non-zero BOUNDARY on x (a test-only state) the fold must not happen: r = b - A x then sees those values."""
+    pd = problems.poisson_2d(lo, lo + 1)
+    n = (1 << lo) + 1
+    rng = np.random.default_rng(50 + lo)
+    rhs = rng.standard_normal((n, n))
+    copy = abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS)
+    zero = abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR)
+    solve = abi.make_op(abi.OP_COARSE_SOLVE, lo)
+    # x0 = None: the error field as a cycle finds it (never touched from outside: zero, boundary known to be zero) — the
+    # fold happens; x0 random incl. its boundary: set_field marks the boundary as unknown, no fold
+    for x0 in (None, rng.standard_normal((n, n))):
+        ho = oracle.create(pd)
+        ho.set_field(lo, abi.F_RHS, rhs)
+        if x0 is not None:
+            ho.set_field(lo, abi.F_SOL, x0)
+        ho.run_ops([copy, zero, solve])
+        want = [ho.get_field(lo, f) for f in (abi.F_SOL, abi.F_RES, abi.F_CGS_RHS)]
+        for programs, knob in (([[copy, zero, solve]], None), ([[copy], [zero], [solve]], None), ([[copy, zero, solve]], "EVOMG_NO_FUSE"),
+                               ([[copy, zero, solve]], "EVOMG_NO_REG_KRYLOV")):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            h = native.create(pd)
+            h.set_field(lo, abi.F_RHS, rhs)
+            if x0 is not None:
+                h.set_field(lo, abi.F_SOL, x0)
+            for prog in programs:
+                h.run_ops(prog)
+            got = [h.get_field(lo, f) for f in (abi.F_SOL, abi.F_RES, abi.F_CGS_RHS)]
+            h.close()
+            if knob:
+                monkeypatch.delenv(knob)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]), (programs, knob)
+            assert np.array_equal(got[1][1:-1, 1:-1], want[1][1:-1, 1:-1])
+
+
 @pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4), (3, 5)])
 def test_coarse_cg_variants_are_bit_identical(native, oracle, dim, lo, monkeypatch):
     """The register-resident CG (2D) / the eight-workgroup CG (33^3), the global-memory single-workgroup CG
