@@ -1552,8 +1552,7 @@ template <typename T> class Impl : public ImplBase {
       if constexpr (!scalar_traits<T>::is_complex) {
         const T* src = fieldptr(L, copy_op->src0);
         T* cgs = fieldptr(L, EVOMG_F_CGS_RHS);
-        hipLaunchKernelGGL((evomg_cg_wave2d<T, true>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, src, r, cgs, prob_.cgs_max_iterations,
-                           prob_.cgs_target_res_reduction, dinfo_);
+        launch_cg_wave2d<true>(lv, x, src, r, cgs);
         bnd_zero_[L][canon(L, copy_op->dst)] = bnd_zero_[L][canon(L, copy_op->src0)];     // the COPY's bookkeeping
         lv.alt_mirror = nullptr;
         apply_bc(L, x);
@@ -1645,6 +1644,18 @@ template <typename T> class Impl : public ImplBase {
     *launched = true;
     return EVOMG_OK;
   }
+  template <bool XZERO> void launch_cg_wave2d(const Level<T>& lv, T* x, const T* b, T* r, T* b_copy) {
+    if constexpr (!scalar_traits<T>::is_complex) {
+      // rows every lane is guaranteed to own: the upper half's share (33^2: 15 of 16)
+      const int m = lv.g.n - 2, upper = m - EVOMG_CG_WAVE_ROWS;
+      if (upper >= EVOMG_CG_WAVE_ROWS - 1)
+        hipLaunchKernelGGL((evomg_cg_wave2d<T, XZERO, EVOMG_CG_WAVE_ROWS - 1>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, b_copy,
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      else
+        hipLaunchKernelGGL((evomg_cg_wave2d<T, XZERO, 0>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, b_copy,
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+    }
+  }
   template <int DIM> int launch_cg_reg(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
     *launched = false;
     if (!use_reg_krylov_) return EVOMG_OK;
@@ -1652,8 +1663,7 @@ template <typename T> class Impl : public ImplBase {
     if (DIM == 2) {
       if (own.wave) {             // up to 33^2: the whole solve in one wave
         if constexpr (!scalar_traits<T>::is_complex) {
-          hipLaunchKernelGGL((evomg_cg_wave2d<T, false>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, (T*)nullptr,
-                             prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+          launch_cg_wave2d<false>(lv, x, b, r, nullptr);
           *launched = true;
         }
         return EVOMG_OK;

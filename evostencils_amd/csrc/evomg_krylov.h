@@ -524,7 +524,10 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
 // XZERO: the solve starts from x = 0 (the SET_ZERO in front of it is folded in): r = b, nothing of x is read.
 // b_copy: the COPY `gen_rhs = RHS` in front of the solve, folded in (the whole array, padding included, as the copy op).
 // Ownership / summation order: krylov_own().wave, restated by the oracle (own_make: wave).
-template <typename T, bool XZERO>
+// MASK_FROM: first unrolled row that may be a slack row in either half (host: min over the halves' row counts, or 0);
+// rows below it are rows of the grid in both halves and need no masking (33^2: 15 — only the upper half's last row is
+// slack). Column-less lanes need none either: their stencil coefficients are zeroed, so A p = 0 there by construction.
+template <typename T, bool XZERO, int MASK_FROM>
 __global__ void __launch_bounds__(64)
 evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, T* __restrict__ b_copy,
                 int maxit, double tol, int* __restrict__ info) {
@@ -540,6 +543,9 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
     for (long q = l; q < elems; q += 64) b_copy[q] = b[q];
   }
   const long c0 = gidx<2>(g, min(ix, m - 1) + 1, min(iy0, m - 1) + 1, 0);
+  Stencil<T> sl;                                   // this lane's coefficients: zero where the lane has no column
+#pragma unroll
+  for (int e = 0; e < 5; ++e) sl.c[e] = col ? st.c[e] : zero;
   T r[R], p[R], ap[R], xv[R];
   T loc = zero;
 #pragma unroll
@@ -574,12 +580,12 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
         const T pw = from_left(pc), pe = from_right(pc);
         const T ps = (i == 0) ? p_south : p[i > 0 ? i - 1 : 0];
         const T pn = (i == R - 1) ? p_north : p[i < R - 1 ? i + 1 : i];
-        T a = sc_mul(st.c[0], pc);
-        a = sc_fma(st.c[1], pw, a);
-        a = sc_fma(st.c[2], pe, a);
-        a = sc_fma(st.c[3], ps, a);
-        a = sc_fma(st.c[4], pn, a);
-        a = (col && i < rows) ? a : zero;          // column-less lanes and slack rows: p = r = 0 for good
+        T a = sc_mul(sl.c[0], pc);
+        a = sc_fma(sl.c[1], pw, a);
+        a = sc_fma(sl.c[2], pe, a);
+        a = sc_fma(sl.c[3], ps, a);
+        a = sc_fma(sl.c[4], pn, a);
+        if (i >= MASK_FROM) a = (i < rows) ? a : zero;   // slack rows: p = r = 0 for good (column-less lanes: sl = 0)
         ap[i] = a;
         loc = sc_fma(pc, a, loc);
       }
