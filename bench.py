@@ -29,6 +29,9 @@ import subprocess
 import sys
 import time
 
+# hardware queues for the candidates-in-flight modes: must be in the environment before the HIP runtime initialises
+# (evostencils_amd/__init__.py explains; ranks started by the launcher inherit it)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
@@ -53,7 +56,7 @@ def parse_args():
     ap.add_argument("--concurrency", type=int, default=1,
                     help="candidates in flight per GPU inside the HEADLINE timed region (1 = isolated timing, the "
                          "reference's sequential semantics)")
-    ap.add_argument("--throughput-workers", type=int, default=6,
+    ap.add_argument("--throughput-workers", type=int, default=12,
                     help="after the headline region, also time a throughput-mode region with this many candidates in "
                          "flight per GPU and report it as `throughput_mode` (0/1 = skip)")
     ap.add_argument("--population", type=int, default=256,
