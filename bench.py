@@ -223,7 +223,7 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
                     "iteration counts identical — checked, see the flag — while a candidate's measured time includes its neighbours)."}
 
 
-def reference_size_section(local_rank, rank, steps=20, warmup=3):
+def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):
     """Second configuration (rank 0, N = 1): the size the reference's own optimisation runs at — 2D Poisson level 9
     (513^2), five levels, `notebooks/tutorial.ipynb` — with the headline's V(1,1) red-black cycle. Small grids are
     launch- and latency-bound: reported per V-cycle, not against the HBM roofline."""
@@ -241,8 +241,33 @@ def reference_size_section(local_rank, rank, steps=20, warmup=3):
         t_ms, rho, its = gen.generate_and_evaluate(expression, storages, lo, hi, "", evaluation_samples=1)
     wall = time.perf_counter() - t0
     gen.close()
+    flight = None
+    if in_flight > 1:
+        # the same candidate evaluated by `in_flight` workers at once (own generator, stream and fields each): what a
+        # population run at this size sees. Lowering runs under the interpreter lock, the solves do not.
+        from evostencils_amd import population
+
+        def make():
+            g = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library())
+            g.initialize_code_generation(lo, hi)
+            return g
+        workers = population.ConcurrentEvaluator(make, in_flight)
+        cands = [build_candidate(g, lo, hi) for g in workers.generators]
+        by_gen = {id(g): c for g, c in zip(workers.generators, cands)}
+
+        def one(g, _):
+            return g.generate_and_evaluate(by_gen[id(g)], None, lo, hi, "", evaluation_samples=1)
+        workers.map(one, range(4 * in_flight))
+        n = 40 * in_flight
+        t1 = time.perf_counter()
+        out = workers.map(one, range(n))
+        wall2 = time.perf_counter() - t1
+        workers.close()
+        flight = {"candidates_in_flight_per_gpu": in_flight, "steps": n, "value": n / wall2, "unit": "solves/s",
+                  "iterations_identical": all(r[2] == its for r in out)}
     return {"workload": f"2D Poisson 5-pt, {1 << hi}^2 grid (level {hi}), {hi - lo + 1}-level V(1,1) RB-Gauss-Seidel cycle, "
                         "CG coarse solve on 33^2 to 1e-12",
+            "in_flight": flight,
             "steps": steps, "value": steps / wall, "unit": "solves/s", "ms_per_step": 1e3 * wall / steps,
             "solve_time_ms": t_ms, "iterations_per_solve": its, "convergence_factor": rho,
             "ms_per_vcycle": t_ms / its if its else None,
@@ -445,7 +470,7 @@ def main():
             line["population"] = pop_section
         if world == 1 and not args.no_reference_size:
             try:                                             # auxiliary, rank-local: must not cost the headline line
-                line["reference_size"] = reference_size_section(local_rank, rank)
+                line["reference_size"] = reference_size_section(local_rank, rank, in_flight=args.throughput_workers)
             except Exception as exc:                         # noqa: BLE001
                 line["reference_size"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N = 1 only

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=1)
     ap.add_argument("--seed", type=int, default=2024)
     args = ap.parse_args()
+    import evostencils_amd  # noqa: F401  (first: sets GPU_MAX_HW_QUEUES before the HIP runtime initialises)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
