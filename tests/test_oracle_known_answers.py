@@ -135,3 +135,17 @@ def test_tutorial_cycle_converges_slowly_like_the_recorded_run():
     out = h.evaluate(ops, 1, 0, 128)
     assert out.status == abi.SOLVE_MAXITER and out.n_iterations == 100
     assert 0.85 < out.conv_factor < 0.97
+
+
+def test_host_tuned_build_of_the_oracle_gives_the_same_bits():
+    """bench.py times the oracle built with -march=native on the host it runs on (oracle.native_library); same source, same
+    -ffp-contract=off: the residual history of a solve is bit-identical to the portable build's."""
+    import numpy as np
+    from evostencils_amd import abi, problems
+    from oracle import oracle
+    from test_full_size_gpu import vcycle
+    lo, hi = 3, 6
+    ops = vcycle(lo, hi, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.15))
+    a = oracle.create(problems.poisson_2d(lo, hi)).evaluate(ops, 1, 0, 64)
+    b = oracle.create(problems.poisson_2d(lo, hi), lib=oracle.native_library()).evaluate(ops, 1, 0, 64)
+    assert a.n_iterations == b.n_iterations and np.array_equal(a.history, b.history)
