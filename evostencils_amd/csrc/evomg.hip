@@ -1120,6 +1120,10 @@ template <typename T> class Impl : public ImplBase {
       const long cost = rounds * (r + 4);
       if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = r; }     // ties: the taller chunk (less halo)
     }
+    // small grids (less than one block of four waves per compute unit even with the shortest chunks): a launch lasts as
+    // long as one wave's march — a chain of dependent row steps — so the shortest chunks win (513^2 and below: 4 rows,
+    // tutorial-size solve 1.87 -> 1.77 ms); the halo they re-read comes from L2
+    if (best_cost < 0 && lo == 8 && quantum == 2 && ((long)strips * ((n + 7) / 8) + 3) / 4 < n_cu_) return 4;
     return best;
   }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
