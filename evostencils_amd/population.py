@@ -254,3 +254,25 @@ def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[
         if failure is not None:
             raise failure
     return rows
+
+
+def collective_selftest(local_rank: int = 0):
+    """The three collectives of this module (gather, all_gather, all_reduce of small float64 tables) issued directly on
+    the initialised process group's device, whatever the world size — with one rank on the `nccl` backend this is what
+    runs RCCL's kernels on the GPU without a second device (tests/test_population_rccl_gpu.py). Returns the values
+    received, for the caller to check."""
+    import torch
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = _device(local_rank)
+    t = torch.tensor([[float(rank), 0.5, 12.0, 7.0]], dtype=torch.float64, device=dev)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, out, dst=0)
+    table = torch.zeros((4, 4), dtype=torch.float64)
+    table[rank % 4] = torch.tensor([1.0, 0.25, 3.0, 9.0], dtype=torch.float64)
+    table = table.to(dev)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    return {"backend": dist.get_backend(), "device": str(dev), "all_gather": [g.cpu().tolist() for g in gathered],
+            "gather": [g.cpu().tolist() for g in out] if out is not None else None, "all_reduce": table.cpu().tolist()}
