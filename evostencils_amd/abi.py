@@ -124,7 +124,7 @@ def ops_array(ops: Sequence[Op]):
 # every symbol include/evomg.h declares, without prefix
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
             "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
-            "profile_begin", "profile_end"]
+            "profile_begin", "profile_end", "device_count"]
 
 
 class BackendError(RuntimeError):
@@ -150,6 +150,9 @@ class Library:
         f["last_error"].restype = C.c_char_p
         f["abi_version"].argtypes = []
         f["abi_version"].restype = C.c_int
+        if "device_count" in f:
+            f["device_count"].argtypes = []
+            f["device_count"].restype = C.c_int
         for name in ("set_initial_field", "get_field", "set_field"):
             f[name].argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
             f[name].restype = C.c_int

@@ -122,7 +122,7 @@ class ProgramGenerator:
         self._problem = problem
         self._original_min_level = problem.min_level
         self._original_max_level = problem.max_level
-        self._device_id = device_id if device_id is not None else int(os.environ.get("LOCAL_RANK", mpi_rank))
+        self._device_id = device_id if device_id is not None else self._default_device(mpi_rank, library)
         self._library = library
         self._handle = None
         self._handle_levels = None
@@ -177,6 +177,32 @@ class ProgramGenerator:
             from evostencils_amd import native
             self._library = native.library()     # raises if the HIP library is missing
         return self._library
+
+    @staticmethod
+    def _default_device(mpi_rank, library=None):
+        """One process per GPU: the rank's index ON ITS NODE, as the launcher exports it (torchrun: LOCAL_RANK; Open MPI,
+        MVAPICH2, Intel MPI / MPICH hydra, Slurm — the reference is started with `mpiexec -n N`, README.md), else the MPI
+        rank; modulo the number of GPUs the process sees, so that ranks beyond one node's GPUs wrap around instead of
+        asking for a device that does not exist."""
+        local = mpi_rank
+        for name in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
+            if os.environ.get(name, "").lstrip("-").isdigit():
+                local = int(os.environ[name])
+                break
+        count = 0
+        if library is None:
+            try:
+                from evostencils_amd import native
+                library = native.library()
+            except Exception:      # noqa: BLE001 — not built: the constructor must still work for lowering-only use
+                library = None
+        fn = getattr(library, "fn", {}) if library is not None else {}
+        if "device_count" in fn:
+            try:
+                count = int(fn["device_count"]())
+            except Exception:      # noqa: BLE001 — no usable runtime: keep the plain index, evomg_create reports the failure
+                count = 0
+        return local % count if count > 0 else local
 
     def _ensure_handle(self, min_level, max_level, parameters=None):
         """One native solver instance per (level window, problem); operators are re-targeted in place

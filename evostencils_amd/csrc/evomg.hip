@@ -2693,6 +2693,10 @@ struct evomg_handle {
 extern "C" {
 
 int evomg_abi_version(void) { return EVOMG_ABI_VERSION; }
+int evomg_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
 
 int evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t** out) {
   if (!out) return EVOMG_ERR_INVALID;

@@ -225,6 +225,9 @@ int  evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t*
 void evomg_destroy(evomg_handle_t* h);
 const char* evomg_last_error(const evomg_handle_t* h);  /* h may be NULL: error of the last failed create */
 int  evomg_abi_version(void);
+/* Number of GPUs this process can use (0: none, or the runtime failed to start). One process per GPU picks its device
+ * as local_rank % evomg_device_count() (the reference runs one MPI rank per worker, README.md: `mpiexec -n N`). */
+int  evomg_device_count(void);
 
 /* -- problem data (K10): dense host arrays, x fastest, (2^L+1)^d scalars; complex = interleaved re,im -- */
 /* Sets the *initial* content of a field (restored at the start of every solve). Only SOL and RHS of the

@@ -68,3 +68,24 @@ def test_create_rejects_bad_descriptors_without_touching_the_gpu(libpath):
     p.abi_version, p.dimension = abi.ABI_VERSION, 4
     with pytest.raises(abi.BackendError):
         abi.Handle(lib, p, 0)
+
+
+def test_default_device_follows_the_launchers_local_rank(monkeypatch):
+    """One process per GPU: torchrun's LOCAL_RANK, Open MPI's OMPI_COMM_WORLD_LOCAL_RANK (the reference is started with
+    mpiexec), Slurm's SLURM_LOCALID ... decide the device, wrapped to the number of visible GPUs; without any of them the
+    MPI rank does."""
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+
+    class Lib:
+        def __init__(self, n):
+            self.fn = {"device_count": lambda: n}
+
+    for name in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
+        monkeypatch.delenv(name, raising=False)
+    assert ProgramGenerator._default_device(5, Lib(8)) == 5
+    assert ProgramGenerator._default_device(11, Lib(8)) == 3          # second node of an 8-GPU-per-node job
+    assert ProgramGenerator._default_device(11, Lib(0)) == 11         # no runtime: evomg_create reports it
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "6")
+    assert ProgramGenerator._default_device(14, Lib(8)) == 6
+    monkeypatch.setenv("LOCAL_RANK", "2")                             # torchrun wins
+    assert ProgramGenerator._default_device(14, Lib(8)) == 2
