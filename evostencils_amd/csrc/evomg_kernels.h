@@ -613,6 +613,80 @@ __global__ void __launch_bounds__(256) evomg_dot_final(const T* __restrict__ par
   if (threadIdx.x == 0) out[0] = s;
 }
 
+// ---- fused passes of the outer (preconditioned BiCGStab) solver ------------------------------------------------------
+// Both kernels walk the inner nodes in evomg_dot_partial's order (block b: rows b, b + gridDim, ...; thread i: columns
+// i, i + 256, ...) and accumulate their dot products exactly as that kernel does (s = s + a * b, unfused), so
+// partial sums — and with evomg_dot_final the dot products — carry the same bits as the separate passes they replace.
+// 2D. partial: [NDOT][gridDim.x].
+// v = A x (stored); dot 0 = w0 . v; dot 1 (NDOT == 2) = v . v
+template <typename T, int NDOT>
+__global__ void __launch_bounds__(256) evomg_apply_dots(Geo g, Stencil<T> st, const T* __restrict__ x, T* __restrict__ v,
+                                                        const T* __restrict__ w0, T* __restrict__ partial) {
+  __shared__ T red[17];
+  const int m = g.n - 2;
+  T s0 = scalar_traits<T>::zero(), s1 = scalar_traits<T>::zero();
+  for (long r = blockIdx.x; r < m; r += gridDim.x) {
+    const long base = gidx<2>(g, 0, 1 + (int)r, 0);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
+      const long c = base + i;
+      const T ax = apply_stencil<T, 2>(st, x, g, c);
+      v[c] = ax;
+      s0 = sc_add(s0, sc_mul(w0[c], ax));
+      if (NDOT == 2) s1 = sc_add(s1, sc_mul(ax, ax));
+    }
+  }
+  s0 = block_sum(s0, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s0;
+  if (NDOT == 2) {
+    s1 = block_sum(s1, red);
+    if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = s1;
+  }
+}
+// z = x + a y (stored); dot 0 = z . z; dot 1 = w . z
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_axpy_dots(Geo g, T* __restrict__ z, const T* __restrict__ x, T a, const T* __restrict__ y,
+                                                       const T* __restrict__ w, T* __restrict__ partial) {
+  __shared__ T red[17];
+  const int m = g.n - 2;
+  T s0 = scalar_traits<T>::zero(), s1 = scalar_traits<T>::zero();
+  for (long r = blockIdx.x; r < m; r += gridDim.x) {
+    const long base = gidx<2>(g, 0, 1 + (int)r, 0);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
+      const long c = base + i;
+      const T zv = sc_add(x[c], sc_mul(a, y[c]));
+      z[c] = zv;
+      s0 = sc_add(s0, sc_mul(zv, zv));
+      s1 = sc_add(s1, sc_mul(w[c], zv));
+    }
+  }
+  s0 = block_sum(s0, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s0;
+  s1 = block_sum(s1, red);
+  if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = s1;
+}
+// z = x2 + b (x1 + a y1) on inner nodes: two consecutive axpy steps (z = x1 + a y1, then z = x2 + b z) in one pass
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_axpy2(Geo g, T* __restrict__ z, const T* __restrict__ x1, T a, const T* __restrict__ y1,
+                                                   const T* __restrict__ x2, T b) {
+  int i, j, k;
+  if (!node_of_thread<2>(g, i, j, k)) return;
+  if (!is_inner<2>(g, i, j, k)) return;
+  const long c = gidx<2>(g, i, j, k);
+  const T t = sc_add(x1[c], sc_mul(a, y1[c]));
+  z[c] = sc_add(x2[c], sc_mul(b, t));
+}
+// up to two final reductions in one launch: out[d] = sum of partial[d][0 .. count)
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_dot_final2(const T* __restrict__ partial, int count, int ndot, T* __restrict__ out) {
+  __shared__ T red[17];
+  for (int d = 0; d < ndot; ++d) {
+    T s = scalar_traits<T>::zero();
+    for (int i = threadIdx.x; i < count; i += blockDim.x) s = sc_add(s, partial[(long)d * count + i]);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[d] = s;
+  }
+}
+
 // z = x + a*y on inner nodes
 template <typename T, int DIM>
 __global__ void __launch_bounds__(256) evomg_axpy(Geo g, T* __restrict__ z, const T* __restrict__ x, T a,

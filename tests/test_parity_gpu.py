@@ -207,6 +207,33 @@ def test_helmholtz_pbicgstab_matches_the_oracle(native, oracle):
     assert np.abs(sg - so).max() <= REL_TOL * np.abs(so).max()
 
 
+@pytest.mark.parametrize("lo,hi", [(3, 6), (5, 9)])
+def test_outer_bicgstab_fused_passes_do_not_change_a_bit(native, oracle, lo, hi, monkeypatch):
+    """The preconditioned BiCGStab loop with its fused passes (right-hand side of the preconditioner read in place, both
+    updates of p in one pass, A u with its dot products, residual update with norm and next rho) against the same solve
+    with EVOMG_NO_OUTER_FUSE: identical histories and solutions; and the oracle's history to 1e-10."""
+    from test_helmholtz_oracle import reference_vcycle_ops
+    pd = problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
+    ops = reference_vcycle_ops(lo, hi)
+    results = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("EVOMG_NO_OUTER_FUSE", "1")
+        else:
+            monkeypatch.delenv("EVOMG_NO_OUTER_FUSE", raising=False)
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 1024)
+        results.append((out, h.get_field(hi, abi.F_CORR), h.get_field(hi, abi.F_RES)))
+        h.close()
+    (a, xa, ra), (b, xb, rb) = results
+    assert a.status == b.status and a.n_iterations == b.n_iterations and a.n_iterations > 3
+    assert np.array_equal(a.history, b.history) and np.array_equal(xa, xb) and np.array_equal(ra, rb)
+    if hi <= 6:
+        oo = oracle.create(pd).evaluate(ops, 1, 0, 1024)
+        assert oo.n_iterations == a.n_iterations
+        assert (np.abs(a.history - oo.history) / oo.history).max() <= REL_TOL
+
+
 def test_evolved_helmholtz_cycle(native, oracle):
     """The frozen evolved Helmholtz preconditioner (tests/test_helmholtz_oracle.py: two V(2,1) corrections per
     application): against the oracle at 65^2, and at 257^2 (k = 160) by the invariants of the returned solution —
