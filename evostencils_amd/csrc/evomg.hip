@@ -1085,15 +1085,24 @@ template <typename T> class Impl : public ImplBase {
     if (!fuse_enabled_ || !zero_elision_ || dim_ != 2 || i + 1 >= n_ops) return false;
     const evomg_op_t &z = ops[i], &sm = ops[i + 1];
     if (z.opcode != EVOMG_OP_SET_ZERO || sm.opcode != EVOMG_OP_SMOOTH || z.level != sm.level) return false;
-    if (jacobi_lost(sm)) return false;        // the sweep's output is discarded: the field has to be zeroed for real
-    if (canon(z.level, z.dst) != canon(sm.level, sm.dst) || sm.block[0] * sm.block[1] != 1) return false;
-    if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
+    if (canon(z.level, z.dst) != canon(sm.level, sm.dst)) return false;
     if (!bnd_zero_[z.level][canon(z.level, z.dst)]) return false;
     if (prof_matches(z)) return false;
+    return zero_input_sweep(ops, n_ops, i + 1);
+  }
+  // ops[i] is a sweep that can run as the zero-input variant of its strip kernel (its field is zero everywhere, boundary
+  // included; the variant loads nothing of it and writes every node of the output)
+  bool zero_input_sweep(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || !zero_elision_ || dim_ != 2 || i >= n_ops) return false;
+    const evomg_op_t& sm = ops[i];
+    if (sm.opcode != EVOMG_OP_SMOOTH || sm.block[0] * sm.block[1] != 1) return false;
+    if (jacobi_lost(sm)) return false;        // the sweep's output is discarded: the field has to be zeroed for real
+    if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
+    if (prof_matches(sm)) return false;
     // the zero-input variants exist for the plain sweep and the sweep + residual + restriction; a sweep that is the
     // tail of the iteration (norm) would go another way
-    if (tail_norm_candidate(ops, n_ops, i + 1)) return false;
-    return use_strip(lv_[z.level].g);
+    if (tail_norm_candidate(ops, n_ops, i)) return false;
+    return use_strip(lv_[sm.level].g);
   }
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
   // Non-temporal placement of the 2D strip kernels (template flag NT_XY): on a level whose three arrays (x, y, f) exceed
@@ -1894,8 +1903,11 @@ template <typename T> class Impl : public ImplBase {
         rhs_written = rhs_written || w;
       }
     }
+    // `u = 0` in front of a cycle that starts with a point sweep on u: the sweep's zero-input variant instead of a memset
+    const bool zero_by_sweep = fuse && n_ops > 0 && ops[0].level == L && canon(L, ops[0].dst) == EVOMG_F_SOL && zero_input_sweep(ops, n_ops, 0);
     auto precondition = [&](const T* rhs_src) -> int {   // u = 0 ; f = rhs ; gen_mgCycle()
-      HIP_TRY(hipMemsetAsync(fieldptr(L, EVOMG_F_SOL), 0, bytes, stream_));
+      if (zero_by_sweep) x_zero_next_ = true;
+      else HIP_TRY(hipMemsetAsync(fieldptr(L, EVOMG_F_SOL), 0, bytes, stream_));
       if (fuse && !rhs_written) {
         T* own = lv.f[EVOMG_F_RHS];
         lv.f[EVOMG_F_RHS] = const_cast<T*>(rhs_src);
