@@ -2679,6 +2679,16 @@ class FASImpl : public ImplBase {
       case EVOMG_OP_FAS_CGS:
         if (lv.g.n <= 65 && fas_cgs_one_launch_) {
           // all sweeps in one single-workgroup launch (evomg_fas.h); an odd count leaves the result in the other slot
+          if (fas_cgs_lds_) {
+            // both slots in LDS for the whole call (evomg_fas_cgs_lds)
+            const size_t lds_bytes = 2 * (size_t)lv.g.n * lv.g.n * sizeof(double);
+            if (!fas_lds_attr_set_) {
+              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_fas_cgs_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+              fas_lds_attr_set_ = true;
+            }
+            hipLaunchKernelGGL(evomg_fas_cgs_lds, dim3(1), dim3(1024), lds_bytes, stream_, lv.g, lv.st, gam, lv.f[EVOMG_F_SOL], lv.next,
+                               (const double*)lv.f[EVOMG_F_RHS], prob_.fas_cgs_omega, prob_.cgs_max_iterations);
+          } else
           hipLaunchKernelGGL(evomg_fas_cgs, dim3(1), dim3(1024), 0, stream_, lv.g, lv.st, gam, lv.f[EVOMG_F_SOL], lv.next,
                              (const double*)lv.f[EVOMG_F_RHS], prob_.fas_cgs_omega, prob_.cgs_max_iterations);
           if (prob_.cgs_max_iterations & 1) std::swap(lv.f[EVOMG_F_SOL], lv.next);
@@ -2719,6 +2729,8 @@ class FASImpl : public ImplBase {
   evomg_problem_t prob_;
   int device_;
   bool fas_cgs_one_launch_ = getenv("EVOMG_NO_FAS_CGS_KERNEL") == nullptr;
+  bool fas_cgs_lds_ = getenv("EVOMG_NO_FAS_CGS_LDS") == nullptr;      // ... with both slots in LDS
+  bool fas_lds_attr_set_ = false;
   FLevel lv_[EVOMG_MAX_LEVELS];
   hipStream_t stream_ = nullptr;
   double* partials_ = nullptr;

@@ -105,3 +105,67 @@ __global__ void __launch_bounds__(1024) evomg_fas_cgs(Geo g, Stencil<double> st,
     double* t = x; x = y; y = t;
   }
 }
+
+// The same sweeps with the iterate in LDS: both slots of the 65^2 field (2 x 33 KB) stay on the compute unit
+// for the whole call (each with the boundary values its array holds), the right-hand side of a thread's (up to four) nodes in registers; a sweep reads its five values from
+// one LDS image and writes the other — no global-memory round trip between the sweeps, what is left is the arithmetic
+// (one exponential, one division per node). Per-node formula and operation order = fas_relax(.., newton = 1, n_steps = 1):
+// bit-identical to evomg_fas_cgs and to the launch-per-sweep form. a / b: as evomg_fas_cgs (the result of the last sweep
+// and of the one before it are written back to the slots where the global-memory form would have left them).
+// dynamic LDS: 2 * n * n doubles.
+__global__ void __launch_bounds__(1024) evomg_fas_cgs_lds(Geo g, Stencil<double> st, double gam, double* a, double* b, const double* f,
+                                                          double om, int sweeps) {
+  extern __shared__ __align__(16) double fas_lds[];
+  const int n = g.n, m = n - 2, total = m * m, nn = n * n;
+  double* cur = fas_lds;
+  double* nxt = fas_lds + nn;
+  for (int q = threadIdx.x; q < nn; q += 1024) {
+    const int i = q % n, j = q / n;
+    const bool inner = i >= 1 && i <= m && j >= 1 && j <= m;
+    cur[q] = a[gidx<2>(g, i, j, 0)];
+    nxt[q] = inner ? 0.0 : b[gidx<2>(g, i, j, 0)];        // each slot keeps its own boundary values, as in global memory
+  }
+  constexpr int MAXN = 4;                                  // 63^2 inner nodes / 1024 threads
+  double fv[MAXN];
+  int lq[MAXN];
+#pragma unroll
+  for (int e = 0; e < MAXN; ++e) {
+    const int q = threadIdx.x + 1024 * e;
+    const bool ok = q < total;
+    const int i = 1 + (ok ? q % m : 0), j = 1 + (ok ? q / m : 0);
+    lq[e] = ok ? j * n + i : -1;
+    fv[e] = ok ? f[gidx<2>(g, i, j, 0)] : 0.0;
+  }
+  __syncthreads();
+  for (int s = 0; s < sweeps; ++s) {
+#pragma unroll
+    for (int e = 0; e < MAXN; ++e) {
+      if (lq[e] < 0) continue;
+      const int c = lq[e];
+      const double u = cur[c];
+      double ap = st.c[0] * u;
+      ap = ap + st.c[1] * cur[c - 1];
+      ap = ap + st.c[2] * cur[c + 1];
+      ap = ap + st.c[3] * cur[c - n];
+      ap = ap + st.c[4] * cur[c + n];
+      const double ex = exp(u);
+      ap = ap + (gam * ex) * u;
+      const double num = fv[e] - ap;
+      const double den = st.c[0] + (gam * (u + 1.0)) * ex;
+      nxt[c] = u + om * (num / den);
+    }
+    __syncthreads();
+    double* t = cur; cur = nxt; nxt = t;
+  }
+  // cur = result of the last sweep, nxt = of the one before; the global-memory form leaves sweep k's output in b for odd k
+  double* out_last = (sweeps & 1) ? b : a;
+  double* out_prev = (sweeps & 1) ? a : b;
+#pragma unroll
+  for (int e = 0; e < MAXN; ++e) {
+    if (lq[e] < 0) continue;
+    const int q = threadIdx.x + 1024 * e;
+    const long c = gidx<2>(g, 1 + q % m, 1 + q / m, 0);
+    out_last[c] = cur[lq[e]];
+    if (sweeps > 0) out_prev[c] = nxt[lq[e]];
+  }
+}

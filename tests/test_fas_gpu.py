@@ -102,3 +102,33 @@ def test_generate_and_evaluate_at_the_reference_size(native):
     hh = 1.0 / 1024
     assert np.abs(sol - exact_solution(gen.template, 10)).max() < 0.3 * hh * hh * np.pi ** 2
     gen.close()
+
+
+@pytest.mark.parametrize("level,sweeps", [(6, 200), (5, 7), (3, 1)])
+def test_coarse_sweeps_in_lds_are_bit_identical(native, level, sweeps, monkeypatch):
+    """CGS@coarsest: all Newton-Jacobi sweeps in one launch with both slots in LDS (evomg_fas_cgs_lds), in one launch with
+    the slots in global memory (EVOMG_NO_FAS_CGS_LDS) and one launch per sweep (EVOMG_NO_FAS_CGS_KERNEL): the same formula
+    in the same order, so the same bits — even and odd sweep counts (the result's slot alternates)."""
+    import dataclasses
+    _, pd, _ = fas_problem(level, level + 1)
+    pd = dataclasses.replace(pd, cgs_max_iterations=sweeps)
+    rng = np.random.default_rng(5 + level)
+    n = (1 << level) + 1
+    u0 = np.zeros((n, n)); u0[1:-1, 1:-1] = 0.3 * rng.standard_normal((n - 2, n - 2))
+    f0 = np.zeros((n, n)); f0[1:-1, 1:-1] = 50.0 * rng.standard_normal((n - 2, n - 2))
+    op = abi.make_op(abi.OP_FAS_CGS, level, abi.F_SOL, 0, abi.F_RHS)
+    results = []
+    for knob in (None, "EVOMG_NO_FAS_CGS_LDS", "EVOMG_NO_FAS_CGS_KERNEL"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        h = native.create(pd)
+        h.set_field(level, abi.F_SOL, u0)
+        h.set_field(level, abi.F_RHS, f0)
+        h.run_ops([op, abi.make_op(abi.OP_FAS_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)])
+        results.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
+        h.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    for got in results[1:]:
+        assert np.array_equal(got[0], results[0][0]) and np.array_equal(got[1], results[0][1])
+    assert not np.array_equal(results[0][0], u0)
