@@ -2346,13 +2346,20 @@ class SystemImpl : public ImplBase {
         const int tx = (inner + bx - 1) / bx, ty = (inner + by - 1) / by;
         const int passes = op.partitioning == EVOMG_PART_RED_BLACK ? 2 : 1;
         const SysConstFields f = slot_fields(L, rhs_slot);
+        // point blocks: the straight-line kernel that writes every node of y (no copy of x first)
+        const bool point = bx == 1 && by == 1 && sys_point_fast_ && nf_ == 2;
         for (int pass = 0; pass < passes; ++pass) {
           const SysConstFields x = slot_fields(L, sol_slot);
           SysFields y{};
           for (int u = 0; u < nf_; ++u) {
             y.p[u] = lv.alt[u];
-            if ((mask >> u) & 1) HIP_TRY(hipMemcpyAsync(lv.alt[u], x.p[u], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+            if (!point && ((mask >> u) & 1)) HIP_TRY(hipMemcpyAsync(lv.alt[u], x.p[u], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
           }
+          const int col = passes == 2 ? pass : -1;
+          if (point && mask == 3) hipLaunchKernelGGL(evomg_sys_point_smooth<3>, grd(g.n, g.n), blk(), 0, stream_, g, lv.st, nf_, col, x, f, y, op.omega);
+          else if (point && mask == 1) hipLaunchKernelGGL(evomg_sys_point_smooth<1>, grd(g.n, g.n), blk(), 0, stream_, g, lv.st, nf_, col, x, f, y, op.omega);
+          else if (point && mask == 2) hipLaunchKernelGGL(evomg_sys_point_smooth<2>, grd(g.n, g.n), blk(), 0, stream_, g, lv.st, nf_, col, x, f, y, op.omega);
+          else
           hipLaunchKernelGGL(evomg_sys_smooth, grd(tx, ty), blk(), 0, stream_, g, lv.st, nf_, mask, sh, bx, by, tx, ty,
                              passes == 2 ? pass : -1, x, f, y, op.omega);
           // a colour pass always takes effect; a `with jacobi` sweep only where the next slot is advanced (evomg.h)
@@ -2397,6 +2404,10 @@ class SystemImpl : public ImplBase {
           p.p[u] = lv.tmp[2 * u];
           ap.p[u] = lv.tmp[2 * u + 1];
         }
+        if ((long)(g.n - 2) * (g.n - 2) * nf_ <= 512 && sys_cg_small_)
+          hipLaunchKernelGGL(evomg_sys_cg_small, dim3(1), dim3(512), (size_t)nf_ * g.n * g.n * sizeof(double), stream_, g, lv.st, nf_, x, b, r,
+                             prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+        else
         hipLaunchKernelGGL(evomg_sys_cg, dim3(1), dim3(1024), 0, stream_, g, lv.st, nf_, x, b, r, p, ap, prob_.cgs_max_iterations,
                            prob_.cgs_target_res_reduction, dinfo_);
         break;
@@ -2439,6 +2450,8 @@ class SystemImpl : public ImplBase {
   evomg_problem_t prob_;
   int device_;
   int nf_;
+  bool sys_cg_small_ = getenv("EVOMG_NO_SYS_CG_SMALL") == nullptr;       // register / LDS form of the stacked CG (<= 512 unknowns)
+  bool sys_point_fast_ = getenv("EVOMG_NO_SYS_POINT_FAST") == nullptr;   // straight-line kernel for point blocks (evomg_system.h)
   SLevel lv_[EVOMG_MAX_LEVELS];
   hipStream_t stream_ = nullptr;
   double* partials_ = nullptr;

@@ -108,6 +108,70 @@ __global__ void __launch_bounds__(256) evomg_sys_smooth(Geo g, SysStencil st, in
   }
 }
 
+// Point blocks (every listed unknown has the block shape (1, 1): collective / decoupled Jacobi and their red-black forms —
+// the smoothers a cycle mostly consists of): one thread per NODE of the whole grid, straight-line code for the 1 x 1 or
+// 2 x 2 local system instead of the generic kernel's run-time cell lists and 8 x 8 elimination in scratch memory, and
+// every node of y written — the relaxed value, or x where the node is a boundary node / of the other colour — so the
+// caller needs no copy of x into y first. Operation for operation the generic kernel (same order of the right-hand-side
+// subtractions: unknown j ascending, entry e ascending, centre entries of listed unknowns skipped; same elimination with
+// its skipped zero multiplier; same relaxation): bit-identical.
+template <int MASK>
+__global__ void __launch_bounds__(256) evomg_sys_point_smooth(Geo g, SysStencil st, int nf, int colour, SysConstFields x, SysConstFields f,
+                                                              SysFields y, double om) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int n = g.n;
+  if (a >= n || b >= n) return;
+  const long c = (long)g.pitch * b + a;
+  const bool inner = a >= 1 && b >= 1 && a <= n - 2 && b <= n - 2;
+  if (!inner || (colour >= 0 && ((a + b) & 1) != colour)) {
+#pragma unroll
+    for (int u = 0; u < EVOMG_MAX_UNKNOWNS; ++u)
+      if ((MASK >> u) & 1) y.p[u][c] = x.p[u][c];
+    return;
+  }
+  constexpr int M0 = (MASK & 1) ? 0 : 1;                  // first listed unknown
+  constexpr bool TWO = MASK == 3;
+  double rhs[2], xv[EVOMG_MAX_UNKNOWNS][9];
+  // the nine values of both unknowns around the node (loaded once; the generic kernel reads them entry by entry)
+#pragma unroll
+  for (int j = 0; j < EVOMG_MAX_UNKNOWNS; ++j)      // host-checked: nf == EVOMG_MAX_UNKNOWNS
+#pragma unroll
+    for (int e = 0; e < 9; ++e) xv[j][e] = x.p[j][(long)g.pitch * (b + sys_oy(e)) + a + sys_ox(e)];
+#pragma unroll
+  for (int p = 0; p < (TWO ? 2 : 1); ++p) {
+    const int i = TWO ? p : M0;
+    double s = f.p[i][c];
+#pragma unroll
+    for (int j = 0; j < EVOMG_MAX_UNKNOWNS; ++j)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        if (e == 0 && ((MASK >> j) & 1)) continue;        // a listed unknown: goes into the local matrix
+        s = s - st.a[i][j][e] * xv[j][e];
+      }
+    rhs[p] = s;
+  }
+  const double omm = 1.0 - om;
+  if (TWO) {
+    const double m00 = st.a[0][0][0], m01 = st.a[0][1][0], m10 = st.a[1][0][0];
+    double m11 = st.a[1][1][0];
+    double r0 = rhs[0], r1 = rhs[1];
+    if (m10 != 0.0) {
+      const double fac = m10 / m00;
+      m11 = m11 - fac * m01;
+      r1 = r1 - fac * r0;
+    }
+    r1 = r1 / m11;
+    double s0 = r0;
+    s0 = s0 - m01 * r1;
+    r0 = s0 / m00;
+    y.p[0][c] = omm * xv[0][0] + om * r0;
+    y.p[1][c] = omm * xv[1][0] + om * r1;
+  } else {
+    const double r0 = rhs[0] / st.a[M0][M0][0];
+    y.p[M0][c] = omm * xv[M0][0] + om * r0;
+  }
+}
+
 // Coarse-grid CG on the stacked unknowns: ONE 1024-thread workgroup, vectors in global memory (L2-resident on the small
 // coarsest grids these problems have), thread t owns the stacked inner nodes t, t + 1024, ... (unknown-major, rows,
 // columns); dots: per-thread fma chain in that order, then the block_sum trees. Restated by the oracle (sys_dot).
@@ -169,6 +233,68 @@ __global__ void __launch_bounds__(1024) evomg_sys_cg(Geo g, SysStencil st, int n
       }
       rr = rrn;
     }
+  }
+  if (t == 0) info[0] = it;
+}
+
+// The same solve for coarsest grids with at most 512 stacked unknowns (17^2 nodes x 2 unknowns: the reference's level range
+// 4..8 ends there): every thread of ONE 512-thread workgroup owns the stacked node t (exactly evomg_sys_cg's ownership when
+// there are fewer unknowns than threads) and keeps its x, r, p and A p in registers; only p lives in an LDS image (zero
+// boundary) for the neighbours' 9-point reads; one barrier per reduction. Arithmetic, ownership and summation order are
+// evomg_sys_cg's (the extra waves of the 1024-thread form contribute exact zeros): bit-identical to it and to the oracle.
+// dynamic LDS: nf * n * n doubles.
+__global__ void __launch_bounds__(512) evomg_sys_cg_small(Geo g, SysStencil st, int nf, SysFields x, SysConstFields b, SysFields r,
+                                                          int maxit, double tol, int* __restrict__ info) {
+  extern __shared__ __align__(16) double sys_img[];
+  __shared__ double red[32];
+  const int n = g.n, m = n - 2, nn = n * n;
+  const int per = m * m, total = per * nf;
+  const int t = threadIdx.x;
+  const bool own = t < total;
+  const int u = own ? t / per : 0, k = own ? t % per : 0;
+  const int a = 1 + k % m, bb = 1 + k / m;
+  const long c = (long)g.pitch * bb + a;
+  const int li = u * nn + bb * n + a;
+  auto apply_row = [&](int i) {
+    double s = 0.0;
+    for (int j = 0; j < nf; ++j)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) s = s + st.a[i][j][e] * sys_img[j * nn + (bb + sys_oy(e)) * n + a + sys_ox(e)];
+    return s;
+  };
+  // image of x (all nodes, boundary included) for the initial residual
+  for (int q = t; q < nf * nn; q += 512) {
+    const int uu = q / nn, rem = q % nn;
+    sys_img[q] = x.p[uu][(long)g.pitch * (rem / n) + rem % n];
+  }
+  __syncthreads();
+  double xv = own ? sys_img[li] : 0.0;
+  double rv = own ? b.p[u][c] - apply_row(u) : 0.0;
+  double pv = rv, apv = 0.0;
+  int phase = 0;
+  double rr = block_sum_fast(__builtin_fma(rv, rv, 0.0), red, phase);     // its barrier: everybody has read the x image
+  const double res0 = sqrt(rr);
+  for (int q = t; q < nf * nn; q += 512) sys_img[q] = 0.0;               // from here on: the image of p (zero boundary)
+  int it = 0;
+  if (res0 != 0.0) {
+    __syncthreads();
+    for (; it < maxit; ++it) {
+      if (own) sys_img[li] = pv;
+      __syncthreads();                       // p complete
+      apv = own ? apply_row(u) : 0.0;
+      const double alpha = rr / block_sum_fast(__builtin_fma(pv, apv, 0.0), red, phase);   // its barrier: all reads of p done
+      xv = __builtin_fma(alpha, pv, xv);
+      rv = __builtin_fma(-alpha, apv, rv);
+      const double rrn = block_sum_fast(__builtin_fma(rv, rv, 0.0), red, phase);
+      if (!(sqrt(rrn) > tol * res0)) { ++it; break; }
+      const double beta = rrn / rr;
+      pv = __builtin_fma(beta, pv, rv);
+      rr = rrn;
+    }
+  }
+  if (own) {
+    x.p[u][c] = xv;
+    r.p[u][c] = rv;
   }
   if (t == 0) info[0] = it;
 }

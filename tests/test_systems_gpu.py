@@ -134,3 +134,30 @@ def test_manufactured_solution_on_the_gpu(native):
     for u in range(2):
         assert np.abs(h.get_field(hi, F(abi.F_SOL, u)) - w[u]).max() < 1e-8 * np.abs(w[u]).max()
     h.close()
+
+
+def test_fast_system_kernels_do_not_change_a_bit(native, monkeypatch):
+    """The straight-line point-block smoother (evomg_sys_point_smooth: collective / decoupled, Jacobi / red-black, no copy
+    of x) and the register / LDS form of the stacked coarse CG (evomg_sys_cg_small) against the generic kernels they
+    replace (EVOMG_NO_SYS_POINT_FAST, EVOMG_NO_SYS_CG_SMALL): whole solves with identical histories and solutions."""
+    gen, ops = None, None
+    from helpers import ops_for_case
+    gen, ops = ops_for_case("elasticity2d_L6_mixed")
+    _, lo, hi, _ = cycles.CASES["elasticity2d_L6_mixed"]
+    pd = problems.linear_elasticity_2d(lo, hi)
+    results = []
+    for plain in (False, True):
+        for k in ("EVOMG_NO_SYS_POINT_FAST", "EVOMG_NO_SYS_CG_SMALL"):
+            if plain:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 128)
+        results.append((out, [h.get_field(hi, F(abi.F_SOL, u)) for u in range(2)]))
+        h.close()
+    (a, xa), (b, xb) = results
+    assert a.status == b.status and a.n_iterations == b.n_iterations and a.n_iterations > 3
+    assert np.array_equal(a.history, b.history)
+    for p, q in zip(xa, xb):
+        assert np.array_equal(p, q)

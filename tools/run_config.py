@@ -1,5 +1,5 @@
 """Developer tool: run one of the BASELINE.json configurations once on the GPU (for rocprofv3).
-usage: python tools/run_config.py c4|c2|c3|c5|t9|t8|fas"""
+usage: python tools/run_config.py c4|c2|c3|c5|t9|t8|fas|ela"""
 import os, sys, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
@@ -27,6 +27,17 @@ elif cfg == "fas":
     sm = [[cycles._nw(14)] for _ in range(4)]
     ops = gen.generate_op_program(cycles.fas_v_cycle(fas_context(gen, 4), 4, sm, sm)[0])
     pd, lo, hi = gen.problem_description(), 6, 10
+elif cfg == "ela":
+    # the reference's linear-elasticity example at its own level range (4..8, 257^2, two unknowns): the problem's own
+    # solver settings as a candidate — V(2,1), collective red-black w = 1.25
+    import cycles
+    from helpers import build_case, context_for, generator_for
+    lo, hi = 4, 8
+    gen = generator_for("2D_FD_LinearElasticity_fromL2", lo, hi)
+    rb = [("rbgs", 23)]
+    expression, _ = cycles.v_cycle(context_for(gen, lo, hi), hi - lo, [rb * 2] * (hi - lo), [rb] * (hi - lo))
+    ops = gen.generate_op_program(expression, lo, hi)
+    pd = gen.problem
 elif cfg in ("t9", "t8"):
     # the reference's own operating size (notebooks/tutorial.ipynb: levels 5..9 = 513^2, five levels)
     lo, hi = (5, 9) if cfg == "t9" else (4, 8)
