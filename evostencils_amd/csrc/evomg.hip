@@ -1904,7 +1904,8 @@ template <typename T> class Impl : public ImplBase {
       }
     }
     // `u = 0` in front of a cycle that starts with a point sweep on u: the sweep's zero-input variant instead of a memset
-    const bool zero_by_sweep = fuse && n_ops > 0 && ops[0].level == L && canon(L, ops[0].dst) == EVOMG_F_SOL && zero_input_sweep(ops, n_ops, 0);
+    // (not with the coarse-level batches: a batched first op would never consume the flag)
+    const bool zero_by_sweep = fuse && !batch_enabled_ && n_ops > 0 && ops[0].level == L && canon(L, ops[0].dst) == EVOMG_F_SOL && zero_input_sweep(ops, n_ops, 0);
     auto precondition = [&](const T* rhs_src) -> int {   // u = 0 ; f = rhs ; gen_mgCycle()
       if (zero_by_sweep) x_zero_next_ = true;
       else HIP_TRY(hipMemsetAsync(fieldptr(L, EVOMG_F_SOL), 0, bytes, stream_));

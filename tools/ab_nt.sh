@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): the libraries under build/ were -DEVOMG_EXPERIMENT_NT_X builds of commit 3250de9's strip kernels; the
+# placement they measured (profiles/r03_nt_placement.md) is what evomg_strip2d<.., NT_XY> now does. Kept as the record of the method.
 # A/B of the non-temporal placement in the 2D strip kernels on the bench line (same box, interleaved).
 # build/libevomg_nt<v>.so = the library built with -DEVOMG_EXPERIMENT_NT_X=<v> (bit 0: x loads, bit 1: y stores non-temporal)
 run() {

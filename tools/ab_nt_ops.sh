@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): the libraries under build/ were -DEVOMG_EXPERIMENT_NT_X builds of commit 3250de9's strip kernels; the
+# placement they measured (profiles/r03_nt_placement.md) is what evomg_strip2d<.., NT_XY> now does. Kept as the record of the method.
 # per-op timings under the four non-temporal placements (see tools/ab_nt.sh)
 for lvl in 12 13; do
   for pol in "A:f:" "B:none:0" "C:xy:0:ntx" "D:all:1:ntx"; do

@@ -1,5 +1,5 @@
 """Developer tool: run one of the BASELINE.json configurations once on the GPU (for rocprofv3).
-usage: python tools/run_config.py c4|c2|c3|c5|t9|t8|fas|ela"""
+usage: python tools/run_config.py c4|c2|c3|c5|t9|t8|fas|ela|p3d|h7"""
 import os, sys, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
@@ -38,6 +38,17 @@ elif cfg == "ela":
     expression, _ = cycles.v_cycle(context_for(gen, lo, hi), hi - lo, [rb * 2] * (hi - lo), [rb] * (hi - lo))
     ops = gen.generate_op_program(expression, lo, hi)
     pd = gen.problem
+elif cfg == "p3d":
+    # the reference's 3D Poisson example at its own level range (2..6, 65^3): its solver settings, V(2,1) red-black w = 1.25
+    lo, hi = 2, 6
+    pd = problems.poisson_3d(lo, hi)
+    ops = vcycle(lo, hi, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.25))
+elif cfg == "h7":
+    # the reference's Helmholtz example at its own level range (3..7, 129^2, k = 80): its hand-written V(2,1) cycle
+    from test_helmholtz_oracle import reference_vcycle_ops
+    lo, hi = 3, 7
+    pd = problems.helmholtz_2d(lo, hi, k=80.0)
+    ops = reference_vcycle_ops(lo, hi)
 elif cfg in ("t9", "t8"):
     # the reference's own operating size (notebooks/tutorial.ipynb: levels 5..9 = 513^2, five levels)
     lo, hi = (5, 9) if cfg == "t9" else (4, 8)
