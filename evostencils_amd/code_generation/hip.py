@@ -424,6 +424,15 @@ class ProgramGenerator:
             ops = self.generate_op_program(expression, min_level, max_level, solver_program)
         except lowering.UnsupportedExpression:
             return infinity, infinity, infinity
+        return self.evaluate_op_program(ops, min_level, max_level, solver_program, infinity, evaluation_samples,
+                                        global_variable_values)
+
+    def evaluate_op_program(self, ops, min_level: int, max_level: int, solver_program: str = "", infinity=1e100,
+                            evaluation_samples=3, global_variable_values=None):
+        """The second half of generate_and_evaluate: run an op program `generate_op_program` returned (the part that
+        releases the interpreter lock; ProgramGeneratorPool lowers under a lock and evaluates outside it)."""
+        if global_variable_values is None:
+            global_variable_values = {}
         if solver_program or max_level < self._problem.max_level or min_level > self._problem.min_level:
             # the executable always solves the problem on its finest level with the whole hierarchy underneath
             min_level, max_level = self._problem.min_level, self._problem.max_level
@@ -539,3 +548,77 @@ class ProgramGenerator:
         if self._handle is not None:
             self._handle.close()
             self._handle = None
+
+
+class ProgramGeneratorPool:
+    """Several candidates in flight on ONE GPU behind the ProgramGenerator interface: `n_workers` generators (own HIP
+    stream and own set of level fields each) and a thread-safe `generate_and_evaluate` that hands every call to a free
+    one. On the reference side this is two lines — the pool instead of the generator, and a thread pool as the toolbox's
+    `map` (the optimizer evaluates a population with `toolbox.map(toolbox.evaluate, ...)`, optimization/program.py:491,577):
+
+        program_generator = ProgramGeneratorPool(lambda: ProgramGenerator(compiler_path, base_path, ...), 12)
+        optimizer.toolbox.register("map", multiprocessing.pool.ThreadPool(12).map)          # after Optimizer(...)
+
+    Why it pays: a candidate's coarse-grid Krylov solve is a 1 ms latency chain on one of 256 compute units; the sweeps of
+    the other candidates use the rest of the GPU meanwhile (5.5x on BASELINE's 256-candidate population at 2048^2,
+    profiles/r03_throughput_queues.md). Convergence factors and iteration counts are those of the sequential evaluation;
+    a candidate's measured time includes its neighbours, so keep one worker when the time objective must be isolated.
+
+    Everything that is not an evaluation — attributes, generate_storage, generate_cycle_function ... — is answered by the
+    first generator; level-range set-up calls go to all of them; the cycle functions of earlier optimisation runs
+    (`solver_program`) are known to all (one shared table). Lowering mutates flags on the DAG, whose terminals all
+    candidates share: it runs under one lock (it holds the interpreter lock anyway); the solve itself does not."""
+
+    def __init__(self, make_generator, n_workers: int):
+        import queue
+        import threading
+        if n_workers < 1:
+            raise ValueError("n_workers must be at least 1")
+        self._generators = [make_generator() for _ in range(n_workers)]
+        shared = self._generators[0]._cycle_functions
+        for g in self._generators[1:]:
+            g._cycle_functions = shared
+        self._free = queue.Queue()
+        for g in self._generators:
+            self._free.put(g)
+        self._lower_lock = threading.Lock()
+
+    def __getattr__(self, name):            # only reached for names the pool itself does not define
+        return getattr(self._generators[0], name)
+
+    def __setattr__(self, name, value):
+        if name in ("_counter", "_average_generation_time"):        # reset by the optimizer (program.py:850-851)
+            for g in self._generators:
+                setattr(g, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    @property
+    def generators(self):
+        return list(self._generators)
+
+    def initialize_code_generation(self, min_level: int, max_level: int):
+        for g in self._generators:
+            g.initialize_code_generation(min_level, max_level)
+
+    def reinitialize(self, min_level, max_level, global_expressions):
+        for g in self._generators:
+            g.reinitialize(min_level, max_level, global_expressions)
+
+    def generate_and_evaluate(self, expression, storages, min_level: int, max_level: int, solver_program: str,
+                              infinity=1e100, evaluation_samples=3, global_variable_values=None):
+        g = self._free.get()
+        try:
+            with self._lower_lock:
+                try:
+                    ops = g.generate_op_program(expression, min_level, max_level, solver_program)
+                except lowering.UnsupportedExpression:
+                    return infinity, infinity, infinity
+            return g.evaluate_op_program(ops, min_level, max_level, solver_program, infinity, evaluation_samples,
+                                         global_variable_values)
+        finally:
+            self._free.put(g)
+
+    def close(self):
+        for g in self._generators:
+            g.close()

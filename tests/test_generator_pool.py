@@ -1,0 +1,100 @@
+"""ProgramGeneratorPool: the thread-safe facade that keeps several candidates in flight behind the ProgramGenerator
+interface (host logic on the CPU; the GPU test compares pooled against sequential evaluation)."""
+import threading
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+import pytest
+
+from evostencils_amd.code_generation.hip import ProgramGeneratorPool
+from evostencils_amd.code_generation import lowering
+
+
+class _FakeGenerator:
+    """Records what reaches it; `evaluate_op_program` blocks until two calls are inside (proves concurrency)."""
+    barrier = None
+
+    def __init__(self):
+        self._cycle_functions = {}
+        self._counter = 7
+        self._average_generation_time = 3
+        self.dimension = 2
+        self.calls, self.inits = [], []
+        self.lowering_now = 0
+        self.closed = False
+
+    def initialize_code_generation(self, lo, hi):
+        self.inits.append((lo, hi))
+
+    def reinitialize(self, lo, hi, g):
+        self.inits.append(("re", lo, hi, dict(g)))
+
+    def generate_op_program(self, expression, lo, hi, solver_program=""):
+        if expression == "bad":
+            raise lowering.UnsupportedExpression("bad")
+        return ["op", expression]
+
+    def evaluate_op_program(self, ops, lo, hi, solver_program, infinity, samples, gv):
+        self.calls.append(ops[1])
+        if _FakeGenerator.barrier is not None:
+            _FakeGenerator.barrier.wait(timeout=30)
+        return (1.0 + ops[1], 0.5, 9.0)
+
+    def generate_cycle_function(self, *a, **k):
+        self._cycle_functions["text"] = (1, 0, [])
+        return "text"
+
+    def close(self):
+        self.closed = True
+
+
+def test_pool_dispatches_concurrently_and_forwards_the_interface():
+    pool = ProgramGeneratorPool(_FakeGenerator, 3)
+    gens = pool.generators
+    assert pool.dimension == 2 and pool._counter == 7
+    pool._counter = 0                                   # the optimizer's reset reaches every worker
+    pool._average_generation_time = 0
+    assert all(g._counter == 0 and g._average_generation_time == 0 for g in gens)
+    pool.initialize_code_generation(5, 9)
+    pool.reinitialize(6, 10, {"k": 160.0})
+    assert all(g.inits == [(5, 9), ("re", 6, 10, {"k": 160.0})] for g in gens)
+    assert pool.generate_cycle_function(None) == "text"
+    assert all(g._cycle_functions is gens[0]._cycle_functions for g in gens)      # one table of earlier runs' functions
+    _FakeGenerator.barrier = threading.Barrier(3)       # three evaluations must be inside at the same time
+    try:
+        with ThreadPool(3) as tp:
+            out = tp.map(lambda i: pool.generate_and_evaluate(i, None, 5, 9, ""), range(3))
+    finally:
+        _FakeGenerator.barrier = None
+    assert sorted(o[0] for o in out) == [1.0, 2.0, 3.0]
+    assert sorted(c for g in gens for c in g.calls) == [0, 1, 2] and all(len(g.calls) == 1 for g in gens)
+    assert pool.generate_and_evaluate("bad", None, 5, 9, "", infinity=1e100) == (1e100, 1e100, 1e100)
+    pool.close()
+    assert all(g.closed for g in gens)
+    with pytest.raises(ValueError):
+        ProgramGeneratorPool(_FakeGenerator, 0)
+
+
+@pytest.mark.gpu
+def test_pooled_evaluation_equals_sequential_on_the_gpu():
+    """Twelve seeded candidates (2D Poisson 257^2, four levels) through a pool of four workers from four threads: the same
+    convergence factors and iteration counts as one generator evaluating them one after the other."""
+    from evostencils_amd import candidates, native, problems
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    from helpers import context_for
+    lo, hi = 5, 8
+
+    def make():
+        g = ProgramGenerator(problem=problems.poisson_2d(lo, hi), library=native.library())
+        g.initialize_code_generation(lo, hi)
+        return g
+    single = make()
+    pop = candidates.population(lambda: context_for(single, lo, hi), hi - lo, 2, 12, seed=7)
+    want = [single.generate_and_evaluate(e, None, lo, hi, "", evaluation_samples=1) for e in pop]
+    single.close()
+    pool = ProgramGeneratorPool(make, 4)
+    with ThreadPool(4) as tp:
+        got = tp.map(lambda e: pool.generate_and_evaluate(e, None, lo, hi, "", evaluation_samples=1), pop)
+    pool.close()
+    assert [g[1:] for g in got] == [w[1:] for w in want]
+    assert all(np.isfinite(g[0]) and g[0] > 0 for g in got)
