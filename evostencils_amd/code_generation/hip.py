@@ -97,13 +97,13 @@ class ProgramGenerator:
             config = settings.get("configName")
             l2_path = os.path.join(base_path, settings.get("basePathPrefix", "."), settings.get("l2file", f"{config}.exa2"))
             problem = None
-            if os.path.exists(l2_path):
-                try:
-                    problem = problem_files.load_problem(base_path, settings_path, knowledge_path)
-                except problem_files.UnsupportedProblem:
-                    # outside the front end's subset: the built-in descriptor of the same configuration, if there is one
-                    if config not in problems.BY_NAME:
-                        raise
+            try:
+                # layer-2 files, or the layer-3 / layer-4 pair of a Helmholtz-type problem
+                problem = problem_files.load_problem(base_path, settings_path, knowledge_path)
+            except problem_files.UnsupportedProblem:
+                # outside the front end's subset: the built-in descriptor of the same configuration, if there is one
+                if config not in problems.BY_NAME:
+                    raise
             if problem is not None:
                 pass
             elif config in problems.BY_NAME:

@@ -7,8 +7,9 @@ compiler writes (code_generation/parser.py:25-111 `extract_l2_information`, :114
 user wrote. Supported: one scalar `Real` field on the nodes of one rectangular domain, one constant-coefficient star
 stencil written in terms of `vf_gridWidth_*` (rediscretised on every level, like ExaStencils does for such stencils),
 one equation `Op * u == RHS`; Dirichlet boundary values and right-hand side given as arithmetic expressions of the
-node position. Everything else raises `UnsupportedProblem` with the construct that was not understood. The complex
-Helmholtz problem enters at layer 3 and stays a built-in descriptor (problems.helmholtz_2d).
+node position; systems of two such fields (`describe_system`); and — round 3 — complex Helmholtz-type problems that enter at
+layer 3 (`describe_layer3_helmholtz`: the `.exa3` / `.exa4` pair of the reference's Helmholtz example and problems of the same
+shape). Everything else raises `UnsupportedProblem` with the construct that was not understood.
 
 Layer-2 statements (keywords `Domain`, `Field`, `Operator`, `Equation` are optional — the reference's own
 Poisson/2D_FD_Poisson_fromL2.exa2 omits them):
@@ -79,9 +80,10 @@ def resolve_settings(settings: Dict[str, str]) -> Dict[str, str]:
 
 
 # ---- expressions -----------------------------------------------------------------------------------------------------
-_TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+(?:[eE][+-]?\d+)?)|([A-Za-z_]\w*)|(\*\*|[-+*/(),]))")
+_TOKEN = re.compile(r"\s*(?:((?:\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+(?:[eE][+-]?\d+)?)j?)|([A-Za-z_]\w*)|(\*\*|[-+*/(),]))")
 _FUNCTIONS = {"sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "sqrt": np.sqrt, "log": np.log,
               "abs": np.abs, "fabs": np.abs}
+_FUNCTIONS2 = {"max": np.maximum, "min": np.minimum}        # two arguments (Helmholtz right-hand side, exa3:24)
 
 
 def tokenize(text: str) -> List[Tuple[str, str]]:
@@ -156,14 +158,19 @@ class Expression:
         k, v = self._peek()
         if k == "num":
             self._take()
-            return ("num", float(v))
+            return ("num", complex(0.0, float(v[:-1])) if v.endswith("j") else float(v))     # 0.5j: imaginary literal
         if k == "id":
             self._take()
             if self._peek() == ("op", "("):
-                if v not in _FUNCTIONS:
+                if v not in _FUNCTIONS and v not in _FUNCTIONS2:
                     raise UnsupportedProblem(f"unknown function {v!r} in expression {self.text!r}")
                 self._take()
                 arg = self._sum()
+                if v in _FUNCTIONS2:
+                    self._take("op", ",")
+                    arg2 = self._sum()
+                    self._take("op", ")")
+                    return ("call2", v, arg, arg2)
                 self._take("op", ")")
                 return ("call", v, arg)
             return ("id", v)
@@ -185,6 +192,9 @@ class Expression:
                 walk(n[1])
             elif n[0] == "call":
                 walk(n[2])
+            elif n[0] == "call2":
+                walk(n[2])
+                walk(n[3])
             elif n[0] != "num":
                 walk(n[1])
                 walk(n[2])
@@ -206,6 +216,8 @@ class Expression:
                 return ev(n[1])
             if t == "call":
                 return _FUNCTIONS[n[1]](ev(n[2]))
+            if t == "call2":
+                return _FUNCTIONS2[n[1]](ev(n[2]), ev(n[3]))
             a, b = ev(n[1]), ev(n[2])
             if t == "+":
                 return a + b
@@ -595,6 +607,147 @@ def describe_system(l2: Layer2, name: str, dimension: int, min_level: int, max_l
         solver_hints={k: v for k, v in hints.items() if k.startswith("solver_")})
 
 
+# ---- problems that enter at layer 3: complex Helmholtz-type problems with a hand-written Krylov solver ------------------
+def _function_body(src: str, name: str) -> Optional[str]:
+    """Text between the braces of `Function <name> ... {`, None if there is no such function."""
+    m = re.search(r"\bFunction\s+" + re.escape(name) + r"\b[^{]*\{", src)
+    if not m:
+        return None
+    depth, i = 1, m.end()
+    while i < len(src) and depth:
+        depth += {"{": 1, "}": -1}.get(src[i], 0)
+        i += 1
+    return src[m.end():i - 1]
+
+
+def _loop_limits(body: str, what: str) -> Tuple[int, float]:
+    """(`repeat N times count ...`, the factor in `fabs(curRes) < F * fabs(initRes)`) of a hand-written solver loop."""
+    r = re.search(r"\brepeat\s+(\d+)\s+times\s+count\b", body)
+    t = re.search(r"fabs\s*\(\s*curRes\s*\)\s*<\s*(" + _NUM + r")\s*\*\s*fabs\s*\(\s*initRes\s*\)", body)
+    if not r or not t:
+        raise UnsupportedProblem(f"{what}: `repeat N times count ...` with `fabs(curRes) < F * fabs(initRes)` expected")
+    return int(r.group(1)), float(t.group(1))
+
+
+def describe_layer3_helmholtz(l3_text: str, l4_text: str, name: str, dimension: int, min_level: int, max_level: int
+                              ) -> problems.ProblemDescription:
+    """Layer-3 entry of the reference's Helmholtz example (Helmholtz/2D_FD_Helmholtz_fromL3.exa3/.exa4) and problems of
+    the same shape: ONE complex node field; the outer operator and the operator the multigrid cycle acts on as star
+    stencils over `vf_gridWidth_*` and `Globals` (k, shift, ...); `Equation <eq> { <M> * <u> == <f> }`; the right-hand
+    side `Field RHS@finest ... = <expr>`; boundaries through `applyBC_<u>` functions on layer 4 that are the first-order
+    Robin condition left / right and homogeneous Dirichlet top / bottom (exa4:43-59); `Solve@finest` = the hand-written
+    preconditioned BiCGStab (exa3:144-200) and `gen_mgCycle@coarsest` = the hand-written BiCGStab (exa3:396-433) — their
+    texts ARE the algorithms the backend implements, so only their iteration caps and tolerances are read, and everything
+    else about them is checked for presence, not interpreted. Anything that does not fit raises UnsupportedProblem."""
+    if dimension != 2:
+        raise UnsupportedProblem("layer-3 Helmholtz-type problems are 2D")
+    text = re.sub(r"/\*.*?\*/", "", l3_text, flags=re.S)
+    src = "\n".join(_strip_comment(l) for l in text.splitlines())
+    l4 = "\n".join(_strip_comment(l) for l in re.sub(r"/\*.*?\*/", "", l4_text, flags=re.S).splitlines())
+
+    def stencil(op_name):
+        m = re.search(r"\bOperator\s+" + re.escape(op_name) + r"\s+from\s+Stencil\s*\{([^}]*)\}", src)
+        if not m:
+            raise UnsupportedProblem(f"operator {op_name!r} is not a `from Stencil` operator")
+        entries = {}
+        for line in m.group(1).splitlines():
+            line = line.strip()
+            if not line:
+                continue
+            e = re.match(r"\[([^\]]*)\]\s*=>\s*(.+)$", line)
+            if not e:
+                raise UnsupportedProblem(f"stencil entry not understood: {line!r}")
+            off = tuple(int(c) for c in e.group(1).split(","))
+            if _star_slot(off) is None or off in entries:
+                raise UnsupportedProblem(f"operator {op_name!r}: only 5-point star stencils are supported")
+            entries[off] = Expression(e.group(2))
+        return entries
+
+    eq = re.search(r"\bEquation\s+(\w+)\s*\{\s*(\w+)\s*\*\s*(\w+)\s*==\s*(\w+)\s*\}", src)
+    if not eq:
+        raise UnsupportedProblem("`Equation <name> { <Op> * <field> == <rhs> }` expected")
+    eq_name, mg_op, field_name, rhs_name = eq.groups()
+    fld = re.search(r"\bField\s+" + re.escape(field_name) + r"\s+with\s+Complex\s*<\s*Real\s*>\s+on\s+Node\b", src)
+    if not fld:
+        raise UnsupportedProblem(f"field {field_name!r}: `with Complex<Real> on Node` expected")
+    glob = re.search(r"\bGlobals\s*\{([^}]*)\}", src)
+    globals_ = {}
+    if glob:
+        for line in glob.group(1).splitlines():
+            g = re.match(r"\s*(?:Expr|Val|Var)\s+(\w+)\s*(?::\s*[\w<>]+\s*)?=\s*(.+)$", line)
+            if g:
+                globals_[g.group(1)] = Expression(g.group(2))
+    values = {}
+    for gname, expr in globals_.items():               # in file order: later globals may use earlier ones
+        values[gname] = expr.evaluate(dict(values, PI=np.pi))
+    if "k" not in values:
+        raise UnsupportedProblem("a Helmholtz-type problem needs the wavenumber `Expr k = ...` among its Globals")
+    # outer solver
+    solve = _function_body(src, "Solve@finest")
+    call = re.match(r"\s*(\w+)\s*@\s*finest\s*\(\s*\)\s*$", " ".join((solve or "").split()))
+    if not call:
+        raise UnsupportedProblem("`Function Solve@finest { <solver>@finest ( ) }` expected")
+    outer = _function_body(src, call.group(1) + "@finest")
+    if outer is None or "gen_mgCycle" not in outer and "VCycle" not in outer and "mgCycle" not in outer:
+        raise UnsupportedProblem(f"outer solver {call.group(1)!r}: a multigrid-preconditioned Krylov loop expected")
+    m_outer = re.search(r"=\s*RHS\s*-\s*(\w+)\s*\*\s*Solution", outer)
+    if not m_outer or "resHat" not in outer:
+        raise UnsupportedProblem("outer solver: `Residual = RHS - <A> * Solution` of the preconditioned BiCGStab expected")
+    outer_op = m_outer.group(1)
+    max_its, tol = _loop_limits(outer, "outer solver")
+    coarse = _function_body(src, "gen_mgCycle@coarsest")
+    if coarse is None or "resHat" not in coarse:
+        raise UnsupportedProblem("`Function gen_mgCycle@coarsest` = the hand-written BiCGStab expected")
+    cgs_its, cgs_tol = _loop_limits(coarse, "coarse-grid solver")
+    # boundary: the first-order Robin condition x_b = x_in / (1 - i k h) left / right, zero top / bottom
+    bc = _function_body(l4, f"applyBC_{field_name}@all")
+    robin = re.compile(r"\[\s*0\s*,\s*0\s*\]\s*=\s*\w+@\[\s*-?1\s*,\s*0\s*\]\s*/\s*\(\s*1\.0\s*-\s*\(\s*0\.0\s*\+\s*1\.0j\s*\)\s*\*\s*k\s*\*\s*vf_gridWidth_x\s*\)")
+    if bc is None or len(robin.findall(bc)) != 2 or len(re.findall(r"\[\s*0\s*,\s*0\s*\]\s*=\s*0\.0", bc)) != 2:
+        raise UnsupportedProblem(f"applyBC_{field_name}: first-order Robin left / right and zero top / bottom expected")
+    m_ops, a_ops = stencil(mg_op), stencil(outer_op)
+    rhs_m = re.search(r"\bField\s+RHS\s*@\s*finest\s+with\s+Complex\s*<\s*Real\s*>\s+on\s+Node\s+of\s+\w+\s*=\s*(.+)$", src, flags=re.M)
+    rhs_expr = Expression(rhs_m.group(1)) if rhs_m else Expression("0.0")
+    restr = re.search(r"\bOperator\s+(\w+)\s+from\s+default\s+restriction\b", src)
+    prol = re.search(r"\bOperator\s+(\w+)\s+from\s+default\s+prolongation\b", src)
+    constants = {g: v for g, v in values.items() if g != "k"}
+
+    def env(level, params):
+        h = 1.0 / (1 << level)
+        return dict(constants, k=params["k"], PI=np.pi, vf_gridWidth_x=h, vf_gridWidth_y=h)
+
+    def make_stencil(entries):
+        def st(level, params):
+            out = [0.0] * 7
+            e = env(level, params)
+            for off, expr in entries.items():
+                out[_star_slot(off)] = expr.evaluate(e)
+            return out
+        return st
+
+    def u0(level):
+        n = (1 << level) + 1
+        return np.zeros((n, n), dtype=np.complex128)
+
+    def rhs(level):
+        n = (1 << level) + 1
+        x = np.arange(n) / (n - 1)
+        h = 1.0 / (n - 1)
+        e = dict(constants, k=values["k"], PI=np.pi, vf_gridWidth_x=h, vf_gridWidth_y=h,
+                 vf_nodePos_x=x[None, :], vf_nodePos_y=x[:, None])
+        return (np.zeros((n, n)) + rhs_expr.evaluate(e)).astype(np.complex128)
+
+    return problems.ProblemDescription(name, 2, min_level, max_level,
+                                       scalar_kind=abi.COMPLEX_F64, bc_kind=abi.BC_HELMHOLTZ_ROBIN,
+                                       outer_kind=abi.OUTER_PBICGSTAB, cgs_kind=abi.CGS_BICGSTAB,
+                                       max_iterations=max_its, cgs_max_iterations=cgs_its,
+                                       target_res_reduction=tol, cgs_target_res_reduction=cgs_tol,
+                                       field_name=field_name, rhs_name=rhs_name, operator_name=mg_op, equation_name=eq_name,
+                                       restriction_name=restr.group(1) if restr else f"Restriction_{field_name}",
+                                       prolongation_name=prol.group(1) if prol else f"Prolongation_{field_name}",
+                                       mg_stencil=make_stencil(m_ops), outer_stencil=make_stencil(a_ops),
+                                       initial_solution=u0, right_hand_side=rhs, parameters={"k": float(np.real(values["k"]))})
+
+
 def load_problem(base_path: str, settings_path: str, knowledge_path: str,
                  min_level: Optional[int] = None, max_level: Optional[int] = None) -> problems.ProblemDescription:
     """The three constructor arguments of the reference's ProgramGenerator (exastencils.py:40-43) -> descriptor."""
@@ -606,8 +759,15 @@ def load_problem(base_path: str, settings_path: str, knowledge_path: str,
     prefix = os.path.join(base_path, settings.get("basePathPrefix", "."))
     l2_path = os.path.join(prefix, settings.get("l2file", name + ".exa2"))
     if not os.path.exists(l2_path):
-        raise UnsupportedProblem(f"no layer-2 file {l2_path}: problems that enter at layer 3/4 need a built-in "
-                                 f"descriptor (known: {sorted(problems.BY_NAME)})")
+        l3_path = os.path.join(prefix, settings.get("l3file", name + ".exa3"))
+        l4_path = os.path.join(prefix, settings.get("l4file", name + ".exa4"))
+        if os.path.exists(l3_path) and os.path.exists(l4_path):
+            with open(l3_path, "r") as f3, open(l4_path, "r") as f4:
+                return describe_layer3_helmholtz(f3.read(), f4.read(), name, int(knowledge["dimensionality"]),
+                                                 int(knowledge["minLevel"]) if min_level is None else min_level,
+                                                 int(knowledge["maxLevel"]) if max_level is None else max_level)
+        raise UnsupportedProblem(f"no layer-2 file {l2_path} and no layer-3 / layer-4 pair: nothing to read the problem from "
+                                 f"(built-in descriptors: {sorted(problems.BY_NAME)})")
     with open(l2_path, "r") as fh:
         l2 = parse_layer2(fh.read())
     hints = {}

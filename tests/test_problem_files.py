@@ -229,3 +229,68 @@ def test_reference_elasticity_files_reproduce_the_builtin_descriptor():
     L = b.max_level
     for x, y in zip(p.system.initial_solution(L) + p.system.right_hand_side(L), b.system.initial_solution(L) + b.system.right_hand_side(L)):
         assert np.array_equal(x, y)
+
+
+def test_layer3_helmholtz_type_problem_is_read_from_its_files():
+    """A Helmholtz-type problem enters at layer 3 (no .exa2): complex field, outer and preconditioner operators over
+    Globals, Robin / Dirichlet boundaries on layer 4, hand-written Krylov solvers whose caps and tolerances are read. The
+    fixture is this repository's own problem (tests/golden/problems/Waveguide) with numbers that differ from the
+    reference's example everywhere."""
+    p = _load("Waveguide", "2D_FD_Waveguide_fromL3")
+    assert (p.name, p.dimension, p.min_level, p.max_level) == ("2D_FD_Waveguide_fromL3", 2, 3, 6)
+    assert (p.field_name, p.rhs_name, p.operator_name, p.equation_name) == ("w", "g", "Damped", "DampedEq")
+    assert (p.restriction_name, p.prolongation_name) == ("Restrict_w", "Prolong_w")
+    assert p.scalar_kind == abi.COMPLEX_F64 and p.bc_kind == abi.BC_HELMHOLTZ_ROBIN
+    assert p.outer_kind == abi.OUTER_PBICGSTAB and p.cgs_kind == abi.CGS_BICGSTAB
+    assert (p.max_iterations, p.target_res_reduction, p.cgs_max_iterations, p.cgs_target_res_reduction) == (400, 1e-8, 300, 1e-5)
+    assert p.parameters == {"k": 24.0}
+    for level in (3, 6):
+        h = 1.0 / (1 << level)
+        o = -1.0 / (h ** 2)
+        assert p.mg_stencil(level, {"k": 24.0}) == [2.0 / (h ** 2) + 2.0 / (h ** 2) - 24.0 ** 2 * (1.0 + 0.7j), o, o, o, o, 0.0, 0.0]
+        assert p.outer_stencil(level, {"k": 48.0}) == [2.0 / (h ** 2) + 2.0 / (h ** 2) - 48.0 ** 2, o, o, o, o, 0.0, 0.0]
+    f = p.right_hand_side(5)
+    x = np.arange(33) / 32.0
+    want = np.exp(-60.0 * ((x[None, :] - 0.25) ** 2 + (x[:, None] - 0.5) ** 2))
+    assert f.dtype == np.complex128 and np.array_equal(f, want.astype(np.complex128))
+    assert not p.initial_solution(4).any()
+
+
+def test_layer3_problem_solves_through_the_oracle():
+    """files -> ProgramGenerator -> op program -> oracle: the preconditioned BiCGStab converges to the file's tolerance and
+    the returned field satisfies the file's equation and Robin condition."""
+    gen = ProgramGenerator(None, FIXTURES, "Waveguide/2D_FD_Waveguide_fromL3.settings", "Waveguide/2D_FD_Waveguide_fromL3.knowledge",
+                           library=object())
+    p = gen.problem
+    assert p.parameters == {"k": 24.0} and p.max_iterations == 400
+    from test_helmholtz_oracle import reference_vcycle_ops
+    ops = reference_vcycle_ops(p.min_level, p.max_level)
+    h = oracle.create(p)
+    out = h.evaluate(ops, 1, 0, 512)
+    assert out.status == abi.SOLVE_CONVERGED and out.final_res_norm < 1e-8 * out.init_res_norm
+    u = h.get_field(p.max_level, abi.F_CORR)
+    n = (1 << p.max_level) + 1
+    hh = 1.0 / (n - 1)
+    f = p.right_hand_side(p.max_level)
+    a = (4.0 / hh ** 2 - 24.0 ** 2) * u[1:-1, 1:-1] - (u[1:-1, :-2] + u[1:-1, 2:] + u[:-2, 1:-1] + u[2:, 1:-1]) / hh ** 2
+    assert np.abs(a - f[1:-1, 1:-1]).max() <= 1e-6 * np.abs(f).max()
+    assert np.abs(u[1:-1, 0] - u[1:-1, 1] / (1.0 - 1j * 24.0 * hh)).max() <= 1e-12 * np.abs(u).max()
+    h.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not present")
+def test_reference_helmholtz_files_reproduce_the_builtin_descriptor():
+    """The reference's Helmholtz directory (layer-3 entry) parses to exactly problems.helmholtz_2d."""
+    p = pf.load_problem(REFERENCE, "Helmholtz/2D_FD_Helmholtz_fromL3.settings", "Helmholtz/2D_FD_Helmholtz_fromL3.knowledge")
+    b = problems.helmholtz_2d(3, 7)
+    for attr in ("name", "dimension", "min_level", "max_level", "scalar_kind", "bc_kind", "outer_kind", "cgs_kind", "max_iterations",
+                 "cgs_max_iterations", "target_res_reduction", "cgs_target_res_reduction", "field_name", "rhs_name", "operator_name",
+                 "equation_name", "restriction_name", "prolongation_name", "parameters"):
+        assert getattr(p, attr) == getattr(b, attr), attr
+    for level in (3, 5, 7, 11):
+        for k in (80.0, 160.0, 1280.0):
+            assert p.mg_stencil(level, {"k": k}) == b.mg_stencil(level, {"k": k})
+            assert p.outer_stencil(level, {"k": k}) == b.outer_stencil(level, {"k": k})
+    for level in (3, 7):
+        assert np.array_equal(p.right_hand_side(level), b.right_hand_side(level))
+        assert np.array_equal(p.initial_solution(level), b.initial_solution(level))

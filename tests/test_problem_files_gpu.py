@@ -57,3 +57,25 @@ def test_file_defined_problem_matches_oracle(case):
     assert np.max(np.abs(ug - uo)) <= 1e-10 * np.max(np.abs(uo))
     ho.close()
     gen.close()
+
+
+def test_layer3_helmholtz_type_problem_from_files_matches_oracle():
+    """The repository's own wave-guide problem (layer-3 / layer-4 entry, tests/golden/problems/Waveguide) through the
+    reference-style constructor on the GPU: same outer iteration count as the oracle, history and solution within 1e-10."""
+    from oracle import oracle
+    from test_helmholtz_oracle import reference_vcycle_ops
+    stem = "Waveguide/2D_FD_Waveguide_fromL3"
+    gen = ProgramGenerator("unused.jar", FIXTURES, stem + ".settings", stem + ".knowledge", "unused.platform")
+    pd = gen.problem
+    assert pd.parameters == {"k": 24.0} and (pd.min_level, pd.max_level) == (3, 6)
+    ops = reference_vcycle_ops(pd.min_level, pd.max_level)
+    handle = gen._ensure_handle(pd.min_level, pd.max_level, None)
+    got = handle.evaluate(ops, 1, 0, 512)
+    ho = oracle.create(pd)
+    want = ho.evaluate(ops, 1, 0, 512)
+    assert got.status == want.status == abi.SOLVE_CONVERGED and got.n_iterations == want.n_iterations
+    assert (np.abs(got.history - want.history) / want.history).max() <= REL_TOL
+    a, b = handle.get_field(pd.max_level, abi.F_CORR), ho.get_field(pd.max_level, abi.F_CORR)
+    assert np.abs(a - b).max() <= REL_TOL * np.abs(b).max()
+    ho.close()
+    gen.close()
