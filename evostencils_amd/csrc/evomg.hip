@@ -1696,7 +1696,16 @@ template <typename T> class Impl : public ImplBase {
       }
       return EVOMG_OK;
     }
-    return EVOMG_OK;   // 3D: evomg_cg_multi_wg3d (33^3) or the global-memory kernel with column ownership
+    // 3D: up to 9^3 the whole solve in one wave (column ownership: nothing changes for the oracle); else
+    // evomg_cg_multi_wg3d (33^3) or the global-memory kernel with column ownership
+    if constexpr (!scalar_traits<T>::is_complex) {
+      if (own.column && own.m <= EVOMG_CG_WAVE3D_MAX_M && own.m * own.m <= 64) {
+        hipLaunchKernelGGL((evomg_cg_wave3d<T>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
+                           prob_.cgs_target_res_reduction, dinfo_);
+        *launched = true;
+      }
+    }
+    return EVOMG_OK;
   }
 
   // ---- reductions ----------------------------------------------------------------------------------------------------

@@ -619,6 +619,100 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
   if (l == 0) info[0] = it;
 }
 
+// ---- CG on 3D grids up to 9^3 in ONE wave ---------------------------------------------------------------------------
+// The reference's 3D example ends on 5^3 (knowledge: levels 2..6): 27 unknowns, for which the 1024-thread kernel above
+// spends 30 us per solve on barriers and L2 round trips. Here lane t < m^2 owns the z-column (t % m, t / m) — the canonical
+// "column" ownership, so nothing changes for the oracle: with m^2 <= 64 all partial sums live in wave 0 and the 16-wave
+// tree of the big kernel only adds exact zeros — and keeps r, x, p, A p of its (up to 8) nodes in registers; in-plane
+// neighbours come from an LDS image of p with a zero halo (one wave: the barrier is a formality), z neighbours are the
+// lane's own registers; reductions are the wave tree alone.
+#define EVOMG_CG_WAVE3D_MAX_M 8
+template <typename T>
+__global__ void __launch_bounds__(64)
+evomg_cg_wave3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit, double tol,
+                int* __restrict__ info) {
+  constexpr int S = EVOMG_CG_WAVE3D_MAX_M;
+  __shared__ T img[S * (S + 2) * (S + 2)];
+  const int m = g.n - 2, W = m + 2, PS = W * W;
+  const int t = threadIdx.x;
+  const bool col = t < m * m;
+  const int ix = col ? t % m : 0, iy = col ? t / m : 0;
+  const int o0 = col ? (iy + 1) * W + ix + 1 : 0;          // column-less lanes sit on the halo corner (always zero)
+  const long c0 = gidx<3>(g, ix + 1, iy + 1, 1);
+  const T zero = scalar_traits<T>::zero();
+  for (int i = t; i < S * PS; i += 64) img[i] = zero;
+  __syncthreads();
+  T r[S], xr[S], pr[S], ap[S];
+  T loc = zero;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const bool ok = col && i < m;
+    const long c = c0 + g.plane * (i < m ? i : 0);
+    const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 3>(st, x, g, c)) : zero;
+    r[i] = v;
+    pr[i] = v;
+    xr[i] = x[c];
+    loc = sc_fma(v, v, loc);
+  }
+  T rr = first_lane(wave_sum_fast(loc));
+  const double res0 = sc_norm_from_dot(rr);
+  int it = 0;
+  if (res0 != 0.0) {
+    for (; it < maxit; ++it) {
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+        if (col && i < m) img[i * PS + o0] = pr[i];
+      __syncthreads();
+      loc = zero;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const bool ok = col && i < m;
+        const T* q = img + (i < m ? i : 0) * PS + o0;
+        const T pc = pr[i];
+        const T pd = (i == 0) ? zero : pr[i > 0 ? i - 1 : 0];
+        const T pu = (i + 1 < m && i + 1 < S) ? pr[i + 1 < S ? i + 1 : i] : zero;
+        T a = sc_mul(st.c[0], pc);
+        a = sc_fma(st.c[1], q[-1], a);
+        a = sc_fma(st.c[2], q[1], a);
+        a = sc_fma(st.c[3], q[-W], a);
+        a = sc_fma(st.c[4], q[W], a);
+        a = sc_fma(st.c[5], pd, a);
+        a = sc_fma(st.c[6], pu, a);
+        a = ok ? a : zero;
+        ap[i] = a;
+        loc = sc_fma(pc, a, loc);
+      }
+      const T pap = first_lane(wave_sum_fast(loc));
+      const T alpha = sc_div(rr, pap);
+      const T nalpha = sc_neg(alpha);
+      loc = zero;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        xr[i] = sc_fma(alpha, pr[i], xr[i]);
+        const T rv = sc_fma(nalpha, ap[i], r[i]);
+        r[i] = rv;
+        loc = sc_fma(rv, rv, loc);
+      }
+      const T rrn = first_lane(wave_sum_fast(loc));
+      const double res = sc_norm_from_dot(rrn);
+      if (!(res > tol * res0)) { ++it; break; }
+      const T beta = sc_div(rrn, rr);
+#pragma unroll
+      for (int i = 0; i < S; ++i) pr[i] = sc_fma(beta, pr[i], r[i]);
+      rr = rrn;
+      __syncthreads();                       // all reads of the image done before the next iteration overwrites it
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+    if (col && i < m) {
+      const long c = c0 + g.plane * i;
+      x[c] = xr[i];
+      r_out[c] = r[i];
+    }
+  if (t == 0) info[0] = it;
+}
+
 // ---- CG on 33^3 across EVOMG_CG_GROUPS compute units (3D column ownership, m >= 16) ------------------------------------
 // One CU moves 64 B/clk: with 29 791 unknowns and 17 vector accesses per unknown and iteration the single-workgroup
 // kernel above needs ~60 us per iteration, and the 3D configuration spends half its time there. Here the grid is cut
