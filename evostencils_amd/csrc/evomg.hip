@@ -1583,7 +1583,14 @@ template <typename T> class Impl : public ImplBase {
     const bool real_cg = prob_.cgs_kind != EVOMG_CGS_BICGSTAB && !scalar_traits<T>::is_complex;   // ownership of the real-valued CG
     const int lanes = (dim_ == 2 ? krylov_own<2>(lv.g.n, real_cg) : krylov_own<3>(lv.g.n, real_cg)).lanes;
     const dim3 one(1), thr(lanes);
-    if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
+    if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB && dim_ == 2 && lv.g.n <= 9 && use_reg_krylov_) {
+      // up to 9^2: the whole solve in one wave, one node per lane (evomg_bicgstab_wave2d; canonical order unchanged)
+      const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
+      if (robin) hipLaunchKernelGGL((evomg_bicgstab_wave2d<T, true>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
+                                    prob_.cgs_target_res_reduction, kh(L), dinfo_);
+      else hipLaunchKernelGGL((evomg_bicgstab_wave2d<T, false>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
+                              prob_.cgs_target_res_reduction, 0.0, dinfo_);
+    } else if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
       const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
       if constexpr (scalar_traits<T>::is_complex) {
         if (dim_ != 2) return invalid("complex problems are 2D only");

@@ -338,6 +338,92 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
   if (threadIdx.x == 0) info[0] = it;
 }
 
+// ---- BiCGStab on 2D grids up to 9^2 in ONE wave ------------------------------------------------------------------------
+// The reference's Helmholtz example ends on 9^2 (knowledge: levels 3..7): 49 unknowns, two solves per outer iteration; the
+// 512-thread kernel above spends 42 us per solve on barriers and L2 round trips. Canonical ownership there (tile, m <= 8):
+// thread (wave w, lane l) owns node (column l, row w), ONE node; sums = tree over a wave's columns, then tree over the
+// wave sums. Here the same nodes sit in one wave as lane = 8 * column + row: the wave tree's offsets 32, 16, 8 then add
+// columns 4, 2, 1 apart and its offsets 4, 2, 1 rows 4, 2, 1 apart — exactly that order (the zeros the big kernel adds
+// are exact), so nothing changes for the oracle. All eight vectors are one register value per lane; west / east are
+// the lanes 8 away (the Robin columns are the own value over (1 - i k h)), south / north the adjacent lanes (row 7 of a
+// column never holds a node: its zero is the Dirichlet row).
+template <typename T> __device__ __forceinline__ T lane_value(T v, int src);
+template <> __device__ __forceinline__ double lane_value<double>(double v, int src) { return __shfl(v, src, 64); }
+template <> __device__ __forceinline__ cplx lane_value<cplx>(cplx v, int src) { return cplx{__shfl(v.re, src, 64), __shfl(v.im, src, 64)}; }
+
+template <typename T, bool ROBIN>
+__global__ void __launch_bounds__(64)
+evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r_out, int maxit, double tol,
+                      double kh, int* __restrict__ info) {
+  const int m = g.n - 2;                         // host-checked: 1 <= m <= 7
+  const int l = threadIdx.x, col = l >> 3, row = l & 7;
+  const bool own = col < m && row < m;
+  const long c = gidx<2>(g, min(col, m - 1) + 1, min(row, m - 1) + 1, 0);
+  const T zero = scalar_traits<T>::zero();
+  const cplx den{1.0, -kh};
+  // value of a neighbouring column's node (same row); beyond the first / last inner column: the boundary value
+  auto robin = [&](T own_value) -> T {
+    if constexpr (ROBIN && scalar_traits<T>::is_complex) return sc_div(own_value, den);
+    else return zero;
+  };
+  auto apply = [&](T pc) -> T {                  // (A p) at the lane's node, operation order of apply_stencil_fma
+    const T from_w = lane_value<T>(pc, (l + 56) & 63), from_e = lane_value<T>(pc, (l + 8) & 63);
+    const T from_s = lane_value<T>(pc, (l + 63) & 63), from_n = lane_value<T>(pc, (l + 1) & 63);
+    const T pw = col == 0 ? robin(pc) : from_w;
+    const T pe = col == m - 1 ? robin(pc) : from_e;
+    const T ps = row == 0 ? zero : from_s;
+    const T pn = row == m - 1 ? zero : from_n;
+    T a = sc_mul(st.c[0], pc);
+    a = sc_fma(st.c[1], pw, a);
+    a = sc_fma(st.c[2], pe, a);
+    a = sc_fma(st.c[3], ps, a);
+    a = sc_fma(st.c[4], pn, a);
+    return own ? a : zero;
+  };
+  auto dot = [&](T a, T b) -> T { return first_lane(wave_sum_fast(sc_fma(a, b, zero))); };
+  T xv = x[c];
+  T r = own ? sc_sub(f[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
+  if (!own) xv = zero;
+  const T rhat = r;
+  T nu = zero, p = zero, hh = zero, s = zero, tt = zero;
+  const double res0 = sc_norm_from_dot(dot(r, r));
+  int it = 0;
+  if (res0 != 0.0) {
+    T alpha = scalar_traits<T>::from_real(1.0), beta, rho, rho_new = scalar_traits<T>::from_real(1.0),
+      omega = scalar_traits<T>::from_real(1.0);
+    for (; it < maxit; ++it) {
+      rho = rho_new;
+      rho_new = dot(rhat, r);
+      beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
+      const T pv = sc_fma(sc_neg(omega), nu, p);
+      p = own ? sc_fma(beta, pv, r) : zero;
+      nu = apply(p);
+      alpha = sc_div(rho_new, dot(rhat, nu));
+      hh = sc_fma(alpha, p, xv);
+      s = own ? sc_fma(sc_neg(alpha), nu, r) : zero;
+      tt = apply(s);
+      const T ts = dot(tt, s);
+      const T t2 = dot(tt, tt);
+      omega = sc_div(ts, t2);
+      xv = sc_fma(omega, s, hh);
+      r = own ? sc_fma(sc_neg(omega), tt, s) : zero;
+      const double res = sc_norm_from_dot(dot(r, r));
+      if (res < tol * res0) { ++it; break; }
+      if (!(res == res)) { ++it; break; }
+    }
+  }
+  if (own) {
+    x[c] = xv;
+    r_out[c] = r;
+    if constexpr (ROBIN && scalar_traits<T>::is_complex) {
+      // the boundary columns of r and — once an iteration has run — of x, as wg_apply_bc leaves them
+      if (col == 0) { r_out[c - 1] = sc_div(r, den); if (it > 0) x[c - 1] = sc_div(xv, den); }
+      if (col == m - 1) { r_out[c + 1] = sc_div(r, den); if (it > 0) x[c + 1] = sc_div(xv, den); }
+    }
+  }
+  if (l == 0) info[0] = it;
+}
+
 // ---- CG held in registers (2D tile ownership) ------------------------------------------------------------------------
 // For coarsest grids up to 129^2 (real) one 512-thread workgroup (8 waves = 8 bands of rows) runs the whole solve out
 // of registers:

@@ -645,3 +645,41 @@ def test_diverging_candidate_3d_tiles(native, oracle, smoother, monkeypatch):
     rel = np.abs(og.history[finite] - oo.history[finite]) / oo.history[finite]
     assert rel.max() <= REL_TOL
     hg.close()
+
+
+@pytest.mark.parametrize("kind,lo", [("helmholtz", 3), ("helmholtz", 2), ("helmholtz", 1), ("poisson", 3), ("poisson", 2)])
+def test_one_wave_bicgstab_is_bit_identical(native, oracle, kind, lo, monkeypatch):
+    """BiCGStab on 2D grids up to 9^2 in one wave (evomg_bicgstab_wave2d, lane = 8 * column + row: the wave tree then IS the
+    canonical column-tree / row-tree order) against the 512-thread global-memory kernel (EVOMG_NO_REG_KRYLOV) and the
+    oracle: solution and residual fields incl. the Robin columns, bit for bit. Complex with the Helmholtz Robin condition
+    and a real problem with BiCGStab as its coarse solver."""
+    import dataclasses
+    if kind == "helmholtz":
+        pd = problems.helmholtz_2d(lo, lo + 1, k=0.625 * (1 << (lo + 1)))
+    else:
+        pd = dataclasses.replace(problems.poisson_2d(lo, lo + 1), cgs_kind=abi.CGS_BICGSTAB, cgs_target_res_reduction=1e-9)
+    n = (1 << lo) + 1
+    rng = np.random.default_rng(17 + lo)
+    cplx = kind == "helmholtz"
+    rhs = random_field(rng, (n, n), cplx)
+    x0 = zero_boundary(random_field(rng, (n, n), cplx)) * 1e-2
+    ops = [abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+    ho = oracle.create(pd)
+    ho.set_field(lo, abi.F_CGS_RHS, rhs)
+    ho.set_field(lo, abi.F_CORR, x0)
+    ho.run_ops(ops)
+    want = ho.get_field(lo, abi.F_CORR), ho.get_field(lo, abi.F_RES)
+    for knob in (None, "EVOMG_NO_REG_KRYLOV"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        h = native.create(pd)
+        h.set_field(lo, abi.F_CGS_RHS, rhs)
+        h.set_field(lo, abi.F_CORR, x0)
+        h.run_ops(ops)
+        got = h.get_field(lo, abi.F_CORR), h.get_field(lo, abi.F_RES)
+        h.close()
+        if knob:
+            monkeypatch.delenv(knob)
+        assert np.array_equal(got[0], want[0]), (kind, lo, knob)
+        assert np.array_equal(got[1][1:-1, :], want[1][1:-1, :]), (kind, lo, knob)
+    assert not np.array_equal(want[0], x0)
