@@ -2188,7 +2188,7 @@ class SystemImpl : public ImplBase {
     HIP_TRY(hipSetDevice(device_));
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
-    for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+    if ((rc = exec_all(ops, n_ops)) != EVOMG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream_));
     return EVOMG_OK;
   }
@@ -2233,7 +2233,7 @@ class SystemImpl : public ImplBase {
       if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
       else
         for (it = 1; it <= prob_.max_iterations; ++it) {
-          for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+          if ((rc = exec_all(ops, n_ops)) != EVOMG_OK) return rc;
           if ((rc = residual_norm(&res)) != EVOMG_OK) return rc;
           if (hist && nh < cap) hist[nh] = res;
           ++nh;
@@ -2436,6 +2436,65 @@ class SystemImpl : public ImplBase {
     HIP_TRY(hipGetLastError());
     return EVOMG_OK;
   }
+  // ops[i], ops[i + 1]: the same statement for unknown 0 and unknown 1 (what a cycle emits back to back), independent of
+  // each other -> one launch with blockIdx.z = unknown (evomg_system.h)
+  bool same_statement_for_both_unknowns(const evomg_op_t& a, const evomg_op_t& b) const {
+    if (!sys_pair_fuse_ || nf_ != 2 || a.opcode != b.opcode || a.level != b.level) return false;
+    if (a.dst / EVOMG_F_COUNT != 0 || b.dst != a.dst + EVOMG_F_COUNT) return false;
+    switch (a.opcode) {
+      case EVOMG_OP_RESIDUAL:        // row i reads every unknown's solution slot (src0 names unknown 0's) and its own rhs
+        return b.src0 == a.src0 && a.src1 / EVOMG_F_COUNT == 0 && b.src1 == a.src1 + EVOMG_F_COUNT &&
+               canon(a.level, a.dst) % EVOMG_F_COUNT != canon(a.level, a.src0) % EVOMG_F_COUNT &&
+               canon(a.level, a.dst) % EVOMG_F_COUNT != canon(a.level, a.src1) % EVOMG_F_COUNT;
+      case EVOMG_OP_RESTRICT: return a.src0 / EVOMG_F_COUNT == 0 && b.src0 == a.src0 + EVOMG_F_COUNT;
+      case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET:
+        return a.src0 / EVOMG_F_COUNT == 0 && b.src0 == a.src0 + EVOMG_F_COUNT && a.omega == b.omega;
+      case EVOMG_OP_SET_ZERO: return true;
+      default: return false;
+    }
+  }
+  int exec_pair(const evomg_op_t& op) {
+    const int L = op.level;
+    const Geo& g = lv_[L].g;
+    const dim3 grid2((g.n + 63) / 64, (g.n + 3) / 4, 2);
+    SysFields d{};
+    for (int u = 0; u < 2; ++u) d.p[u] = fieldptr(L, op.dst + EVOMG_F_COUNT * u);
+    switch (op.opcode) {
+      case EVOMG_OP_RESIDUAL: {
+        const SysConstFields x = slot_fields(L, canon(L, op.src0) % EVOMG_F_COUNT);
+        const SysConstFields f = slot_fields(L, op.src1 % EVOMG_F_COUNT);
+        hipLaunchKernelGGL(evomg_sys_residual2, grid2, blk(), 0, stream_, g, lv_[L].st, nf_, x, f, d);
+        break;
+      }
+      case EVOMG_OP_RESTRICT: {
+        SysConstFields s{};
+        for (int u = 0; u < 2; ++u) s.p[u] = fieldptr(L + 1, op.src0 + EVOMG_F_COUNT * u);
+        hipLaunchKernelGGL(evomg_sys_restrict2, grid2, blk(), 0, stream_, g, lv_[L + 1].g, s, d);
+        break;
+      }
+      case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: {
+        SysConstFields s{};
+        for (int u = 0; u < 2; ++u) s.p[u] = fieldptr(L - 1, op.src0 + EVOMG_F_COUNT * u);
+        if (op.opcode == EVOMG_OP_PROLONG_ADD) hipLaunchKernelGGL(evomg_sys_prolong2<true>, grid2, blk(), 0, stream_, g, lv_[L - 1].g, s, d, op.omega);
+        else hipLaunchKernelGGL(evomg_sys_prolong2<false>, grid2, blk(), 0, stream_, g, lv_[L - 1].g, s, d, 1.0);
+        break;
+      }
+      case EVOMG_OP_SET_ZERO: hipLaunchKernelGGL(evomg_sys_zero2, grid2, blk(), 0, stream_, g, d); break;
+      default: return invalid("exec_pair: unsupported opcode");
+    }
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }
+  int exec_all(const evomg_op_t* ops, int n_ops) {
+    for (int i = 0; i < n_ops; ++i) {
+      int rc;
+      if (i + 1 < n_ops && same_statement_for_both_unknowns(ops[i], ops[i + 1])) {
+        if ((rc = exec_pair(ops[i])) != EVOMG_OK) return rc;
+        ++i;
+      } else if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
+    }
+    return EVOMG_OK;
+  }
   int dot_to_host(int L, const double* a, double* out) {
     const Geo& g = lv_[L].g;
     const int m = g.n - 2;
@@ -2470,6 +2529,7 @@ class SystemImpl : public ImplBase {
   int device_;
   int nf_;
   bool sys_cg_small_ = getenv("EVOMG_NO_SYS_CG_SMALL") == nullptr;       // register / LDS form of the stacked CG (<= 512 unknowns)
+  bool sys_pair_fuse_ = getenv("EVOMG_NO_SYS_PAIR_FUSE") == nullptr;     // one launch for a statement emitted once per unknown
   bool sys_point_fast_ = getenv("EVOMG_NO_SYS_POINT_FAST") == nullptr;   // straight-line kernel for point blocks (evomg_system.h)
   SLevel lv_[EVOMG_MAX_LEVELS];
   hipStream_t stream_ = nullptr;

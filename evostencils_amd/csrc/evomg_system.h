@@ -298,3 +298,42 @@ __global__ void __launch_bounds__(512) evomg_sys_cg_small(Geo g, SysStencil st, 
   }
   if (t == 0) info[0] = it;
 }
+
+// ---- the same statement for both unknowns in ONE launch (blockIdx.z = unknown) ---------------------------------------------
+// A cycle on a system emits its residual / restriction / prolongation / zero statements once per unknown, back to back and
+// independent of each other; on the small levels these problems live on every launch is ~3.5 us of dispatch for well under
+// a microsecond of work. Bodies = the per-unknown kernels' (evomg_sys_residual, evomg_restrict<double, 2>,
+// evomg_prolong<double, 2, ACC>, evomg_zero_inner<double, 2>): bit-identical.
+__global__ void __launch_bounds__(256) evomg_sys_residual2(Geo g, SysStencil st, int nf, SysConstFields x, SysConstFields f, SysFields r) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y, i = blockIdx.z;
+  if (a < 1 || b < 1 || a > g.n - 2 || b > g.n - 2) return;
+  const long c = (long)g.pitch * b + a;
+  r.p[i][c] = f.p[i][c] - sys_apply_row(g, st, nf, i, x, a, b);
+}
+__global__ void __launch_bounds__(256) evomg_sys_restrict2(Geo gc, Geo gf, SysConstFields fine_u, SysFields coarse_u) {
+  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y * blockDim.y + threadIdx.y;
+  if (I < 1 || J < 1 || I > gc.n - 2 || J > gc.n - 2) return;
+  const double* __restrict__ fine = fine_u.p[blockIdx.z];
+  const long c = gidx<2>(gf, 2 * I, 2 * J, 0);
+  const long p = gf.pitch;
+  const double e = sc_add(sc_add(fine[c - 1], fine[c + 1]), sc_add(fine[c - p], fine[c + p]));
+  const double q = sc_add(sc_add(fine[c - p - 1], fine[c - p + 1]), sc_add(fine[c + p - 1], fine[c + p + 1]));
+  double v = sc_rmul(0.25, fine[c]);
+  v = sc_add(v, sc_rmul(0.125, e));
+  v = sc_add(v, sc_rmul(0.0625, q));
+  coarse_u.p[blockIdx.z][gidx<2>(gc, I, J, 0)] = v;
+}
+template <bool ACC>
+__global__ void __launch_bounds__(256) evomg_sys_prolong2(Geo gf, Geo gc, SysConstFields coarse_u, SysFields fine_u, double om) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < 1 || j < 1 || i > gf.n - 2 || j > gf.n - 2) return;
+  const long c = gidx<2>(gf, i, j, 0);
+  double* __restrict__ fine = fine_u.p[blockIdx.z];
+  const double v = interpolate<double, 2>(gc, coarse_u.p[blockIdx.z], i, j, 0);
+  fine[c] = ACC ? sc_add(fine[c], sc_rmul(om, v)) : v;
+}
+__global__ void __launch_bounds__(256) evomg_sys_zero2(Geo g, SysFields x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < 1 || j < 1 || i > g.n - 2 || j > g.n - 2) return;
+  x.p[blockIdx.z][gidx<2>(g, i, j, 0)] = 0.0;
+}

@@ -139,7 +139,8 @@ def test_manufactured_solution_on_the_gpu(native):
 def test_fast_system_kernels_do_not_change_a_bit(native, monkeypatch):
     """The straight-line point-block smoother (evomg_sys_point_smooth: collective / decoupled, Jacobi / red-black, no copy
     of x) and the register / LDS form of the stacked coarse CG (evomg_sys_cg_small) against the generic kernels they
-    replace (EVOMG_NO_SYS_POINT_FAST, EVOMG_NO_SYS_CG_SMALL): whole solves with identical histories and solutions."""
+    replace (EVOMG_NO_SYS_POINT_FAST, EVOMG_NO_SYS_CG_SMALL), and one launch for a statement the cycle emits once per
+    unknown (EVOMG_NO_SYS_PAIR_FUSE): whole solves with identical histories and solutions."""
     gen, ops = None, None
     from helpers import ops_for_case
     gen, ops = ops_for_case("elasticity2d_L6_mixed")
@@ -147,7 +148,7 @@ def test_fast_system_kernels_do_not_change_a_bit(native, monkeypatch):
     pd = problems.linear_elasticity_2d(lo, hi)
     results = []
     for plain in (False, True):
-        for k in ("EVOMG_NO_SYS_POINT_FAST", "EVOMG_NO_SYS_CG_SMALL"):
+        for k in ("EVOMG_NO_SYS_POINT_FAST", "EVOMG_NO_SYS_CG_SMALL", "EVOMG_NO_SYS_PAIR_FUSE"):
             if plain:
                 monkeypatch.setenv(k, "1")
             else:
