@@ -39,13 +39,18 @@ def install_deap_stub():
         def __init__(self, name, in_types, ret_type, prefix="ARG"):
             self.name, self.ins, self.ret = name, in_types, ret_type
             self.context = {}
+            # typed registrations (for tests/test_reference_grammar_fuzz.py): return type -> what produces it
+            self.typed_primitives = {}       # ret_type -> [(name, callable, [argument types])]
+            self.typed_terminals = {}        # ret_type -> [(name or None, object)]
 
         def addPrimitive(self, primitive, in_types, ret_type, name=None):
             self.context[name or primitive.__name__] = primitive
+            self.typed_primitives.setdefault(ret_type, []).append((name or primitive.__name__, primitive, list(in_types)))
 
         def addTerminal(self, terminal, ret_type, name=None):
             if name is not None:
                 self.context[name] = terminal
+            self.typed_terminals.setdefault(ret_type, []).append((name, terminal))
 
     class Primitive:
         pass
@@ -55,8 +60,8 @@ def install_deap_stub():
     sys.modules["deap"], sys.modules["deap.gp"] = deap, gp
 
 
-def reference_context(problem, min_level, max_level):
-    """(context dict of the reference's productions, ProgramGenerator instance, storages)."""
+def reference_context(problem, min_level, max_level, return_pset=False):
+    """(context dict of the reference's productions — or the primitive set itself —, ProgramGenerator instance, storages)."""
     import sympy
     from evostencils.ir import base, system
     from evostencils.stencils import constant
@@ -123,10 +128,10 @@ def reference_context(problem, min_level, max_level):
     pset, _ = mg.generate_primitive_set(approximation, rhs, d, g._coarsening_factor, max_level, equations,
                                         operators, fields, maximum_local_system_size=8,
                                         depth=max_level - min_level)
-    return pset.context, g, storages
+    return (pset if return_pset else pset.context), g, storages
 
 
-def fas_reference_context(depth):
+def fas_reference_context(depth, return_pset=False):
     """(context of the reference's FAS productions, the reference's ProgramGeneratorFAS) for this repository's own FAS
     problem files (tests/golden/problems/FAS_2D_Exponential). The reference class is constructed normally: its constructor
     only reads the .knowledge file and the template (no JVM, exastencils_FAS.py:12-96)."""
@@ -141,7 +146,7 @@ def fas_reference_context(depth):
     rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, gr) for eq, gr in zip(top, g.finest_grid)])
     pset, _ = mg.generate_primitive_set(approximation, rhs, g.dimension, g.coarsening_factor, g.max_level, g.equations,
                                         g.operators, g.fields, maximum_local_system_size=8, depth=depth, FAS=True)
-    return pset.context, g
+    return (pset if return_pset else pset.context), g
 
 
 def extract_tutorial_cycle():

@@ -1,0 +1,140 @@
+"""Randomised differential test of the lowering against the REFERENCE ITSELF (build container only; skipped where the
+read-only reference checkout is absent): individuals are grown at random over the reference's own typed primitive set
+(grammar/multigrid.py: generate_primitive_set — every production, partitioning, relaxation-factor index and block-shape
+terminal it registers), built with the reference's productions into the reference's IR, and lowered twice — by the
+reference's ProgramGenerator.generate_cycle_function and by ours on the very same IR objects. The two ExaSlang texts
+must be identical, and our op-program encoder must accept what the reference can lower (no candidate the grammar can
+produce may come back as `(infinity,)*3` for lack of support). DEAP itself is absent here: a stub records the typed
+registrations (tests/golden/generate_golden.py), and the tree is grown by a small typed generator of this file."""
+import os
+import random
+import sys
+
+import pytest
+
+from helpers import generator_for
+
+REFERENCE = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "evostencils")),
+                                reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def golden_module():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import generate_golden as gg
+    gg.install_deap_stub()
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    yield gg
+    for name in [m for m in sys.modules if m == "deap" or m.startswith("deap.") or m == "evostencils" or m.startswith("evostencils.")]:
+        del sys.modules[name]
+    sys.path.remove(REFERENCE)
+
+
+class Grower:
+    """Typed random growth over the stub's registrations, evaluating as it goes (arguments left to right, innermost
+    first: the order in which DEAP's compiled prefix expression would call the productions, which matters because they
+    mutate the cycle objects they are handed)."""
+
+    def __init__(self, pset, rng):
+        self.prims, self.terms, self.rng = pset.typed_primitives, pset.typed_terminals, rng
+        # shortest completion per type (fixed point): a terminal costs 0, a primitive 1 + its most expensive argument
+        types = set(self.prims) | set(self.terms) | {t for v in self.prims.values() for _, _, a in v for t in a}
+        self.cost = {t: (0 if self.terms.get(t) else None) for t in types}
+        changed = True
+        while changed:
+            changed = False
+            for t in types:
+                for _, _, args in self.prims.get(t, []):
+                    if all(self.cost[a] is not None for a in args):
+                        c = 1 + max([self.cost[a] for a in args], default=0)
+                        if self.cost[t] is None or c < self.cost[t]:
+                            self.cost[t], changed = c, True
+
+    def grow(self, type_, budget):
+        options = []
+        for name, f, args in self.prims.get(type_, []):
+            need = 1 + max([self.cost[a] for a in args if self.cost[a] is not None], default=0)
+            if all(self.cost[a] is not None for a in args) and need <= budget:
+                options.append((name, f, args))
+        terms = self.terms.get(type_, [])
+        if options and (not terms or self.rng.random() < 0.85):
+            name, f, args = self.rng.choice(options)
+            values = [self.grow(a, budget - 1) for a in args]
+            return f(*values)
+        if not terms:
+            raise RuntimeError(f"type {type_.identifier} cannot be completed within the budget")
+        return self.rng.choice(terms)[1]
+
+
+CASES = [("2D_FD_Poisson_fromL2", 3, 6, 60), ("2D_FD_Poisson_fromL2", 5, 9, 30), ("3D_FD_Poisson_fromL2", 2, 4, 40), ("2D_FD_LinearElasticity_fromL2", 3, 5, 60),
+         ("2D_FD_LinearElasticity_fromL2", 4, 8, 20)]
+
+
+@pytest.mark.parametrize("problem,lo,hi,count", CASES)
+def test_random_grammar_individuals_lower_like_the_reference(golden_module, problem, lo, hi, count):
+    from evostencils_amd.code_generation import lowering
+    ours = generator_for(problem, lo, hi)
+    rng = random.Random(20260000 + 10 * hi + lo)
+    produced = unsupported = 0
+    kinds = set()
+    for attempt in range(4 * count):
+        if produced >= count:
+            break
+        # a fresh primitive set per individual: the productions mutate the terminals' cycle objects
+        pset, ref_gen, storages = golden_module.reference_context(problem, lo, hi, return_pset=True)
+        grower = Grower(pset, rng)
+        try:
+            state = grower.grow(pset.ret, budget=rng.randint(6, 18))
+        except (AssertionError, RuntimeError):
+            continue                                     # a production rejected its argument (grammar/multigrid.py asserts)
+        expression = state[0]
+        try:
+            want = ref_gen.generate_cycle_function(expression, storages, lo, hi, hi)
+        except Exception:                                # noqa: BLE001 — the reference itself cannot lower it: not our concern
+            continue
+        produced += 1
+        got = ours.generate_cycle_function(expression, None, lo, hi, hi)
+        assert got == want, f"individual {produced} of {problem} lowers differently"
+        for line in want.splitlines():
+            if "solve locally" in line:
+                kinds.add("jacobi" if "with jacobi" in line else "colored")
+        try:
+            ops = ours.generate_op_program(expression, lo, hi)
+            assert len(ops) > 0
+        except lowering.UnsupportedExpression as exc:
+            unsupported += 1
+            print("unsupported:", exc)
+    assert produced >= count // 2, f"only {produced} individuals could be grown and lowered by the reference"
+    assert unsupported == 0, f"{unsupported} of {produced} grammar-generated candidates are rejected by the op-program encoder"
+    assert kinds == {"jacobi", "colored"}
+
+
+@pytest.mark.parametrize("depth,count", [(3, 40), (2, 30)])
+def test_random_fas_individuals_lower_like_the_reference(golden_module, depth, count):
+    """The reference's SECOND backend (exastencils_FAS.py) the same way: individuals grown over the FAS primitive set
+    (`generate_primitive_set(..., FAS=True)`: Picard / Newton-Jacobi smoothers, Newton steps, FAS coarsening and
+    corrections), layer-4 text of the reference's ProgramGeneratorFAS against ours on the same IR objects, and the FAS op
+    program encodes."""
+    from test_fas_lowering import fas_generator
+    ours = fas_generator()
+    rng = random.Random(4242 + depth)
+    produced = 0
+    for attempt in range(4 * count):
+        if produced >= count:
+            break
+        pset, ref_gen = golden_module.fas_reference_context(depth, return_pset=True)
+        try:
+            state = Grower(pset, rng).grow(pset.ret, budget=rng.randint(6, 16))
+        except (AssertionError, RuntimeError):
+            continue
+        expression = state[0]
+        try:
+            want = ref_gen.generate_cycle_function(expression)
+        except Exception:                                # noqa: BLE001
+            continue
+        produced += 1
+        assert ours.generate_cycle_function(expression) == want, f"FAS individual {produced} lowers differently"
+        assert len(ours.generate_op_program(expression)) > 0
+    assert produced >= count // 2
