@@ -67,6 +67,24 @@ class Grower:
             raise RuntimeError(f"type {type_.identifier} cannot be completed within the budget")
         return self.rng.choice(terms)[1]
 
+    def grow_with_string(self, type_, budget):
+        """(value, the individual as DEAP prints it: `name(arg, ...)`, terminals by their registered name, unnamed ones —
+        relaxation-factor indices, block shapes — by their value)."""
+        options = []
+        for name, f, args in self.prims.get(type_, []):
+            need = 1 + max([self.cost[a] for a in args if self.cost[a] is not None], default=0)
+            if all(self.cost[a] is not None for a in args) and need <= budget:
+                options.append((name, f, args))
+        terms = self.terms.get(type_, [])
+        if options and (not terms or self.rng.random() < 0.85):
+            name, f, args = self.rng.choice(options)
+            parts = [self.grow_with_string(a, budget - 1) for a in args]
+            return f(*[v for v, _ in parts]), f"{name}({', '.join(t for _, t in parts)})"
+        if not terms:
+            raise RuntimeError(f"type {type_.identifier} cannot be completed within the budget")
+        tname, value = self.rng.choice(terms)
+        return value, (tname if tname is not None else repr(value))
+
 
 CASES = [("2D_FD_Poisson_fromL2", 3, 6, 60), ("2D_FD_Poisson_fromL2", 5, 9, 30), ("3D_FD_Poisson_fromL2", 2, 4, 40), ("2D_FD_LinearElasticity_fromL2", 3, 5, 60),
          ("2D_FD_LinearElasticity_fromL2", 4, 8, 20)]
@@ -137,4 +155,31 @@ def test_random_fas_individuals_lower_like_the_reference(golden_module, depth, c
         produced += 1
         assert ours.generate_cycle_function(expression) == want, f"FAS individual {produced} lowers differently"
         assert len(ours.generate_op_program(expression)) > 0
+    assert produced >= count // 2
+
+
+@pytest.mark.parametrize("problem,lo,hi,count", [("2D_FD_Poisson_fromL2", 3, 6, 40), ("3D_FD_Poisson_fromL2", 2, 4, 25),
+                                                 ("2D_FD_LinearElasticity_fromL2", 3, 5, 40)])
+def test_our_productions_build_the_same_cycles_from_the_same_individual_strings(golden_module, problem, lo, hi, count):
+    """The same random individuals as STRINGS (what DEAP prints and the optimizer stores, optimization/program.py:904-933):
+    compiled with OUR productions (grammar/productions.py: compile_individual — parsed, not eval-ed) into OUR IR and lowered
+    by us, against the reference's productions + IR + lowering: identical text. This pins the state machine of the
+    productions (in-place cycle mutation, predecessor links) under arbitrary nesting, not just on the hand-written cases."""
+    from evostencils_amd.grammar import productions
+    from helpers import context_for
+    ours = generator_for(problem, lo, hi)
+    rng = random.Random(777 + hi)
+    produced = 0
+    for attempt in range(4 * count):
+        if produced >= count:
+            break
+        pset, ref_gen, storages = golden_module.reference_context(problem, lo, hi, return_pset=True)
+        try:
+            state, text = Grower(pset, rng).grow_with_string(pset.ret, budget=rng.randint(6, 16))
+            want = ref_gen.generate_cycle_function(state[0], storages, lo, hi, hi)
+        except Exception:                                # noqa: BLE001
+            continue
+        produced += 1
+        own_state = productions.compile_individual(text, context_for(ours, lo, hi))
+        assert ours.generate_cycle_function(own_state[0], None, lo, hi, hi) == want, text
     assert produced >= count // 2
