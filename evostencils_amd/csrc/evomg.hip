@@ -107,6 +107,8 @@ template <typename T> class Impl : public ImplBase {
     if (cg_xpart_) (void)hipFree(cg_xpart_);
     if (cg_xface_) (void)hipFree(cg_xface_);
     if (cg_flags_) (void)hipFree(cg_flags_);
+    if (kcg_state_) (void)hipFree(kcg_state_);
+    if (kcg_host_) (void)hipHostFree(kcg_host_);
     if (hscalar_) (void)hipHostFree(hscalar_);
     for (auto e : prof_events_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -1617,6 +1619,12 @@ template <typename T> class Impl : public ImplBase {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
                            prob_.cgs_target_res_reduction, dinfo_, cg_xpart_, cg_xface_, cg_flags_);
       apply_bc(L, x);
+    } else if (!scalar_traits<T>::is_complex && kcg_enabled_ &&
+               (dim_ == 2 ? krylov_cg_per_launch<2>(lv.g.n) : krylov_cg_per_launch<3>(lv.g.n))) {
+      // a LARGE coarsest grid (257^2 / 65^3 and up): three many-unit launches per iteration (evomg_krylov.h: kcg_*)
+      const int rc = (dim_ == 2) ? coarse_cg_per_launch<2>(lv, x, b, r, w[0], w[1]) : coarse_cg_per_launch<3>(lv, x, b, r, w[0], w[1]);
+      if (rc != EVOMG_OK) return rc;
+      apply_bc(L, x);
     } else {
       bool launched = false;
       int rc = (dim_ == 2) ? launch_cg_reg<2>(lv, x, b, r, &launched) : launch_cg_reg<3>(lv, x, b, r, &launched);
@@ -1629,6 +1637,48 @@ template <typename T> class Impl : public ImplBase {
     }
     HIP_TRY(hipGetLastError());
     return EVOMG_OK;
+  }
+
+  // CG as a sequence of launches (large coarsest grids): batches of 16 iterations are queued, the done flag is read between
+  // batches; kernels of iterations past convergence return at once
+  template <int DIM> int coarse_cg_per_launch(const Level<T>& lv, T* x, const T* b, T* r, T* p, T* ap) {
+    if constexpr (!scalar_traits<T>::is_complex) {
+      if (!kcg_state_) {
+        HIP_TRY(hipMalloc(&kcg_state_, 2 * sizeof(KcgState)));
+        HIP_TRY(hipHostMalloc(&kcg_host_, sizeof(KcgState)));
+      }
+      const Geo& g = lv.g;
+      const int m = g.n - 2;
+      const long rows = DIM == 2 ? m : (long)m * m;
+      const int blocks = (int)(rows < kDotBlocks ? rows : kDotBlocks);
+      T* part_a = partials_;
+      T* part_b = partials_ + kDotBlocks;
+      const dim3 grid(blocks), block(256);
+      hipLaunchKernelGGL((kcg_init<T, DIM>), grid, block, 0, stream_, g, lv.st, (const T*)x, b, r, p, part_a);
+      hipLaunchKernelGGL((kcg_start<T>), dim3(1), block, 0, stream_, (const T*)part_a, blocks, kcg_state_);
+      const int maxit = prob_.cgs_max_iterations;
+      int k = 0;
+      kcg_host_->done = 0;
+      kcg_host_->it = 0;
+      while (k < maxit) {
+        const int batch = maxit - k < 16 ? maxit - k : 16;
+        for (int j = 0; j < batch; ++j, ++k) {
+          const int cur = k & 1;
+          hipLaunchKernelGGL((kcg_apply<T, DIM>), grid, block, 0, stream_, g, lv.st, (const T*)p, ap, part_a, (const KcgState*)kcg_state_, cur);
+          hipLaunchKernelGGL((kcg_update<T, DIM>), grid, block, 0, stream_, g, x, r, (const T*)p, (const T*)ap, (const T*)part_a, blocks, part_b,
+                             (const KcgState*)kcg_state_, cur);
+          hipLaunchKernelGGL((kcg_direct<T, DIM>), grid, block, 0, stream_, g, (const T*)r, p, (const T*)part_b, blocks, kcg_state_, cur,
+                             prob_.cgs_target_res_reduction);
+        }
+        HIP_TRY(hipMemcpyAsync(kcg_host_, kcg_state_ + (k & 1), sizeof(KcgState), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (kcg_host_->done) break;
+      }
+      HIP_TRY(hipMemcpyAsync(dinfo_, &kcg_state_[k & 1].it, sizeof(int), hipMemcpyDeviceToDevice, stream_));
+      HIP_TRY(hipGetLastError());
+      return EVOMG_OK;
+    }
+    return invalid("coarse_cg_per_launch: real problems only");
   }
 
   // register-resident CG when a thread's share of the coarsest grid fits its registers (2D, up to 129^2); otherwise the
@@ -2055,6 +2105,9 @@ template <typename T> class Impl : public ImplBase {
   bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
   hipEvent_t norm_event_ = nullptr;
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
+  bool kcg_enabled_ = getenv("EVOMG_NO_LAUNCH_CG") == nullptr;       // large coarsest grids: CG as a sequence of launches
+  KcgState* kcg_state_ = nullptr;
+  KcgState* kcg_host_ = nullptr;
   bool outer_fuse_ = getenv("EVOMG_NO_OUTER_FUSE") == nullptr;      // fused passes of the preconditioned BiCGStab loop
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
   T* norm_partials_ = nullptr;

@@ -799,6 +799,118 @@ evomg_cg_wave3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
   if (t == 0) info[0] = it;
 }
 
+// ---- CG on LARGE coarsest grids as a sequence of many-unit launches ------------------------------------------------------
+// A cycle over few levels leaves a big coarsest grid (2049^2 over four levels: 257^2; 257^3 over three: 65^3). One
+// workgroup then streams every vector through ONE compute unit's 64 B/clk, hundreds of iterations long: 62 ms per
+// solve at 257^2, 174 ms at 65^3 (tools/coarse_big.py) — a cliff, not a slope. From 257^2 / 65^3 up the solve is three
+// ordinary launches per iteration instead, all compute units busy:
+//   apply:   A p -> ap, partial sums of p . A p                                   (kcg_apply)
+//   update:  every block reduces those partials itself (same order as evomg_dot_final), alpha = rr / pAp,
+//            x += alpha p, r -= alpha A p, partial sums of r . r                  (kcg_update)
+//   direct:  every block reduces them, tests convergence, beta = rr' / rr, p = r + beta p; block 0 publishes the next
+//            state (rr, iteration count, done flag)                               (kcg_direct)
+// The scalars never visit the host: they live in a two-slot state (slot = iteration parity, so that a block still reading
+// rr is never overtaken by block 0 writing the next one); the host queues 16 iterations at a time and looks at the done
+// flag between batches; kernels of iterations past convergence return at once. Arithmetic: the Krylov kernels' (fma
+// SpMV, fma updates); dot products: fma accumulation in evomg_dot_partial's node order, then the block trees, then
+// evomg_dot_final's order over the partials — restated by the oracle (FN(dot_blocked_fma)).
+struct KcgState {
+  double rr, res0;
+  int it, done;
+};
+template <int DIM> __host__ __device__ inline bool krylov_cg_per_launch(int n) { return DIM == 2 ? n >= 257 : n >= 65; }
+
+template <typename T> __device__ __forceinline__ T kcg_reduce(const T* __restrict__ partial, int count, T* red) {
+  T s = scalar_traits<T>::zero();
+  for (int i = threadIdx.x; i < count; i += blockDim.x) s = sc_add(s, partial[i]);
+  return block_sum(s, red);
+}
+// visits this block's inner nodes in evomg_dot_partial's order
+template <int DIM, typename F> __device__ __forceinline__ void kcg_nodes(const Geo& g, F&& f) {
+  const int m = g.n - 2;
+  const long rows = (DIM == 2) ? m : (long)m * m;
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int j = 1 + (int)(r % m), k = (DIM == 3) ? 1 + (int)(r / m) : 0;
+    const long base = gidx<DIM>(g, 0, j, k);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) f(base + i);
+  }
+}
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) kcg_init(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r,
+                                                T* __restrict__ p, T* __restrict__ partial) {
+  __shared__ T red[17];
+  T s = scalar_traits<T>::zero();
+  kcg_nodes<DIM>(g, [&](long c) {
+    const T v = sc_sub(b[c], apply_stencil_fma<T, DIM>(st, x, g, c));
+    r[c] = v;
+    p[c] = v;
+    s = sc_fma(v, v, s);
+  });
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) kcg_start(const T* __restrict__ partial, int count, KcgState* state) {
+  __shared__ T red[17];
+  const T rr = kcg_reduce(partial, count, red);
+  if (threadIdx.x == 0) {
+    const double res0 = sc_norm_from_dot(rr);
+    state[0] = KcgState{rr, res0, 0, res0 == 0.0 ? 1 : 0};
+  }
+}
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) kcg_apply(Geo g, Stencil<T> st, const T* __restrict__ p, T* __restrict__ ap, T* __restrict__ partial,
+                                                 const KcgState* state, int cur) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  T s = scalar_traits<T>::zero();
+  kcg_nodes<DIM>(g, [&](long c) {
+    const T v = apply_stencil_fma<T, DIM>(st, p, g, c);
+    ap[c] = v;
+    s = sc_fma(p[c], v, s);
+  });
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) kcg_update(Geo g, T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p, const T* __restrict__ ap,
+                                                  const T* __restrict__ partial_in, int count, T* __restrict__ partial_out,
+                                                  const KcgState* state, int cur) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  const T pap = kcg_reduce(partial_in, count, red);
+  const T alpha = sc_div(state[cur].rr, pap);
+  const T nalpha = sc_neg(alpha);
+  T s = scalar_traits<T>::zero();
+  kcg_nodes<DIM>(g, [&](long c) {
+    x[c] = sc_fma(alpha, p[c], x[c]);
+    const T rv = sc_fma(nalpha, ap[c], r[c]);
+    r[c] = rv;
+    s = sc_fma(rv, rv, s);
+  });
+  __syncthreads();
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial_out[blockIdx.x] = s;
+}
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) kcg_direct(Geo g, const T* __restrict__ r, T* __restrict__ p, const T* __restrict__ partial_in, int count,
+                                                  KcgState* state, int cur, double tol) {
+  __shared__ T red[17];
+  const KcgState st0 = state[cur];
+  if (st0.done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[cur ^ 1] = st0;       // hand the final state on
+    return;
+  }
+  const T rrn = kcg_reduce(partial_in, count, red);
+  const double res = sc_norm_from_dot(rrn);
+  const bool converged = !(res > tol * st0.res0);
+  if (!converged) {
+    const T beta = sc_div(rrn, st0.rr);
+    kcg_nodes<DIM>(g, [&](long c) { p[c] = sc_fma(beta, p[c], r[c]); });
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) state[cur ^ 1] = KcgState{rrn, st0.res0, st0.it + 1, converged ? 1 : 0};
+}
+
 // ---- CG on 33^3 across EVOMG_CG_GROUPS compute units (3D column ownership, m >= 16) ------------------------------------
 // One CU moves 64 B/clk: with 29 791 unknowns and 17 vector accesses per unknown and iteration the single-workgroup
 // kernel above needs ~60 us per iteration, and the 3D configuration spends half its time there. Here the grid is cut

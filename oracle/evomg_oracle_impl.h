@@ -405,7 +405,11 @@ static SC FN(block_tree)(SC* th) {
   for (int w = 0; w < DOT_THREADS / 64; ++w) waves[w] = FN(tree64)(&th[64 * w]);
   return FN(tree64)(waves);
 }
-static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
+static SC FN(dot_blocked)(FN(ctx_t)* c, int level, const SC* a, const SC* b, int fused);
+static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) { return FN(dot_blocked)(c, level, a, b, 0); }
+/* fused: the per-thread accumulation is a fused multiply-add chain (the launch-per-iteration CG on large coarsest grids,
+ * csrc/evomg_krylov.h kcg_*); the node order and the trees are the same */
+static SC FN(dot_blocked)(FN(ctx_t)* c, int level, const SC* a, const SC* b, int fused) {
   const int n = c->lv[level].n, m = n - 2;
   const long rows = (c->dim == 2) ? m : (long)m * m;
   const int B = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
@@ -419,7 +423,7 @@ static SC FN(dot)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
       const size_t base = (c->dim == 3) ? IDX3(n, 0, j, k) : IDX2(n, 0, j);
       for (int i = 1; i <= m; ++i) {
         const int t = (i - 1) % DOT_THREADS;
-        th[t] = sc_add(th[t], sc_mul(a[base + i], b[base + i]));
+        th[t] = fused ? sc_fma(a[base + i], b[base + i], th[t]) : sc_add(th[t], sc_mul(a[base + i], b[base + i]));
       }
     }
     partial[blk] = FN(block_tree)(th);
@@ -659,7 +663,10 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   SC* p = FN(tmpvec)(c, L, 0);
   SC* ap = FN(tmpvec)(c, L, 1);
   const int grouped = FN(cg_groups)(c, L) > 1;
-#define CG_DOT(u, v) (grouped ? FN(dot_canon_grouped)(c, L, u, v) : FN(dot_canon_for)(c, L, u, v, 1))
+  /* LARGE coarsest grids (257^2 / 65^3 and up): the device runs the solve as many-unit launches whose dot products follow
+   * the blocked order of the fine-level reductions with fused accumulation (csrc/evomg_krylov.h: krylov_cg_per_launch) */
+  const int per_launch = !SC_IS_COMPLEX && ((c->dim == 2) ? lv->n >= 257 : lv->n >= 65);
+#define CG_DOT(u, v) (per_launch ? FN(dot_blocked)(c, L, u, v, 1) : grouped ? FN(dot_canon_grouped)(c, L, u, v) : FN(dot_canon_for)(c, L, u, v, 1))
   FN(krylov_apply)(c, L, lv->st, x, b, r, 1);
   SC rr = CG_DOT(r, r);
   const double res0 = sc_norm_from_dot(rr);

@@ -355,6 +355,31 @@ def test_one_wave_cg_and_its_folded_copy_and_zero(native, oracle, lo, monkeypatc
             assert np.array_equal(got[1][1:-1, 1:-1], want[1][1:-1, 1:-1])
 
 
+@pytest.mark.parametrize("dim,lo", [(2, 8), (3, 6)])
+def test_large_coarsest_grids_run_cg_as_launches(native, oracle, dim, lo):
+    """257^2 / 65^3 and up: the coarse CG as three many-unit launches per iteration with the scalars in a device-side state
+    (kcg_*), dot products in the blocked order with fused accumulation that the oracle restates: solution and residual bit
+    for bit, and two orders of magnitude faster than one workgroup (tools/coarse_big.py)."""
+    pd = problems.poisson_2d(lo, lo + 1) if dim == 2 else problems.poisson_3d(lo, lo + 1)
+    rng = np.random.default_rng(lo * 10 + dim)
+    shape = ((1 << lo) + 1,) * dim
+    rhs = rng.standard_normal(shape)
+    x0 = zero_boundary(rng.standard_normal(shape)) * 1e-3
+    ops = [abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+    h = native.create(pd)
+    ho = oracle.create(pd)
+    for hh in (h, ho):
+        hh.set_field(lo, abi.F_CGS_RHS, rhs)
+        hh.set_field(lo, abi.F_CORR, x0)
+        hh.run_ops(ops)
+    inner = (slice(1, -1),) * dim
+    assert np.array_equal(h.get_field(lo, abi.F_CORR), ho.get_field(lo, abi.F_CORR))
+    assert np.array_equal(h.get_field(lo, abi.F_RES)[inner], ho.get_field(lo, abi.F_RES)[inner])
+    assert not np.array_equal(h.get_field(lo, abi.F_CORR), x0)
+    h.close()
+    ho.close()
+
+
 @pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4), (3, 5)])
 def test_coarse_cg_variants_are_bit_identical(native, oracle, dim, lo, monkeypatch):
     """The register-resident CG (2D) / the eight-workgroup CG (33^3), the global-memory single-workgroup CG
