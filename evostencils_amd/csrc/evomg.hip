@@ -108,6 +108,9 @@ template <typename T> class Impl : public ImplBase {
     if (cg_xface_) (void)hipFree(cg_xface_);
     if (cg_flags_) (void)hipFree(cg_flags_);
     if (kcg_state_) (void)hipFree(kcg_state_);
+    if (kb_state_) (void)hipFree(kb_state_);
+    if (kb_scal_) (void)hipFree(kb_scal_);
+    if (kb_host_) (void)hipHostFree(kb_host_);
     if (kcg_host_) (void)hipHostFree(kcg_host_);
     if (hscalar_) (void)hipHostFree(hscalar_);
     for (auto e : prof_events_) (void)hipEventDestroy(e);
@@ -128,7 +131,7 @@ template <typename T> class Impl : public ImplBase {
     if (hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || n_cu_ <= 0) n_cu_ = 256;
     HIP_TRY(hipEventCreate(&ev0_));
     HIP_TRY(hipEventCreate(&ev1_));
-    HIP_TRY(hipMalloc(&partials_, sizeof(T) * 2 * kDotBlocks));   // two dot products per fused pass
+    HIP_TRY(hipMalloc(&partials_, sizeof(T) * 5 * kDotBlocks));   // two dot products per fused pass; five sets in kb_*
     HIP_TRY(hipMalloc(&dscalar_, sizeof(T) * 8));
     HIP_TRY(hipMalloc(&dinfo_, sizeof(int) * 4));
     HIP_TRY(hipMemset(dinfo_, 0, sizeof(int) * 4));
@@ -1592,6 +1595,11 @@ template <typename T> class Impl : public ImplBase {
                                     prob_.cgs_target_res_reduction, kh(L), dinfo_);
       else hipLaunchKernelGGL((evomg_bicgstab_wave2d<T, false>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
                               prob_.cgs_target_res_reduction, 0.0, dinfo_);
+    } else if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB && dim_ == 2 && kcg_enabled_ && lv.g.n >= kb_min_n_) {
+      // 129^2 and up (C3's coarsest grid): six many-unit launches per iteration (evomg_krylov.h: kb_*)
+      const int rc = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN ? coarse_bicgstab_per_launch<true>(L, lv, x, b, r, w)
+                                                               : coarse_bicgstab_per_launch<false>(L, lv, x, b, r, w);
+      if (rc != EVOMG_OK) return rc;
     } else if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
       const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
       if constexpr (scalar_traits<T>::is_complex) {
@@ -1679,6 +1687,57 @@ template <typename T> class Impl : public ImplBase {
       return EVOMG_OK;
     }
     return invalid("coarse_cg_per_launch: real problems only");
+  }
+
+  // BiCGStab as a sequence of launches (2D, 129^2 and up). The batches between two reads of the done flag start small
+  // (C3 converges in two iterations) and double up to 16.
+  template <bool ROBIN> int coarse_bicgstab_per_launch(int L, const Level<T>& lv, T* x, const T* b, T* r, T* const* w) {
+    if constexpr (ROBIN && !scalar_traits<T>::is_complex) return invalid("Robin columns on a real problem");
+    else {
+      if (!kb_state_) {
+        HIP_TRY(hipMalloc(&kb_state_, 2 * sizeof(KbState<T>)));
+        HIP_TRY(hipMalloc(&kb_scal_, 4 * sizeof(T)));
+        HIP_TRY(hipHostMalloc(&kb_host_, sizeof(KbState<T>)));
+      }
+      T *p = w[0], *nu = w[1], *hh = w[2], *s = w[3], *t = w[4], *rhat = w[5];
+      const Geo& g = lv.g;
+      const int m = g.n - 2;
+      const int blocks = m < kDotBlocks ? m : kDotBlocks;
+      T* part_r = partials_;                     // [0] r . r, [1] rhat . r
+      T* part_nu = partials_ + 2 * kDotBlocks;   // rhat . nu
+      T* part_t = partials_ + 3 * kDotBlocks;    // [0] t . s, [1] t . t
+      const dim3 grid(blocks), block(256);
+      const double khv = ROBIN ? kh(L) : 0.0;
+      const double tol = prob_.cgs_target_res_reduction;
+      hipLaunchKernelGGL((kb_init<T, ROBIN>), grid, block, 0, stream_, g, lv.st, (const T*)x, b, r, rhat, nu, p, part_r, khv);
+      hipLaunchKernelGGL((kb_start<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, kb_scal_);
+      const int maxit = prob_.cgs_max_iterations;
+      int k = 0, batch = 2;
+      kb_host_->done = 0;
+      while (k < maxit) {
+        const int todo = maxit - k < batch ? maxit - k : batch;
+        for (int j = 0; j < todo; ++j, ++k) {
+          const int cur = k & 1;
+          const KbState<T>* st = kb_state_;
+          hipLaunchKernelGGL((kb_p<T, ROBIN>), grid, block, 0, stream_, g, (const T*)r, (const T*)nu, p, (const T*)(part_r + blocks), blocks, st, cur,
+                             kb_scal_, khv);
+          hipLaunchKernelGGL((kb_spmv<T, 1>), grid, block, 0, stream_, g, lv.st, (const T*)p, nu, (const T*)rhat, part_nu, st, cur);
+          hipLaunchKernelGGL((kb_hs<T, ROBIN>), grid, block, 0, stream_, g, (const T*)x, (const T*)r, (const T*)p, (const T*)nu, hh, s,
+                             (const T*)part_nu, blocks, st, cur, kb_scal_, khv);
+          hipLaunchKernelGGL((kb_spmv<T, 2>), grid, block, 0, stream_, g, lv.st, (const T*)s, t, (const T*)s, part_t, st, cur);
+          hipLaunchKernelGGL((kb_xr<T, ROBIN>), grid, block, 0, stream_, g, x, r, (const T*)s, (const T*)hh, (const T*)t, (const T*)rhat,
+                             (const T*)part_t, blocks, part_r, st, cur, kb_scal_, khv);
+          hipLaunchKernelGGL((kb_check<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, (const T*)kb_scal_, tol);
+        }
+        HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + (k & 1), sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (kb_host_->done) break;
+        if (batch < 16) batch *= 2;
+      }
+      HIP_TRY(hipMemcpyAsync(dinfo_, &kb_state_[k & 1].it, sizeof(int), hipMemcpyDeviceToDevice, stream_));
+      HIP_TRY(hipGetLastError());
+      return EVOMG_OK;
+    }
   }
 
   // register-resident CG when a thread's share of the coarsest grid fits its registers (2D, up to 129^2); otherwise the
@@ -2105,9 +2164,14 @@ template <typename T> class Impl : public ImplBase {
   bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
   hipEvent_t norm_event_ = nullptr;
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
+  // experiments only: the oracle restates the default (krylov_bicgstab_per_launch)
+  int kb_min_n_ = getenv("EVOMG_KB_MIN_N") ? atoi(getenv("EVOMG_KB_MIN_N")) : 129;
   bool kcg_enabled_ = getenv("EVOMG_NO_LAUNCH_CG") == nullptr;       // large coarsest grids: CG as a sequence of launches
   KcgState* kcg_state_ = nullptr;
   KcgState* kcg_host_ = nullptr;
+  KbState<T>* kb_state_ = nullptr;
+  KbState<T>* kb_host_ = nullptr;
+  T* kb_scal_ = nullptr;
   bool outer_fuse_ = getenv("EVOMG_NO_OUTER_FUSE") == nullptr;      // fused passes of the preconditioned BiCGStab loop
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
   T* norm_partials_ = nullptr;

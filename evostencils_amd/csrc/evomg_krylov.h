@@ -911,6 +911,169 @@ __global__ void __launch_bounds__(256) kcg_direct(Geo g, const T* __restrict__ r
   if (blockIdx.x == 0 && threadIdx.x == 0) state[cur ^ 1] = KcgState{rrn, st0.res0, st0.it + 1, converged ? 1 : 0};
 }
 
+// ---- BiCGStab on larger coarsest grids as a sequence of many-unit launches (2D) -----------------------------------------
+// Same idea as kcg_* for the BiCGStab of Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 (complex, Robin columns) from
+// 129^2 up — C3's coarsest grid: two iterations there, 260 us on one compute unit (45 passes over 266 KB vectors at 64 B/clk),
+// and a cliff on anything larger. Six launches per iteration, every scalar formed by every block from the partial sums of
+// the launch before (evomg_dot_final's order) — kb_p: rho' = rhat . r, beta, p = r + beta (p - omega nu) [+ Robin columns];
+// kb_spmv<1>: nu = A p, rhat . nu; kb_hs: alpha, h = x + alpha p, s = r - alpha nu [+ Robin]; kb_spmv<2>: t = A s, t . s, t . t;
+// kb_xr: omega, x = h + omega s, r = s - omega t [+ Robin], r . r, rhat . r; kb_check (one block): convergence, next state.
+// The Robin column next to an inner column is written by the thread that wrote the inner node. Dot products: fused
+// accumulation in evomg_dot_partial's node order with the operand order of the single-workgroup kernel; restated by the
+// oracle (coarse_bicgstab with FN(dot_blocked)). scal: [0] alpha, [1] omega, [2] rho'.
+template <typename T> struct KbState {
+  T rho;
+  double res0;
+  int it, done;
+};
+__host__ __device__ inline bool krylov_bicgstab_per_launch(int n) { return n >= 129; }
+
+template <typename F> __device__ __forceinline__ void kb_nodes(const Geo& g, F&& f) {       // f(index, column)
+  const int m = g.n - 2;
+  for (long r = blockIdx.x; r < m; r += gridDim.x) {
+    const long base = gidx<2>(g, 0, 1 + (int)r, 0);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) f(base + i, i);
+  }
+}
+// the Robin column beside an inner column: x_b = x_in / (1 - i k h)
+template <typename T, bool ROBIN> __device__ __forceinline__ void kb_robin(const Geo& g, T* __restrict__ v, long c, int i, T value, double kh) {
+  if constexpr (ROBIN && scalar_traits<T>::is_complex) {
+    const cplx den{1.0, -kh};
+    if (i == 1) v[c - 1] = sc_div(value, den);
+    if (i == g.n - 2) v[c + 1] = sc_div(value, den);
+  }
+}
+template <typename T, bool ROBIN>
+__global__ void __launch_bounds__(256) kb_init(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r,
+                                               T* __restrict__ rhat, T* __restrict__ nu, T* __restrict__ p, T* __restrict__ partial, double kh) {
+  __shared__ T red[17];
+  const T zero = scalar_traits<T>::zero();
+  T s0 = zero, s1 = zero;
+  kb_nodes(g, [&](long c, int i) {
+    const T v = sc_sub(f[c], apply_stencil_fma<T, 2>(st, x, g, c));
+    r[c] = v;
+    rhat[c] = v;
+    nu[c] = zero;
+    p[c] = zero;
+    s0 = sc_fma(v, v, s0);
+    s1 = sc_fma(v, v, s1);                      // rhat . r with rhat = r
+    kb_robin<T, ROBIN>(g, r, c, i, v, kh);
+    kb_robin<T, ROBIN>(g, rhat, c, i, v, kh);
+    if constexpr (ROBIN) {
+      if (i == 1) { p[c - 1] = zero; nu[c - 1] = zero; }
+      if (i == g.n - 2) { p[c + 1] = zero; nu[c + 1] = zero; }
+    }
+  });
+  s0 = block_sum(s0, red);
+  s1 = block_sum(s1, red);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = s0; partial[gridDim.x + blockIdx.x] = s1; }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) kb_start(const T* __restrict__ partial, int count, KbState<T>* state, T* scal) {
+  __shared__ T red[17];
+  const T rr = kcg_reduce(partial, count, red);
+  if (threadIdx.x == 0) {
+    const double res0 = sc_norm_from_dot(rr);
+    const T one = scalar_traits<T>::from_real(1.0);
+    state[0] = KbState<T>{one, res0, 0, res0 == 0.0 ? 1 : 0};
+    scal[0] = one;
+    scal[1] = one;
+  }
+}
+template <typename T, bool ROBIN>
+__global__ void __launch_bounds__(256) kb_p(Geo g, const T* __restrict__ r, const T* __restrict__ nu, T* __restrict__ p,
+                                            const T* __restrict__ partial_rhat_r, int count, const KbState<T>* state, int cur, T* scal, double kh) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  const T rho_new = kcg_reduce(partial_rhat_r, count, red);
+  const T alpha = scal[0], omega = scal[1];
+  const T beta = sc_mul(sc_div(rho_new, state[cur].rho), sc_div(alpha, omega));
+  const T nomega = sc_neg(omega);
+  kb_nodes(g, [&](long c, int i) {
+    const T pv = sc_fma(nomega, nu[c], p[c]);
+    const T v = sc_fma(beta, pv, r[c]);
+    p[c] = v;
+    kb_robin<T, ROBIN>(g, p, c, i, v, kh);
+  });
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[2] = rho_new;
+}
+// out = A in; NDOT == 1: partial = w . out; NDOT == 2: partial[0] = out . w, partial[1] = out . out
+template <typename T, int NDOT>
+__global__ void __launch_bounds__(256) kb_spmv(Geo g, Stencil<T> st, const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ w,
+                                               T* __restrict__ partial, const KbState<T>* state, int cur) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  const T zero = scalar_traits<T>::zero();
+  T s0 = zero, s1 = zero;
+  kb_nodes(g, [&](long c, int) {
+    const T v = apply_stencil_fma<T, 2>(st, in, g, c);
+    out[c] = v;
+    if (NDOT == 1) s0 = sc_fma(w[c], v, s0);
+    else { s0 = sc_fma(v, w[c], s0); s1 = sc_fma(v, v, s1); }
+  });
+  s0 = block_sum(s0, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s0;
+  if (NDOT == 2) {
+    s1 = block_sum(s1, red);
+    if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = s1;
+  }
+}
+template <typename T, bool ROBIN>
+__global__ void __launch_bounds__(256) kb_hs(Geo g, const T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ p, const T* __restrict__ nu,
+                                             T* __restrict__ hh, T* __restrict__ s, const T* __restrict__ partial_in, int count,
+                                             const KbState<T>* state, int cur, T* scal, double kh) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  const T alpha = sc_div(scal[2], kcg_reduce(partial_in, count, red));
+  const T nalpha = sc_neg(alpha);
+  kb_nodes(g, [&](long c, int i) {
+    hh[c] = sc_fma(alpha, p[c], x[c]);
+    const T v = sc_fma(nalpha, nu[c], r[c]);
+    s[c] = v;
+    kb_robin<T, ROBIN>(g, s, c, i, v, kh);
+  });
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = alpha;
+}
+template <typename T, bool ROBIN>
+__global__ void __launch_bounds__(256) kb_xr(Geo g, T* __restrict__ x, T* __restrict__ r, const T* __restrict__ s, const T* __restrict__ hh,
+                                             const T* __restrict__ t, const T* __restrict__ rhat, const T* __restrict__ partial_in, int count,
+                                             T* __restrict__ partial_out, const KbState<T>* state, int cur, T* scal, double kh) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  const T ts = kcg_reduce(partial_in, count, red);
+  const T tt = kcg_reduce(partial_in + count, count, red);
+  const T omega = sc_div(ts, tt);
+  const T nomega = sc_neg(omega);
+  const T zero = scalar_traits<T>::zero();
+  T s0 = zero, s1 = zero;
+  kb_nodes(g, [&](long c, int i) {
+    const T xv = sc_fma(omega, s[c], hh[c]);
+    x[c] = xv;
+    const T rv = sc_fma(nomega, t[c], s[c]);
+    r[c] = rv;
+    s0 = sc_fma(rv, rv, s0);
+    s1 = sc_fma(rhat[c], rv, s1);
+    kb_robin<T, ROBIN>(g, x, c, i, xv, kh);
+    kb_robin<T, ROBIN>(g, r, c, i, rv, kh);
+  });
+  s0 = block_sum(s0, red);
+  s1 = block_sum(s1, red);
+  if (threadIdx.x == 0) { partial_out[blockIdx.x] = s0; partial_out[count + blockIdx.x] = s1; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = omega;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) kb_check(const T* __restrict__ partial_rr, int count, KbState<T>* state, int cur, const T* scal, double tol) {
+  __shared__ T red[17];
+  const KbState<T> st0 = state[cur];
+  if (st0.done) {
+    if (threadIdx.x == 0) state[cur ^ 1] = st0;
+    return;
+  }
+  const double res = sc_norm_from_dot(kcg_reduce(partial_rr, count, red));
+  if (threadIdx.x == 0) state[cur ^ 1] = KbState<T>{scal[2], st0.res0, st0.it + 1, (res < tol * st0.res0 || !(res == res)) ? 1 : 0};
+}
+
 // ---- CG on 33^3 across EVOMG_CG_GROUPS compute units (3D column ownership, m >= 16) ------------------------------------
 // One CU moves 64 B/clk: with 29 791 unknowns and 17 vector accesses per unknown and iteration the single-workgroup
 // kernel above needs ~60 us per iteration, and the 3D configuration spends half its time there. Here the grid is cut

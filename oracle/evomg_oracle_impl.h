@@ -708,8 +708,12 @@ static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
   SC* t = FN(tmpvec)(c, L, 4);
   SC* rhat = FN(tmpvec)(c, L, 5);
   const SC* st = lv->st;
+  /* 129^2 and up (2D): the device runs the solve as many-unit launches whose dot products follow the blocked order of the
+   * fine-level reductions with fused accumulation (csrc/evomg_krylov.h: krylov_bicgstab_per_launch) */
+  const int per_launch = c->dim == 2 && lv->n >= 129;
+#define B_DOT(u, v) (per_launch ? FN(dot_blocked)(c, L, u, v, 1) : FN(dot_canon)(c, L, u, v))
   FN(krylov_apply)(c, L, st, x, f, r, 1);
-  const double res0 = sc_norm_from_dot(FN(dot_canon)(c, L, r, r));
+  const double res0 = sc_norm_from_dot(B_DOT(r, r));
   FN(apply_bc)(c, L, r);
   memcpy(rhat, r, lv->count * sizeof(SC));
   memset(nu, 0, lv->count * sizeof(SC));
@@ -719,28 +723,29 @@ static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
   int it = 0;
   for (; it < c->prob.cgs_max_iterations; ++it) {
     rho = rho_new;
-    rho_new = FN(dot_canon)(c, L, rhat, r);
+    rho_new = B_DOT(rhat, r);
     beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
     /* p = r + beta * (p - omega * nu) ; boundary of p handled by applyBC_p@coarsest */
     FN(krylov_axpy)(c, L, p, sc_neg(omega), nu, p);
     FN(krylov_axpy)(c, L, p, beta, p, r);
     FN(apply_bc)(c, L, p);
     FN(krylov_apply)(c, L, st, p, NULL, nu, 0);
-    alpha = sc_div(rho_new, FN(dot_canon)(c, L, rhat, nu));
+    alpha = sc_div(rho_new, B_DOT(rhat, nu));
     FN(krylov_axpy)(c, L, hh, alpha, p, x);
     FN(krylov_axpy)(c, L, s, sc_neg(alpha), nu, r);
     FN(apply_bc)(c, L, s);
     FN(krylov_apply)(c, L, st, s, NULL, t, 0);
-    omega = sc_div(FN(dot_canon)(c, L, t, s), FN(dot_canon)(c, L, t, t));
+    omega = sc_div(B_DOT(t, s), B_DOT(t, t));
     FN(krylov_axpy)(c, L, x, omega, s, hh);
     FN(apply_bc)(c, L, x);
     FN(krylov_axpy)(c, L, r, sc_neg(omega), t, s);
-    const double res = sc_norm_from_dot(FN(dot_canon)(c, L, r, r));
+    const double res = sc_norm_from_dot(B_DOT(r, r));
     FN(apply_bc)(c, L, r);
     if (res < c->prob.cgs_target_res_reduction * res0) { ++it; break; }
     if (!(res == res)) { ++it; break; }  /* NaN guard: the DSL would spin to the iteration cap */
   }
   if (getenv("EVOMG_ORACLE_DEBUG")) fprintf(stderr, "[oracle] coarse BiCGStab: %d iterations (cap %d)\n", it, c->prob.cgs_max_iterations);
+#undef B_DOT
   return it;
 }
 

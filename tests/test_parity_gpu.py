@@ -708,3 +708,35 @@ def test_one_wave_bicgstab_is_bit_identical(native, oracle, kind, lo, monkeypatc
         assert np.array_equal(got[0], want[0]), (kind, lo, knob)
         assert np.array_equal(got[1][1:-1, :], want[1][1:-1, :]), (kind, lo, knob)
     assert not np.array_equal(want[0], x0)
+
+
+@pytest.mark.parametrize("kind,lo", [("helmholtz", 7), ("helmholtz", 8), ("poisson", 7)])
+def test_large_coarsest_grids_run_bicgstab_as_launches(native, oracle, kind, lo):
+    """129^2 and up (C3's coarsest grid): BiCGStab as six many-unit launches per iteration with the scalars in a device-side
+    state (kb_*), Robin columns written beside their inner neighbours, dot products in the blocked order with fused
+    accumulation that the oracle restates: solution and residual incl. the Robin columns bit for bit, same iteration count
+    (a cap of 7 iterations exercises the batches 2 + 4 + 1 and kernels launched past the last iteration)."""
+    import dataclasses
+    if kind == "helmholtz":
+        pd = problems.helmholtz_2d(lo, lo + 1, k=0.625 * (1 << (lo + 1)))
+    else:
+        pd = dataclasses.replace(problems.poisson_2d(lo, lo + 1), cgs_kind=abi.CGS_BICGSTAB, cgs_target_res_reduction=1e-9)
+    n = (1 << lo) + 1
+    cplx = kind == "helmholtz"
+    for cap in (None, 7):
+        pdc = pd if cap is None else dataclasses.replace(pd, cgs_max_iterations=cap)
+        rng = np.random.default_rng(29 + lo)
+        rhs = random_field(rng, (n, n), cplx)
+        x0 = zero_boundary(random_field(rng, (n, n), cplx)) * 1e-2
+        ops = [abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+        got = []
+        for lib in (native, oracle):
+            h = lib.create(pdc)
+            h.set_field(lo, abi.F_CGS_RHS, rhs)
+            h.set_field(lo, abi.F_CORR, x0)
+            h.run_ops(ops)
+            got.append((h.get_field(lo, abi.F_CORR), h.get_field(lo, abi.F_RES)))
+            h.close()
+        assert np.array_equal(got[0][0], got[1][0]), (kind, lo, cap)
+        assert np.array_equal(got[0][1][1:-1, :], got[1][1][1:-1, :]), (kind, lo, cap)
+        assert not np.array_equal(got[0][0], x0)
