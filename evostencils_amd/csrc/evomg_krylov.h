@@ -11,6 +11,7 @@
 // arithmetic are the ones the oracle restates (oracle/evomg_oracle_impl.h, "Krylov solvers on the coarsest grid"),
 // so every variant below (global-memory, register-resident, multi-workgroup) produces the same bits as the oracle.
 #pragma once
+#include <type_traits>
 #include "evomg_kernels.h"
 
 #define EVOMG_KRYLOV_THREADS 1024
@@ -434,7 +435,12 @@ evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restri
 //     element pair and direction, no memory access (an LDS-resident p was bound by LDS bandwidth: 6 accesses x 8 B
 //     per node and iteration = 2.5 us of a 3.4 us iteration; single-column lanes with DPP were VALU bound by the
 //     shifts). What is left in LDS:
-//       - x, thread-private, touched once per iteration (x += alpha p): LDS as spill space, conflict-free layout;
+//       - x, thread-private, touched once per iteration (x += alpha p): LDS as spill space, conflict-free layout. Its
+//         round trip (ds_write is 6 LDS cycles per 8 bytes and lane) stood alone in the r update as 30 % of an iteration;
+//         it now rides one row ahead of the stencil in the A p pass of the NEXT iteration together with p = r + beta p
+//         (both need the old p), where the arithmetic hides it: 129^2 2.6 -> 2.1 us per iteration (tools/cg129_time.py;
+//         one row of lead and groups of four rows measured best; rows split between the two passes, x in registers
+//         with A p in LDS instead (spills) measured worse);
 //       - the band seams: every wave publishes its first and last row of r before the r . r reduction and reads the
 //         neighbouring bands' rows after it (2 KB); the neighbours' p rows are recomputed, not exchanged, so an
 //         iteration has exactly two barriers (the two reductions);
@@ -442,7 +448,7 @@ evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restri
 //     step length), and A p of slack rows is forced to zero; nothing else needs masking;
 //   * reductions: permlane-swap / DPP wave trees and one barrier each (block_sum_fast).
 // Arithmetic and summation order are those of evomg_cg_single_wg with the same ownership, and of the oracle.
-// LDS (elements of T): 32 reduction slots | row seams [8 waves][first, last][E][64] | x [R * E][512].
+// LDS (elements of T): 32 reduction slots | row seams [8 waves][first, last][E][64] | x [R][512][E].
 __host__ __device__ inline long cg_reg2d_lds_elems(int rt, int e) { return 32 + 8L * 2 * e * 64 + (long)rt * e * 512; }
 
 // MASK_FROM: first unrolled row that may lie outside the thread's band (needs masking); rows below it are always
@@ -470,7 +476,10 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   const T* south_src = row_seam + (((w - 1) * 2 + 1) * E) * 64 + l;          // row R-1 of the band below
   const T* north_src = row_seam + (((w + 1) * 2) * E) * 64 + l;              // first row of the band above
   T* const my_seam = row_seam + ((w * 2) * E) * 64 + l;
-  T* const myx = xs + tid;
+  // a thread's x values of one row sit side by side: with E = 2 real elements one 16-byte LDS access per row and
+  // direction (ds_read_b128 is 4 LDS cycles where two ds_read_b64 issued as ds_read2st64_b64 are 8; the store 13 either way)
+  struct alignas(sizeof(T) * E) XRow { T v[E]; };
+  XRow* const myx = reinterpret_cast<XRow*>(xs) + tid;     // [row][thread]
   const long c0 = gidx<2>(g, min(ix0, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
 
   T r[R][E], p[R][E], ap[R][E];
@@ -485,7 +494,7 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
       r[i][e] = v;
       p[i][e] = v;
-      myx[(i * E + e) * 512] = x[c];
+      myx[i * 512].v[e] = x[c];
       loc = sc_fma(v, v, loc);
     }
     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -516,56 +525,78 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
 #pragma unroll
   for (int e = 0; e < E; ++e) { p_south[e] = r_south[e]; p_north[e] = r_north[e]; }
   const double res0 = sc_norm_from_dot(rr);
-  int it = 0;
-  if (res0 != 0.0) {
-    for (; it < maxit; ++it) {
-      // ---- pass 1: A p (kept in registers) and p . A p ----
-      loc = zero;
-      {
+  T alpha_e[E], nalpha_e[E];                       // zero step for column-less elements: their r, p and x never move
+  // A p (kept in registers) and p . A p. With UPD the two updates that use the OLD p ride along, one row ahead of the
+  // stencil: x += alpha p (the LDS round trip of x hides behind the stencil's arithmetic instead of standing alone in
+  // the r update: it was 30 % of the iteration there) and p = r + beta p, own rows and the neighbouring bands' seam rows.
+  auto apply_pass = [&](auto upd, T beta) {
+    constexpr bool UPD = decltype(upd)::value;
+    loc = zero;
+    auto update_row = [&](int j) {
+      XRow xv = myx[j * 512];
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-          const T from_w = from_left(p[i][E - 1]);      // west of the lane's first element
-          const T from_e = from_right(p[i][0]);         // east of the lane's last element
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const T pc = p[i][e];
-            const T pw = (e == 0) ? from_w : p[i][e > 0 ? e - 1 : 0];
-            const T pe = (e == E - 1) ? from_e : p[i][e < E - 1 ? e + 1 : e];
-            const T ps = (i == 0) ? p_south[e] : p[i > 0 ? i - 1 : 0][e];
-            const T pn = (i == R - 1) ? p_north[e] : p[i < R - 1 ? i + 1 : i][e];
-            T a = sc_mul(st.c[0], pc);
-            a = sc_fma(st.c[1], pw, a);
-            a = sc_fma(st.c[2], pe, a);
-            a = sc_fma(st.c[3], ps, a);
-            a = sc_fma(st.c[4], pn, a);
-            if (i >= MASK_FROM) a = (i < rows) ? a : zero;   // slack row: p is zero there but the stencil sum is not
-            ap[i][e] = a;
-            loc = sc_fma(pc, a, loc);                        // column-less elements: p = 0, contributes exactly 0
-          }
-          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler look-ahead (VGPR budget)
-        }
+      for (int e = 0; e < E; ++e) {
+        xv.v[e] = sc_fma(alpha_e[e], p[j][e], xv.v[e]);
+        p[j][e] = sc_fma(beta, p[j][e], r[j][e]);
       }
+      myx[j * 512] = xv;
+    };
+    if constexpr (UPD) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        p_south[e] = sc_fma(beta, p_south[e], r_south[e]);
+        p_north[e] = sc_fma(beta, p_north[e], r_north[e]);
+      }
+      update_row(0);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if constexpr (UPD) {
+        if (i + 1 < R) update_row(i + 1);
+      }
+      const T from_w = from_left(p[i][E - 1]);      // west of the lane's first element
+      const T from_e = from_right(p[i][0]);         // east of the lane's last element
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const T pc = p[i][e];
+        const T pw = (e == 0) ? from_w : p[i][e > 0 ? e - 1 : 0];
+        const T pe = (e == E - 1) ? from_e : p[i][e < E - 1 ? e + 1 : e];
+        const T ps = (i == 0) ? p_south[e] : p[i > 0 ? i - 1 : 0][e];
+        const T pn = (i == R - 1) ? p_north[e] : p[i < R - 1 ? i + 1 : i][e];
+        T a = sc_mul(st.c[0], pc);
+        a = sc_fma(st.c[1], pw, a);
+        a = sc_fma(st.c[2], pe, a);
+        a = sc_fma(st.c[3], ps, a);
+        a = sc_fma(st.c[4], pn, a);
+        if (i >= MASK_FROM) a = (i < rows) ? a : zero;   // slack row: p is zero there but the stencil sum is not
+        ap[i][e] = a;
+        loc = sc_fma(pc, a, loc);                        // column-less elements: p = 0, contributes exactly 0
+      }
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler look-ahead (VGPR budget)
+    }
+  };
+  int it = 0;
+  if (res0 != 0.0 && maxit > 0) {
+    apply_pass(std::false_type{}, zero);
+    for (;;) {
       const T pap = block_sum_fast(loc, red, red_phase);
       const T alpha = sc_div(rr, pap);
       const T nalpha = sc_neg(alpha);
-      T alpha_e[E], nalpha_e[E];                   // zero step for column-less elements: their r, p and x never move
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         alpha_e[e] = ok_e[e] ? alpha : zero;
         nalpha_e[e] = ok_e[e] ? nalpha : zero;
       }
-      // ---- pass 2: x += alpha p (LDS) ; r -= alpha A p ; r . r ----
+      // ---- r -= alpha A p ; r . r ----
       loc = zero;
 #pragma unroll
       for (int i = 0; i < R; ++i) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          myx[(i * E + e) * 512] = sc_fma(alpha_e[e], p[i][e], myx[(i * E + e) * 512]);
           const T rv = sc_fma(nalpha_e[e], ap[i][e], r[i][e]);     // slack rows: A p = 0, r stays 0
           r[i][e] = rv;
           loc = sc_fma(rv, rv, loc);
         }
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       // the previous r seams were read right after the previous r . r reduction, i.e. before every wave passed the
       // p . A p barrier of this iteration: overwriting them here is safe
@@ -573,18 +604,17 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
       const T rrn = block_sum_fast(loc, red, red_phase);    // its barrier publishes the seams
       read_seams();
       const double res = sc_norm_from_dot(rrn);
-      if (!(res > tol * res0)) { ++it; break; }
-      const T beta = sc_div(rrn, rr);
-      // ---- pass 3: p = r + beta p in registers, own rows and the neighbouring bands' seam rows ----
+      ++it;
+      if (!(res > tol * res0) || it >= maxit) {
+        // the last step of x (the iterations before it took theirs inside apply_pass)
 #pragma unroll
-      for (int i = 0; i < R; ++i)
+        for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int e = 0; e < E; ++e) p[i][e] = sc_fma(beta, p[i][e], r[i][e]);
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        p_south[e] = sc_fma(beta, p_south[e], r_south[e]);
-        p_north[e] = sc_fma(beta, p_north[e], r_north[e]);
+          for (int e = 0; e < E; ++e) myx[i * 512].v[e] = sc_fma(alpha_e[e], p[i][e], myx[i * 512].v[e]);
+        break;
       }
+      // ---- x += alpha p ; p = r + beta p ; A p ; p . A p ----
+      apply_pass(std::true_type{}, sc_div(rrn, rr));
       rr = rrn;
     }
   }
@@ -594,7 +624,7 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
     for (int e = 0; e < E; ++e)
       if (ok_e[e] && i < rows) {
         const long c = c0 + (long)g.pitch * i + e;
-        x[c] = myx[(i * E + e) * 512];
+        x[c] = myx[i * 512].v[e];
         r_out[c] = r[i][e];
       }
   if (threadIdx.x == 0) info[0] = it;
