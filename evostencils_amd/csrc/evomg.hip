@@ -2667,7 +2667,11 @@ class FASImpl : public ImplBase {
       for (auto* q : lv.f) if (q) (void)hipFree(q);
       for (auto* q : lv.init) if (q) (void)hipFree(q);
       if (lv.next) (void)hipFree(lv.next);
+      if (lv.xchg) (void)hipFree(lv.xchg);
     }
+    if (fas_flags_) (void)hipFree(fas_flags_);
+    if (fas_info_) (void)hipFree(fas_info_);
+    if (fas_info_host_) (void)hipHostFree(fas_info_host_);
     if (partials_) (void)hipFree(partials_);
     if (dscalar_) (void)hipFree(dscalar_);
     if (hscalar_) (void)hipHostFree(hscalar_);
@@ -2727,7 +2731,7 @@ class FASImpl : public ImplBase {
     if (rc != EVOMG_OK) return rc;
     for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream_));
-    return EVOMG_OK;
+    return fas_health();
   }
   int norm(int level, int field, double* out) override {
     if (!level_ok(level) || !out || !fieldptr(level, field)) return invalid("norm: bad level/field/pointer");
@@ -2790,6 +2794,7 @@ class FASImpl : public ImplBase {
       r.conv_factor = (it > 0 && res0 > 0) ? pow(res / res0, 1.0 / (double)it) : 0.0;
       tsum += r.time_ms;
       ++done;
+      if ((rc = fas_health()) != EVOMG_OK) return rc;
       if (status != EVOMG_SOLVE_CONVERGED) break;
     }
     *out = r;
@@ -2814,6 +2819,7 @@ class FASImpl : public ImplBase {
     double* f[kFields] = {};
     double* init[kFields] = {};
     double* next = nullptr;
+    double* xchg = nullptr;      // exchange slots of evomg_fas_cgs_tiles
     Stencil<double> st{};
   };
   hipError_t alloc_zero(double** p, size_t elems) {
@@ -2886,7 +2892,23 @@ class FASImpl : public ImplBase {
         hipLaunchKernelGGL(evomg_fas_subtract, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.f[EVOMG_F_SOL], (const double*)lv.f[EVOMG_F_CORR]);
         break;
       case EVOMG_OP_FAS_CGS:
-        if (lv.g.n <= 65 && fas_cgs_one_launch_) {
+        if (lv.g.n >= 65 && lv.g.n <= 129 && fas_cgs_tiles_ && prob_.cgs_max_iterations > 0) {
+          // 65^2 (the reference's coarsest grid) and 129^2: overlapping tiles on 16 / 64 compute units (evomg_fas_cgs_tiles)
+          const int groups = fas_tiles_per_side(lv.g.n) * fas_tiles_per_side(lv.g.n);
+          if (!lv.xchg) HIP_TRY(hipMalloc(&lv.xchg, 2 * lv.elems * sizeof(double)));
+          if (!fas_flags_) {
+            HIP_TRY(hipMalloc(&fas_flags_, sizeof(unsigned) * 64));
+            HIP_TRY(hipMalloc(&fas_info_, sizeof(int)));
+            HIP_TRY(hipMemsetAsync(fas_info_, 0, sizeof(int), stream_));
+            HIP_TRY(hipHostMalloc(&fas_info_host_, sizeof(int)));
+            *fas_info_host_ = 0;
+          }
+          HIP_TRY(hipMemsetAsync(fas_flags_, 0, sizeof(unsigned) * 64, stream_));
+          hipLaunchKernelGGL(evomg_fas_cgs_tiles, dim3(groups), dim3(1024), 0, stream_, lv.g, lv.st, gam, lv.f[EVOMG_F_SOL], lv.next,
+                             (const double*)lv.f[EVOMG_F_RHS], prob_.fas_cgs_omega, prob_.cgs_max_iterations, lv.xchg, fas_flags_, fas_info_);
+          fas_tiles_used_ = true;
+          if (prob_.cgs_max_iterations & 1) std::swap(lv.f[EVOMG_F_SOL], lv.next);
+        } else if (lv.g.n <= 65 && fas_cgs_one_launch_) {
           // all sweeps in one single-workgroup launch (evomg_fas.h); an odd count leaves the result in the other slot
           if (fas_cgs_lds_) {
             // both slots in LDS for the whole call (evomg_fas_cgs_lds)
@@ -2939,6 +2961,22 @@ class FASImpl : public ImplBase {
   int device_;
   bool fas_cgs_one_launch_ = getenv("EVOMG_NO_FAS_CGS_KERNEL") == nullptr;
   bool fas_cgs_lds_ = getenv("EVOMG_NO_FAS_CGS_LDS") == nullptr;      // ... with both slots in LDS
+  bool fas_cgs_tiles_ = getenv("EVOMG_NO_FAS_CGS_TILES") == nullptr;  // 65^2 / 129^2: overlapping tiles on several compute units
+  bool fas_tiles_used_ = false;
+  unsigned* fas_flags_ = nullptr;
+  int* fas_info_ = nullptr;
+  int* fas_info_host_ = nullptr;
+  // a missed rendezvous of the tiled coarse sweeps is an error, not a hang (call after a stream synchronisation point)
+  int fas_health() {
+    if (!fas_tiles_used_) return EVOMG_OK;
+    HIP_TRY(hipMemcpyAsync(fas_info_host_, fas_info_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (*fas_info_host_ != 0) {
+      snprintf(err, sizeof err, "FAS coarse sweeps: the workgroups did not rendezvous (GPU oversubscribed?)");
+      return EVOMG_ERR_DEVICE;
+    }
+    return EVOMG_OK;
+  }
   bool fas_lds_attr_set_ = false;
   FLevel lv_[EVOMG_MAX_LEVELS];
   hipStream_t stream_ = nullptr;

@@ -9,6 +9,7 @@
 //   A(X; S) := ( ( Laplace * X ) + ( gamSten * X ) ),  gamSten = gam * exp( S )
 #pragma once
 #include "evomg_kernels.h"
+#include "evomg_krylov.h"   // the cross-workgroup exchange primitives (xchg_store / xchg_load / grid_publish)
 
 // `centre`: the value of X at the node (the smoother's local iterate); s: Solution at the node (what gamSten reads)
 __device__ __forceinline__ double fas_apply(const Stencil<double>& st, double gam, const double* x, const Geo& g, long c, double centre, double s) {
@@ -168,4 +169,111 @@ __global__ void __launch_bounds__(1024) evomg_fas_cgs_lds(Geo g, Stencil<double>
     out_last[c] = cur[lq[e]];
     if (sweeps > 0) out_prev[c] = nxt[lq[e]];
   }
+}
+
+// ---- CGS@coarsest across several compute units: overlapping tiles, a rendezvous every nine sweeps ------------------------
+// The 200 Newton-Jacobi sweeps on 65^2 are VALU bound on ONE compute unit (an exponential and a division per node:
+// ~70 FP64 operations x 4 nodes per thread, 2.25 us per sweep, 75 % of a FAS solve at levels 6..10). A rendezvous per
+// sweep would cost more than the sweep (1.0-1.8 us, profiles/r03_rendezvous.md), so the grid is cut into 16 x 16 tiles with
+// a halo of EIGHT nodes: a workgroup holds the 32 x 32 extended tile (one node per thread) plus one read-only ring in LDS
+// and runs NINE sweeps on a region that shrinks by one node per sweep — sweep s of a round updates the nodes at least s
+// away from the extended tile's edge, which read only values that sweep s - 1 computed from true data — after which
+// exactly the owned tile is still exact. Then the owned values are published (agent-scope stores, one sequence flag per
+// workgroup, as evomg_cg_multi_wg3d), every workgroup waits for all flags (bounded: a peer that never arrives sets
+// info[0] = 1 instead of hanging) and reloads its extended tile. The redundant halo work is 2.6x the nodes, spread over
+// 16 compute units; the per-node formula is fas_relax(.., newton = 1, n_steps = 1) = evomg_fas_cgs_lds: bit-identical.
+// Two LDS images alternate by the parity of the GLOBAL sweep number; each carries the boundary values of its global
+// slot (a: even, b: odd), as the global-memory form does. a / b afterwards: as evomg_fas_cgs_lds.
+// xchg: [2][pitch * n] exchange slots (alternating by round); flags: [groups], zeroed by the host.
+#define EVOMG_FAS_TILE 16
+#define EVOMG_FAS_HALO 8
+__host__ __device__ inline int fas_tiles_per_side(int n) { return (n - 2 + EVOMG_FAS_TILE - 1) / EVOMG_FAS_TILE; }
+__device__ __forceinline__ bool grid_wait(const unsigned* flags, int groups, unsigned seq, int* lds_flag) {
+  if (threadIdx.x == 0) *lds_flag = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < groups) {
+    int budget = 1 << 22;
+    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+      if (--budget == 0) { *lds_flag = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  return *lds_flag == 0;
+}
+__global__ void __launch_bounds__(1024) evomg_fas_cgs_tiles(Geo g, Stencil<double> st, double gam, double* a, double* b, const double* f,
+                                                            double om, int sweeps, double* xchg, unsigned* flags, int* info) {
+  constexpr int T = EVOMG_FAS_TILE, H = EVOMG_FAS_HALO, W = T + 2 * H, IW = W + 2;
+  static_assert(W * W == 1024, "one node of the extended tile per thread");
+  __shared__ double img[2][IW * IW];
+  __shared__ int lds_flag;
+  const int n = g.n, m = n - 2;
+  const int tiles = fas_tiles_per_side(n), groups = tiles * tiles;          // gridDim.x == groups (host)
+  const int w = (int)blockIdx.x, tx = w % tiles, ty = w / tiles;
+  const int tid = (int)threadIdx.x, lx = tid % W, ly = tid / W;
+  const int gi = tx * T + 1 - H + lx, gj = ty * T + 1 - H + ly;             // this thread's node
+  const bool inner = gi >= 1 && gi <= m && gj >= 1 && gj <= m;
+  const bool owned = inner && lx >= H && lx < H + T && ly >= H && ly < H + T;
+  const long c = inner ? gidx<2>(g, gi, gj, 0) : 0;
+  const double fv = inner ? f[c] : 0.0;
+  const int me = (ly + 1) * IW + lx + 1;
+  const size_t slot = (size_t)g.pitch * n;
+  unsigned seq = 0;
+  bool alive = true;
+  double prev = 0.0, last = 0.0;
+  const double* src = a;             // where the field after `done` sweeps lies (inner nodes)
+  bool src_plain = true;             // ... written before this launch (plain loads) or by peers during it
+  int done = 0;
+  while (done < sweeps && alive) {
+    const int todo = (sweeps - done) < H + 1 ? (sweeps - done) : H + 1;
+    const int p0 = done & 1;
+    for (int q = tid; q < IW * IW; q += 1024) {
+      const int ei = tx * T - H + q % IW, ej = ty * T - H + q / IW;         // the node behind image position q
+      double v0 = 0.0, v1 = 0.0;                                           // image p0 (the field now) and the other one
+      if (ei >= 0 && ei < n && ej >= 0 && ej < n) {
+        const long cq = gidx<2>(g, ei, ej, 0);
+        if (ei >= 1 && ei <= m && ej >= 1 && ej <= m) v0 = src_plain ? src[cq] : xchg_load(src + cq);
+        else {                                                              // each slot keeps its own boundary values
+          v0 = (p0 ? b : a)[cq];
+          v1 = (p0 ? a : b)[cq];
+        }
+      }
+      img[p0][q] = v0;
+      img[p0 ^ 1][q] = v1;
+    }
+    __syncthreads();
+    for (int s = 0; s < todo; ++s) {
+      const int cur = (done + s) & 1;
+      if (inner && lx >= s && lx < W - s && ly >= s && ly < W - s) {
+        const double* im = img[cur];
+        const double u = im[me];
+        double ap = st.c[0] * u;
+        ap = ap + st.c[1] * im[me - 1];
+        ap = ap + st.c[2] * im[me + 1];
+        ap = ap + st.c[3] * im[me - IW];
+        ap = ap + st.c[4] * im[me + IW];
+        const double ex = exp(u);
+        ap = ap + (gam * ex) * u;
+        const double num = fv - ap;
+        const double den = st.c[0] + (gam * (u + 1.0)) * ex;
+        const double un = u + om * (num / den);
+        img[cur ^ 1][me] = un;
+        prev = u;
+        last = un;
+      }
+      __syncthreads();
+    }
+    done += todo;
+    double* dst = xchg + (size_t)(seq & 1) * slot;
+    if (owned) xchg_store(dst + c, last);
+    grid_publish(flags, w, ++seq);
+    alive = grid_wait(flags, groups, seq, &lds_flag);
+    src = dst;
+    src_plain = false;
+  }
+  if (alive && sweeps > 0 && owned) {
+    ((sweeps & 1) ? b : a)[c] = last;
+    ((sweeps & 1) ? a : b)[c] = prev;
+  }
+  if (!alive && tid == 0) info[0] = 1;
 }

@@ -104,11 +104,13 @@ def test_generate_and_evaluate_at_the_reference_size(native):
     gen.close()
 
 
-@pytest.mark.parametrize("level,sweeps", [(6, 200), (5, 7), (3, 1)])
+@pytest.mark.parametrize("level,sweeps", [(6, 200), (6, 13), (6, 9), (6, 10), (6, 1), (7, 21), (5, 7), (3, 1)])
 def test_coarse_sweeps_in_lds_are_bit_identical(native, level, sweeps, monkeypatch):
-    """CGS@coarsest: all Newton-Jacobi sweeps in one launch with both slots in LDS (evomg_fas_cgs_lds), in one launch with
-    the slots in global memory (EVOMG_NO_FAS_CGS_LDS) and one launch per sweep (EVOMG_NO_FAS_CGS_KERNEL): the same formula
-    in the same order, so the same bits — even and odd sweep counts (the result's slot alternates)."""
+    """CGS@coarsest: the Newton-Jacobi sweeps on overlapping tiles across 16 / 64 compute units with a rendezvous every nine
+    sweeps (evomg_fas_cgs_tiles: 65^2 and 129^2), in one launch with both slots in LDS (evomg_fas_cgs_lds), in one launch
+    with the slots in global memory and one launch per sweep: the same formula in the same order, so the same bits —
+    sweep counts that are even, odd, one round, one round plus one, a single sweep (the result's slot alternates; the
+    slot of the sweep before the last is part of the contract too)."""
     import dataclasses
     _, pd, _ = fas_problem(level, level + 1)
     pd = dataclasses.replace(pd, cgs_max_iterations=sweeps)
@@ -117,18 +119,24 @@ def test_coarse_sweeps_in_lds_are_bit_identical(native, level, sweeps, monkeypat
     u0 = np.zeros((n, n)); u0[1:-1, 1:-1] = 0.3 * rng.standard_normal((n - 2, n - 2))
     f0 = np.zeros((n, n)); f0[1:-1, 1:-1] = 50.0 * rng.standard_normal((n - 2, n - 2))
     op = abi.make_op(abi.OP_FAS_CGS, level, abi.F_SOL, 0, abi.F_RHS)
+    # one more Jacobi sweep afterwards reads the slot the coarse sweeps left as "next": its boundary must be intact
+    after = [abi.make_op(abi.OP_FAS_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (1, 1, 1), 0.8),
+             abi.make_op(abi.OP_FAS_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)]
     results = []
-    for knob in (None, "EVOMG_NO_FAS_CGS_LDS", "EVOMG_NO_FAS_CGS_KERNEL"):
-        if knob:
+    for knobs in ((), ("EVOMG_NO_FAS_CGS_TILES",), ("EVOMG_NO_FAS_CGS_TILES", "EVOMG_NO_FAS_CGS_LDS"),
+                  ("EVOMG_NO_FAS_CGS_TILES", "EVOMG_NO_FAS_CGS_KERNEL")):
+        for knob in knobs:
             monkeypatch.setenv(knob, "1")
         h = native.create(pd)
         h.set_field(level, abi.F_SOL, u0)
         h.set_field(level, abi.F_RHS, f0)
-        h.run_ops([op, abi.make_op(abi.OP_FAS_RESIDUAL, level, abi.F_RES, abi.F_SOL, abi.F_RHS)])
-        results.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
+        h.run_ops([op])
+        first = h.get_field(level, abi.F_SOL)
+        h.run_ops(after)
+        results.append((first, h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
         h.close()
-        if knob:
+        for knob in knobs:
             monkeypatch.delenv(knob)
     for got in results[1:]:
-        assert np.array_equal(got[0], results[0][0]) and np.array_equal(got[1], results[0][1])
+        assert all(np.array_equal(x, y) for x, y in zip(got, results[0]))
     assert not np.array_equal(results[0][0], u0)
