@@ -16,9 +16,12 @@
 #include <vector>
 
 #include "../../include/evomg.h"
+#include <cstdint>
+#include <set>
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
+#include "evomg_small2d.h"
 #include "evomg_tile3d.h"
 #include "evomg_batch.h"
 #include "evomg_strip_block.h"
@@ -319,6 +322,10 @@ template <typename T> class Impl : public ImplBase {
       case EVOMG_OP_SMOOTH: {
         const int cells = op->block[0] * op->block[1] * (dim_ == 3 ? op->block[2] : 1);
         base = cells > 1 ? (block_fast_ ? "evomg_block_jacobi_fast" : "evomg_block_jacobi") : op->partitioning == EVOMG_PART_RED_BLACK ? "evomg_rbgs_colour" : "evomg_jacobi";
+        if (cells == 1 && use_strip(lv_[op->level].g) && small2d_ok(lv_[op->level].g)) {
+          snprintf(buf, len, "evomg_small2d<%s, %d, ", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI);
+          return EVOMG_OK;
+        }
         if (cells == 1 && use_strip(lv_[op->level].g)) {
           snprintf(buf, len, "evomg_strip2d<%s, %d, 2, %s>", type_name<T>::get(), op->partitioning == EVOMG_PART_RED_BLACK ? STRIP_RBGS : STRIP_JACOBI, strip_streams(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
@@ -1140,6 +1147,20 @@ template <typename T> class Impl : public ImplBase {
     if (best_cost < 0 && lo == 8 && quantum == 2 && ((long)strips * ((n + 7) / 8) + 3) / 4 < n_cu_) return 4;
     return best;
   }
+  // point smoothers on grids up to 65^2: one workgroup, the field in LDS (evomg_small2d.h); same results as the strip form
+  bool small2d_ok(const Geo& g) const { return small2d_enabled_ && dim_ == 2 && g.n <= 65; }
+  template <int MODE, bool PRO, bool TAILR, bool XZ>
+  void launch_small2d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, double rkh, int rout,
+                      const ProlongIn<T>& pro) {
+    auto kern = evomg_small2d<T, MODE, PRO, TAILR, XZ>;
+    const size_t lds_bytes = (size_t)((MODE == STRIP_JACOBI || TAILR) ? 2 : 1) * g.n * g.n * sizeof(T);
+    const void* key = reinterpret_cast<const void*>(kern);
+    if (lds_bytes > 48 * 1024 && !small2d_attr_set_.count(key)) {
+      (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+      small2d_attr_set_.insert(key);
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_bytes, stream_, g, st, x, f, y, om, omm, rkh, rout, pro);
+  }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
     // enough waves to fill 256 CUs several times over, but chunks tall enough to amortise the vertical halo
@@ -1159,6 +1180,11 @@ template <typename T> class Impl : public ImplBase {
     const ProlongIn<T> pro{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0};
     const int rout = (bc_out && strip_bc_) ? 1 : 0;
     if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RBGS) {
+      if (small2d_ok(g)) {      // up to 65^2: the whole field in LDS (evomg_small2d.h)
+        if (take_x_zero()) launch_small2d<MODE, false, false, true>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
+        else launch_small2d<MODE, false, false, false>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
+        return;
+      }
       if (take_x_zero()) {      // SET_ZERO elided: zero-input variant (small levels: never streams)
         hipLaunchKernelGGL((evomg_strip2d<T, MODE, 2, false, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, robin_kh, (T*)nullptr, rout, pro);
         return;
@@ -1198,6 +1224,12 @@ template <typename T> class Impl : public ImplBase {
     const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
     const int rout = (robin && strip_bc_) ? 1 : 0;
+    if constexpr (PRO && !TAIL) {
+      if (small2d_ok(g)) {
+        launch_small2d<MODE, true, false, false>(g, st, x, f, y, om, omm, rkh, rout, pro);
+        return EVOMG_OK;
+      }
+    }
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, parts, rout, pro);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, PRO, TAIL>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, parts, rout, pro);
     return EVOMG_OK;
@@ -1218,6 +1250,11 @@ template <typename T> class Impl : public ImplBase {
     const double rkhc = robin ? prob_.wavenumber / (double)(gc.n - 1) : 0.0;
     const int rout = (robin && strip_bc_) ? 1 : 0;
     const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc};
+    if (small2d_ok(g)) {
+      if (take_x_zero()) launch_small2d<MODE, false, true, true>(g, st, x, f, y, om, omm, rkh, rout, pro);
+      else launch_small2d<MODE, false, true, false>(g, st, x, f, y, om, omm, rkh, rout, pro);
+      return;
+    }
     if (take_x_zero()) {
       hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
       return;
@@ -2194,6 +2231,8 @@ template <typename T> class Impl : public ImplBase {
   bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
+  bool small2d_enabled_ = getenv("EVOMG_NO_SMALL2D") == nullptr;
+  std::set<const void*> small2d_attr_set_;
   bool batch_enabled_ = (getenv("EVOMG_BATCH") != nullptr) && (getenv("EVOMG_NO_STRIP") == nullptr);
   int batch_max_n_ = getenv("EVOMG_BATCH_MAX_N") ? atoi(getenv("EVOMG_BATCH_MAX_N")) : 129;
   MicroBatch batch_ = {};

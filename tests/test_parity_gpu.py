@@ -740,3 +740,32 @@ def test_large_coarsest_grids_run_bicgstab_as_launches(native, oracle, kind, lo)
         assert np.array_equal(got[0][0], got[1][0]), (kind, lo, cap)
         assert np.array_equal(got[0][1][1:-1, :], got[1][1][1:-1, :]), (kind, lo, cap)
         assert not np.array_equal(got[0][0], x0)
+
+
+@pytest.mark.parametrize("kind,smoother,pre,post", [("poisson", "rbgs", 1, 1), ("poisson", "jacobi", 2, 1), ("helmholtz", "rbgs", 2, 1),
+                                                    ("helmholtz", "jacobi", 1, 2), ("poisson", "rbgs", 0, 2)])
+def test_small_grid_lds_sweeps_do_not_change_a_bit(native, kind, smoother, pre, post, monkeypatch):
+    """Point smoothers on grids up to 65^2 with the field in LDS (evomg_small2d: plain, zero-input, prolongation + sweep,
+    sweep + residual + restriction, the Robin columns of Helmholtz problems at every stage) against the marching-strip
+    kernels they replace (EVOMG_NO_SMALL2D): identical residual histories, solutions, residuals and coarse right-hand
+    sides on every level of a 9^2 .. 129^2 hierarchy."""
+    from test_full_size_gpu import vcycle
+    lo, hi = 3, 7
+    pd = problems.poisson_2d(lo, hi) if kind == "poisson" else problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
+    part, om = (abi.PART_RED_BLACK, 1.1 if kind == "poisson" else 0.6) if smoother == "rbgs" else (abi.PART_SINGLE, 0.8 if kind == "poisson" else 0.6)
+    ops = vcycle(lo, hi, pre, post, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, (1, 1, 1), om))
+    results = []
+    for knob in (None, "EVOMG_NO_SMALL2D"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 64)
+        results.append((out, [h.get_field(L, f) for L in range(lo + 1, hi + 1) for f in (abi.F_SOL, abi.F_RHS)] + [h.get_field(hi, abi.F_RES)]))
+        h.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    (a, fa), (b, fb) = results
+    assert a.n_iterations == b.n_iterations and a.n_iterations >= 1
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
