@@ -255,11 +255,21 @@ __global__ void __launch_bounds__(512) evomg_sys_cg_small(Geo g, SysStencil st, 
   const int a = 1 + k % m, bb = 1 + k / m;
   const long c = (long)g.pitch * bb + a;
   const int li = u * nn + bb * n + a;
-  auto apply_row = [&](int i) {
-    double s = 0.0;
-    for (int j = 0; j < nf; ++j)
+  // the thread's matrix row in registers: indexed by the thread's unknown, the by-value stencil would otherwise be re-read
+  // from the kernel-argument segment with eighteen global loads in every iteration (2.0 -> 1.x us per iteration)
+  double cf[EVOMG_MAX_UNKNOWNS][9];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) s = s + st.a[i][j][e] * sys_img[j * nn + (bb + sys_oy(e)) * n + a + sys_ox(e)];
+  for (int j = 0; j < EVOMG_MAX_UNKNOWNS; ++j)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) cf[j][e] = j < nf ? st.a[u][j][e] : 0.0;
+  auto apply_row = [&](int) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < EVOMG_MAX_UNKNOWNS; ++j)
+      if (j < nf) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) s = s + cf[j][e] * sys_img[j * nn + (bb + sys_oy(e)) * n + a + sys_ox(e)];
+      }
     return s;
   };
   // image of x (all nodes, boundary included) for the initial residual
