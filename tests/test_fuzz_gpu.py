@@ -112,6 +112,31 @@ def test_random_programs_are_bit_exact(native, oracle, dim, lo, hi, seed, semant
     ho.close()
 
 
+@pytest.mark.parametrize("lo,hi,seed,semantics", [(3, 7, s, "textbook") for s in range(4)] + [(4, 8, s, "exastencils-v1.1") for s in range(4, 7)])
+def test_random_programs_on_helmholtz_are_bit_exact(native, oracle, lo, hi, seed, semantics):
+    """The same random programs on the complex Helmholtz problem: Robin columns after every op that writes a field, the
+    LDS-resident small-level sweeps, the one-wave BiCGStab on the coarsest grid — every field of every level bit for bit
+    (tools/fuzz_more.py runs as many further seeds as one likes)."""
+    pd = with_semantics(problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi)), semantics)
+    rng = np.random.default_rng(500 + 31 * seed + lo)
+    ops = random_program(rng, 2, lo, hi, 28)
+    hg, ho = native.create(pd), oracle.create(pd)
+    for L in range(lo, hi + 1):
+        shape = hg.field_shape(L)
+        for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+            a = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+            hg.set_field(L, f, a)
+            ho.set_field(L, f, a)
+    hg.run_ops(ops)
+    ho.run_ops(ops)
+    for L in range(lo, hi + 1):
+        for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+            got, want = hg.get_field(L, f), ho.get_field(L, f)
+            assert np.array_equal(got, want, equal_nan=True), (seed, L, f, np.nanmax(np.abs(got - want)))
+    hg.close()
+    ho.close()
+
+
 CYCLES = ([(2, 3, 7, s) for s in range(6)] + [(3, 2, 5, s) for s in range(6)] + [(2, 5, 9, 6), (2, 5, 9, 7), (3, 3, 6, 8), (3, 4, 7, 9)])
 
 
