@@ -2051,6 +2051,7 @@ template <typename T> class Impl : public ImplBase {
     // one pass; A u with the dot product(s) of its result; the last update of the residual with its norm and the next
     // iteration's rho. Per iteration: 670 MB of 2049^2 complex traffic and two of five host round trips less.
     const bool fuse = outer_fuse_;
+    const bool dev_steps = fuse && outer_dev_steps_;
     bool rhs_written = false;
     for (int i = 0; i < n_ops; ++i) {
       bool reads;
@@ -2109,19 +2110,43 @@ template <typename T> class Impl : public ImplBase {
         if ((rc = precondition(p)) != EVOMG_OK) return rc;
         T* u = fieldptr(L, EVOMG_F_SOL);
         T ra;
-        if (fuse) {
+        if (dev_steps) {
+          // alpha and omega are formed and consumed on the device (evomg_dot_final_quot: dscalar_[2], [3]); the host reads
+          // them with the residual norm at the end of the iteration — one round trip per iteration instead of three
           hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
-          if ((rc = fetch_dots(1, &ra, &ra)) != EVOMG_OK) return rc;
+          hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 1, rho_new, dscalar_, 2);
+          hipLaunchKernelGGL((evomg_axpy_pair_dev<T>), node_grid(g), node_block(), 0, stream_, g, hh, (const T*)Sol, (const T*)u, s, (const T*)Res, (const T*)ap,
+                             (const T*)(dscalar_ + 2));
         } else {
-          apply_operator(L, outer_st_, u, ap);
-          if ((rc = dot_to_host(L, rhat, ap, &ra)) != EVOMG_OK) return rc;
+          if (fuse) {
+            hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
+            if ((rc = fetch_dots(1, &ra, &ra)) != EVOMG_OK) return rc;
+          } else {
+            apply_operator(L, outer_st_, u, ap);
+            if ((rc = dot_to_host(L, rhat, ap, &ra)) != EVOMG_OK) return rc;
+          }
+          alpha = sc_div(rho_new, ra);
+          axpy(L, hh, Sol, alpha, u);
+          axpy(L, s, Res, sc_neg(alpha), ap);
         }
-        alpha = sc_div(rho_new, ra);
-        axpy(L, hh, Sol, alpha, u);
-        axpy(L, s, Res, sc_neg(alpha), ap);
         if ((rc = precondition(s)) != EVOMG_OK) return rc;
         u = fieldptr(L, EVOMG_F_SOL);
         T ts, tt;
+        if (dev_steps) {
+          hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
+          hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 2, one, dscalar_, 3);
+          hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u);
+          apply_bc(L, Sol);
+          hipLaunchKernelGGL((evomg_axpy_dots_dev<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, (const T*)(dscalar_ + 3), (const T*)t, (const T*)rhat, partials_);
+          hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_);
+          HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T) * 4, hipMemcpyDeviceToHost, stream_));
+          HIP_TRY(hipStreamSynchronize(stream_));
+          d = hscalar_[0];
+          rho_next = hscalar_[1];
+          alpha = hscalar_[2];
+          omega = hscalar_[3];
+          have_rho = true;
+        } else {
         if (fuse) {
           hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
           if ((rc = fetch_dots(2, &ts, &tt)) != EVOMG_OK) return rc;
@@ -2140,6 +2165,7 @@ template <typename T> class Impl : public ImplBase {
         } else {
           axpy(L, Res, s, sc_neg(omega), t);
           if ((rc = dot_to_host(L, Res, Res, &d)) != EVOMG_OK) return rc;
+        }
         }
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
@@ -2210,6 +2236,7 @@ template <typename T> class Impl : public ImplBase {
   KbState<T>* kb_host_ = nullptr;
   T* kb_scal_ = nullptr;
   bool outer_fuse_ = getenv("EVOMG_NO_OUTER_FUSE") == nullptr;      // fused passes of the preconditioned BiCGStab loop
+  bool outer_dev_steps_ = getenv("EVOMG_NO_OUTER_DEV_STEPS") == nullptr;   // ... with alpha and omega formed on the device
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
   T* norm_partials_ = nullptr;
   size_t norm_partials_cap_ = 0;

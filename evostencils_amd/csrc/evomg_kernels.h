@@ -664,6 +664,73 @@ __global__ void __launch_bounds__(256) evomg_axpy_dots(Geo g, T* __restrict__ z,
   s1 = block_sum(s1, red);
   if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = s1;
 }
+// ---- the outer BiCGStab's step lengths formed and consumed on the device ------------------------------------------------
+// alpha = rho' / (rhat . A u) and omega = (t . s) / (t . t) are needed only by the very next vector updates: a final
+// reduction that also forms the quotient (evomg_dot_final_quot), and updates that read it from device memory, take the
+// host out of two of the three round trips of an iteration. Same operations on the same values as the host loop's
+// sc_div: the same bits. scal[0 .. 1]: the dot product(s); scal[slot]: the quotient.
+//   ndot == 1: scal[slot] = num / dot0          ndot == 2: scal[slot] = dot0 / dot1
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_dot_final_quot(const T* __restrict__ partial, int count, int ndot, T num, T* __restrict__ scal, int slot) {
+  __shared__ T red[17];
+  T d[2] = {scalar_traits<T>::zero(), scalar_traits<T>::zero()};
+  for (int k = 0; k < ndot; ++k) {
+    T s = scalar_traits<T>::zero();
+    for (int i = threadIdx.x; i < count; i += blockDim.x) s = sc_add(s, partial[(long)k * count + i]);
+    d[k] = block_sum(s, red);
+  }
+  if (threadIdx.x == 0) {
+    scal[0] = d[0];
+    if (ndot > 1) scal[1] = d[1];
+    scal[slot] = ndot == 1 ? sc_div(num, d[0]) : sc_div(d[0], d[1]);
+  }
+}
+// z1 = x1 + a y1 ; z2 = x2 - a y2 on inner nodes, a = *ap (two independent axpy steps in one pass)
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_axpy_pair_dev(Geo g, T* __restrict__ z1, const T* __restrict__ x1, const T* __restrict__ y1,
+                                                           T* __restrict__ z2, const T* __restrict__ x2, const T* __restrict__ y2,
+                                                           const T* __restrict__ ap) {
+  int i, j, k;
+  if (!node_of_thread<2>(g, i, j, k)) return;
+  if (!is_inner<2>(g, i, j, k)) return;
+  const long c = gidx<2>(g, i, j, k);
+  const T a = *ap;
+  z1[c] = sc_add(x1[c], sc_mul(a, y1[c]));
+  z2[c] = sc_add(x2[c], sc_mul(sc_neg(a), y2[c]));
+}
+// z = x + a y on inner nodes, a = *ap
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_axpy_dev(Geo g, T* __restrict__ z, const T* __restrict__ x, const T* __restrict__ ap,
+                                                      const T* __restrict__ y) {
+  int i, j, k;
+  if (!node_of_thread<2>(g, i, j, k)) return;
+  if (!is_inner<2>(g, i, j, k)) return;
+  const long c = gidx<2>(g, i, j, k);
+  z[c] = sc_add(x[c], sc_mul(*ap, y[c]));
+}
+// evomg_axpy_dots with a = -(*ap)
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_axpy_dots_dev(Geo g, T* __restrict__ z, const T* __restrict__ x, const T* __restrict__ ap,
+                                                           const T* __restrict__ y, const T* __restrict__ w, T* __restrict__ partial) {
+  __shared__ T red[17];
+  const int m = g.n - 2;
+  const T a = sc_neg(*ap);
+  T s0 = scalar_traits<T>::zero(), s1 = scalar_traits<T>::zero();
+  for (long r = blockIdx.x; r < m; r += gridDim.x) {
+    const long base = gidx<2>(g, 0, 1 + (int)r, 0);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
+      const long c = base + i;
+      const T zv = sc_add(x[c], sc_mul(a, y[c]));
+      z[c] = zv;
+      s0 = sc_add(s0, sc_mul(zv, zv));
+      s1 = sc_add(s1, sc_mul(w[c], zv));
+    }
+  }
+  s0 = block_sum(s0, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s0;
+  s1 = block_sum(s1, red);
+  if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = s1;
+}
 // z = x2 + b (x1 + a y1) on inner nodes: two consecutive axpy steps (z = x1 + a y1, then z = x2 + b z) in one pass
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_axpy2(Geo g, T* __restrict__ z, const T* __restrict__ x1, T a, const T* __restrict__ y1,
