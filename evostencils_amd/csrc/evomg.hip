@@ -542,10 +542,14 @@ template <typename T> class Impl : public ImplBase {
   // COPY gen_rhs@min = ..., SET_ZERO gen_error@min, COARSE_SOLVE@min (what every cycle emits around gen_mgCycle@min,
   // exastencils.py:890-896) on a grid the one-wave CG serves: ONE launch instead of three
   bool fusable_copy_zero_solve(const evomg_op_t* ops, int n_ops, int i) const {
-    if (!fuse_enabled_ || !use_reg_krylov_ || i + 2 >= n_ops || dim_ != 2 || scalar_traits<T>::is_complex) return false;
-    if (prob_.cgs_kind != EVOMG_CGS_CG || prob_.bc_kind != EVOMG_BC_DIRICHLET) return false;
-    const evomg_op_t &cp = ops[i], &z = ops[i + 1], &cs = ops[i + 2];
+    if (!fuse_enabled_ || !use_reg_krylov_ || i + 2 >= n_ops || dim_ != 2) return false;
     const int L = prob_.min_level;
+    // the one-wave CG (real, Dirichlet) or the one-wave BiCGStab (up to 9^2, real or complex with its Robin columns)
+    const bool cg_case = !scalar_traits<T>::is_complex && prob_.cgs_kind == EVOMG_CGS_CG && prob_.bc_kind == EVOMG_BC_DIRICHLET;
+    const bool bicg_case = prob_.cgs_kind == EVOMG_CGS_BICGSTAB && lv_[L].g.n <= 9 &&
+                           (prob_.bc_kind == EVOMG_BC_DIRICHLET || (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && scalar_traits<T>::is_complex));
+    if (!cg_case && !bicg_case) return false;
+    const evomg_op_t &cp = ops[i], &z = ops[i + 1], &cs = ops[i + 2];
     if (cp.opcode != EVOMG_OP_COPY || z.opcode != EVOMG_OP_SET_ZERO || cs.opcode != EVOMG_OP_COARSE_SOLVE) return false;
     if (cp.level != L || z.level != L || cs.level != L) return false;
     if (canon(L, cp.dst) != EVOMG_F_CGS_RHS || canon(L, cp.src0) == EVOMG_F_CGS_RHS) return false;
@@ -554,7 +558,7 @@ template <typename T> class Impl : public ImplBase {
     // "x = 0, so r = b" needs the boundary values of x to be zero as well (SET_ZERO leaves them alone); true for every
     // error field of a cycle, not for a field a test filled with random numbers
     if (!bnd_zero_[L][canon(L, EVOMG_F_CORR)]) return false;
-    return krylov_own<2>(lv_[L].g.n, true).wave != 0;
+    return bicg_case || krylov_own<2>(lv_[L].g.n, true).wave != 0;
   }
   bool fusable_residual_restrict(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || i + 1 >= n_ops) return false;
@@ -1603,6 +1607,20 @@ template <typename T> class Impl : public ImplBase {
     T* x = fieldptr(L, EVOMG_F_CORR);
     const T* b = fieldptr(L, EVOMG_F_CGS_RHS);
     T* r = fieldptr(L, EVOMG_F_RES);
+    if (copy_op && prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
+      const T* src = fieldptr(L, copy_op->src0);
+      T* cgs = fieldptr(L, EVOMG_F_CGS_RHS);
+      if (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN)
+        hipLaunchKernelGGL((evomg_bicgstab_wave2d<T, true, true>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, src, r, prob_.cgs_max_iterations,
+                           prob_.cgs_target_res_reduction, kh(L), dinfo_, cgs);
+      else
+        hipLaunchKernelGGL((evomg_bicgstab_wave2d<T, false, true>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, src, r, prob_.cgs_max_iterations,
+                           prob_.cgs_target_res_reduction, 0.0, dinfo_, cgs);
+      bnd_zero_[L][canon(L, copy_op->dst)] = bnd_zero_[L][canon(L, copy_op->src0)];     // the COPY's bookkeeping
+      lv.alt_mirror = nullptr;
+      HIP_TRY(hipGetLastError());
+      return EVOMG_OK;
+    }
     if (copy_op) {
       if constexpr (!scalar_traits<T>::is_complex) {
         const T* src = fieldptr(L, copy_op->src0);

@@ -352,10 +352,13 @@ template <typename T> __device__ __forceinline__ T lane_value(T v, int src);
 template <> __device__ __forceinline__ double lane_value<double>(double v, int src) { return __shfl(v, src, 64); }
 template <> __device__ __forceinline__ cplx lane_value<cplx>(cplx v, int src) { return cplx{__shfl(v.re, src, 64), __shfl(v.im, src, 64)}; }
 
-template <typename T, bool ROBIN>
+// XZERO (the COPY to the solver's right-hand side and the SET_ZERO of x in front of the solve folded in, as in
+// evomg_cg_wave2d): f is the copy's source, the copy itself is written to copy_dst, x is not read — its inner nodes and
+// Robin columns are zero by the SET_ZERO, its Dirichlet rows by the caller's bookkeeping — so r = f.
+template <typename T, bool ROBIN, bool XZERO = false>
 __global__ void __launch_bounds__(64)
 evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r_out, int maxit, double tol,
-                      double kh, int* __restrict__ info) {
+                      double kh, int* __restrict__ info, T* __restrict__ copy_dst = nullptr) {
   const int m = g.n - 2;                         // host-checked: 1 <= m <= 7
   const int l = threadIdx.x, col = l >> 3, row = l & 7;
   const bool own = col < m && row < m;
@@ -382,9 +385,17 @@ evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restri
     return own ? a : zero;
   };
   auto dot = [&](T a, T b) -> T { return first_lane(wave_sum_fast(sc_fma(a, b, zero))); };
-  T xv = x[c];
-  T r = own ? sc_sub(f[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
-  if (!own) xv = zero;
+  T xv = zero, r;
+  if constexpr (XZERO) {
+    for (int q = l; q < g.n * g.n; q += 64) {
+      const long cq = gidx<2>(g, q % g.n, q / g.n, 0);
+      copy_dst[cq] = f[cq];
+    }
+    r = own ? f[c] : zero;
+  } else {
+    xv = own ? x[c] : zero;
+    r = own ? sc_sub(f[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
+  }
   const T rhat = r;
   T nu = zero, p = zero, hh = zero, s = zero, tt = zero;
   const double res0 = sc_norm_from_dot(dot(r, r));
@@ -418,8 +429,9 @@ evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restri
     r_out[c] = r;
     if constexpr (ROBIN && scalar_traits<T>::is_complex) {
       // the boundary columns of r and — once an iteration has run — of x, as wg_apply_bc leaves them
-      if (col == 0) { r_out[c - 1] = sc_div(r, den); if (it > 0) x[c - 1] = sc_div(xv, den); }
-      if (col == m - 1) { r_out[c + 1] = sc_div(r, den); if (it > 0) x[c + 1] = sc_div(xv, den); }
+      // (XZERO without an iteration: the SET_ZERO's own boundary pass left zeros there)
+      if (col == 0) { r_out[c - 1] = sc_div(r, den); if (it > 0) x[c - 1] = sc_div(xv, den); else if (XZERO) x[c - 1] = zero; }
+      if (col == m - 1) { r_out[c + 1] = sc_div(r, den); if (it > 0) x[c + 1] = sc_div(xv, den); else if (XZERO) x[c + 1] = zero; }
     }
   }
   if (l == 0) info[0] = it;

@@ -769,3 +769,45 @@ def test_small_grid_lds_sweeps_do_not_change_a_bit(native, kind, smoother, pre, 
     assert np.array_equal(a.history, b.history)
     for x, y in zip(fa, fb):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("kind,lo", [("helmholtz", 3), ("helmholtz", 2), ("poisson", 3)])
+def test_one_wave_bicgstab_folds_its_copy_and_zero(native, oracle, kind, lo, monkeypatch):
+    """`gen_rhs = RHS; gen_error = 0; gen_mgCycle@min()` on grids up to 9^2 with BiCGStab as ONE launch (the kernel copies the
+    right-hand side, starts from x = 0 without reading x and leaves the Robin columns as the SET_ZERO's boundary pass and the
+    solver would have) — against the three separate ops, the unfused program and the oracle, bit for bit incl. the Robin
+    columns; a zero right-hand side (no iteration at all); a non-zero boundary on x (no fold)."""
+    import dataclasses
+    if kind == "helmholtz":
+        pd = problems.helmholtz_2d(lo, lo + 1, k=0.625 * (1 << (lo + 1)))
+    else:
+        pd = dataclasses.replace(problems.poisson_2d(lo, lo + 1), cgs_kind=abi.CGS_BICGSTAB, cgs_target_res_reduction=1e-9)
+    n = (1 << lo) + 1
+    cplx = kind == "helmholtz"
+    rng = np.random.default_rng(70 + lo)
+    copy = abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS)
+    zero = abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR)
+    solve = abi.make_op(abi.OP_COARSE_SOLVE, lo)
+    for rhs, x0 in ((random_field(rng, (n, n), cplx), None), (np.zeros((n, n), dtype=complex if cplx else float), None),
+                    (random_field(rng, (n, n), cplx), random_field(rng, (n, n), cplx))):
+        ho = oracle.create(pd)
+        ho.set_field(lo, abi.F_RHS, rhs)
+        if x0 is not None:
+            ho.set_field(lo, abi.F_SOL, x0)
+        ho.run_ops([copy, zero, solve])
+        want = [ho.get_field(lo, f) for f in (abi.F_SOL, abi.F_RES, abi.F_CGS_RHS)]
+        for programs, knob in (([[copy, zero, solve]], None), ([[copy], [zero], [solve]], None), ([[copy, zero, solve]], "EVOMG_NO_FUSE")):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            h = native.create(pd)
+            h.set_field(lo, abi.F_RHS, rhs)
+            if x0 is not None:
+                h.set_field(lo, abi.F_SOL, x0)
+            for prog in programs:
+                h.run_ops(prog)
+            got = [h.get_field(lo, f) for f in (abi.F_SOL, abi.F_RES, abi.F_CGS_RHS)]
+            h.close()
+            if knob:
+                monkeypatch.delenv(knob)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]), (kind, programs, knob, x0 is None)
+            assert np.array_equal(got[1][1:-1, :], want[1][1:-1, :]), (kind, programs, knob)
