@@ -1151,8 +1151,8 @@ template <typename T> class Impl : public ImplBase {
     if (best_cost < 0 && lo == 8 && quantum == 2 && ((long)strips * ((n + 7) / 8) + 3) / 4 < n_cu_) return 4;
     return best;
   }
-  // point smoothers on grids up to 65^2: one workgroup, the field in LDS (evomg_small2d.h); same results as the strip form
-  bool small2d_ok(const Geo& g) const { return small2d_enabled_ && dim_ == 2 && g.n <= 65; }
+  // point smoothers on grids up to 33^2: one workgroup, the field in LDS (evomg_small2d.h); same results as the strip form
+  bool small2d_ok(const Geo& g) const { return small2d_enabled_ && dim_ == 2 && g.n <= 33; }
   template <int MODE, bool PRO, bool TAILR, bool XZ>
   void launch_small2d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, double rkh, int rout,
                       const ProlongIn<T>& pro) {
@@ -1184,7 +1184,7 @@ template <typename T> class Impl : public ImplBase {
     const ProlongIn<T> pro{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0};
     const int rout = (bc_out && strip_bc_) ? 1 : 0;
     if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RBGS) {
-      if (small2d_ok(g)) {      // up to 65^2: the whole field in LDS (evomg_small2d.h)
+      if (small2d_ok(g)) {      // up to 33^2: the whole field in LDS (evomg_small2d.h)
         if (take_x_zero()) launch_small2d<MODE, false, false, true>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
         else launch_small2d<MODE, false, false, false>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
         return;
@@ -2287,7 +2287,8 @@ template <typename T> class Impl : public ImplBase {
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   // complex (Helmholtz) problems: from 17^2 — the strip kernels write the Robin columns themselves, where the generic ones
   // need a boundary launch behind every op (reference-range solve 212-224 -> 197-215 ms)
-  int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : (scalar_traits<T>::is_complex ? 17 : 33);
+  // real problems too since the levels up to 33^2 run in LDS (evomg_small2d: the fused forms instead of one generic launch per op)
+  int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : ((scalar_traits<T>::is_complex || getenv("EVOMG_NO_SMALL2D") == nullptr) ? 17 : 33);
   int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
   int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
   int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;

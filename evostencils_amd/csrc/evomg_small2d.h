@@ -1,11 +1,13 @@
-// evomg_small2d.h — point smoothers on 2D grids up to 65^2 with the whole field in LDS.
+// evomg_small2d.h — point smoothers on 2D grids up to 33^2 with the whole field in LDS.
 //
 // On small levels a strip sweep (evomg_strip.h) is a latency chain: a handful of waves each march eight to ten rows, every
 // row step waiting for the relaxation (a complex division on Helmholtz problems) of the one before — 5.6 us for a plain
 // sweep and 13.2 us for sweep + residual + restriction on a 17^2 ... 65^2 complex grid, whatever its size; at the
 // reference's own level ranges (Helmholtz 3..7, tutorial 5..9) most launches are of this kind. Here ONE 1024-thread
 // workgroup holds the field in LDS and runs the same op fusions as phases separated by barriers, every phase over all
-// rows at once (a thread owns the nodes tid, tid + 1024, ...: at most five):
+// rows at once (a thread owns the nodes tid, tid + 1024: at most two). Measured back to back (tools/bench_small.py, complex
+// RB-GS sweep): 17^2 6.6 -> 3.6 us, 33^2 6.7 -> 4.9 us; at 65^2 (five nodes per thread) 10.7 us against the strips' 6.7 us,
+// so the strips keep that size:
 //   load x (PRO: x + om P(coarse), then the Robin columns of the corrected rows) -> red -> black (Robin between the
 //   colours) -> Robin columns of the result -> store y -> (TAIL_RESTRICT: residual -> coarse right-hand side + its Robin columns)
 // Per-node formulas, their operation order and the boundary handling are those of evomg_strip2d (relax5, residual5, the
@@ -22,7 +24,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
               double robin_kh, int robin_out, ProlongIn<T> pro) {
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "smoother modes only");
   extern __shared__ __align__(16) unsigned char small_lds[];
-  constexpr int MAXK = 5;                                   // 65^2 nodes / 1024 threads
+  constexpr int MAXK = 2;                                   // 33^2 nodes / 1024 threads (host-checked: n <= 33)
   const int n = g.n, nn = n * n;
   T* A = reinterpret_cast<T*>(small_lds);
   T* B = A + nn;
