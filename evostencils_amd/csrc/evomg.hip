@@ -1151,19 +1151,20 @@ template <typename T> class Impl : public ImplBase {
     if (best_cost < 0 && lo == 8 && quantum == 2 && ((long)strips * ((n + 7) / 8) + 3) / 4 < n_cu_) return 4;
     return best;
   }
-  // point smoothers on grids up to 33^2: one workgroup, the field in LDS (evomg_small2d.h); same results as the strip form
-  bool small2d_ok(const Geo& g) const { return small2d_enabled_ && dim_ == 2 && g.n <= 33; }
+  // point smoothers on small and medium grids: tiles of the field in LDS (evomg_small2d.h); same results as the strip form
+  bool small2d_ok(const Geo& g) const { return small2d_enabled_ && dim_ == 2 && g.n <= small2d_max_n_; }
   template <int MODE, bool PRO, bool TAILR, bool XZ>
   void launch_small2d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, double rkh, int rout,
                       const ProlongIn<T>& pro) {
     auto kern = evomg_small2d<T, MODE, PRO, TAILR, XZ>;
-    const size_t lds_bytes = (size_t)((MODE == STRIP_JACOBI || TAILR) ? 2 : 1) * g.n * g.n * sizeof(T);
+    const size_t lds_bytes = (size_t)((MODE == STRIP_JACOBI || TAILR) ? 2 : 1) * small2d_image_elems(g.n) * sizeof(T);
+    const int tiles = small2d_tiles(g.n);
     const void* key = reinterpret_cast<const void*>(kern);
     if (lds_bytes > 48 * 1024 && !small2d_attr_set_.count(key)) {
       (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
       small2d_attr_set_.insert(key);
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_bytes, stream_, g, st, x, f, y, om, omm, rkh, rout, pro);
+    hipLaunchKernelGGL(kern, dim3(tiles * tiles), dim3(1024), lds_bytes, stream_, g, st, x, f, y, om, omm, rkh, rout, pro);
   }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
@@ -1184,7 +1185,7 @@ template <typename T> class Impl : public ImplBase {
     const ProlongIn<T> pro{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0};
     const int rout = (bc_out && strip_bc_) ? 1 : 0;
     if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RBGS) {
-      if (small2d_ok(g)) {      // up to 33^2: the whole field in LDS (evomg_small2d.h)
+      if (small2d_ok(g)) {      // small and medium grids: tiles of the field in LDS (evomg_small2d.h)
         if (take_x_zero()) launch_small2d<MODE, false, false, true>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
         else launch_small2d<MODE, false, false, false>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
         return;
@@ -2277,6 +2278,9 @@ template <typename T> class Impl : public ImplBase {
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
   bool small2d_enabled_ = getenv("EVOMG_NO_SMALL2D") == nullptr;
+  // largest grid that runs as LDS tiles: Helmholtz levels 3..7 149 (33) -> 137-146 (65) -> 131 ms (129), nothing beyond; real
+  // sweeps at 129^2 are no faster than the strips (4.2 vs 3.7 us back to back), at 65^2 they are (3.7 vs 5.8 us)
+  int small2d_max_n_ = getenv("EVOMG_SMALL2D_MAX_N") ? atoi(getenv("EVOMG_SMALL2D_MAX_N")) : (scalar_traits<T>::is_complex ? 129 : 65);
   std::set<const void*> small2d_attr_set_;
   bool batch_enabled_ = (getenv("EVOMG_BATCH") != nullptr) && (getenv("EVOMG_NO_STRIP") == nullptr);
   int batch_max_n_ = getenv("EVOMG_BATCH_MAX_N") ? atoi(getenv("EVOMG_BATCH_MAX_N")) : 129;

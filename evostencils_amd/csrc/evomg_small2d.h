@@ -1,22 +1,31 @@
-// evomg_small2d.h — point smoothers on 2D grids up to 33^2 with the whole field in LDS.
+// evomg_small2d.h — point smoothers on small and medium 2D grids with the field (or a tile of it) in LDS.
 //
 // On small levels a strip sweep (evomg_strip.h) is a latency chain: a handful of waves each march eight to ten rows, every
-// row step waiting for the relaxation (a complex division on Helmholtz problems) of the one before — 5.6 us for a plain
-// sweep and 13.2 us for sweep + residual + restriction on a 17^2 ... 65^2 complex grid, whatever its size; at the
-// reference's own level ranges (Helmholtz 3..7, tutorial 5..9) most launches are of this kind. Here ONE 1024-thread
-// workgroup holds the field in LDS and runs the same op fusions as phases separated by barriers, every phase over all
-// rows at once (a thread owns the nodes tid, tid + 1024: at most two). Measured back to back (tools/bench_small.py, complex
-// RB-GS sweep): 17^2 6.6 -> 3.6 us, 33^2 6.7 -> 4.9 us; at 65^2 (five nodes per thread) 10.7 us against the strips' 6.7 us,
-// so the strips keep that size:
+// row step waiting for the relaxation (a complex division on Helmholtz problems) of the one before — 6.6 us for a plain
+// sweep and 13 us for sweep + residual + restriction on a complex grid, whatever its size; at the reference's own level
+// ranges (Helmholtz 3..7, tutorial 5..9) most launches are of this kind. Here a 1024-thread workgroup holds a tile of at
+// most 33 x 33 nodes plus a halo of four in LDS (grids up to 33^2: the whole field, one workgroup) and runs the same op
+// fusions as phases separated by barriers, every phase over all rows at once (a thread owns at most two nodes):
 //   load x (PRO: x + om P(coarse), then the Robin columns of the corrected rows) -> red -> black (Robin between the
 //   colours) -> Robin columns of the result -> store y -> (TAIL_RESTRICT: residual -> coarse right-hand side + its Robin columns)
-// Per-node formulas, their operation order and the boundary handling are those of evomg_strip2d (relax5, residual5, the
-// prolongation / restriction expressions), which are elementwise: results are bit-identical (tests: the strip form via
-// EVOMG_NO_SMALL2D, and the oracle). The residual-norm tail (TAIL_NORM) stays with the strip kernel: its partial sums
-// have a canonical order tied to strips and only the finest level carries it.
-// dynamic LDS: n * n elements of T, twice for Jacobi (out of place) or TAIL_RESTRICT (residual image).
+// Tiles are independent: each phase is valid one node further inside the extended tile than the one before (red 1, black 2,
+// residual 3 nodes from an edge that is not the domain's; the owned tile and the 3 x 3 neighbourhoods of its coarse nodes
+// lie inside that), the halo is recomputed, x and y are different arrays (host). Per-node formulas, their operation order
+// and the boundary handling are those of evomg_strip2d (relax5, residual5, the prolongation / restriction expressions),
+// which are elementwise: results are bit-identical (tests: the strip form via EVOMG_NO_SMALL2D, and the oracle). The
+// residual-norm tail (TAIL_NORM) stays with the strip kernel: its partial sums have a canonical order tied to strips.
+// dynamic LDS: one image of the extended tile, two for Jacobi (out of place) or TAIL_RESTRICT (residual image).
 #pragma once
 #include "evomg_strip.h"
+
+#define EVOMG_SMALL2D_TILE 33
+#define EVOMG_SMALL2D_HALO 4
+__host__ __device__ inline int small2d_tiles(int n) { return (n - 1 + 31) / 32; }                    // per direction
+__host__ __device__ inline int small2d_tile_size(int n) { const int t = small2d_tiles(n); return (n + t - 1) / t; }
+__host__ __device__ inline int small2d_image_elems(int n) {
+  const int w = small2d_tiles(n) == 1 ? n : small2d_tile_size(n) + 2 * EVOMG_SMALL2D_HALO;
+  return w * w;
+}
 
 template <typename T, int MODE, bool PRO, bool TAIL_RESTRICT, bool XZERO>
 __global__ void __launch_bounds__(1024)
@@ -24,10 +33,17 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
               double robin_kh, int robin_out, ProlongIn<T> pro) {
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "smoother modes only");
   extern __shared__ __align__(16) unsigned char small_lds[];
-  constexpr int MAXK = 2;                                   // 33^2 nodes / 1024 threads (host-checked: n <= 33)
-  const int n = g.n, nn = n * n;
+  constexpr int MAXK = 2;                                   // (33 + 8)^2 nodes / 1024 threads
+  constexpr int H = EVOMG_SMALL2D_HALO, BIG = 1 << 20;
+  const int n = g.n;
+  const int tiles = small2d_tiles(n), ts = small2d_tile_size(n);
+  const int tx = (int)blockIdx.x % tiles, ty = (int)blockIdx.x / tiles;
+  // owned nodes [ox0, ox1) x [oy0, oy1); extended tile [ex0, ex1) x [ey0, ey1), clipped to the grid
+  const int ox0 = tx * ts, ox1 = min(ox0 + ts, n), oy0 = ty * ts, oy1 = min(oy0 + ts, n);
+  const int ex0 = max(ox0 - H, 0), ex1 = min(ox1 + H, n), ey0 = max(oy0 - H, 0), ey1 = min(oy1 + H, n);
+  const int ew = ex1 - ex0, eh = ey1 - ey0, en = ew * eh;
   T* A = reinterpret_cast<T*>(small_lds);
-  T* B = A + nn;
+  T* B = A + en;
   const T zero = scalar_traits<T>::zero();
   const int tid = (int)threadIdx.x;
   constexpr bool CPLX = scalar_traits<T>::is_complex;
@@ -37,22 +53,35 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     if constexpr (CPLX) return sc_div(v, cplx{1.0, -kh});
     else return v;
   };
-  auto robin_columns = [&](T* img, double kh) {             // first and last column of every inner row
-    for (int j = 1 + tid; j < n - 1; j += 1024) {
-      img[j * n] = robin_div(img[j * n + 1], kh);
-      img[j * n + n - 1] = robin_div(img[j * n + n - 2], kh);
+  // nodes away from the edges of the extended tile that are not edges of the grid
+  auto depth = [&](int i, int j) -> int {
+    const int dl = ex0 == 0 ? BIG : i - ex0, dr = ex1 == n ? BIG : ex1 - 1 - i;
+    const int db = ey0 == 0 ? BIG : j - ey0, dt = ey1 == n ? BIG : ey1 - 1 - j;
+    return min(min(dl, dr), min(db, dt));
+  };
+  // first and last column of every inner row of the extended tile at least `need` rows inside (where the tile has them)
+  auto robin_columns = [&](T* img, double kh, int need) {
+    for (int lj = tid; lj < eh; lj += 1024) {
+      const int j = ey0 + lj;
+      if (j < 1 || j > n - 2) continue;
+      const int dv = min(ey0 == 0 ? BIG : j - ey0, ey1 == n ? BIG : ey1 - 1 - j);
+      if (dv < need) continue;
+      if (ex0 == 0) img[lj * ew] = robin_div(img[lj * ew + 1], kh);
+      if (ex1 == n) img[lj * ew + ew - 1] = robin_div(img[lj * ew + ew - 2], kh);
     }
   };
   T fv[MAXK];
-  int qi[MAXK], qj[MAXK];
+  int qi[MAXK], qj[MAXK], ql[MAXK];                         // node (global), image index; qi < 0: no node
   // ---- load (and correct) the input ----
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) {
     const int q = tid + 1024 * k;
-    const bool ok = q < nn;
-    const int i = ok ? q % n : 0, j = ok ? q / n : 0;
+    const bool ok = q < en;
+    const int li = ok ? q % ew : 0, lj = ok ? q / ew : 0;
+    const int i = ex0 + li, j = ey0 + lj;
     qi[k] = ok ? i : -1;
     qj[k] = j;
+    ql[k] = lj * ew + li;
     const long c = gidx<2>(g, i, j, 0);
     fv[k] = f[c];
     T v = zero;
@@ -67,12 +96,12 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
         v = sc_add(v, sc_rmul(pro.om, p));
       }
     }
-    if (ok) A[q] = v;
+    if (ok) A[ql[k]] = v;
   }
   __syncthreads();
   if constexpr (PRO && CPLX) {
     if (robin) {                                            // the prolongation op's apply_bc on the corrected field
-      robin_columns(A, robin_kh);
+      robin_columns(A, robin_kh, 0);
       __syncthreads();
     }
   }
@@ -81,17 +110,17 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     // ---- red (even index sum): all neighbours are black, still old ----
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
-      const int i = qi[k], j = qj[k], q = j * n + i;
-      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && !((i + j) & 1))
-        A[q] = relax5(st, A[q], A[q - 1], A[q + 1], A[q - n], A[q + n], fv[k], om, omm, pro.inv_c0);
+      const int i = qi[k], j = qj[k], q = ql[k];
+      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && !((i + j) & 1) && depth(i, j) >= 1)
+        A[q] = relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, pro.inv_c0);
     }
     __syncthreads();
     // ---- black; Helmholtz: the two-pass form re-applies the Robin condition between the colours, so a black node next
     // to the left / right boundary sees the boundary value derived from its own (still old) value ----
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
-      const int i = qi[k], j = qj[k], q = j * n + i;
-      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && ((i + j) & 1)) {
+      const int i = qi[k], j = qj[k], q = ql[k];
+      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && ((i + j) & 1) && depth(i, j) >= 2) {
         T w = A[q - 1], e = A[q + 1];
         if constexpr (CPLX) {
           if (robin) {
@@ -99,17 +128,17 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             if (i == n - 2) e = robin_div(A[q], robin_kh);
           }
         }
-        A[q] = relax5(st, A[q], w, e, A[q - n], A[q + n], fv[k], om, omm, pro.inv_c0);
+        A[q] = relax5(st, A[q], w, e, A[q - ew], A[q + ew], fv[k], om, omm, pro.inv_c0);
       }
     }
     __syncthreads();
   } else {
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
-      const int i = qi[k], j = qj[k], q = j * n + i;
+      const int i = qi[k], j = qj[k], q = ql[k];
       if (i >= 0) {
-        const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2;
-        B[q] = inner ? relax5(st, A[q], A[q - 1], A[q + 1], A[q - n], A[q + n], fv[k], om, omm, pro.inv_c0) : A[q];
+        const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && depth(i, j) >= 1;
+        B[q] = inner ? relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, pro.inv_c0) : A[q];
       }
     }
     __syncthreads();
@@ -117,41 +146,43 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   }
   if constexpr (CPLX) {
     if (robin && robin_out) {
-      robin_columns(cur, robin_kh);
+      robin_columns(cur, robin_kh, 2);
       __syncthreads();
     }
   }
-  // ---- the sweep's result, boundary included ----
+  // ---- the sweep's result on the owned nodes, boundary included ----
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) {
     const int i = qi[k], j = qj[k];
-    if (i >= 0) y[gidx<2>(g, i, j, 0)] = cur[j * n + i];
+    if (i >= ox0 && i < ox1 && j >= oy0 && j < oy1) y[gidx<2>(g, i, j, 0)] = cur[ql[k]];
   }
   if constexpr (TAIL_RESTRICT) {
     // ---- residual of the result (zero outside the inner nodes) and its full-weighting restriction ----
     T* res = (cur == A) ? B : A;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
-      const int i = qi[k], j = qj[k], q = j * n + i;
+      const int i = qi[k], j = qj[k], q = ql[k];
       if (i >= 0) {
-        const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2;
-        res[q] = inner ? residual5(st, cur[q], cur[q - 1], cur[q + 1], cur[q - n], cur[q + n], fv[k]) : zero;
+        const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && depth(i, j) >= 3;
+        res[q] = inner ? residual5(st, cur[q], cur[q - 1], cur[q + 1], cur[q - ew], cur[q + ew], fv[k]) : zero;
       }
     }
     __syncthreads();
     const int nc = pro.gc.n;
     auto coarse_value = [&](int I, int J) -> T {
-      const T* r = res + (2 * J) * n + 2 * I;
-      const T e4 = sc_add(sc_add(r[-1], r[1]), sc_add(r[-n], r[n]));
-      const T q4 = sc_add(sc_add(r[-n - 1], r[-n + 1]), sc_add(r[n - 1], r[n + 1]));
+      const T* r = res + (2 * J - ey0) * ew + (2 * I - ex0);
+      const T e4 = sc_add(sc_add(r[-1], r[1]), sc_add(r[-ew], r[ew]));
+      const T q4 = sc_add(sc_add(r[-ew - 1], r[-ew + 1]), sc_add(r[ew - 1], r[ew + 1]));
       T v = sc_rmul(0.25, r[0]);
       v = sc_add(v, sc_rmul(0.125, e4));
       v = sc_add(v, sc_rmul(0.0625, q4));
       return v;
     };
     const bool robin_c = CPLX && pro.robin_kh_coarse != 0.0;
-    for (int qc = tid; qc < nc * nc; qc += 1024) {
-      const int I = qc % nc, J = qc / nc;
+    // the coarse nodes whose fine twin (2I, 2J) this tile owns
+    const int I0 = (ox0 + 1) >> 1, I1 = (ox1 + 1) >> 1, J0 = (oy0 + 1) >> 1, J1 = (oy1 + 1) >> 1, cw = I1 - I0;
+    for (int qc = tid; qc < cw * (J1 - J0); qc += 1024) {
+      const int I = I0 + qc % cw, J = J0 + qc / cw;
       if (J < 1 || J > nc - 2) continue;
       T* dst = pro.coarse_out + (long)pro.gc.pitch * J + I;
       if (I >= 1 && I <= nc - 2) *dst = coarse_value(I, J);
