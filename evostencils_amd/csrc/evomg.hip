@@ -1185,7 +1185,8 @@ template <typename T> class Impl : public ImplBase {
     const ProlongIn<T> pro{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0};
     const int rout = (bc_out && strip_bc_) ? 1 : 0;
     if constexpr (MODE == STRIP_JACOBI || MODE == STRIP_RBGS) {
-      if (small2d_ok(g)) {      // small and medium grids: tiles of the field in LDS (evomg_small2d.h)
+      // small and medium grids: tiles of the field in LDS (evomg_small2d.h); tiles read their halo from x while others store y
+      if (small2d_ok(g) && (x != y || small2d_tiles(g.n) == 1)) {
         if (take_x_zero()) launch_small2d<MODE, false, false, true>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
         else launch_small2d<MODE, false, false, false>(g, st, x, f, y, om, omm, robin_kh, rout, pro);
         return;
@@ -1230,7 +1231,7 @@ template <typename T> class Impl : public ImplBase {
     const double rkh = robin ? prob_.wavenumber / (double)(g.n - 1) : 0.0;
     const int rout = (robin && strip_bc_) ? 1 : 0;
     if constexpr (PRO && !TAIL) {
-      if (small2d_ok(g)) {
+      if (small2d_ok(g) && (x != y || small2d_tiles(g.n) == 1)) {   // tiles read their halo from x while others store y
         launch_small2d<MODE, true, false, false>(g, st, x, f, y, om, omm, rkh, rout, pro);
         return EVOMG_OK;
       }
@@ -1255,7 +1256,7 @@ template <typename T> class Impl : public ImplBase {
     const double rkhc = robin ? prob_.wavenumber / (double)(gc.n - 1) : 0.0;
     const int rout = (robin && strip_bc_) ? 1 : 0;
     const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc};
-    if (small2d_ok(g)) {
+    if (small2d_ok(g) && (x != y || small2d_tiles(g.n) == 1)) {   // tiles read their halo from x while others store y
       if (take_x_zero()) launch_small2d<MODE, false, true, true>(g, st, x, f, y, om, omm, rkh, rout, pro);
       else launch_small2d<MODE, false, true, false>(g, st, x, f, y, om, omm, rkh, rout, pro);
       return;
