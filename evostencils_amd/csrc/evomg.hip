@@ -2837,6 +2837,20 @@ class FASImpl : public ImplBase {
   int evaluate(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) override {
     HIP_TRY(hipSetDevice(device_));
     if (!out || samples < 1 || n_ops < 0 || (!ops && n_ops > 0)) return invalid("evaluate: bad arguments");
+    // The tiled coarse sweeps need their workgroups co-resident; with several candidates in flight on one GPU they can miss
+    // a rendezvous. As for the scalar problems' eight-workgroup CG: a property of the moment, not of the candidate — quiesce
+    // the device and evaluate once more, alone, before reporting a device error.
+    int rc = EVOMG_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      fas_missed_ = false;
+      rc = evaluate_attempt(ops, n_ops, samples, wall_limit_ms, out, hist, cap);
+      if (!fas_missed_) return rc;
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemsetAsync(fas_info_, 0, sizeof(int), stream_));
+    }
+    return rc;
+  }
+  int evaluate_attempt(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
     memset(out, 0, sizeof *out);
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
@@ -3053,6 +3067,7 @@ class FASImpl : public ImplBase {
   bool fas_cgs_lds_ = getenv("EVOMG_NO_FAS_CGS_LDS") == nullptr;      // ... with both slots in LDS
   bool fas_cgs_tiles_ = getenv("EVOMG_NO_FAS_CGS_TILES") == nullptr;  // 65^2 / 129^2: overlapping tiles on several compute units
   bool fas_tiles_used_ = false;
+  bool fas_missed_ = false;           // the last health check saw a missed rendezvous
   unsigned* fas_flags_ = nullptr;
   int* fas_info_ = nullptr;
   int* fas_info_host_ = nullptr;
@@ -3062,6 +3077,7 @@ class FASImpl : public ImplBase {
     HIP_TRY(hipMemcpyAsync(fas_info_host_, fas_info_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     if (*fas_info_host_ != 0) {
+      fas_missed_ = true;
       snprintf(err, sizeof err, "FAS coarse sweeps: the workgroups did not rendezvous (GPU oversubscribed?)");
       return EVOMG_ERR_DEVICE;
     }

@@ -140,3 +140,28 @@ def test_coarse_sweeps_in_lds_are_bit_identical(native, level, sweeps, monkeypat
     for got in results[1:]:
         assert all(np.array_equal(x, y) for x, y in zip(got, results[0]))
     assert not np.array_equal(results[0][0], u0)
+
+
+def test_tiled_coarse_sweeps_with_several_candidates_in_flight(native):
+    """Six FAS solves at once on one GPU, each with its own handle and stream: the 16-workgroup coarse sweeps of all of them
+    meet their rendezvous (or are retried alone), and every solve reports exactly what a solve on its own reports."""
+    from concurrent.futures import ThreadPoolExecutor
+    gen = fas_generator(library=native.library(), levels=(6, 9))
+    depth = 3
+    sm = [[cycles._nw(14)] for _ in range(depth)]
+    expression, _ = cycles.fas_v_cycle(fas_context(gen, depth), depth, sm, sm)
+    ops = gen.generate_op_program(expression)
+    pd = gen.problem_description()
+    gen.close()
+    alone = native.create(pd)
+    want = alone.evaluate(ops, 1, 0, 256)
+    alone.close()
+    handles = [native.create(pd) for _ in range(6)]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        outs = list(pool.map(lambda h: [h.evaluate(ops, 1, 0, 256) for _ in range(3)][-1], handles))
+    for h in handles:
+        h.close()
+    assert want.n_iterations >= 3
+    for got in outs:
+        assert got.status == want.status and got.n_iterations == want.n_iterations
+        assert np.array_equal(got.history, want.history)
