@@ -22,6 +22,7 @@
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
 #include "evomg_small2d.h"
+#include "evomg_small3d.h"
 #include "evomg_tile3d.h"
 #include "evomg_batch.h"
 #include "evomg_strip_block.h"
@@ -541,6 +542,70 @@ template <typename T> class Impl : public ImplBase {
   }
   // COPY gen_rhs@min = ..., SET_ZERO gen_error@min, COARSE_SOLVE@min (what every cycle emits around gen_mgCycle@min,
   // exastencils.py:890-896) on a grid the one-wave CG serves: ONE launch instead of three
+  // One visit of a small 3D level in one launch (evomg_small3d.h): [SET_ZERO u | PROLONG_ADD u] + 1..4 identical red-black
+  // point sweeps on u + [RESIDUAL + RESTRICT of it], as many of these as the program has at position i. Returns the
+  // number of ops consumed (0: not this shape), -1 on a launch error.
+  int small3d_chain(const evomg_op_t* ops, int n_ops, int i) {
+    if constexpr (scalar_traits<T>::is_complex) return 0;
+    else {
+      if (!small3d_enabled_ || !fuse_enabled_ || dim_ != 3 || prob_.bc_kind != EVOMG_BC_DIRICHLET) return 0;
+      const int L = ops[i].level;
+      if (L < prob_.min_level || L > prob_.max_level || lv_[L].g.n > 17) return 0;
+      int p = i, zero_first = 0;
+      const T* coarse_in = nullptr;
+      double om_p = 0.0;
+      int head_field = -1;
+      if (ops[p].opcode == EVOMG_OP_SET_ZERO) {
+        zero_first = 1;
+        head_field = canon(L, ops[p].dst);
+        ++p;
+      } else if (ops[p].opcode == EVOMG_OP_PROLONG_ADD && L > prob_.min_level) {
+        head_field = canon(L, ops[p].dst);
+        coarse_in = fieldptr(L - 1, ops[p].src0);
+        om_p = ops[p].omega;
+        ++p;
+      }
+      if (p < n_ops && prof_matches(ops[i])) return 0;
+      if (p >= n_ops || ops[p].opcode != EVOMG_OP_SMOOTH || ops[p].level != L) return 0;
+      const evomg_op_t& sm = ops[p];
+      if (sm.partitioning != EVOMG_PART_RED_BLACK || sm.block[0] * sm.block[1] * sm.block[2] != 1) return 0;
+      const int xf = canon(L, sm.dst), ff = canon(L, sm.src1);
+      if (xf == ff || (head_field >= 0 && head_field != xf)) return 0;
+      if (coarse_in && coarse_in == fieldptr(L, sm.dst)) return 0;
+      int nsweeps = 0;
+      while (p < n_ops && nsweeps < 4 && ops[p].opcode == EVOMG_OP_SMOOTH && ops[p].level == L && ops[p].partitioning == EVOMG_PART_RED_BLACK &&
+             ops[p].block[0] * ops[p].block[1] * ops[p].block[2] == 1 && canon(L, ops[p].dst) == xf && canon(L, ops[p].src1) == ff &&
+             ops[p].omega == sm.omega && !prof_matches(ops[p])) {
+        ++nsweeps;
+        ++p;
+      }
+      if (nsweeps == 0) return 0;
+      T* res_out = nullptr;
+      T* coarse_out = nullptr;
+      if (p + 1 < n_ops && L > prob_.min_level && ops[p].opcode == EVOMG_OP_RESIDUAL && ops[p].level == L && canon(L, ops[p].src0) == xf &&
+          canon(L, ops[p].src1) == ff && canon(L, ops[p].dst) != xf && canon(L, ops[p].dst) != ff && ops[p + 1].opcode == EVOMG_OP_RESTRICT &&
+          ops[p + 1].level == L - 1 && canon(L, ops[p + 1].src0) == canon(L, ops[p].dst) && !prof_matches(ops[p]) && !prof_matches(ops[p + 1])) {
+        res_out = fieldptr(L, ops[p].dst);
+        coarse_out = fieldptr(L - 1, ops[p + 1].dst);
+        // the coarse field written must not be one the launch reads
+        if (coarse_out == coarse_in) { res_out = nullptr; coarse_out = nullptr; }
+        else p += 2;
+      }
+      Level<T>& lv = lv_[L];
+      const Geo& g = lv.g;
+      const size_t nn = (size_t)g.n * g.n * g.n;
+      const size_t lds_bytes = (coarse_out ? 3 : 2) * nn * sizeof(T);
+      if (lds_bytes > 48 * 1024 && !small3d_attr_set_) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_small3d_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        small3d_attr_set_ = true;
+      }
+      const Geo gc = L > prob_.min_level ? lv_[L - 1].g : g;
+      hipLaunchKernelGGL(evomg_small3d_chain, dim3(1), dim3(1024), lds_bytes, stream_, g, lv.st, fieldptr(L, sm.dst), (const T*)fieldptr(L, sm.src1),
+                         sm.omega, 1.0 - sm.omega, nsweeps, zero_first, coarse_in, gc, om_p, res_out, coarse_out);
+      if (hipGetLastError() != hipSuccess) { snprintf(err, sizeof err, "evomg_small3d_chain: launch failed"); return -1; }
+      return p - i;
+    }
+  }
   bool fusable_copy_zero_solve(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || !use_reg_krylov_ || i + 2 >= n_ops || dim_ != 2) return false;
     const int L = prob_.min_level;
@@ -584,6 +649,14 @@ template <typename T> class Impl : public ImplBase {
       if (elidable_zero(ops, n_ops, i)) {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
         continue;
+      }
+      {
+        const int len = small3d_chain(ops, n_ops, i);
+        if (len < 0) return EVOMG_ERR_DEVICE;
+        if (len > 0) {
+          i += len - 1;
+          continue;
+        }
       }
       if (fusable_copy_zero_solve(ops, n_ops, i)) {
         const int rc = coarse_solve(&ops[i]);
@@ -2278,6 +2351,8 @@ template <typename T> class Impl : public ImplBase {
   bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
+  bool small3d_enabled_ = getenv("EVOMG_NO_SMALL3D") == nullptr;
+  bool small3d_attr_set_ = false;
   bool small2d_enabled_ = getenv("EVOMG_NO_SMALL2D") == nullptr;
   // largest grid that runs as LDS tiles: Helmholtz levels 3..7 149 (33) -> 137-146 (65) -> 131 ms (129), nothing beyond; real
   // sweeps at 129^2 are no faster than the strips (4.2 vs 3.7 us back to back), at 65^2 they are (3.7 vs 5.8 us)

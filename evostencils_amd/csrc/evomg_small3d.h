@@ -1,0 +1,100 @@
+// evomg_small3d.h — one visit of a small 3D level (up to 17^3) in ONE launch with the field in LDS.
+//
+// Below 129^3 the 3D levels run one thread-per-node launch per op and colour: the reference's 3D example at its own level
+// range (2..6, V(2,1) red-black) is 48 launches per cycle at the 3.1 us launch floor, and the marching tiles are slower
+// still there (a handful of waves marching planes). On the levels that fit one compute unit's LDS whole — 17^3 doubles are
+// 39 KB — one 1024-thread workgroup runs a whole visit of the level as phases separated by barriers:
+//   [u = 0 | u += w P(coarse)]  ->  k red-black sweeps in place  ->  store u  ->  [r = f - A u  ->  store r  ->  R r to the coarse level]
+// with the device functions of the generic kernels (relax_point, apply_stencil, interpolate, the 27-point weighting of
+// evomg_restrict) applied to the LDS image — same formulas, same operation order, elementwise: bit-identical to the
+// separate launches (tests: EVOMG_NO_SMALL3D, and the oracle through every small 3D parity test).
+// dynamic LDS: u and f images (n^3 each), and the residual image when the tail is present.
+#pragma once
+#include "evomg_kernels.h"
+
+__global__ void __launch_bounds__(1024)
+evomg_small3d_chain(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ f, double om, double omm, int nsweeps,
+                    int zero_first, const double* __restrict__ coarse_in, Geo gc, double om_p, double* __restrict__ res_out,
+                    double* __restrict__ coarse_out) {
+  extern __shared__ __align__(16) double small3d_lds[];
+  const int n = g.n, n2 = n * n, nn = n2 * n;
+  double* A = small3d_lds;
+  double* F = A + nn;
+  double* R = F + nn;
+  Geo gl;                                                   // the LDS images: rows and planes packed
+  gl.n = n;
+  gl.pitch = n;
+  gl.plane = n2;
+  const int tid = (int)threadIdx.x;
+  for (int q = tid; q < nn; q += 1024) {
+    const int i = q % n, j = (q / n) % n, k = q / n2;
+    const long c = gidx<3>(g, i, j, k);
+    const bool inner = is_inner<3>(g, i, j, k);
+    double v = (zero_first && inner) ? 0.0 : x[c];
+    if (coarse_in && inner) v = v + om_p * interpolate<double, 3>(gc, coarse_in, i, j, k);
+    A[q] = v;
+    F[q] = f[c];
+  }
+  __syncthreads();
+  // n is odd, so the colour of node q = i + n j + n^2 k is q & 1: the threads enumerate the nodes of one colour only
+  // (a checkerboard mask would idle half of every wave through the division); the quotient by the stencil centre in
+  // three operations with the bits of the division (evomg_scalar.h: const_div, as in the 3D tile kernels)
+  const ConstDiv<double> cd0 = const_div_make(st.c[0]);
+  for (int s = 0; s < nsweeps; ++s)
+    for (int colour = 0; colour < 2; ++colour) {
+      for (int q = 2 * tid + colour; q < nn; q += 2048) {
+        const int i = q % n, j = (q / n) % n, k = q / n2;
+        if (!is_inner<3>(g, i, j, k)) continue;
+        double r = F[q];                                    // relax_point<double, 3>, operation for operation
+        r = r - st.c[1] * A[q - 1];
+        r = r - st.c[2] * A[q + 1];
+        r = r - st.c[3] * A[q - n];
+        r = r - st.c[4] * A[q + n];
+        r = r - st.c[5] * A[q - n2];
+        r = r - st.c[6] * A[q + n2];
+        const double xs = const_div(r, cd0);
+        A[q] = omm * A[q] + om * xs;
+      }
+      __syncthreads();
+    }
+  for (int q = tid; q < nn; q += 1024) {
+    const int i = q % n, j = (q / n) % n, k = q / n2;
+    if (is_inner<3>(g, i, j, k)) x[gidx<3>(g, i, j, k)] = A[q];
+  }
+  if (!coarse_out) return;
+  for (int q = tid; q < nn; q += 1024) {
+    const int i = q % n, j = (q / n) % n, k = q / n2;
+    double r = 0.0;
+    if (is_inner<3>(g, i, j, k)) {
+      r = F[q] - apply_stencil<double, 3>(st, A, gl, q);
+      res_out[gidx<3>(g, i, j, k)] = r;
+    }
+    R[q] = r;
+  }
+  __syncthreads();
+  const int nc = gc.n, nc2 = nc * nc;
+  for (int qc = tid; qc < nc2 * nc; qc += 1024) {
+    const int I = qc % nc, J = (qc / nc) % nc, K = qc / nc2;
+    if (!is_inner<3>(gc, I, J, K)) continue;
+    const int i = 2 * I, j = 2 * J, k = 2 * K;
+    double face = 0.0, edge = 0.0, corner = 0.0;
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+          if (nz == 0) continue;
+          const double v = R[gidx<3>(gl, i + dx, j + dy, k + dz)];
+          if (nz == 1) face = face + v;
+          else if (nz == 2) edge = edge + v;
+          else corner = corner + v;
+        }
+    double v = 0.125 * R[gidx<3>(gl, i, j, k)];
+    v = v + 0.0625 * face;
+    v = v + 0.03125 * edge;
+    v = v + 0.015625 * corner;
+    coarse_out[gidx<3>(gc, I, J, K)] = v;
+  }
+}

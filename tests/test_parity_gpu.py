@@ -812,3 +812,29 @@ def test_one_wave_bicgstab_folds_its_copy_and_zero(native, oracle, kind, lo, mon
                 monkeypatch.delenv(knob)
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]), (kind, programs, knob, x0 is None)
             assert np.array_equal(got[1][1:-1, :], want[1][1:-1, :]), (kind, programs, knob)
+
+
+@pytest.mark.parametrize("pre,post", [(2, 1), (1, 2), (3, 0)])
+def test_small_3d_level_visits_do_not_change_a_bit(native, pre, post, monkeypatch):
+    """Levels up to 17^3: a whole visit of the level — [u = 0 | u += w P coarse], the red-black sweeps, residual and
+    restriction — as ONE launch with the field in LDS (evomg_small3d_chain) against one launch per op and colour
+    (EVOMG_NO_SMALL3D): identical residual histories and fields on every level of a 5^3 .. 33^3 hierarchy."""
+    from test_full_size_gpu import vcycle
+    lo, hi = 2, 5
+    pd = problems.poisson_3d(lo, hi)
+    ops = vcycle(lo, hi, pre, post, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.25))
+    results = []
+    for knob in (None, "EVOMG_NO_SMALL3D"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 64)
+        results.append((out, [h.get_field(L, f) for L in range(lo + 1, hi + 1) for f in (abi.F_SOL, abi.F_RHS, abi.F_RES)]))
+        h.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    (a, fa), (b, fb) = results
+    assert a.n_iterations == b.n_iterations and a.n_iterations >= 1
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
