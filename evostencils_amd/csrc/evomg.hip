@@ -676,6 +676,22 @@ template <typename T> class Impl : public ImplBase {
         ++i;
         continue;
       }
+      if (fusable_two_sweeps_residual_restrict(ops, n_ops, i, cyclic)) {
+        // pre-smoothing with two identical red-black sweeps on a level that is ONE LDS tile: both sweeps, the residual and
+        // the restriction in one launch (evomg_small2d with nsweeps = 2)
+        const evomg_op_t &sm = ops[i], &rs = ops[i + 3];
+        const int L = sm.level;
+        Level<T>& lv = lv_[L];
+        T* x = fieldptr(L, sm.dst);
+        T* y = lv.alt;
+        launch_strip_restrict_tail<STRIP_RBGS>(lv.g, lv_[L - 1].g, lv.st, x, fieldptr(L, sm.src1), y, sm.omega, 1.0 - sm.omega, fieldptr(L - 1, rs.dst), 2);
+        lv.alt = x;
+        set_fieldptr(L, sm.dst, y);
+        lv.alt_mirror = y;
+        HIP_TRY(hipGetLastError());
+        i += 3;
+        continue;
+      }
       if (fusable_smooth_residual_restrict(ops, n_ops, i, cyclic)) {
         const evomg_op_t &sm = ops[i], &rs = ops[i + 2];
         const int L = sm.level;
@@ -1228,7 +1244,7 @@ template <typename T> class Impl : public ImplBase {
   bool small2d_ok(const Geo& g) const { return small2d_enabled_ && dim_ == 2 && g.n <= small2d_max_n_; }
   template <int MODE, bool PRO, bool TAILR, bool XZ>
   void launch_small2d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, double rkh, int rout,
-                      const ProlongIn<T>& pro) {
+                      const ProlongIn<T>& pro, int nsweeps = 1) {
     auto kern = evomg_small2d<T, MODE, PRO, TAILR, XZ>;
     const size_t lds_bytes = (size_t)((MODE == STRIP_JACOBI || TAILR) ? 2 : 1) * small2d_image_elems(g.n) * sizeof(T);
     const int tiles = small2d_tiles(g.n);
@@ -1237,7 +1253,7 @@ template <typename T> class Impl : public ImplBase {
       (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
       small2d_attr_set_.insert(key);
     }
-    hipLaunchKernelGGL(kern, dim3(tiles * tiles), dim3(1024), lds_bytes, stream_, g, st, x, f, y, om, omm, rkh, rout, pro);
+    hipLaunchKernelGGL(kern, dim3(tiles * tiles), dim3(1024), lds_bytes, stream_, g, st, x, f, y, om, omm, rkh, rout, pro, nsweeps);
   }
   template <int MODE> void launch_strip(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, bool bc_out = true) {
     const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
@@ -1315,7 +1331,7 @@ template <typename T> class Impl : public ImplBase {
   }
   // SMOOTH@L + RESIDUAL@L + RESTRICT@(L-1) with a residual nobody else reads: one sweep (evomg_strip2d<.., TAIL_RESTRICT>)
   template <int MODE> void launch_strip_restrict_tail(const Geo& g, const Geo& gc, const Stencil<T>& st, const T* x, const T* f, T* y,
-                                                       double om, double omm, T* coarse_out) {
+                                                       double om, double omm, T* coarse_out, int nsweeps = 1) {
     const int strips = (g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS;     // two halo lanes per side
     int rows = strip_rows_ > 0 ? strip_rows_ : 64;
     while (rows > 8 && (long)strips * ((g.n + rows - 1) / rows) < 2048) rows /= 2;
@@ -1330,8 +1346,8 @@ template <typename T> class Impl : public ImplBase {
     const int rout = (robin && strip_bc_) ? 1 : 0;
     const ProlongIn<T> pro{nullptr, gc, 0.0, coarse_out, inv_c0(st), rkhc};
     if (small2d_ok(g) && (x != y || small2d_tiles(g.n) == 1)) {   // tiles read their halo from x while others store y
-      if (take_x_zero()) launch_small2d<MODE, false, true, true>(g, st, x, f, y, om, omm, rkh, rout, pro);
-      else launch_small2d<MODE, false, true, false>(g, st, x, f, y, om, omm, rkh, rout, pro);
+      if (take_x_zero()) launch_small2d<MODE, false, true, true>(g, st, x, f, y, om, omm, rkh, rout, pro, nsweeps);
+      else launch_small2d<MODE, false, true, false>(g, st, x, f, y, om, omm, rkh, rout, pro, nsweeps);
       return;
     }
     if (take_x_zero()) {
@@ -1340,6 +1356,16 @@ template <typename T> class Impl : public ImplBase {
     }
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, true, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
     else hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
+  }
+  bool fusable_two_sweeps_residual_restrict(const evomg_op_t* ops, int n_ops, int i, bool cyclic) const {
+    if (i + 3 >= n_ops || !fusable_smooth_residual_restrict(ops, n_ops, i + 1, cyclic)) return false;
+    const evomg_op_t &a = ops[i], &b = ops[i + 1];
+    if (a.opcode != EVOMG_OP_SMOOTH || a.partitioning != EVOMG_PART_RED_BLACK || b.partitioning != EVOMG_PART_RED_BLACK) return false;
+    if (a.level != b.level || a.omega != b.omega || a.block[0] * a.block[1] != 1) return false;
+    if (canon(a.level, a.dst) != canon(b.level, b.dst) || canon(a.level, a.src1) != canon(b.level, b.src1)) return false;
+    if (prof_matches(a) || prof_matches(b) || prof_matches(ops[i + 2]) || prof_matches(ops[i + 3])) return false;
+    const Geo& g = lv_[a.level].g;
+    return small2d_ok(g) && small2d_tiles(g.n) == 1 && use_strip(g);
   }
   bool fusable_smooth_residual_restrict(const evomg_op_t* ops, int n_ops, int i, bool cyclic) const {
     if (!fuse_enabled_ || !tail_restrict_enabled_ || !cyclic || i + 2 >= n_ops || dim_ != 2) return false;

@@ -30,7 +30,9 @@ __host__ __device__ inline int small2d_image_elems(int n) {
 template <typename T, int MODE, bool PRO, bool TAIL_RESTRICT, bool XZERO>
 __global__ void __launch_bounds__(1024)
 evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om, double omm,
-              double robin_kh, int robin_out, ProlongIn<T> pro) {
+              double robin_kh, int robin_out, ProlongIn<T> pro, int nsweeps) {
+  // nsweeps > 1 (red-black, ONE tile only — host-checked): that many identical sweeps in place before the tail, each followed
+  // by the Robin columns as the separate ops would leave them
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "smoother modes only");
   extern __shared__ __align__(16) unsigned char small_lds[];
   constexpr int MAXK = 2;                                   // (33 + 8)^2 nodes / 1024 threads
@@ -107,6 +109,15 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   }
   T* cur = A;
   if constexpr (MODE == STRIP_RBGS) {
+   for (int sweep = 0; sweep < nsweeps; ++sweep) {
+    if (sweep > 0) {
+      if constexpr (CPLX) {
+        if (robin && robin_out) {
+          robin_columns(A, robin_kh, 2);
+          __syncthreads();
+        }
+      }
+    }
     // ---- red (even index sum): all neighbours are black, still old ----
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
@@ -132,6 +143,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
       }
     }
     __syncthreads();
+   }
   } else {
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
