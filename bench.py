@@ -429,6 +429,21 @@ def main():
                         f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC passes (profiles/pmc_traffic.json names the "
                         f"profile), null when no profile matches the launched kernel and level"}
 
+    # ---- where the rest of an isolated solve goes: the coarse-grid solve, timed the same way over three more solves ----
+    handle.profile_begin(abi.OP_COARSE_SOLVE, lo)
+    extra = run_steps(3)
+    fence()
+    cs = handle.profile_end()
+    coarse_op = next(o for o in ops if o.opcode == abi.OP_COARSE_SOLVE)
+    coarse_solve = {"kernel": handle.kernel_name(coarse_op), "grid": f"{(1 << lo) + 1}^2", "ms_per_call": cs.ms,
+                    "calls_per_solve": cs.launches / 3.0, "share_of_solve": cs.ms * cs.launches / 3.0 / float(extra[0][1]),
+                    "bound": "VALU issue of ONE compute unit",
+                    "note": "CG to 1e-12 on the coarsest grid (the reference's solver settings): two dependent reductions per iteration; "
+                            "a grid-wide rendezvous costs more than the arithmetic it would spread (profiles/r03_rendezvous.md), so it "
+                            "runs as one 512-thread workgroup out of registers, 2.1 us per iteration, VALU active 72 % of its busy "
+                            "cycles (profiles/r03_pmc_tables.txt). What the other 255 compute units do meanwhile is the next "
+                            "candidate: throughput_mode"}
+
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:
         k = args.throughput_workers
@@ -468,6 +483,7 @@ def main():
                        "parallelism": f"candidates sharded 1/GPU x {world}, RCCL fitness gather",
                        "candidates_in_flight_per_gpu": args.concurrency},
             "roofline": roofline,
+            "coarse_solve": coarse_solve,
         }
         if throughput is not None:
             line["throughput_mode"] = throughput
