@@ -1,6 +1,6 @@
 """Developer tool: more seeds of tests/test_fuzz_gpu.py's random op programs than the suite runs, real (Poisson) and complex
 (Helmholtz with its Robin columns) 2D problems, HIP backend vs CPU oracle bit for bit on every field of every level.
-usage: python tools/fuzz_more.py [first_seed] [count]"""
+usage: python tools/fuzz_more.py [first_seed] [count] [3d]   (3d: random programs on 3D Poisson hierarchies instead)"""
 import os, sys
 os.environ.setdefault("OMP_NUM_THREADS", "4")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,17 +12,21 @@ from test_fuzz_gpu import random_program, with_semantics
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+three_d = len(sys.argv) > 3 and sys.argv[3] == "3d"
 bad = 0
 for seed in range(first, first + count):
-    for kind, lo, hi in (("poisson", 3, 7), ("helmholtz", 3, 7), ("helmholtz", 4, 8), ("poisson", 4, 8)):
+    for kind, lo, hi in ((("poisson3d", 2, 5), ("poisson3d", 1, 4), ("poisson3d", 3, 6)) if three_d else
+                         (("poisson", 3, 7), ("helmholtz", 3, 7), ("helmholtz", 4, 8), ("poisson", 4, 8))):
         for semantics in ("textbook", "exastencils-v1.1"):
-            if kind == "poisson":
+            if kind == "poisson3d":
+                pd = problems.poisson_3d(lo, hi)
+            elif kind == "poisson":
                 pd = problems.poisson_2d(lo, hi)
             else:
                 pd = problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
             pd = with_semantics(pd, semantics)
             rng = np.random.default_rng(31 * seed + lo)
-            ops = random_program(rng, 2, lo, hi, 28)
+            ops = random_program(rng, 3 if three_d else 2, lo, hi, 28)
             hg, ho = native.create(pd), oracle.create(pd)
             cplx = kind == "helmholtz"
             for L in range(lo, hi + 1):
