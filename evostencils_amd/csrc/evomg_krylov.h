@@ -655,6 +655,14 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
 // MASK_FROM: first unrolled row that may be a slack row in either half (host: min over the halves' row counts, or 0);
 // rows below it are rows of the grid in both halves and need no masking (33^2: 15 — only the upper half's last row is
 // slack). Column-less lanes need none either: their stencil coefficients are zeroed, so A p = 0 there by construction.
+// v = s * v + a in place (one v_fma_f64 with v as destination and second factor). For a live addend the compiler prefers
+// "copy a, then v_fmac" into a fresh register and copies every row back at the loop head: 52 moves per iteration of the
+// one-wave CG. Same instruction, same rounding as sc_fma(s, v, a).
+__device__ __forceinline__ void scale_add_in_place(double& v, double s, double a) {
+  asm("v_fma_f64 %0, %1, %0, %2" : "+v"(v) : "v"(s), "v"(a));
+}
+__device__ __forceinline__ void scale_add_in_place(cplx& v, cplx s, cplx a) { v = sc_fma(s, v, a); }
+
 template <typename T, bool XZERO, int MASK_FROM>
 __global__ void __launch_bounds__(64)
 evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, T* __restrict__ b_copy,
@@ -695,8 +703,17 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
   T rr = first_lane(wave_sum_fast(loc));
   const double res0 = sc_norm_from_dot(rr);
   int it = 0;
-  if (res0 != 0.0) {
-    for (; it < maxit; ++it) {
+  if (res0 != 0.0 && maxit > 0) {
+    // p = r + beta p at the TOP of the next iteration (not behind the convergence test of this one): definition and uses of
+    // p then share a block and the update happens in place — at the bottom the compiler wrote it to fresh registers and
+    // copied all sixteen rows back at the loop head (52 moves of 387 vector instructions per iteration)
+    T beta = zero;
+    bool have_beta = false;
+    for (;;) {
+      if (have_beta) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) scale_add_in_place(p[i], beta, r[i]);
+      }
       // the row across the seam: the lower half needs the upper half's first row, the upper half the lower half's last
       const T mine = h ? p[0] : p[R - 1];
       const T theirs = lanes_swap32(mine);
@@ -730,10 +747,10 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
       }
       const T rrn = first_lane(wave_sum_fast(loc));
       const double res = sc_norm_from_dot(rrn);
-      if (!(res > tol * res0)) { ++it; break; }
-      const T beta = sc_div(rrn, rr);
-#pragma unroll
-      for (int i = 0; i < R; ++i) p[i] = sc_fma(beta, p[i], r[i]);
+      ++it;
+      if (!(res > tol * res0) || it >= maxit) break;
+      beta = sc_div(rrn, rr);
+      have_beta = true;
       rr = rrn;
     }
   }
