@@ -107,6 +107,7 @@ template <typename T> class Impl : public ImplBase {
     if (dscalar_) (void)hipFree(dscalar_);
     if (dinfo_) (void)hipFree(dinfo_);
     if (norm_event_) (void)hipEventDestroy(norm_event_);
+    if (outer_event_) (void)hipEventDestroy(outer_event_);
     if (norm_partials_) (void)hipFree(norm_partials_);
     if (cg_xpart_) (void)hipFree(cg_xpart_);
     if (cg_xface_) (void)hipFree(cg_xface_);
@@ -2228,7 +2229,52 @@ template <typename T> class Impl : public ImplBase {
     };
     bool have_rho = false;        // rho_new of the next iteration came out of the residual update
     if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
-    else
+    else if (dev_steps) {
+      // Every scalar of the recurrence lives on the device (dscalar_: [0] r.r, [1] rho', [2] alpha, [3] omega, [4] rho,
+      // [5] beta), so the first half of the NEXT iteration — beta, the update of p, the preconditioner on p — is queued before
+      // the host waits for this iteration's norm: the round trip hides behind it. Speculative only in what it touches: p and
+      // the multigrid fields, none of which the result (Sol, Res) reads once the loop has stopped. The host still decides,
+      // on the same norm with the same arithmetic.
+      if ((rc = dot_to_host(L, rhat, Res, &rho_new)) != EVOMG_OK) return rc;
+      // staging: [0] r.r (unused), [1] rho' = rhat . r, [2] alpha = 1, [3] omega = 1, [4] rho = 1
+      const T zero_t = scalar_traits<T>::zero();
+      T init[5] = {zero_t, rho_new, one, one, one};
+      HIP_TRY(hipMemcpyAsync(dscalar_, init, sizeof init, hipMemcpyHostToDevice, stream_));
+      HIP_TRY(hipStreamSynchronize(stream_));         // `init` is a stack array
+      if (!outer_event_) HIP_TRY(hipEventCreateWithFlags(&outer_event_, hipEventDisableTiming));
+      auto front = [&]() -> int {                     // beta ; p = Res + beta (p - omega ap) ; u = M^-1 p
+        hipLaunchKernelGGL((evomg_bicg_beta<T>), dim3(1), dim3(64), 0, stream_, dscalar_);
+        hipLaunchKernelGGL((evomg_axpy2_dev<T>), node_grid(g), node_block(), 0, stream_, g, p, (const T*)p, (const T*)ap, (const T*)Res, (const T*)dscalar_);
+        return precondition(p);
+      };
+      if ((rc = front()) != EVOMG_OK) return rc;
+      for (it = 1; it <= prob_.max_iterations; ++it) {
+        T* u = fieldptr(L, EVOMG_F_SOL);
+        hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
+        hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 1, one, dscalar_, 2, 4);
+        hipLaunchKernelGGL((evomg_axpy_pair_dev<T>), node_grid(g), node_block(), 0, stream_, g, hh, (const T*)Sol, (const T*)u, s, (const T*)Res, (const T*)ap,
+                           (const T*)(dscalar_ + 2));
+        if ((rc = precondition(s)) != EVOMG_OK) return rc;
+        u = fieldptr(L, EVOMG_F_SOL);
+        hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
+        hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 2, one, dscalar_, 3, -1);
+        hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u);
+        apply_bc(L, Sol);
+        hipLaunchKernelGGL((evomg_axpy_dots_dev<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, (const T*)(dscalar_ + 3), (const T*)t, (const T*)rhat, partials_);
+        hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_);
+        HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipEventRecord(outer_event_, stream_));
+        if (it < prob_.max_iterations && (rc = front()) != EVOMG_OK) return rc;      // the next iteration's first half
+        HIP_TRY(hipEventSynchronize(outer_event_));
+        d = hscalar_[0];
+        res = sc_norm_from_dot(d);
+        if (hist && nh < cap) hist[nh] = res;
+        ++nh;
+        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+        if (res < prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+        if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+      }
+    } else
       for (it = 1; it <= prob_.max_iterations; ++it) {
         rho = rho_new;
         if (have_rho) rho_new = rho_next;
@@ -2243,43 +2289,19 @@ template <typename T> class Impl : public ImplBase {
         if ((rc = precondition(p)) != EVOMG_OK) return rc;
         T* u = fieldptr(L, EVOMG_F_SOL);
         T ra;
-        if (dev_steps) {
-          // alpha and omega are formed and consumed on the device (evomg_dot_final_quot: dscalar_[2], [3]); the host reads
-          // them with the residual norm at the end of the iteration — one round trip per iteration instead of three
+        if (fuse) {
           hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
-          hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 1, rho_new, dscalar_, 2);
-          hipLaunchKernelGGL((evomg_axpy_pair_dev<T>), node_grid(g), node_block(), 0, stream_, g, hh, (const T*)Sol, (const T*)u, s, (const T*)Res, (const T*)ap,
-                             (const T*)(dscalar_ + 2));
+          if ((rc = fetch_dots(1, &ra, &ra)) != EVOMG_OK) return rc;
         } else {
-          if (fuse) {
-            hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
-            if ((rc = fetch_dots(1, &ra, &ra)) != EVOMG_OK) return rc;
-          } else {
-            apply_operator(L, outer_st_, u, ap);
-            if ((rc = dot_to_host(L, rhat, ap, &ra)) != EVOMG_OK) return rc;
-          }
-          alpha = sc_div(rho_new, ra);
-          axpy(L, hh, Sol, alpha, u);
-          axpy(L, s, Res, sc_neg(alpha), ap);
+          apply_operator(L, outer_st_, u, ap);
+          if ((rc = dot_to_host(L, rhat, ap, &ra)) != EVOMG_OK) return rc;
         }
+        alpha = sc_div(rho_new, ra);
+        axpy(L, hh, Sol, alpha, u);
+        axpy(L, s, Res, sc_neg(alpha), ap);
         if ((rc = precondition(s)) != EVOMG_OK) return rc;
         u = fieldptr(L, EVOMG_F_SOL);
         T ts, tt;
-        if (dev_steps) {
-          hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
-          hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 2, one, dscalar_, 3);
-          hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u);
-          apply_bc(L, Sol);
-          hipLaunchKernelGGL((evomg_axpy_dots_dev<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, (const T*)(dscalar_ + 3), (const T*)t, (const T*)rhat, partials_);
-          hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_);
-          HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T) * 4, hipMemcpyDeviceToHost, stream_));
-          HIP_TRY(hipStreamSynchronize(stream_));
-          d = hscalar_[0];
-          rho_next = hscalar_[1];
-          alpha = hscalar_[2];
-          omega = hscalar_[3];
-          have_rho = true;
-        } else {
         if (fuse) {
           hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
           if ((rc = fetch_dots(2, &ts, &tt)) != EVOMG_OK) return rc;
@@ -2298,7 +2320,6 @@ template <typename T> class Impl : public ImplBase {
         } else {
           axpy(L, Res, s, sc_neg(omega), t);
           if ((rc = dot_to_host(L, Res, Res, &d)) != EVOMG_OK) return rc;
-        }
         }
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
@@ -2359,6 +2380,7 @@ template <typename T> class Impl : public ImplBase {
   bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
   bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
   hipEvent_t norm_event_ = nullptr;
+  hipEvent_t outer_event_ = nullptr;
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
   // experiments only: the oracle restates the default (krylov_bicgstab_per_launch)
   int kb_min_n_ = getenv("EVOMG_KB_MIN_N") ? atoi(getenv("EVOMG_KB_MIN_N")) : 129;

@@ -670,8 +670,10 @@ __global__ void __launch_bounds__(256) evomg_axpy_dots(Geo g, T* __restrict__ z,
 // host out of two of the three round trips of an iteration. Same operations on the same values as the host loop's
 // sc_div: the same bits. scal[0 .. 1]: the dot product(s); scal[slot]: the quotient.
 //   ndot == 1: scal[slot] = num / dot0          ndot == 2: scal[slot] = dot0 / dot1
+// num_slot >= 0: the numerator is scal[num_slot] instead of `num`
 template <typename T>
-__global__ void __launch_bounds__(256) evomg_dot_final_quot(const T* __restrict__ partial, int count, int ndot, T num, T* __restrict__ scal, int slot) {
+__global__ void __launch_bounds__(256) evomg_dot_final_quot(const T* __restrict__ partial, int count, int ndot, T num, T* __restrict__ scal, int slot,
+                                                            int num_slot = -1) {
   __shared__ T red[17];
   T d[2] = {scalar_traits<T>::zero(), scalar_traits<T>::zero()};
   for (int k = 0; k < ndot; ++k) {
@@ -682,8 +684,33 @@ __global__ void __launch_bounds__(256) evomg_dot_final_quot(const T* __restrict_
   if (threadIdx.x == 0) {
     scal[0] = d[0];
     if (ndot > 1) scal[1] = d[1];
+    if (num_slot >= 0) num = scal[num_slot];
     scal[slot] = ndot == 1 ? sc_div(num, d[0]) : sc_div(d[0], d[1]);
   }
+}
+// the head of a BiCGStab iteration on the device: rho = scal[4] (the previous iteration's rho'), rho' = scal[1] (formed
+// with the residual norm at the end of the previous iteration), alpha = scal[2], omega = scal[3]:
+//   scal[5] = beta = (rho' / rho) * (alpha / omega) ; scal[4] = rho'
+// so that the next iteration can be queued before the host has seen the norm of this one (the host's sc_mul / sc_div on
+// the same values: the same bits)
+template <typename T> __global__ void evomg_bicg_beta(T* __restrict__ scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const T rho = scal[4], rho_new = scal[1];
+    scal[5] = sc_mul(sc_div(rho_new, rho), sc_div(scal[2], scal[3]));
+    scal[4] = rho_new;
+  }
+}
+// evomg_axpy2 with a = -scal[3] (omega) and b = scal[5] (beta)
+template <typename T>
+__global__ void __launch_bounds__(256) evomg_axpy2_dev(Geo g, T* __restrict__ z, const T* __restrict__ x1, const T* __restrict__ y1,
+                                                       const T* __restrict__ x2, const T* __restrict__ scal) {
+  int i, j, k;
+  if (!node_of_thread<2>(g, i, j, k)) return;
+  if (!is_inner<2>(g, i, j, k)) return;
+  const long c = gidx<2>(g, i, j, k);
+  const T a = sc_neg(scal[3]), b = scal[5];
+  const T t = sc_add(x1[c], sc_mul(a, y1[c]));
+  z[c] = sc_add(x2[c], sc_mul(b, t));
 }
 // z1 = x1 + a y1 ; z2 = x2 - a y2 on inner nodes, a = *ap (two independent axpy steps in one pass)
 template <typename T>
