@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-size", action="store_true",
                     help="skip the second configuration (513^2, five levels: the reference's own operating size)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip BASELINE.json configs[2] / configs[3] (Helmholtz 2048^2, 3D Poisson 512^3) on the same line")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--concurrency", type=int, default=1,
                     help="candidates in flight per GPU inside the HEADLINE timed region (1 = isolated timing, the "
@@ -115,12 +117,31 @@ def cpu_baseline(ops, lo, hi, threads):
     h.close()
     # report the faster of the two as the baseline (memory-bound sweeps do not always scale to all host cores)
     best_wall, best_threads = (wall4, 4) if (wall4 is not None and wall4 < wall) else (wall, threads)
-    return {"value": 1.0 / best_wall, "unit": "solves/s", "cores": best_threads, "kind": "port",
+    return {"value": 1.0 / best_wall, "unit": "solves/s", "cores": best_threads, "kind": "port", **host_cpu(),
             "sample": f"1 full solve of the same workload ({int(out.n_iterations)} V-cycles, {best_wall:.1f} s wall)",
             "build": f"oracle/Makefile: {flags}; the Krylov half of the oracle sums in the device's reduction-tree order "
                      "(parity infrastructure, not a tuned CPU solver)",
             "iterations": out.n_iterations, "final_res_norm": out.final_res_norm,
             "by_threads": {str(threads): 1.0 / wall, **({"4": 1.0 / wall4} if wall4 else {})}}
+
+
+def host_cpu():
+    """CPU model, logical CPUs of the host and the share this process may run on (BASELINE.md asks for them beside every
+    CPU number)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"cpu_model": model, "nproc": os.cpu_count(), "nproc_usable": usable}
 
 
 def measured_traffic(kernel_key):
@@ -284,6 +305,75 @@ def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):
                     "clock per generate_and_evaluate call incl. lowering and the host side of the launches"}
 
 
+def _frac(b):
+    return {"ms_per_launch": b.ms, "bytes_per_launch": b.bytes, "launches": b.launches, "achieved_gbps": b.gbps,
+            "frac": b.gbps / 8000.0}
+
+
+def other_configs_section(local_rank):
+    """BASELINE.json configs[2] and configs[3] on the driver's clock (rank 0, N = 1): the same live HIP-event timing as the
+    headline's roofline (evomg_profile_begin/end on the backend's stream, fused launches timed as what they are).
+    Algorithmic bytes per launch (complex x2): sweep 24 B/node (+ 8 B per coarse node where the coarse level is
+    read or written by the same launch; - 8 B/node for a sweep that starts from an elided zero field), 3D double sweep
+    24 B/node for BOTH sweeps, residual + restriction 16 B/node + 8 B per coarse node."""
+    import dataclasses
+    from evostencils_amd import abi, native, problems
+    from test_full_size_gpu import vcycle
+    from test_helmholtz_oracle import reference_vcycle_ops
+    out = {}
+    # ---- C3: 2D Helmholtz 2048^2 (complex), k h = 0.625, preconditioned BiCGStab with the reference's V(2,1) cycle, capped
+    lo, hi, cap = 7, 11, 30
+    pd = dataclasses.replace(problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi)), max_iterations=cap)
+    h = native.create(pd, local_rank)
+    ops = reference_vcycle_ops(lo, hi)
+    h.evaluate(ops, 1, 0, 0)                                  # warm-up: first launch of every kernel
+    h.profile_begin(abi.OP_SMOOTH, hi)
+    res = h.evaluate(ops, 1, 0, 0)
+    sweeps = h.profile_end()
+    smooth = next(o for o in ops if o.opcode == abi.OP_SMOOTH and o.level == hi)
+    out["c3"] = {"workload": f"2D Helmholtz, {1 << hi}^2 (complex128), k = {pd.parameters['k']:g} (k h = 0.625), levels {hi}..{lo}, "
+                             f"MG-preconditioned BiCGStab (2 cycles per iteration), reference V(2,1) RB-GS w = 0.6 cycle, capped at "
+                             f"{cap} outer iterations (no cycle converges inside the reference's cap at this size, DESIGN section 5)",
+                 "ms_per_outer_iteration": res.time_ms / res.n_iterations, "outer_iterations": res.n_iterations,
+                 "solve_time_ms": res.time_ms,
+                 "dominant_kernel": {"name": h.kernel_name(smooth), "what": "finest-level RB-GS sweeps (6 per outer iteration: plain, "
+                                     "sweep + residual + restriction, prolongation + sweep)", **_frac(sweeps),
+                                     "share_of_solve": sweeps.ms * sweeps.launches / res.time_ms}}
+    h.close()
+    # ---- C4: 3D Poisson 512^3, V(2,2) block-Jacobi (2,1,1) w = 0.8, levels 9..5, textbook `with jacobi` semantics
+    lo, hi = 5, 9
+    pd = problems.poisson_3d(lo, hi)
+    h = native.create(pd, local_rank, jacobi_semantics="textbook")
+    ops = vcycle(lo, hi, 2, 2, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (2, 1, 1), 0.8))
+    h.evaluate(ops, 1, 0, 0)
+    kernels = {}
+    solve = None
+    for key, opcode, what in (("double_sweep", abi.OP_SMOOTH, "two block-Jacobi (2,1,1) sweeps in ONE pass (evomg_tile3d_twice; the "
+                                                               "post-smoothing launch also folds the prolongation in)"),
+                              ("residual_restrict", abi.OP_RESIDUAL, "residual + full weighting, residual never written "
+                                                                     "(evomg_tile3d_residual_restrict)"),
+                              ("residual_norm", abi.PROF_LOOP_NORM, "the solver loop's residual + norm pass (evomg_tile3d<RESNORM> + "
+                                                                     "two reduction launches)"),
+                              ("coarse_solve", abi.OP_COARSE_SOLVE, "CG on 33^3, eight rendezvousing workgroups (evomg_cg_multi_wg3d)")):
+        h.profile_begin(opcode, lo if opcode == abi.OP_COARSE_SOLVE else hi)
+        solve = h.evaluate(ops, 1, 0, 0)
+        b = h.profile_end()
+        kernels[key] = {"what": what, **_frac(b), "share_of_solve": b.ms * b.launches / solve.time_ms}
+        if opcode == abi.OP_COARSE_SOLVE:
+            kernels[key].pop("frac"), kernels[key].pop("achieved_gbps"), kernels[key].pop("bytes_per_launch")
+    rb = abi.make_op(abi.OP_SMOOTH, hi, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0)
+    b2b = sorted((h.bench_op(rb, warmup=3, reps=20) for _ in range(3)), key=lambda b: b.ms)[1]
+    kernels["rbgs_back_to_back"] = {"what": "fused two-colour RB-GS sweep (evomg_tile3d_rbgs), 20 back-to-back launches, median of 3",
+                                    **_frac(b2b)}
+    out["c4"] = {"workload": f"3D Poisson 7-pt, {1 << hi}^3 (level {hi}), levels {hi}..{lo}, V(2,2) block-Jacobi (2,1,1) w = 0.8, "
+                             "CG on 33^3, 1e-12 reduction; jacobi_semantics = textbook (under the reference pipeline's semantics the "
+                             "sweeps never take effect and the candidate does not converge: tests/test_baseline_configs_gpu.py)",
+                 "ms_per_solve": solve.time_ms, "iterations": solve.n_iterations, "convergence_factor": solve.conv_factor,
+                 "status": solve.status, "kernels": kernels}
+    h.close()
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -306,12 +396,25 @@ def main():
     elif torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
+    rccl = {"backend": backend, "ranks": world, "error": None}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif backend == "nccl":
+        # N = 1: a ONE-rank RCCL group, so that the per-step fitness gather and the population's per-generation collective
+        # run through RCCL here exactly as they do at N > 1 (population.py goes through the group whenever one exists)
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        except Exception as exc:                              # noqa: BLE001 — must not cost the headline line
+            rccl["error"] = repr(exc)
     reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     from evostencils_amd import abi, native, problems
@@ -480,7 +583,14 @@ def main():
             "config": {"workload": f"2D Poisson 5-pt, {1 << hi}^2 grid (level {hi}), {hi - lo + 1}-level V(1,1) "
                                    f"RB-Gauss-Seidel cycle, CG coarse solve, 1e-12 reduction",
                        "iterations_per_solve": its, "convergence_factor": rho, "solve_time_ms": t_ms,
-                       "parallelism": f"candidates sharded 1/GPU x {world}, RCCL fitness gather",
+                       "parallelism": f"candidates sharded 1/GPU x {world}, "
+                                      + ("RCCL fitness gather" if (dist.is_initialized() and backend == "nccl") else
+                                         f"fitness gather: {'no process group' if not dist.is_initialized() else backend}"),
+                       "collectives": {**rccl, "process_group": dist.is_initialized(),
+                                       "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                                       "per_step": "gather of (rho, time, iterations) to rank 0 inside the timed region",
+                                       "per_generation": "all_gather of [n_local x (index, rho, time, iterations)] + failure flag row "
+                                                         "in the population section"},
                        "candidates_in_flight_per_gpu": args.concurrency},
             "roofline": roofline,
             "coarse_solve": coarse_solve,
@@ -494,6 +604,11 @@ def main():
                 line["reference_size"] = reference_size_section(local_rank, rank, in_flight=args.throughput_workers)
             except Exception as exc:                         # noqa: BLE001
                 line["reference_size"] = {"error": repr(exc)}
+        if world == 1 and not args.no_configs:
+            try:                                             # auxiliary, rank-local: must not cost the headline line
+                line["configs"] = other_configs_section(local_rank)
+            except Exception as exc:                         # noqa: BLE001
+                line["configs"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N = 1 only
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             try:
@@ -501,7 +616,7 @@ def main():
             except Exception as exc:                         # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "", "error": repr(exc)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

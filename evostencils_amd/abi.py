@@ -32,6 +32,7 @@ F_SOL, F_RHS, F_RES, F_CORR, F_CGS_RHS, F_COUNT = 0, 1, 2, 3, 4, 5
  OP_COARSE_SOLVE, OP_RICHARDSON) = range(1, 10)
 # non-linear FAS vocabulary (include/evomg.h; exastencils_FAS.py:99-319)
 (OP_FAS_SMOOTH, OP_FAS_RESIDUAL, OP_FAS_RESTRICT_SOLUTION, OP_FAS_COARSE_RHS, OP_FAS_CGS, OP_FAS_SUBTRACT) = range(16, 22)
+PROF_LOOP_NORM = 64      # pseudo-opcode of profile_begin: the solver loop's own residual + norm pass (EVOMG_PROF_LOOP_NORM)
 PART_SINGLE, PART_RED_BLACK = 0, 1
 
 OP_NAMES = {OP_SMOOTH: "SMOOTH", OP_RESIDUAL: "RESIDUAL", OP_RESTRICT: "RESTRICT",
@@ -124,7 +125,9 @@ def ops_array(ops: Sequence[Op]):
 # every symbol include/evomg.h declares, without prefix
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
             "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
-            "profile_begin", "profile_end", "device_count"]
+            "profile_begin", "profile_end", "device_count",
+            "comm_create", "comm_destroy", "comm_last_error", "allgather_fitness", "gather_fitness", "rccl_version"]
+FITNESS_COLUMNS = 4      # EVOMG_FITNESS_COLUMNS: (candidate index, convergence factor, time ms, iterations)
 
 
 class BackendError(RuntimeError):
@@ -132,9 +135,11 @@ class BackendError(RuntimeError):
 
 
 class Library:
-    """A loaded C-ABI library; `prefix` selects evomg_* (HIP) or oracle_* (CPU oracle)."""
+    """A loaded library exporting the C-ABI of include/evomg.h (`prefix`_`symbol`). The product instantiates it for
+    csrc/libevomg.so only (native.py); test infrastructure binds other implementations of the same header with its own
+    prefix and symbol subset (oracle/oracle.py)."""
 
-    def __init__(self, path: str, prefix: str, symbols: Sequence[str]):
+    def __init__(self, path: str, prefix: str = "evomg", symbols: Sequence[str] = tuple(EXPORTED)):
         self.path, self.prefix = path, prefix
         self.lib = C.CDLL(path)
         self.fn = {}
@@ -176,6 +181,19 @@ class Library:
         if "kernel_name" in f:
             f["kernel_name"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_char_p, C.c_int]
             f["kernel_name"].restype = C.c_int
+        if "comm_create" in f:
+            f["comm_create"].argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+            f["comm_create"].restype = C.c_int
+            f["comm_destroy"].argtypes = [C.c_void_p]
+            f["comm_destroy"].restype = None
+            f["comm_last_error"].argtypes = [C.c_void_p]
+            f["comm_last_error"].restype = C.c_char_p
+            f["allgather_fitness"].argtypes = [C.c_void_p, dp, C.c_int, dp]
+            f["allgather_fitness"].restype = C.c_int
+            f["gather_fitness"].argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int]
+            f["gather_fitness"].restype = C.c_int
+            f["rccl_version"].argtypes = []
+            f["rccl_version"].restype = C.c_int
 
 
 @dataclass
@@ -304,3 +322,52 @@ class Handle:
         buf = C.create_string_buffer(256)
         self._check(self.L.fn["kernel_name"](self._h, C.byref(op), buf, 256), "kernel_name")
         return buf.value.decode()
+
+
+class Communicator:
+    """The population's exchange step behind the C-ABI (include/evomg.h: evomg_comm_create / evomg_allgather_fitness /
+    evomg_gather_fitness): one per process, bound to the process's GPU, RCCL underneath, no torch. `id_path`: a file every
+    rank of the job can see and no other job uses (the RCCL unique id travels through it)."""
+
+    def __init__(self, library: Library, rank: int, world: int, device_id: int, id_path: str, timeout_ms: int = 60000):
+        self.L, self.rank, self.world = library, rank, world
+        self._c = C.c_void_p()
+        rc = library.fn["comm_create"](rank, world, device_id, id_path.encode(), timeout_ms, C.byref(self._c))
+        if rc != OK:
+            msg = library.fn["comm_last_error"](None)
+            raise BackendError(f"evomg_comm_create failed with status {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self._c:
+            self.L.fn["comm_destroy"](self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rows(self, rows):
+        a = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, FITNESS_COLUMNS)
+        return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def _check(self, rc, what):
+        if rc != OK:
+            msg = self.L.fn["comm_last_error"](self._c)
+            raise BackendError(f"evomg_{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+    def allgather(self, rows) -> np.ndarray:
+        """rows: [n_local x 4] (the same n_local on every rank) -> [world * n_local x 4] in rank order, on every rank."""
+        a, pa = self._rows(rows)
+        out = np.empty((self.world * a.shape[0], FITNESS_COLUMNS), dtype=np.float64)
+        self._check(self.L.fn["allgather_fitness"](self._c, pa, a.shape[0], out.ctypes.data_as(C.POINTER(C.c_double))), "allgather_fitness")
+        return out
+
+    def gather(self, rows, root: int = 0):
+        """The same table on `root` only; None elsewhere."""
+        a, pa = self._rows(rows)
+        out = np.empty((self.world * a.shape[0], FITNESS_COLUMNS), dtype=np.float64) if self.rank == root else None
+        po = out.ctypes.data_as(C.POINTER(C.c_double)) if out is not None else None
+        self._check(self.L.fn["gather_fitness"](self._c, pa, a.shape[0], po, root), "gather_fitness")
+        return out

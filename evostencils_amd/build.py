@@ -1,36 +1,69 @@
-"""Builds the HIP backend in-tree: csrc/evomg.hip -> csrc/libevomg.so for gfx950 (MI355X).
+"""Builds the HIP backend in-tree: csrc/*.hip -> csrc/libevomg.so for gfx950 (MI355X).
 
 hipcc cross-compiles without a GPU. -ffp-contract=off keeps the arithmetic order of the kernels
 explicit (bit-for-bit comparable with the CPU oracle); these stencils are bandwidth-bound, FMA
 contraction would buy nothing.
+
+One object per translation unit (the C-ABI, and one per implementation class: real, complex, systems, FAS),
+compiled in parallel, then one link: a change to one implementation recompiles one object.
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libevomg.so")
-SOURCES = ["evomg.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/evomg.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+OBJ_DIR = os.path.join(CSRC, "obj")
+SOURCES = ["evomg.hip", "impl_real.hip", "impl_complex.hip", "impl_system.hip", "impl_fas.hip", "evomg_collective.hip"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-Wall",
+          "-Wno-unused-function", "-fvisibility=hidden"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-ldl"]
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inl"))] + \
+           [os.path.join(HERE, "..", "include", "evomg.h"), os.path.abspath(__file__)]
+
+
+def _newer(deps, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
 
 
 def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return _newer([os.path.join(CSRC, s) for s in _sources()] + _headers(), LIB)
 
 
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = _headers()
+    todo = [s for s in _sources() if force or _newer([os.path.join(CSRC, s)] + headers, _obj(s))]
+
+    def compile_one(src):
+        cmd = [hipcc] + CFLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc] + LDFLAGS + ["-o", LIB] + [_obj(s) for s in _sources()]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -122,7 +122,10 @@ class ProgramGenerator:
         self._problem = problem
         self._original_min_level = problem.min_level
         self._original_max_level = problem.max_level
-        self._device_id = device_id if device_id is not None else self._default_device(mpi_rank, library)
+        # resolved on first use (_ensure_handle): asking the library for the device count initialises the HIP runtime, which a
+        # generator that only lowers must not do (a later fork would inherit a broken runtime), and GPU_MAX_HW_QUEUES
+        # (evostencils_amd/__init__.py) only takes effect if it is set before that first call
+        self._device_id = device_id
         self._library = library
         self._handle = None
         self._handle_levels = None
@@ -186,9 +189,11 @@ class ProgramGenerator:
         asking for a device that does not exist."""
         local = mpi_rank
         for name in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
-            if os.environ.get(name, "").lstrip("-").isdigit():
+            if os.environ.get(name, "").isdigit():          # a negative or malformed value is not a rank
                 local = int(os.environ[name])
                 break
+        if not isinstance(local, int) or local < 0:
+            raise ValueError(f"local rank {local!r} is not a device index")
         count = 0
         if library is None:
             try:
@@ -212,6 +217,8 @@ class ProgramGenerator:
         if parameters:
             params.update(parameters)
         frozen = tuple(sorted(params.items()))
+        if self._device_id is None:
+            self._device_id = self._default_device(self._mpi_rank, self._lib())
         if self._handle is None or self._handle_levels != key:
             if self._handle is not None:
                 self._handle.close()

@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(256) evomg_zero_inner(Geo g, T* __restrict__ x
 }
 
 // ---- K8: Helmholtz Robin boundary at x = 0, 1:  x_b = x_in / (1 - i k h)  (2D complex only) ----------------
-__global__ void __launch_bounds__(256) evomg_robin_bc(Geo g, cplx* __restrict__ x, double kh) {
+// (static: the header is part of several translation units)
+static __global__ void __launch_bounds__(256) evomg_robin_bc(Geo g, cplx* __restrict__ x, double kh) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < 1 || j >= g.n - 1) return;
   const cplx den{1.0, -kh};

@@ -1,0 +1,64 @@
+// evomg_runtime.h — what every implementation class of the backend shares: the interface behind the C-ABI handle,
+// error plumbing, constants. (Split out of evomg.hip in round 4; see impl_*.hip for the implementations.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/evomg.h"
+#include <cstdint>
+#include <set>
+
+namespace evomg_detail {
+
+extern thread_local char g_create_error[512];
+
+inline double wall_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct ImplBase {
+  virtual ~ImplBase() {}
+  virtual int init() = 0;
+  virtual int set_initial_field(int level, int field, const double* host) = 0;
+  virtual int get_field(int level, int field, double* host) = 0;
+  virtual int set_field(int level, int field, const double* host) = 0;
+  virtual int set_operators(const evomg_problem_t* p) = 0;
+  virtual int evaluate(const evomg_op_t* ops, int n_ops, int samples, double wall_limit_ms, evomg_result_t* out,
+                       double* hist, int cap) = 0;
+  virtual int run_ops(const evomg_op_t* ops, int n_ops) = 0;
+  virtual int norm(int level, int field, double* out) = 0;
+  virtual int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) = 0;
+  virtual int kernel_name(const evomg_op_t* op, char* buf, int len) = 0;
+  virtual int profile_begin(int opcode, int level) = 0;
+  virtual int profile_end(evomg_bench_t* out) = 0;
+  char err[512] = "";
+};
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      snprintf(err, sizeof err, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return EVOMG_ERR_DEVICE;                                                                         \
+    }                                                                                                  \
+  } while (0)
+
+constexpr int kDotBlocks = 1024;
+constexpr int kTmpVectors = 6;
+
+// factories of the four implementations (impl_real.hip, impl_complex.hip, impl_system.hip, impl_fas.hip)
+ImplBase* make_impl_real(const evomg_problem_t& p, int device);
+ImplBase* make_impl_complex(const evomg_problem_t& p, int device);
+ImplBase* make_impl_system(const evomg_problem_t& p, int device);
+ImplBase* make_impl_fas(const evomg_problem_t& p, int device);
+
+}  // namespace evomg_detail

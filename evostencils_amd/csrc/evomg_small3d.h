@@ -12,7 +12,7 @@
 #pragma once
 #include "evomg_kernels.h"
 
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)      // static: the header is part of two translation units
 evomg_small3d_chain(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ f, double om, double omm, int nsweeps,
                     int zero_first, const double* __restrict__ coarse_in, Geo gc, double om_p, double* __restrict__ res_out,
                     double* __restrict__ coarse_out) {

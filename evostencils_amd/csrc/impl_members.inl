@@ -1,0 +1,88 @@
+// impl_members.inl — data members and environment knobs
+// Part of the body of `template <typename T> class Impl` (evomg_impl.h includes this file INSIDE the class).
+
+  evomg_problem_t prob_;
+  int device_;
+  int dim_;
+  Level<T> lv_[EVOMG_MAX_LEVELS];
+  Stencil<T> outer_st_{};
+  T* outer_[8] = {};
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  T* partials_ = nullptr;
+  T* dscalar_ = nullptr;
+  T* hscalar_ = nullptr;
+  int* dinfo_ = nullptr;
+  bool mirror_enabled_ = getenv("EVOMG_NO_BOUNDARY_MIRROR") == nullptr;
+  bool x_zero_next_ = false;
+  bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
+  bool bnd_zero_[24][EVOMG_F_COUNT];   // boundary of the field's current array is known to be all zero
+  static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
+  bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
+  bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
+  hipEvent_t norm_event_ = nullptr;
+  hipEvent_t outer_event_ = nullptr;
+  bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
+  // experiments only: the oracle restates the default (krylov_bicgstab_per_launch)
+  int kb_min_n_ = getenv("EVOMG_KB_MIN_N") ? atoi(getenv("EVOMG_KB_MIN_N")) : 129;
+  bool kcg_enabled_ = getenv("EVOMG_NO_LAUNCH_CG") == nullptr;       // large coarsest grids: CG as a sequence of launches
+  KcgState* kcg_state_ = nullptr;
+  KcgState* kcg_host_ = nullptr;
+  KbState<T>* kb_state_ = nullptr;
+  KbState<T>* kb_host_ = nullptr;
+  T* kb_scal_ = nullptr;
+  bool outer_fuse_ = getenv("EVOMG_NO_OUTER_FUSE") == nullptr;      // fused passes of the preconditioned BiCGStab loop
+  bool outer_dev_steps_ = getenv("EVOMG_NO_OUTER_DEV_STEPS") == nullptr;   // ... with alpha and omega formed on the device
+  bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
+  T* norm_partials_ = nullptr;
+  size_t norm_partials_cap_ = 0;
+  T* cg_xpart_ = nullptr;
+  T* cg_xface_ = nullptr;
+  unsigned* cg_flags_ = nullptr;
+  bool cg_multi_attr_set_ = false;
+  bool cg_multi_used_ = false;
+  bool cg_lds_attr_set_[24] = {};
+  int prof_opcode_ = -1, prof_level_ = -1;
+  size_t prof_used_ = 0;
+  double prof_bytes_ = 0.0;
+  std::vector<hipEvent_t> prof_events_;
+  bool use_reg_krylov_ = (getenv("EVOMG_NO_REG_KRYLOV") == nullptr);
+  bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
+  bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
+  bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
+  bool balance_rows_ = (getenv("EVOMG_NO_BALANCED_ROWS") == nullptr);
+  bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
+  // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
+  // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
+  bool small3d_enabled_ = getenv("EVOMG_NO_SMALL3D") == nullptr;
+  bool small3d_attr_set_ = false;
+  bool small2d_enabled_ = getenv("EVOMG_NO_SMALL2D") == nullptr;
+  // largest grid that runs as LDS tiles: Helmholtz levels 3..7 149 (33) -> 137-146 (65) -> 131 ms (129), nothing beyond; real
+  // sweeps at 129^2 are no faster than the strips (4.2 vs 3.7 us back to back), at 65^2 they are (3.7 vs 5.8 us)
+  int small2d_max_n_ = getenv("EVOMG_SMALL2D_MAX_N") ? atoi(getenv("EVOMG_SMALL2D_MAX_N")) : (scalar_traits<T>::is_complex ? 129 : 65);
+  std::set<const void*> small2d_attr_set_;
+  bool batch_enabled_ = (getenv("EVOMG_BATCH") != nullptr) && (getenv("EVOMG_NO_STRIP") == nullptr);
+  int batch_max_n_ = getenv("EVOMG_BATCH_MAX_N") ? atoi(getenv("EVOMG_BATCH_MAX_N")) : 129;
+  MicroBatch batch_ = {};
+  int n_cu_ = 256;
+  size_t max_lds_ = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock, read at init
+  int twice_planes_ = getenv("EVOMG_TWICE_PLANES") ? atoi(getenv("EVOMG_TWICE_PLANES")) : 16;
+  int rr_cplanes_ = getenv("EVOMG_RR_CPLANES") ? atoi(getenv("EVOMG_RR_CPLANES")) : 8;
+  bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
+  // complex (Helmholtz) problems: from 17^2 — the strip kernels write the Robin columns themselves, where the generic ones
+  // need a boundary launch behind every op (reference-range solve 212-224 -> 197-215 ms)
+  // real problems too since the levels up to 33^2 run in LDS (evomg_small2d: the fused forms instead of one generic launch per op)
+  int strip_min_n_ = getenv("EVOMG_STRIP_MIN_N") ? atoi(getenv("EVOMG_STRIP_MIN_N")) : ((scalar_traits<T>::is_complex || getenv("EVOMG_NO_SMALL2D") == nullptr) ? 17 : 33);
+  int strip_rows_ = getenv("EVOMG_STRIP_ROWS") ? atoi(getenv("EVOMG_STRIP_ROWS")) : 0;
+  int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
+  int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
+  bool tile3d_enabled_ = getenv("EVOMG_NO_TILE3D") == nullptr;
+  bool tile3d_rbgs_ = getenv("EVOMG_NO_TILE3D_RBGS") == nullptr;
+  bool tile3d_twice_ = getenv("EVOMG_NO_TILE3D_TWICE") == nullptr;
+  bool tile3d_pro_ = getenv("EVOMG_NO_TILE3D_PRO") == nullptr;
+  int tile3d_nt_ = getenv("EVOMG_TILE3D_NT") ? atoi(getenv("EVOMG_TILE3D_NT")) : 0;   // bit 0: non-temporal f loads (measured slower at 513^3: profiles/r02_pmc_3d.md)
+  int tile3d_order_ = getenv("EVOMG_TILE3D_ORDER") ? atoi(getenv("EVOMG_TILE3D_ORDER")) : 1;
+  int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;
+  bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
+  double nt_lo_mib_ = getenv("EVOMG_NT_LO_MIB") ? atof(getenv("EVOMG_NT_LO_MIB")) : 256.0;   // 3 fields above this: stream x, y
+  double nt_hi_mib_ = getenv("EVOMG_NT_HI_MIB") ? atof(getenv("EVOMG_NT_HI_MIB")) : 192.0;   // ... unless one field exceeds this

@@ -1,0 +1,351 @@
+// impl_solvers.inl — reductions, field reset and the two outer solver loops (generated MG iteration, preconditioned BiCGStab)
+// Part of the body of `template <typename T> class Impl` (evomg_impl.h includes this file INSIDE the class).
+
+  // ---- reductions ----------------------------------------------------------------------------------------------------
+  void dot_async(int L, const T* a, const T* b, T* dev_out) {
+    const Geo& g = lv_[L].g;
+    const int m = g.n - 2;
+    const long rows = dim_ == 2 ? m : (long)m * m;
+    const int blocks = (int)(rows < kDotBlocks ? rows : kDotBlocks);
+    if (dim_ == 2) hipLaunchKernelGGL((evomg_dot_partial<T, 2>), dim3(blocks), dim3(256), 0, stream_, g, a, b, partials_);
+    else hipLaunchKernelGGL((evomg_dot_partial<T, 3>), dim3(blocks), dim3(256), 0, stream_, g, a, b, partials_);
+    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dev_out);
+  }
+  int dot_to_host(int L, const T* a, const T* b, T* out) {
+    dot_async(L, a, b, dscalar_);
+    HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = hscalar_[0];
+    return EVOMG_OK;
+  }
+
+  int reset_fields() {
+    for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
+      Level<T>& lv = lv_[L];
+      lv.alt_mirror = nullptr;
+      for (int f = 0; f < EVOMG_F_COUNT; ++f) {
+        if (!lv.f[f]) continue;
+        if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        else {
+          HIP_TRY(hipMemsetAsync(lv.f[f], 0, lv.elems * sizeof(T), stream_));
+          bnd_zero_[L][f] = true;
+        }
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return EVOMG_OK;
+  }
+
+  int solve_mg(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
+    const int L = prob_.max_level;
+    Level<T>& lv = lv_[L];
+    int nh = 0;
+    const double t0 = wall_ms();
+    T d;
+    if (!norm_event_) HIP_TRY(hipEventCreateWithFlags(&norm_event_, hipEventDisableTiming));
+    bool ahead = false, res_stale = false;
+    // residual + norm of the current iterate: launched, the scalar copied back asynchronously, an event recorded
+    auto residual_norm_launch_all = [&]() -> int {
+      int rc = EVOMG_OK;
+      const bool timed = prof_opcode_ == EVOMG_PROF_LOOP_NORM && prof_level_ == L;
+      bool wrote_r = true;
+      if (timed && (rc = prof_open()) != EVOMG_OK) return rc;
+      if (norm_fused(lv.g)) rc = residual_norm_launch(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+      else if (norm_fused3d(lv.g)) {
+        // the residual field itself is written only if the cycle reads it before overwriting it
+        const bool dead = fuse_enabled_ && loop_residual_is_dead(ops, n_ops);
+        if (dead) res_stale = true;
+        wrote_r = !dead;
+        rc = residual_norm_launch3d(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), !dead);
+      } else {
+        residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+        dot_async(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), dscalar_);
+      }
+      if (rc != EVOMG_OK) return rc;
+      // x, f read (+ the residual field written where the cycle reads it); the reduction launches behind it are included
+      if (timed && (rc = prof_close((wrote_r ? 3.0 : 2.0) * sizeof(T) * pow((double)lv.g.n, dim_))) != EVOMG_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+      HIP_TRY(hipEventRecord(norm_event_, stream_));
+      return EVOMG_OK;
+    };
+    // While the host waits for that scalar the GPU would idle. If the cycle starts with an out-of-place smoother, its
+    // launch is queued behind the norm right away (speculatively): should the norm say "converged", the pointer swap
+    // is simply undone and the sweep's output discarded; otherwise the cycle continues from its second op.
+    T *saved_alt = nullptr, *saved_x = nullptr;
+    const T* saved_mirror = nullptr;
+    auto speculate = [&](bool* launched) -> int {
+      *launched = false;
+      if (!speculate_ || n_ops < 1 || !smoother_is_out_of_place(ops[0])) return EVOMG_OK;
+      // a sweep that fuses with the residual + restriction behind it is worth more than the overlap (and the fused
+      // kernel writes the coarse right-hand side, which a speculative launch must not)
+      if (fusable_smooth_residual_restrict(ops, n_ops, 0, true)) return EVOMG_OK;
+      if (fusable_twice(ops, n_ops, 0)) return EVOMG_OK;          // two sweeps in one pass beat the overlap
+      const int l0 = ops[0].level;
+      saved_alt = lv_[l0].alt;
+      saved_mirror = lv_[l0].alt_mirror;
+      saved_x = fieldptr(l0, ops[0].dst);
+      const int rc = exec(ops[0]);
+      *launched = rc == EVOMG_OK;
+      return rc;
+    };
+    auto undo_speculation = [&]() {
+      const int l0 = ops[0].level;
+      lv_[l0].alt = saved_alt;
+      lv_[l0].alt_mirror = saved_mirror;
+      set_fieldptr(l0, ops[0].dst, saved_x);
+    };
+    auto wait_norm = [&]() -> int {
+      HIP_TRY(hipEventSynchronize(norm_event_));
+      d = hscalar_[0];
+      return EVOMG_OK;
+    };
+    int rc = residual_norm_launch_all();
+    if (rc != EVOMG_OK) return rc;
+    if ((rc = speculate(&ahead)) != EVOMG_OK) return rc;
+    if ((rc = wait_norm()) != EVOMG_OK) return rc;
+    const double res0 = sc_norm_from_dot(d);
+    if (hist && nh < cap) hist[nh] = res0;
+    ++nh;
+    double res = res0;
+    int it = 0, status = EVOMG_SOLVE_MAXITER;
+    if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+    else
+      for (it = 1; it <= prob_.max_iterations; ++it) {
+        bool norm_rode_along = false;
+        rc = exec_program(ops, n_ops, /*cyclic=*/true, ahead ? 1 : 0, &norm_rode_along);
+        ahead = false;
+        if (rc != EVOMG_OK) return rc;
+        if (norm_rode_along) {
+          // the last sweep left the canonical partial sums behind: reduce them, no residual sweep
+          res_stale = true;
+          const Geo& g = lv.g;
+          const int parts = ((g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS) * ((g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS);
+          hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, dscalar_);
+          HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+          HIP_TRY(hipEventRecord(norm_event_, stream_));
+        } else if ((rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
+        if (it < prob_.max_iterations && (rc = speculate(&ahead)) != EVOMG_OK) return rc;
+        if ((rc = wait_norm()) != EVOMG_OK) return rc;
+        res = sc_norm_from_dot(d);
+        if (hist && nh < cap) hist[nh] = res;
+        ++nh;
+        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+        if (res <= prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+        if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+      }
+    if (ahead) undo_speculation();                 // the sweep queued for an iteration that is not going to happen
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const double t_end = wall_ms();
+    if (res_stale) {
+      // leave RES@max as the reference's loop would (the residual of the returned iterate); outside the solve timer
+      residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
+      HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    if (it > prob_.max_iterations) it = prob_.max_iterations;
+    out->time_ms = t_end - t0;
+    out->n_iterations = (double)it;
+    out->init_res_norm = res0;
+    out->final_res_norm = res;
+    out->status = status;
+    out->n_history = (nh < cap || !hist) ? nh : cap;
+    out->conv_factor = (it > 0 && res0 > 0) ? pow(res / res0, 1.0 / (double)it) : 0.0;
+    return EVOMG_OK;
+  }
+
+  // ---- outer loop B: MG-preconditioned BiCGStab (oracle FN(solve_pbicgstab); Helmholtz exa3:144-200) ------------------------
+  int solve_pbicgstab(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {
+    if (dim_ != 2) return invalid("preconditioned BiCGStab outer solver is 2D only");
+    const int L = prob_.max_level;
+    Level<T>& lv = lv_[L];
+    const size_t bytes = lv.elems * sizeof(T);
+    for (auto*& v : outer_)
+      if (!v) HIP_TRY(alloc_zero(&v, lv.elems));
+    T *Sol = outer_[0], *Res = outer_[1], *p = outer_[2], *ap = outer_[3], *s = outer_[4], *t = outer_[5],
+      *hh = outer_[6], *rhat = outer_[7];
+    for (auto* v : outer_) HIP_TRY(hipMemsetAsync(v, 0, bytes, stream_));
+    const T* RHS = lv.init[EVOMG_F_RHS];
+    if (!RHS) return invalid("no right-hand side set");
+    int nh = 0;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const double t0 = wall_ms();
+    if (lv.init[EVOMG_F_SOL]) HIP_TRY(hipMemcpyAsync(Sol, lv.init[EVOMG_F_SOL], bytes, hipMemcpyDeviceToDevice, stream_));
+    apply_bc(L, Sol);
+    residual(L, outer_st_, Sol, RHS, Res);
+    T d;
+    int rc = dot_to_host(L, Res, Res, &d);
+    if (rc != EVOMG_OK) return rc;
+    const double res0 = sc_norm_from_dot(d);
+    if (hist && nh < cap) hist[nh] = res0;
+    ++nh;
+    double res = res0;
+    int it = 0, status = EVOMG_SOLVE_MAXITER;
+    const T one = scalar_traits<T>::from_real(1.0);
+    T alpha = one, beta, rho, rho_new = one, omega = one, rho_next = one;
+    HIP_TRY(hipMemcpyAsync(rhat, Res, bytes, hipMemcpyDeviceToDevice, stream_));
+    // Fused passes (EVOMG_NO_OUTER_FUSE switches them off; same bits either way): the preconditioner's right-hand side is
+    // read where it is — the cycle never writes RHS@max, checked below — instead of being copied; the two updates of p in
+    // one pass; A u with the dot product(s) of its result; the last update of the residual with its norm and the next
+    // iteration's rho. Per iteration: 670 MB of 2049^2 complex traffic and two of five host round trips less.
+    const bool fuse = outer_fuse_;
+    const bool dev_steps = fuse && outer_dev_steps_;
+    bool rhs_written = false;
+    for (int i = 0; i < n_ops; ++i) {
+      bool reads;
+      if (touches(ops[i], L, EVOMG_F_RHS, &reads)) {
+        bool w = false;
+        switch (ops[i].opcode) {
+          case EVOMG_OP_SMOOTH: case EVOMG_OP_RESIDUAL: case EVOMG_OP_RICHARDSON: case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET:
+          case EVOMG_OP_SET_ZERO: case EVOMG_OP_COPY: case EVOMG_OP_RESTRICT:
+            w = ops[i].level == L && canon(L, ops[i].dst) == EVOMG_F_RHS; break;
+          default: break;
+        }
+        rhs_written = rhs_written || w;
+      }
+    }
+    // `u = 0` in front of a cycle that starts with a point sweep on u: the sweep's zero-input variant instead of a memset
+    // (not with the coarse-level batches: a batched first op would never consume the flag)
+    const bool zero_by_sweep = fuse && !batch_enabled_ && n_ops > 0 && ops[0].level == L && canon(L, ops[0].dst) == EVOMG_F_SOL && zero_input_sweep(ops, n_ops, 0);
+    auto precondition = [&](const T* rhs_src) -> int {   // u = 0 ; f = rhs ; gen_mgCycle()
+      if (zero_by_sweep) x_zero_next_ = true;
+      else HIP_TRY(hipMemsetAsync(fieldptr(L, EVOMG_F_SOL), 0, bytes, stream_));
+      if (fuse && !rhs_written) {
+        T* own = lv.f[EVOMG_F_RHS];
+        lv.f[EVOMG_F_RHS] = const_cast<T*>(rhs_src);
+        const int rc2 = exec_program(ops, n_ops, /*cyclic=*/true);
+        lv.f[EVOMG_F_RHS] = own;
+        return rc2;
+      }
+      HIP_TRY(hipMemcpyAsync(fieldptr(L, EVOMG_F_RHS), rhs_src, bytes, hipMemcpyDeviceToDevice, stream_));
+      return exec_program(ops, n_ops, /*cyclic=*/true);
+    };
+    const Geo& g = lv.g;
+    const int dot_blocks = (g.n - 2) < kDotBlocks ? (g.n - 2) : kDotBlocks;
+    // results of a fused pass: `ndot` dot products to the host in one round trip
+    auto fetch_dots = [&](int ndot, T* out0, T* out1) -> int {
+      hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, ndot, dscalar_);
+      HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T) * ndot, hipMemcpyDeviceToHost, stream_));
+      HIP_TRY(hipStreamSynchronize(stream_));
+      *out0 = hscalar_[0];
+      if (ndot > 1) *out1 = hscalar_[1];
+      return EVOMG_OK;
+    };
+    bool have_rho = false;        // rho_new of the next iteration came out of the residual update
+    double t_end = -1.0;          // set when the device-steps loop stops on its norm test
+    if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
+    else if (dev_steps) {
+      // Every scalar of the recurrence lives on the device (dscalar_: [0] r.r, [1] rho', [2] alpha, [3] omega, [4] rho,
+      // [5] beta), so the first half of the NEXT iteration — beta, the update of p, the preconditioner on p — is queued before
+      // the host waits for this iteration's norm: the round trip hides behind it. Speculative only in what it touches: p and
+      // the multigrid fields, none of which the result (Sol, Res) reads once the loop has stopped. The host still decides,
+      // on the same norm with the same arithmetic.
+      if ((rc = dot_to_host(L, rhat, Res, &rho_new)) != EVOMG_OK) return rc;
+      // staging: [0] r.r (unused), [1] rho' = rhat . r, [2] alpha = 1, [3] omega = 1, [4] rho = 1
+      const T zero_t = scalar_traits<T>::zero();
+      T init[5] = {zero_t, rho_new, one, one, one};
+      HIP_TRY(hipMemcpyAsync(dscalar_, init, sizeof init, hipMemcpyHostToDevice, stream_));
+      HIP_TRY(hipStreamSynchronize(stream_));         // `init` is a stack array
+      if (!outer_event_) HIP_TRY(hipEventCreateWithFlags(&outer_event_, hipEventDisableTiming));
+      auto front = [&]() -> int {                     // beta ; p = Res + beta (p - omega ap) ; u = M^-1 p
+        hipLaunchKernelGGL((evomg_bicg_beta<T>), dim3(1), dim3(64), 0, stream_, dscalar_);
+        hipLaunchKernelGGL((evomg_axpy2_dev<T>), node_grid(g), node_block(), 0, stream_, g, p, (const T*)p, (const T*)ap, (const T*)Res, (const T*)dscalar_);
+        return precondition(p);
+      };
+      if ((rc = front()) != EVOMG_OK) return rc;
+      for (it = 1; it <= prob_.max_iterations; ++it) {
+        T* u = fieldptr(L, EVOMG_F_SOL);
+        hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
+        hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 1, one, dscalar_, 2, 4);
+        hipLaunchKernelGGL((evomg_axpy_pair_dev<T>), node_grid(g), node_block(), 0, stream_, g, hh, (const T*)Sol, (const T*)u, s, (const T*)Res, (const T*)ap,
+                           (const T*)(dscalar_ + 2));
+        if ((rc = precondition(s)) != EVOMG_OK) return rc;
+        u = fieldptr(L, EVOMG_F_SOL);
+        hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
+        hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 2, one, dscalar_, 3, -1);
+        hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u);
+        apply_bc(L, Sol);
+        hipLaunchKernelGGL((evomg_axpy_dots_dev<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, (const T*)(dscalar_ + 3), (const T*)t, (const T*)rhat, partials_);
+        hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_);
+        HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipEventRecord(outer_event_, stream_));
+        if (it < prob_.max_iterations && (rc = front()) != EVOMG_OK) return rc;      // the next iteration's first half
+        HIP_TRY(hipEventSynchronize(outer_event_));
+        d = hscalar_[0];
+        res = sc_norm_from_dot(d);
+        if (hist && nh < cap) hist[nh] = res;
+        ++nh;
+        // the solve ends HERE when one of the tests below fires: what is still queued is the next iteration's speculative
+        // first half (a whole preconditioner application), which is drained after the clock has stopped
+        t_end = wall_ms();
+        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+        if (res < prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+        if (wall_limit_ms > 0 && t_end - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+        t_end = -1.0;
+      }
+    } else
+      for (it = 1; it <= prob_.max_iterations; ++it) {
+        rho = rho_new;
+        if (have_rho) rho_new = rho_next;
+        else if ((rc = dot_to_host(L, rhat, Res, &rho_new)) != EVOMG_OK) return rc;
+        beta = sc_mul(sc_div(rho_new, rho), sc_div(alpha, omega));
+        if (fuse) {
+          hipLaunchKernelGGL((evomg_axpy2<T>), node_grid(g), node_block(), 0, stream_, g, p, (const T*)p, sc_neg(omega), (const T*)ap, (const T*)Res, beta);
+        } else {
+          axpy(L, p, p, sc_neg(omega), ap);
+          axpy(L, p, Res, beta, p);
+        }
+        if ((rc = precondition(p)) != EVOMG_OK) return rc;
+        T* u = fieldptr(L, EVOMG_F_SOL);
+        T ra;
+        if (fuse) {
+          hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
+          if ((rc = fetch_dots(1, &ra, &ra)) != EVOMG_OK) return rc;
+        } else {
+          apply_operator(L, outer_st_, u, ap);
+          if ((rc = dot_to_host(L, rhat, ap, &ra)) != EVOMG_OK) return rc;
+        }
+        alpha = sc_div(rho_new, ra);
+        axpy(L, hh, Sol, alpha, u);
+        axpy(L, s, Res, sc_neg(alpha), ap);
+        if ((rc = precondition(s)) != EVOMG_OK) return rc;
+        u = fieldptr(L, EVOMG_F_SOL);
+        T ts, tt;
+        if (fuse) {
+          hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
+          if ((rc = fetch_dots(2, &ts, &tt)) != EVOMG_OK) return rc;
+        } else {
+          apply_operator(L, outer_st_, u, t);
+          if ((rc = dot_to_host(L, t, s, &ts)) != EVOMG_OK) return rc;
+          if ((rc = dot_to_host(L, t, t, &tt)) != EVOMG_OK) return rc;
+        }
+        omega = sc_div(ts, tt);
+        axpy(L, Sol, hh, omega, u);
+        apply_bc(L, Sol);
+        if (fuse) {
+          hipLaunchKernelGGL((evomg_axpy_dots<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, sc_neg(omega), (const T*)t, (const T*)rhat, partials_);
+          if ((rc = fetch_dots(2, &d, &rho_next)) != EVOMG_OK) return rc;
+          have_rho = true;
+        } else {
+          axpy(L, Res, s, sc_neg(omega), t);
+          if ((rc = dot_to_host(L, Res, Res, &d)) != EVOMG_OK) return rc;
+        }
+        res = sc_norm_from_dot(d);
+        if (hist && nh < cap) hist[nh] = res;
+        ++nh;
+        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
+        if (res < prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
+        if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+      }
+    if (it > prob_.max_iterations) it = prob_.max_iterations;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    out->time_ms = (t_end >= 0.0 ? t_end : wall_ms()) - t0;
+    HIP_TRY(hipMemcpyAsync(lv.f[EVOMG_F_CORR], Sol, bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(lv.f[EVOMG_F_RES], Res, bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    out->n_iterations = (double)it;
+    out->init_res_norm = res0;
+    out->final_res_norm = res;
+    out->status = status;
+    out->n_history = (nh < cap || !hist) ? nh : cap;
+    out->conv_factor = res0 > 0 ? res / res0 : 0.0;
+    return EVOMG_OK;
+  }

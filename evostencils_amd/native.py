@@ -16,7 +16,7 @@ def library() -> abi.Library:
             raise RuntimeError(f"HIP backend not built: {LIB_PATH} is missing. "
                                f"Run `python -m evostencils_amd.build` (needs hipcc).")
         try:
-            _library = abi.Library(LIB_PATH, "evomg", abi.EXPORTED)
+            _library = abi.Library(LIB_PATH)
         except OSError as exc:
             raise RuntimeError(f"HIP backend failed to load ({LIB_PATH}): {exc}") from exc
         if _library.fn["abi_version"]() != abi.ABI_VERSION:
@@ -30,3 +30,8 @@ def create(problem_description, device_id=0, parameters=None, jacobi_semantics=N
     h = abi.Handle(library(), problem_description.to_c(parameters, jacobi_semantics), device_id)
     problem_description.upload_initial_fields(h)
     return h
+
+
+def communicator(rank: int, world: int, device_id: int, id_path: str, timeout_ms: int = 60000) -> abi.Communicator:
+    """RCCL communicator behind the C-ABI (one per process / GPU) for the per-generation fitness exchange."""
+    return abi.Communicator(library(), rank, world, device_id, id_path, timeout_ms)

@@ -17,10 +17,31 @@ def _dist():
 
 
 def world_info():
+    if _native_comm is not None:
+        return _native_comm.rank, _native_comm.world
     dist = _dist()
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+_native_comm = None
+
+
+def use_native_collectives(communicator):
+    """Route `allgather_fitness` / `gather_fitness` through the C-ABI communicator (abi.Communicator: evomg_allgather_fitness /
+    evomg_gather_fitness, RCCL without torch) instead of torch.distributed; None switches back. The rank / world of the
+    communicator take the place of the process group's. The dynamic work queue keeps using the rendezvous store for its
+    counter and is not affected."""
+    global _native_comm
+    _native_comm = communicator
+
+
+def _group_exists():
+    """A process group was initialised — possibly with ONE rank: the collectives then run through it (RCCL on a GPU box)
+    exactly as they do with more ranks, instead of being short-circuited."""
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_indices(n_candidates: int, rank: int, world: int) -> List[int]:
@@ -41,7 +62,11 @@ def gather_fitness(local: Sequence[Tuple[float, float, float]], world: int, loca
     """Gather per-rank lists of (rho, time_ms, iterations) to `dst` (north_star: "tiny RCCL gather of the
     fitness scalars back to rank 0"). Every rank must pass the same number of entries. Returns the
     concatenated list on `dst` (rank order), the local list elsewhere. No-op for a single process."""
-    if world <= 1:
+    if _native_comm is not None:
+        rows = [(float(k), float(r[0]), float(r[1]), float(r[2])) for k, r in enumerate(local)]
+        table = _native_comm.gather(rows, dst)
+        return [tuple(r[1:]) for r in table.tolist()] if table is not None else list(local)
+    if world <= 1 and not _group_exists():
         return list(local)
     import torch
     dist = _dist()
@@ -68,20 +93,32 @@ def allgather_fitness(indexed: Sequence[Tuple[int, float, float, float]], n_tota
     the largest shard. Counterpart of `allgather([(i, fitness)])` (program.py:536). The same collective carries one
     flag row per rank (`failed`: this rank's evaluator broke); if any rank set it, every OTHER rank raises
     RemoteEvaluationFailure after the collective (the failing rank re-raises its own exception)."""
-    if world <= 1:
+    if _native_comm is not None:
+        world = _native_comm.world
+        per = (n_total + world - 1) // world
+        rows = [[_FLAG_OK] * 4 for _ in range(per + 1)]
+        for k, r in enumerate(indexed):
+            rows[k] = [float(v) for v in r]
+        if failed:
+            rows[per][0] = _FLAG_FAILED
+        table = _native_comm.allgather(rows).reshape(world, per + 1, 4)
+        chunks = [chunk.tolist() for chunk in table]
+    elif world <= 1 and not _group_exists():
         return sorted(indexed)
-    import torch
-    dist = _dist()
-    per = (n_total + world - 1) // world
-    t = torch.full((per + 1, 4), _FLAG_OK, dtype=torch.float64)
-    if indexed:
-        t[:len(indexed)] = torch.tensor(list(indexed), dtype=torch.float64)
-    if failed:
-        t[per, 0] = _FLAG_FAILED
-    t = t.to(_device(local_rank))
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    chunks = [chunk.cpu().tolist() for chunk in out]
+    else:
+        import torch
+        dist = _dist()
+        world = max(world, 1)
+        per = (n_total + world - 1) // world
+        t = torch.full((per + 1, 4), _FLAG_OK, dtype=torch.float64)
+        if indexed:
+            t[:len(indexed)] = torch.tensor(list(indexed), dtype=torch.float64)
+        if failed:
+            t[per, 0] = _FLAG_FAILED
+        t = t.to(_device(local_rank))
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        chunks = [chunk.cpu().tolist() for chunk in out]
     sick = [r for r, chunk in enumerate(chunks) if chunk[per][0] == _FLAG_FAILED]
     if sick and not failed:
         raise RemoteEvaluationFailure("evaluator failed on rank(s) %s: this generation's fitness table is invalid" % sick)

@@ -176,6 +176,10 @@ enum {
   EVOMG_OP_FAS_SUBTRACT = 21           /* Solution@L -= Approximation@L                               :182-193 */
 };
 
+/* Pseudo-opcode for evomg_profile_begin only: the solver loop's own residual + norm pass on the finest level (it is not an
+ * op of the cycle; SURVEY 3.1: `gen_solve` computes the residual norm once per iteration). */
+#define EVOMG_PROF_LOOP_NORM 64
+
 enum { EVOMG_PART_SINGLE = 0, EVOMG_PART_RED_BLACK = 1 };  /* ir/partitioning.py:18,34 */
 
 typedef struct {
@@ -194,7 +198,11 @@ typedef struct {
                             unknown's cells when it differs from the first's (`block`); all zero = the same shape. The
                             grammar registers one BlockShape terminal per combination of per-unknown shapes
                             (grammar/multigrid.py:388-407), so most collective block smoothers of a system look like this.
-                            Tiles repeat with the componentwise maximum of the two shapes */
+                            Tiles repeat with the componentwise maximum of the two shapes — an [EXTERNAL] guess: the loop
+                            ExaStencils generates around such a `solve locally` is not visible from the reference. Accepted
+                            only under EVOMG_JACOBI_EXASTENCILS_V11, where the sweep is launched for its time and its
+                            result never becomes the field (rho / iterations exact); EVOMG_ERR_UNSUPPORTED under
+                            EVOMG_JACOBI_TEXTBOOK, where the unverified tiling would decide the candidate's fitness */
   int32_t reserved;
   double  omega;         /* relaxation factor */
 } evomg_op_t;
@@ -261,6 +269,27 @@ int  evomg_profile_begin(evomg_handle_t* h, int opcode, int level);
 int  evomg_profile_end(evomg_handle_t* h, evomg_bench_t* out);
 /* Name of the device kernel an op dispatches to (for matching rocprofv3 kernel-trace rows). */
 int  evomg_kernel_name(evomg_handle_t* h, const evomg_op_t* op, char* buf, int buf_len);
+
+/* -- population exchange: one collective per generation ----------------------------------------------
+ * Candidates shard embarrassingly across the GPUs of a node, one process per GPU; the ONLY exchange is the fitness table of
+ * a generation — the RCCL-over-xGMI counterpart of the reference's mpi4py `allgather` (optimization/program.py:285-310,
+ * :534-536 after the round-robin re-evaluation, :582 per generation). Rows are EVOMG_FITNESS_COLUMNS doubles:
+ * (candidate index, convergence factor, time-to-solution ms, iterations). librccl is opened on first use. */
+#define EVOMG_FITNESS_COLUMNS 4
+typedef struct evomg_comm evomg_comm_t;
+/* One communicator per process: rank of `world`, bound to GPU `device_id`. The RCCL unique id travels through the file
+ * `id_path` (unique per job, on a file system all ranks see: /dev/shm or /tmp on one node): rank 0 writes it atomically, the
+ * others wait at most timeout_ms (< 0: forever) for it. Collective: every rank must call it. */
+int  evomg_comm_create(int rank, int world, int device_id, const char* id_path, int timeout_ms, evomg_comm_t** out);
+void evomg_comm_destroy(evomg_comm_t* c);
+const char* evomg_comm_last_error(const evomg_comm_t* c);   /* c may be NULL: error of the last failed create */
+/* Every rank contributes n_local rows (the same n_local everywhere: pad); `all` receives world * n_local rows in rank
+ * order on EVERY rank (ncclAllGather) — program.py:536,582. Host pointers; staged through device buffers of the handle. */
+int  evomg_allgather_fitness(evomg_comm_t* c, const double* local, int n_local, double* all);
+/* The same table on rank `root` only (`all` may be NULL elsewhere) — north_star's "tiny gather back to rank 0". */
+int  evomg_gather_fitness(evomg_comm_t* c, const double* local, int n_local, double* all, int root);
+/* RCCL's version code (e.g. 22707), 0 when librccl cannot be opened. Initialises nothing on the GPU. */
+int  evomg_rccl_version(void);
 
 #ifdef __cplusplus
 }

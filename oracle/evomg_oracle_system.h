@@ -336,6 +336,10 @@ static int sys_check_op(sys_ctx_t* c, const evomg_op_t* op) {
       const int cells = op->block[0] * op->block[1] + (k == 2 ? (other ? op->block_other[0] * op->block_other[1] : op->block[0] * op->block[1]) : 0);
       if (cells > EVOMG_MAX_BLOCK_CELLS) return EVOMG_ERR_INVALID;
       if (op->partitioning == EVOMG_PART_RED_BLACK && cells != k) return EVOMG_ERR_UNSUPPORTED;
+      /* differing per-unknown shapes: the tiling around such a `solve locally` is [EXTERNAL]; accepted only where the sweep's
+       * result is never used (EVOMG_JACOBI_EXASTENCILS_V11), rejected where it would be (see csrc/impl_system.hip) */
+      if (other && (op->block_other[0] != op->block[0] || op->block_other[1] != op->block[1]) &&
+          c->prob.jacobi_semantics == EVOMG_JACOBI_TEXTBOOK) return EVOMG_ERR_UNSUPPORTED;
       if (op->partitioning != EVOMG_PART_SINGLE && op->partitioning != EVOMG_PART_RED_BLACK) return EVOMG_ERR_INVALID;
       /* dst / src1 name the slots of the first unknown of the mask */
       int first = 0;

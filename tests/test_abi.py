@@ -89,3 +89,26 @@ def test_default_device_follows_the_launchers_local_rank(monkeypatch):
     assert ProgramGenerator._default_device(14, Lib(8)) == 6
     monkeypatch.setenv("LOCAL_RANK", "2")                             # torchrun wins
     assert ProgramGenerator._default_device(14, Lib(8)) == 2
+    monkeypatch.setenv("LOCAL_RANK", "-1")                            # not a rank: ignored, the next launcher's counts
+    assert ProgramGenerator._default_device(14, Lib(8)) == 6
+    monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_RANK")
+    assert ProgramGenerator._default_device(14, Lib(8)) == 6          # ... or the MPI rank
+    with pytest.raises(ValueError):
+        ProgramGenerator._default_device(-1, Lib(8))
+
+
+def test_constructing_a_generator_does_not_touch_the_hip_runtime(monkeypatch):
+    """Lowering-only use (and everything before the first evaluation) must not initialise HIP: the device is resolved when the
+    first handle is created, not in the constructor (a later fork would inherit a broken runtime, and
+    GPU_MAX_HW_QUEUES has to be in the environment before the first HIP call)."""
+    from evostencils_amd import problems
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    called = []
+
+    class Lib:
+        fn = {"device_count": lambda: called.append(1) or 8}
+
+    gen = ProgramGenerator(problem=problems.poisson_2d(3, 5), library=Lib(), mpi_rank=3)
+    assert gen._device_id is None and not called
+    explicit = ProgramGenerator(problem=problems.poisson_2d(3, 5), library=Lib(), device_id=5)
+    assert explicit._device_id == 5 and not called

@@ -41,12 +41,20 @@ def test_grammar_individuals_match_the_oracle(problem, semantics, monkeypatch):
     gen = ProgramGenerator(problem=pd, library=native.library(), jacobi_semantics=semantics)
     gen.initialize_code_generation(lo, hi)
     ho = oracle.create(gen.problem)
-    compared = converged = 0
+    compared = converged = rejected = 0
     for text in entry["individuals"]:
         state = productions.compile_individual(text, context_for(gen, lo, hi))
         ops = gen.generate_op_program(state[0], lo, hi)
-        got = gen._handle.evaluate(ops, 1, 0, 128)
-        want = ho.evaluate(ops, 1, 0, 128)
+        rc_got, got = gen._handle.try_evaluate(ops, 1, 0, 128)
+        rc_want, want = ho.try_evaluate(ops, 1, 0, 128)
+        assert rc_got == rc_want, text
+        if rc_want == abi.ERR_UNSUPPORTED:
+            # a block smoother with one shape per unknown where its result would be used (textbook semantics): rejected by
+            # both sides (tests/test_systems_oracle.py::test_mixed_shape_blocks_only_where_their_result_is_never_used)
+            assert semantics == "textbook" and any(any(o.block_other) for o in ops), text
+            rejected += 1
+            continue
+        assert rc_want == abi.OK, text
         assert got.status == want.status and got.n_iterations == want.n_iterations, text
         finite = np.isfinite(want.history) & (want.history > 1e-13 * want.history[0])
         assert np.array_equal(np.isfinite(got.history), np.isfinite(want.history)), text
@@ -54,6 +62,6 @@ def test_grammar_individuals_match_the_oracle(problem, semantics, monkeypatch):
         assert rel.max() <= 1e-10, (text, rel.max())
         compared += 1
         converged += want.status == abi.SOLVE_CONVERGED
-    assert compared == len(entry["individuals"])
+    assert compared + rejected == len(entry["individuals"]) and compared >= rejected
     ho.close()
     gen.close()
