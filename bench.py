@@ -378,6 +378,11 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to stdout when its first communicator comes up
+    # (one-rank group at N = 1 included), so everything below writes to stderr's file and only the line goes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -615,7 +620,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(ops, lo, hi, threads)
             except Exception as exc:                         # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "", "error": repr(exc)}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=real_stdout, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -6,6 +6,7 @@
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"
 #include "evomg_strip.h"
+#include "evomg_strip_cross.h"
 #include "evomg_small2d.h"
 #include "evomg_small3d.h"
 #include "evomg_tile3d.h"

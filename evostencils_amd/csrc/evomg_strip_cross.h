@@ -1,0 +1,274 @@
+// evomg_strip_cross.h — the finest 2D level's work ACROSS the solver loop's iteration boundary in one marching-strip pass.
+//
+// A V-type cycle ends with [PROLONG_ADD +] SMOOTH on the finest level (followed by the loop's residual norm) and the next
+// iteration starts with SMOOTH + RESIDUAL + RESTRICT on the same arrays: two passes of 26 B/node each over the one level that
+// carries three quarters of a cycle's traffic (evomg_strip2d<.., PRO, TAIL_NORM> and <.., TAIL_RESTRICT>). This kernel runs
+// both red-black sweeps, the norm and the restriction in ONE pass:
+//
+//   x (+ om_p * P coarse)  --sweep A-->  z  --sweep B-->  w  --residual, full weighting-->  coarse right-hand side
+//                                        |
+//                                        +--> squared residual norm of z (the iterate the loop tests)
+//
+// reading x, f and the coarse correction once and writing w and the coarse right-hand side: 28 B/node instead of 52. z — the
+// iterate the loop would return if the norm says "converged" — is NOT written: the launch is speculative exactly like the
+// solver loop's early launch of the next cycle's first sweep (w and the coarse right-hand side go to spare arrays that only a
+// host-side pointer swap makes current); when the loop stops, the ordinary post-smoothing kernel forms z from x, which is
+// still intact. Per node the formulas, operand order and masks are those of evomg_strip2d (relax5 / residual5, the
+// prolongation's `corrected`, the restriction's e4 / q4 sums), so z, w, the coarse field and the norm carry the same bits.
+//
+// Geometry: wave = 128 columns (lane = column pair), THREE halo lanes per side — sweep A is exact on columns [2, 125] of the
+// strip, sweep B on [4, 123], w's residual on [5, 122], so coarse columns with 2I in [6, 121] and the 116 stored columns
+// [6, 121] tile the row. Rows: at step j the wave relaxes A's reds on row j and A's blacks on row j-1 (z row j-1 final), forms
+// the norm's residual on z row j-2, relaxes B's reds on row j-2 and B's blacks on row j-3 (w row j-3 final), forms w's
+// residual on row j-4 and, every second step, coarse row (j-5)/2: a chunk of H rows reads H + 11 rows of x.
+// Register windows (x, z, w: 3 rows; f: 6 rows; reds and residuals: 2) are rings addressed with compile-time indices — the row
+// loop is unrolled SIX times, the least common multiple of the ring lengths — so advancing a row costs no register moves.
+//
+// The norm keeps its canonical summation order although the strips are 116 instead of 120 columns wide: every lane writes
+// the sum of its column pair per 16-row chunk (4 MB at 4097^2, 1 % of the pass), and evomg_norm_from_lane_sums replays
+// TAIL_NORM's wave tree over the canonical 120-column strips on those sums.
+#pragma once
+#include "evomg_strip.h"
+
+#define EVOMG_CROSS_STRIP_COLS 116
+#define EVOMG_CROSS_UNROLL 6
+
+struct CrossArgs {
+  const double* coarse_in;   // PRO: coarse correction
+  Geo gc;                    // coarse level (PRO and TAILR)
+  double om_p;               // PRO: weight of the correction
+  double* coarse_out;        // TAILR: coarse right-hand side (spare array)
+  double om_a, omm_a;        // sweep A (the cycle's last smoother)
+  double om_b, omm_b;        // sweep B (the next cycle's first smoother)
+  double inv_c0;             // exact reciprocal of the centre coefficient, or 0
+  double* lane_sums;         // [chunk16][sums_pitch]: per column pair, sum over the chunk's rows of the squared residual of z
+  int sums_pitch;
+};
+
+// one fused two-colour step: reds of row j from (xm, xc, xp) = rows j-1, j, j+1, then blacks of row j-1 from the new reds of
+// rows j-2 (red_slot on entry), j-1 (rm1), j; returns the finished row j-1 and leaves row j's reds in red_slot
+__device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st, int parity, const Pair<double>& xm, const Pair<double>& xc,
+                                                       const Pair<double>& xp, const Pair<double>& fc, const Pair<double>& fm, double& red_slot,
+                                                       double rm1, bool row_inner, bool brow_inner, bool inner_a, bool inner_b, double om,
+                                                       double omm, double inv_c0) {
+  const double rm2 = red_slot;
+  double rc;
+  if (parity == 0) {
+    const double w = from_left(xc.b);
+    rc = (row_inner && inner_a) ? relax5(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0) : xc.a;
+  } else {
+    const double e = from_right(xc.a);
+    rc = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0) : xc.b;
+  }
+  Pair<double> out;
+  if (parity == 1) {            // row j-1 even: red = a, black = b
+    const double e = from_right(rm1);
+    const double bl = (brow_inner && inner_b) ? relax5(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0) : xm.b;
+    out.a = rm1;
+    out.b = bl;
+  } else {                      // red = b, black = a
+    const double w = from_left(rm1);
+    const double bl = (brow_inner && inner_a) ? relax5(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0) : xm.a;
+    out.a = bl;
+    out.b = rm1;
+  }
+  red_slot = rc;
+  return out;
+}
+
+// grid: ceil(strips * chunks / 4) blocks (multiple of 8) of 256 threads = 4 independent waves; rows_per_chunk: multiple of 16
+template <bool NT_XY, bool PRO, bool TAILR>
+__global__ void __launch_bounds__(256)
+evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ y,
+                    int rows_per_chunk, int n_strips, int n_waves, CrossArgs a) {
+  const int per_xcd = gridDim.x >> 3;
+  const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
+  if (wave >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  const int strip = wave % n_strips;
+  const int chunk = wave / n_strips;
+  const int n = g.n;
+  const long pitch = g.pitch;
+  constexpr int HALO = 3, COLS = EVOMG_CROSS_STRIP_COLS, U = EVOMG_CROSS_UNROLL;
+  static_assert(COLS == 128 - 4 * HALO, "strip width");
+  const int c0 = strip * COLS - 2 * HALO + 2 * lane;
+  const bool col_ok = c0 >= 0 && c0 < n;
+  const int y0 = chunk * rows_per_chunk;                     // multiple of 16
+  const int y1 = min(y0 + rows_per_chunk, n);
+  const Pair<double> zpair{0.0, 0.0};
+  const bool inner_a = c0 >= 1 && c0 <= n - 2;
+  const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+  const bool store_lane = lane >= HALO && lane <= 63 - HALO && col_ok;
+  const int c_clamped = min(max(c0, 0), n - 1);
+  auto load_row = [&](const double* __restrict__ base, int row) -> Pair<double> {
+    const int r = min(max(row, 0), n - 1);
+    if constexpr (NT_XY) return load_pair_nt<double>(base + pitch * r + c_clamped);
+    else return load_pair<double>(base + pitch * r + c_clamped);
+  };
+  auto load_row_f = [&](const double* __restrict__ base, int row) -> Pair<double> {
+    const int r = min(max(row, 0), n - 1);
+    return load_pair<double>(base + pitch * r + c_clamped);
+  };
+  const int nc = a.gc.n;
+  const int Ic = min(max(c0 >> 1, 0), nc - 1);
+  auto load_coarse = [&](int row) -> Pair<double> {
+    const int r = min(max(row, 0), nc - 1);
+    return load_pair<double>(a.coarse_in + (long)a.gc.pitch * r + Ic);
+  };
+  // fine row `row` of x + om_p P coarse (evomg_strip2d's `corrected`, real Dirichlet case)
+  auto corrected = [&](const Pair<double>& raw, int row, bool odd, const Pair<double>& cJp, const Pair<double>& cJ1p) -> Pair<double> {
+    const bool row_in = row >= 1 && row <= n - 2;
+    const double cJ = cJp.a, cJr = cJp.b;
+    double va, vb;
+    if (!odd) {
+      va = cJ;
+      vb = 0.5 * (cJ + cJr);
+    } else {
+      const double cJ1 = cJ1p.a, cJ1r = cJ1p.b;
+      va = 0.5 * (cJ + cJ1);
+      vb = 0.25 * ((cJ + cJr) + (cJ1 + cJ1r));
+    }
+    Pair<double> out;
+    out.a = (row_in && inner_a) ? raw.a + a.om_p * va : raw.a;
+    out.b = (row_in && inner_b) ? raw.b + a.om_p * vb : raw.b;
+    return out;
+  };
+  const int js = y0 - 5;                                     // odd: first row whose A-reds are relaxed
+  const int je = y1 + 4;                                     // one past the last
+  // rings: slot of row js + k is k mod (ring length); the loop below is unrolled U = 6 times, so every index is static
+  Pair<double> xw[3], zw[3], ww[3], fw[6], xq[2], fq[2], rs[2];
+  double ra[2] = {0.0, 0.0}, rb[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) xw[k] = zw[k] = ww[k] = zpair;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) fw[k] = zpair;
+  rs[0] = rs[1] = zpair;
+  xw[2] = load_row(x, js - 1);                               // k = -1
+  xw[0] = load_row(x, js);                                   // k = 0
+  if constexpr (PRO) {
+    // js is odd, js - 1 even
+    const int rm = max(js - 1, 0), rc0 = max(js, 0);
+    xw[2] = corrected(xw[2], js - 1, false, load_coarse(rm >> 1), zpair);
+    xw[0] = corrected(xw[0], js, true, load_coarse(rc0 >> 1), load_coarse((rc0 >> 1) + 1));
+  }
+  xq[0] = load_row(x, js + 1);
+  xq[1] = load_row(x, js + 2);
+  fq[0] = load_row_f(f, js);
+  fq[1] = load_row_f(f, js + 1);
+  Pair<double> c_lo = zpair, c_hi = zpair;
+  if constexpr (PRO) {
+    const int r0 = js + 1;                                   // may be negative: >> floors, load_coarse clamps
+    c_lo = load_coarse(r0 >> 1);
+    c_hi = load_coarse((r0 >> 1) + 1);
+  }
+  double nrm = 0.0;
+  const int ncr = a.gc.n;
+  const int Icr = c0 >> 1;
+
+  for (int base = js; base < je; base += U) {
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      const int j = base + d;
+      if (j < je) {                                          // wave-uniform
+        const int parity = (1 + d) & 1;                      // js is odd
+        Pair<double> xp = xq[d & 1];
+        const Pair<double> fc = fq[d & 1];
+        xq[d & 1] = load_row(x, j + 3);
+        fq[d & 1] = load_row_f(f, j + 2);
+        if constexpr (PRO) {
+          const bool odd_next = ((parity + 1) & 1) != 0;     // row j + 1
+          xp = corrected(xp, j + 1, odd_next, c_lo, c_hi);
+          if (odd_next) {
+            c_lo = c_hi;
+            c_hi = load_coarse(((j + 1) >> 1) + 2);
+          }
+        }
+        xw[(d + 1) % 3] = xp;
+        fw[d % 6] = fc;
+        // ---- sweep A: reds of row j, blacks of row j-1 -> z row j-1 ----
+        {
+          const bool row_inner = j >= 1 && j <= n - 2, brow_inner = j - 1 >= 1 && j - 1 <= n - 2;
+          zw[(d + 2) % 3] = cross_rb_step(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
+                                          row_inner, brow_inner, inner_a, inner_b, a.om_a, a.omm_a, a.inv_c0);
+        }
+        const Pair<double>& z3 = zw[d % 3];                  // z rows j-3, j-2, j-1
+        const Pair<double>& z2 = zw[(d + 1) % 3];
+        const Pair<double>& z1 = zw[(d + 2) % 3];
+        const Pair<double>& f2 = fw[(d + 4) % 6];            // f rows j-2, j-3, j-4
+        const Pair<double>& f3 = fw[(d + 3) % 6];
+        const Pair<double>& f4 = fw[(d + 2) % 6];
+        // ---- the loop's norm: residual of z row j-2 (TAIL_NORM of evomg_strip2d) ----
+        {
+          const int rr = j - 2;
+          const double wa = from_left(z2.b), eb = from_right(z2.a);
+          if (rr >= y0 && rr < y1) {                         // wave-uniform
+            if (rr >= 1 && rr <= n - 2 && store_lane) {
+              const double qa = residual5(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
+              const double qb = residual5(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
+              if (inner_a) nrm = nrm + qa * qa;
+              if (inner_b) nrm = nrm + qb * qb;
+            }
+            if ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1) {
+              if (store_lane) a.lane_sums[(long)(rr / EVOMG_NORM_ROWS) * a.sums_pitch + (c0 >> 1)] = nrm;
+              nrm = 0.0;
+            }
+          }
+        }
+        // ---- sweep B on z: reds of row j-2, blacks of row j-3 -> w row j-3 ----
+        {
+          const int jb = j - 2;
+          const bool row_inner = jb >= 1 && jb <= n - 2, brow_inner = jb - 1 >= 1 && jb - 1 <= n - 2;
+          const Pair<double> wrow = cross_rb_step(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, inner_a,
+                                                  inner_b, a.om_b, a.omm_b, a.inv_c0);
+          ww[d % 3] = wrow;
+          const int jw = j - 3;
+          if (store_lane && jw >= y0 && jw < y1) store_pair<NT_XY>(y + pitch * jw + c0, wrow);
+        }
+        if constexpr (TAILR) {
+          // ---- residual of w row j-4 and, on odd rows, one coarse row (TAIL_RESTRICT of evomg_strip2d) ----
+          const Pair<double>& w5 = ww[(d + 1) % 3];          // w rows j-5, j-4, j-3
+          const Pair<double>& w4 = ww[(d + 2) % 3];
+          const Pair<double>& w3 = ww[d % 3];
+          const int rr = j - 4;
+          const bool rin = rr >= 1 && rr <= n - 2;
+          const double wa = from_left(w4.b), eb = from_right(w4.a);
+          Pair<double> rcur;
+          rcur.a = (rin && inner_a) ? residual5(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a) : 0.0;
+          rcur.b = (rin && inner_b) ? residual5(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b) : 0.0;
+          const Pair<double>& res1 = rs[(d + 1) & 1];        // residual rows rr-1, rr-2
+          const Pair<double>& res2 = rs[d & 1];
+          if (parity == 1) {                                 // rr odd: rows rr-2, rr-1, rr = 2J-1, 2J, 2J+1
+            const int J = (rr - 1) >> 1;
+            const double w = from_left(res1.b), sw = from_left(res2.b), nw = from_left(rcur.b);
+            const double e4 = (w + res1.b) + (res2.a + rcur.a);
+            const double q4 = (sw + res2.b) + (nw + rcur.b);
+            double v = 0.25 * res1.a;
+            v = v + 0.125 * e4;
+            v = v + 0.0625 * q4;
+            if (store_lane && Icr >= 1 && Icr <= ncr - 2 && J >= 1 && J <= ncr - 2 && 2 * J >= y0 && 2 * J < y1)
+              a.coarse_out[(long)a.gc.pitch * J + Icr] = v;
+          }
+          rs[d & 1] = rcur;
+        }
+      }
+    }
+  }
+}
+
+// The canonical partial sums of the squared residual norm — one per (120-column strip, 16-row chunk), wave64 tree over the
+// lanes' column-pair sums, exactly what evomg_strip2d<.., TAIL_NORM> and <STRIP_RESNORM> emit — from the per-pair sums the
+// cross kernel left behind. One wave per partial; grid: ceil(n_waves / 4) blocks of 256 threads.
+__global__ void __launch_bounds__(256)
+static evomg_norm_from_lane_sums(const double* __restrict__ lane_sums, int sums_pitch, int n, int n_strips, int n_waves,
+                                 double* __restrict__ partials) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (wave >= n_waves) return;
+  const int lane = threadIdx.x & 63;
+  const int strip = wave % n_strips, c16 = wave / n_strips;
+  const int c0 = strip * EVOMG_NORM_STRIP_COLS - 4 + 2 * lane;
+  const bool store_lane = lane >= 2 && lane <= 61 && c0 >= 0 && c0 < n;
+  const double v = store_lane ? lane_sums[(long)c16 * sums_pitch + (c0 >> 1)] : 0.0;
+  const double tot = wave_sum(v);
+  if (lane == 0) partials[c16 * n_strips + strip] = tot;
+}

@@ -22,6 +22,8 @@
     if (norm_event_) (void)hipEventDestroy(norm_event_);
     if (outer_event_) (void)hipEventDestroy(outer_event_);
     if (norm_partials_) (void)hipFree(norm_partials_);
+    if (xf_rhs_spare_) (void)hipFree(xf_rhs_spare_);
+    if (xf_lane_sums_) (void)hipFree(xf_lane_sums_);
     if (cg_xpart_) (void)hipFree(cg_xpart_);
     if (cg_xface_) (void)hipFree(cg_xface_);
     if (cg_flags_) (void)hipFree(cg_flags_);

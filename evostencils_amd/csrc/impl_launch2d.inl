@@ -352,3 +352,109 @@
     if (acc) hipLaunchKernelGGL((evomg_strip_prolong<T, true>), grid, block, 0, stream_, g, gc, coarse, fine, om, rows, strips, waves, rkh);
     else hipLaunchKernelGGL((evomg_strip_prolong<T, false>), grid, block, 0, stream_, g, gc, coarse, fine, 1.0, rows, strips, waves, rkh);
   }
+
+  // ---- cross-iteration launch (evomg_strip_cross.h): tail of this iteration + head of the next on the finest level -------
+  // Reads SOL@max (x), RHS@max, the coarse correction; writes w into the level's spare array, the next iteration's coarse
+  // right-hand side into xf_rhs_spare_, the per-pair norm sums; then reduces those to the canonical partial sums in
+  // norm_partials_. Nothing it writes is current until cross_commit().
+  int launch_cross(const evomg_op_t* ops, int n_ops, const CrossPlan& plan) {
+    if constexpr (scalar_traits<T>::is_complex) return invalid("cross-iteration fusion: real problems only");
+    else {
+      const int L = prob_.max_level;
+      Level<T>& lv = lv_[L];
+      const Geo& g = lv.g;
+      const Geo& gc = lv_[L - 1].g;
+      const evomg_op_t &sa = ops[n_ops - 1], &sb = ops[0];
+      const int strips = (g.n + EVOMG_CROSS_STRIP_COLS - 1) / EVOMG_CROSS_STRIP_COLS;
+      int rows = strip_rows_ > 0 ? ((strip_rows_ + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : 4 * EVOMG_NORM_ROWS;
+      if (strip_rows_ <= 0 && balance_rows_) rows = balanced_rows(g.n, strips, EVOMG_NORM_ROWS, EVOMG_NORM_ROWS, 6 * EVOMG_NORM_ROWS);
+      const int chunks = (g.n + rows - 1) / rows;
+      const int waves = strips * chunks;
+      const int chunks16 = (g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS;
+      const int sums_pitch = (((g.n + 1) / 2 + 15) / 16) * 16;
+      const size_t need = (size_t)chunks16 * sums_pitch;
+      if (need > xf_lane_sums_cap_) {
+        if (xf_lane_sums_) (void)hipFree(xf_lane_sums_);
+        xf_lane_sums_ = nullptr;
+        HIP_TRY(hipMalloc(&xf_lane_sums_, sizeof(T) * need));
+        xf_lane_sums_cap_ = need;
+      }
+      if (plan.tailr && !xf_rhs_spare_) HIP_TRY(alloc_zero(&xf_rhs_spare_, lv_[L - 1].elems));
+      const int nstrips_norm = (g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS;
+      {
+        const int rc = ensure_norm_partials((size_t)nstrips_norm * chunks16);
+        if (rc != EVOMG_OK) return rc;
+      }
+      CrossArgs a;
+      a.coarse_in = plan.pro ? fieldptr(L - 1, ops[n_ops - 2].src0) : nullptr;
+      a.gc = gc;
+      a.om_p = plan.pro ? ops[n_ops - 2].omega : 0.0;
+      a.coarse_out = xf_rhs_spare_;
+      a.om_a = sa.omega; a.omm_a = 1.0 - sa.omega;
+      a.om_b = sb.omega; a.omm_b = 1.0 - sb.omega;
+      a.inv_c0 = inv_c0(lv.st);
+      a.lane_sums = xf_lane_sums_;
+      a.sums_pitch = sums_pitch;
+      const T* x = fieldptr(L, EVOMG_F_SOL);
+      const T* f = fieldptr(L, EVOMG_F_RHS);
+      T* y = lv.alt;
+      const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
+      const bool nt = strip_streams(g);
+      const bool timed = prof_matches(sa) || prof_matches(sb);
+      if (timed) { const int rc = prof_open(); if (rc != EVOMG_OK) return rc; }
+#define EVOMG_CROSS_LAUNCH(NT, PRO, TR) hipLaunchKernelGGL((evomg_strip2d_cross<NT, PRO, TR>), grid, block, 0, stream_, g, lv.st, x, f, y, rows, strips, waves, a)
+#define EVOMG_CROSS_NT(PRO, TR) do { if (nt) EVOMG_CROSS_LAUNCH(true, PRO, TR); else EVOMG_CROSS_LAUNCH(false, PRO, TR); } while (0)
+      if (plan.pro && plan.tailr) EVOMG_CROSS_NT(true, true);
+      else if (plan.pro) EVOMG_CROSS_NT(true, false);
+      else if (plan.tailr) EVOMG_CROSS_NT(false, true);
+      else EVOMG_CROSS_NT(false, false);
+#undef EVOMG_CROSS_NT
+#undef EVOMG_CROSS_LAUNCH
+      // x, f read, w written; the coarse correction read and the coarse right-hand side written (8 B per coarse node each)
+      if (timed) {
+        const double nc2 = (double)gc.n * gc.n * sizeof(T);
+        const int rc = prof_close(3.0 * sizeof(T) * (double)g.n * g.n + (plan.pro ? nc2 : 0.0) + (plan.tailr ? nc2 : 0.0));
+        if (rc != EVOMG_OK) return rc;
+      }
+      const int nwaves_norm = nstrips_norm * chunks16;
+      hipLaunchKernelGGL(evomg_norm_from_lane_sums, dim3((nwaves_norm + 3) / 4), dim3(256), 0, stream_, (const double*)xf_lane_sums_, sums_pitch,
+                         g.n, nstrips_norm, nwaves_norm, norm_partials_);
+      HIP_TRY(hipGetLastError());
+      return EVOMG_OK;
+    }
+  }
+  // the loop goes on: what the cross launch wrote becomes current (w = the iterate after the next cycle's first sweep; the
+  // coarse right-hand side of the next cycle)
+  void cross_commit(const evomg_op_t* ops, const CrossPlan& plan) {
+    const int L = prob_.max_level;
+    Level<T>& lv = lv_[L];
+    T* x = fieldptr(L, EVOMG_F_SOL);
+    T* y = lv.alt;
+    lv.alt = x;
+    set_fieldptr(L, EVOMG_F_SOL, y);
+    lv.alt_mirror = y;
+    if (plan.tailr) {
+      const int slot = canon(L - 1, ops[2].dst);
+      std::swap(lv_[L - 1].f[slot], xf_rhs_spare_);
+    }
+  }
+  // the loop stops: the iterate it returns is z = the cycle's last sweep applied to x — formed now, by the kernel the
+  // unfused path runs for that op (x is untouched; w and the spare coarse field are simply dropped)
+  int cross_finalize(const evomg_op_t* ops, int n_ops, const CrossPlan& plan) {
+    const int L = prob_.max_level;
+    Level<T>& lv = lv_[L];
+    const evomg_op_t& sa = ops[n_ops - 1];
+    T* x = fieldptr(L, EVOMG_F_SOL);
+    T* y = lv.alt;
+    const T* f = fieldptr(L, EVOMG_F_RHS);
+    const double om = sa.omega, omm = 1.0 - sa.omega;
+    int rc;
+    if (plan.pro) rc = launch_strip_fused<STRIP_RBGS, true, false>(lv.g, lv_[L - 1].g, lv.st, x, f, y, om, omm, fieldptr(L - 1, ops[n_ops - 2].src0), ops[n_ops - 2].omega);
+    else rc = launch_strip_fused<STRIP_RBGS, false, false>(lv.g, lv.g, lv.st, x, f, y, om, omm, nullptr, 0.0);
+    if (rc != EVOMG_OK) return rc;
+    lv.alt = x;
+    set_fieldptr(L, EVOMG_F_SOL, y);
+    lv.alt_mirror = y;
+    HIP_TRY(hipGetLastError());
+    return EVOMG_OK;
+  }

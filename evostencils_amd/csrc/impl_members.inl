@@ -18,6 +18,12 @@
   bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
   bool bnd_zero_[24][EVOMG_F_COUNT];   // boundary of the field's current array is known to be all zero
   static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
+  // cross-iteration fusion on the finest 2D level (evomg_strip_cross.h): EVOMG_NO_XFUSE switches it off (same bits either way)
+  bool xfuse_enabled_ = getenv("EVOMG_NO_XFUSE") == nullptr;
+  int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 513;
+  T* xf_rhs_spare_ = nullptr;        // spare coarse right-hand side of level max - 1 (speculative output, swapped in on commit)
+  T* xf_lane_sums_ = nullptr;        // per (16-row chunk, column pair) sums of the squared residual
+  size_t xf_lane_sums_cap_ = 0;
   bool tail_norm_enabled_ = getenv("EVOMG_NO_TAIL_NORM") == nullptr;
   bool tail_restrict_enabled_ = getenv("EVOMG_NO_TAIL_RESTRICT") == nullptr;
   hipEvent_t norm_event_ = nullptr;

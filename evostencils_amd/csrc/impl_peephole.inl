@@ -279,18 +279,57 @@
     }
   }
 
+  // ---- cross-iteration fusion (evomg_strip_cross.h) ------------------------------------------------------------------
+  // The cycle ends with [PROLONG_ADD +] a red-black point sweep on SOL@max and starts with one, (normally) followed by
+  // RESIDUAL + RESTRICT of a residual nobody else reads: the solver loop then runs tail and head of consecutive iterations
+  // as ONE launch. head_len / tail_len: ops the launch stands for at the start / end of the program.
+  struct CrossPlan {
+    bool ok = false, pro = false, tailr = false;
+    int head_len = 0, tail_len = 0;
+  };
+  CrossPlan cross_plan(const evomg_op_t* ops, int n_ops) const {
+    CrossPlan p;
+    if constexpr (scalar_traits<T>::is_complex) return p;
+    if (!xfuse_enabled_ || !fuse_enabled_ || dim_ != 2 || prob_.bc_kind != EVOMG_BC_DIRICHLET || n_ops < 2 || batch_enabled_) return p;
+    const int L = prob_.max_level;
+    const Geo& g = lv_[L].g;
+    if (L <= prob_.min_level || g.n < xfuse_min_n_ || !use_strip(g) || small2d_ok(g)) return p;
+    const evomg_op_t &first = ops[0], &last = ops[n_ops - 1];
+    if (!tail_norm_candidate(ops, n_ops, n_ops - 1) || last.partitioning != EVOMG_PART_RED_BLACK) return p;
+    if (first.opcode != EVOMG_OP_SMOOTH || first.level != L || first.partitioning != EVOMG_PART_RED_BLACK ||
+        first.block[0] * first.block[1] != 1 || canon(L, first.dst) != EVOMG_F_SOL || canon(L, first.src1) != EVOMG_F_RHS) return p;
+    p.pro = fusable_prolong_smooth(ops, n_ops, n_ops - 2);
+    p.tail_len = p.pro ? 2 : 1;
+    p.tailr = fusable_smooth_residual_restrict(ops, n_ops, 0, true);
+    p.head_len = p.tailr ? 3 : 1;
+    if (p.head_len + p.tail_len > n_ops) return p;
+    if (p.tailr) {
+      // the coarse right-hand side goes to a spare array that a pointer swap makes current: its boundary (never written by a
+      // restriction) has to be what the field's is — zero
+      const int slot = canon(L - 1, ops[2].dst);
+      if (slot < 0 || !bnd_zero_[L - 1][slot] || !lv_[L - 1].f[slot]) return p;
+      const int csrc = p.pro ? canon(L - 1, ops[n_ops - 2].src0) : 0;
+      if (csrc < 0 || !lv_[L - 1].f[csrc]) return p;
+    }
+    p.ok = true;
+    return p;
+  }
+
   // tail_norm (solver loop only): set to true when the last sweep of the program also produced the canonical partial
   // sums of the squared residual norm (norm_partials_)
-  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0, bool* tail_norm = nullptr) {
+  // stop >= 0: execute ops[first .. stop) only (the solver loop runs the cycle's last ops itself: cross_plan); the liveness
+  // scans still see the whole program
+  int exec_program(const evomg_op_t* ops, int n_ops, bool cyclic, int first = 0, bool* tail_norm = nullptr, int stop = -1) {
     if (tail_norm) *tail_norm = false;
-    for (int i = first; i < n_ops; ++i) {
+    const int end = stop >= 0 ? stop : n_ops;
+    for (int i = first; i < end; ++i) {
       if (batchable(ops[i])) {              // small level: the op joins the list one workgroup runs in one launch
         const int rc = exec_batched(ops[i]);
         if (rc != EVOMG_OK) return rc;
         continue;
       }
       flush_batch();
-      if (elidable_zero(ops, n_ops, i)) {
+      if (i + 1 < end && elidable_zero(ops, n_ops, i)) {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
         continue;
       }

@@ -73,8 +73,13 @@
     // is simply undone and the sweep's output discarded; otherwise the cycle continues from its second op.
     T *saved_alt = nullptr, *saved_x = nullptr;
     const T* saved_mirror = nullptr;
+    // Cross-iteration fusion (evomg_strip_cross.h): the cycle's last sweep (+ prolongation, + the norm) and the next cycle's
+    // first sweep (+ residual + restriction) on the finest level as ONE speculative launch per iteration
+    const CrossPlan xplan = cross_plan(ops, n_ops);
+    bool head_done = false;       // ops[0 .. head_len) of the coming iteration ran inside the previous iteration's cross launch
     auto speculate = [&](bool* launched) -> int {
       *launched = false;
+      if (xplan.ok) return EVOMG_OK;
       if (!speculate_ || n_ops < 1 || !smoother_is_out_of_place(ops[0])) return EVOMG_OK;
       // a sweep that fuses with the residual + restriction behind it is worth more than the overlap (and the fused
       // kernel writes the coarse right-hand side, which a speculative launch must not)
@@ -112,7 +117,15 @@
     else
       for (it = 1; it <= prob_.max_iterations; ++it) {
         bool norm_rode_along = false;
-        rc = exec_program(ops, n_ops, /*cyclic=*/true, ahead ? 1 : 0, &norm_rode_along);
+        // not in the last iteration the loop may run: there is no next cycle to start
+        const bool cross = xplan.ok && it < prob_.max_iterations;
+        const int first = head_done ? xplan.head_len : (ahead ? 1 : 0);
+        head_done = false;
+        if (cross) {
+          if ((rc = exec_program(ops, n_ops, /*cyclic=*/true, first, nullptr, n_ops - xplan.tail_len)) != EVOMG_OK) return rc;
+          if ((rc = launch_cross(ops, n_ops, xplan)) != EVOMG_OK) return rc;
+          norm_rode_along = true;
+        } else rc = exec_program(ops, n_ops, /*cyclic=*/true, first, &norm_rode_along);
         ahead = false;
         if (rc != EVOMG_OK) return rc;
         if (norm_rode_along) {
@@ -129,9 +142,20 @@
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
         ++nh;
-        if (!(res == res) || res > 1.7e308) { status = EVOMG_SOLVE_DIVERGED; break; }
-        if (res <= prob_.target_res_reduction * res0) { status = EVOMG_SOLVE_CONVERGED; break; }
-        if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
+        bool stop = true;
+        if (!(res == res) || res > 1.7e308) status = EVOMG_SOLVE_DIVERGED;
+        else if (res <= prob_.target_res_reduction * res0) status = EVOMG_SOLVE_CONVERGED;
+        else if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) status = EVOMG_SOLVE_WALL_LIMIT;
+        else stop = false;
+        if (cross) {
+          if (stop) {
+            if ((rc = cross_finalize(ops, n_ops, xplan)) != EVOMG_OK) return rc;      // the iterate of THIS iteration, from x
+          } else {
+            cross_commit(ops, xplan);                                                  // the next cycle has already begun
+            head_done = true;
+          }
+        }
+        if (stop) break;
       }
     if (ahead) undo_speculation();                 // the sweep queued for an iteration that is not going to happen
     HIP_TRY(hipStreamSynchronize(stream_));

@@ -178,6 +178,10 @@ def test_whole_solves_match_the_oracle(native, oracle, name):
     problem, lo, hi, _ = cycles.CASES[name]
     gen, ops = ops_for_case(name)
     pd = problems.BY_NAME[problem](lo, hi)
+    if name == "elasticity2d_L5_mixed_shapes":
+        # one block shape per unknown: accepted only where the sweep's result is never used (include/evomg.h: block_other)
+        import dataclasses
+        pd = dataclasses.replace(pd, jacobi_semantics=abi.JACOBI_SEMANTICS["exastencils-v1.1"])
     hg, ho = make_pair(native, oracle, pd)
     og = hg.evaluate(ops, 1, 0, 128)
     oo = ho.evaluate(ops, 1, 0, 128)
