@@ -125,7 +125,7 @@ def ops_array(ops: Sequence[Op]):
 # every symbol include/evomg.h declares, without prefix
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
             "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
-            "profile_begin", "profile_end", "device_count",
+            "profile_begin", "profile_end", "device_count", "time_iterations",
             "comm_create", "comm_destroy", "comm_last_error", "allgather_fitness", "gather_fitness", "rccl_version"]
 FITNESS_COLUMNS = 4      # EVOMG_FITNESS_COLUMNS: (candidate index, convergence factor, time ms, iterations)
 
@@ -181,6 +181,9 @@ class Library:
         if "kernel_name" in f:
             f["kernel_name"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_char_p, C.c_int]
             f["kernel_name"].restype = C.c_int
+        if "time_iterations" in f:
+            f["time_iterations"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
+            f["time_iterations"].restype = C.c_int
         if "comm_create" in f:
             f["comm_create"].argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
             f["comm_create"].restype = C.c_int
@@ -299,6 +302,14 @@ class Handle:
         rc, out = self.try_evaluate(ops, evaluation_samples, wall_limit_ms, history_capacity)
         self._check(rc, "evaluate")
         return out
+
+    def time_iterations(self, ops: Sequence[Op], n_iterations: int = 3):
+        """(mean wall ms of one solver-loop iteration, iterations run) over exactly n_iterations iterations from the initial
+        state, no convergence test (evomg_time_iterations): the contention-free time objective's probe."""
+        arr = ops_array(ops)
+        ms, done = C.c_double(), C.c_int()
+        self._check(self.L.fn["time_iterations"](self._h, arr, len(ops), n_iterations, C.byref(ms), C.byref(done)), "time_iterations")
+        return ms.value, done.value
 
     def norm(self, level, field) -> float:
         v = C.c_double()

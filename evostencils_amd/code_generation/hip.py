@@ -460,6 +460,22 @@ class ProgramGenerator:
                 mapping["k"] *= 2
         return total_t / n, total_rho / n, total_it / n
 
+    def isolated_time_ms(self, ops, min_level: int, max_level: int, iterations: float, solver_program: str = "",
+                         global_variable_values=None, probe_iterations: int = 3):
+        """Time-to-solution of a candidate as it would be ALONE on the GPU, for an evaluation that ran with other candidates
+        in flight (where the measured wall time includes the neighbours and would change the selection pressure of the time
+        objective, optimization/program.py:449-451): `probe_iterations` solver-loop iterations are timed with
+        evomg_time_iterations — the caller makes sure nothing else runs on the device meanwhile — and scaled to the
+        `iterations` the real evaluation took. Iterations of one candidate cost the same (same launches; the coarse-grid
+        Krylov solve reduces its residual by the same factor every time), so this is within a few per cent of the
+        sequential evaluation's time (tests/test_time_objective_gpu.py)."""
+        if solver_program or max_level < self._problem.max_level or min_level > self._problem.min_level:
+            min_level, max_level = self._problem.min_level, self._problem.max_level
+        handle = self._ensure_handle(min_level, max_level, dict(global_variable_values or {}))
+        n = max(1, min(int(probe_iterations), int(iterations) if iterations >= 1 else 1))
+        ms, done = handle.time_iterations(ops, n)
+        return ms * float(iterations)
+
     def compile_and_run(self, ops, min_level, max_level, mapping=None, infinity=1e100, evaluation_samples=3):
         """exastencils.py:468-483 + evaluate :417-443; nothing is compiled here.
 
@@ -576,11 +592,24 @@ class ProgramGeneratorPool:
     (`solver_program`) are known to all (one shared table). Lowering mutates flags on the DAG, whose terminals all
     candidates share: it runs under one lock (it holds the interpreter lock anyway); the solve itself does not."""
 
-    def __init__(self, make_generator, n_workers: int):
+    def __init__(self, make_generator, n_workers: int, time_objective: str = "contended", probe_iterations: int = 3):
+        """time_objective: "contended" — a candidate's time is the wall time of its solve, neighbours included (fastest);
+        "isolated" — every evaluation is followed by a short probe of the same candidate while NOTHING else runs on the
+        GPU (ProgramGenerator.isolated_time_ms): the workers finish the solves they have in flight, one of them runs the
+        pending probes one after the other, then all go on. rho and iteration counts are the same either way; with
+        "isolated" the time objective is the one a sequential evaluation would have measured, so the pool can stand behind
+        the optimizer without changing its selection (optimization/program.py:449-451)."""
         import queue
         import threading
         if n_workers < 1:
             raise ValueError("n_workers must be at least 1")
+        if time_objective not in ("contended", "isolated"):
+            raise ValueError("time_objective must be 'contended' or 'isolated'")
+        self._time_objective, self._probe_iterations = time_objective, probe_iterations
+        self._cond = threading.Condition()
+        self._active = 0                # solves in flight
+        self._probing = False           # a probe batch owns the GPU: no new solve starts
+        self._pending = []              # probe requests of workers whose solve is done
         self._generators = [make_generator() for _ in range(n_workers)]
         shared = self._generators[0]._cycle_functions
         for g in self._generators[1:]:
@@ -621,10 +650,61 @@ class ProgramGeneratorPool:
                     ops = g.generate_op_program(expression, min_level, max_level, solver_program)
                 except lowering.UnsupportedExpression:
                     return infinity, infinity, infinity
-            return g.evaluate_op_program(ops, min_level, max_level, solver_program, infinity, evaluation_samples,
-                                         global_variable_values)
+            if self._time_objective != "isolated":
+                return g.evaluate_op_program(ops, min_level, max_level, solver_program, infinity, evaluation_samples,
+                                             global_variable_values)
+            with self._cond:
+                while self._probing:
+                    self._cond.wait()
+                self._active += 1
+            try:
+                t, rho, its = g.evaluate_op_program(ops, min_level, max_level, solver_program, infinity, evaluation_samples,
+                                                    global_variable_values)
+            except BaseException:
+                with self._cond:
+                    self._active -= 1
+                    self._cond.notify_all()
+                raise
+            return self._probe(g, ops, min_level, max_level, solver_program, global_variable_values, t, rho, its, infinity)
         finally:
             self._free.put(g)
+
+    def _probe(self, g, ops, min_level, max_level, solver_program, global_variable_values, t, rho, its, infinity):
+        """Second half of an evaluation under time_objective="isolated": queue this candidate's probe, and — if this worker's
+        solve was the last one in flight — run every queued probe alone on the GPU; otherwise wait for the worker that does."""
+        request = None
+        if t < infinity and its < infinity and its >= 1:
+            request = {"g": g, "args": (ops, min_level, max_level, its, solver_program, global_variable_values, self._probe_iterations),
+                       "done": False, "time": t, "error": None}
+        with self._cond:
+            self._active -= 1
+            if request is not None:
+                self._pending.append(request)
+            if self._active == 0 and self._pending and not self._probing:
+                self._probing = True
+                batch, self._pending = self._pending, []
+            else:
+                batch = None
+                self._cond.notify_all()
+        if batch is not None:
+            for r in batch:                     # nothing else is in flight: the wall time of the probe is the candidate's own
+                try:
+                    r["time"] = r["g"].isolated_time_ms(*r["args"])
+                except Exception as exc:        # noqa: BLE001 — handed to the worker that owns the request
+                    r["error"] = exc
+            with self._cond:
+                for r in batch:
+                    r["done"] = True
+                self._probing = False
+                self._cond.notify_all()
+        if request is None:
+            return t, rho, its
+        with self._cond:
+            while not request["done"]:
+                self._cond.wait()
+        if request["error"] is not None:
+            raise request["error"]
+        return request["time"], rho, its
 
     def close(self):
         for g in self._generators:

@@ -103,6 +103,23 @@ int evomg_evaluate(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int eval
   return h ? h->impl->evaluate(ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity)
            : EVOMG_ERR_INVALID;
 }
+int evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_iterations, double* ms_per_iteration, int* n_done) {
+  if (!h || !ms_per_iteration || n_iterations < 1 || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
+  evomg_problem_t& p = h->impl->problem();
+  const int saved_max = p.max_iterations;
+  const double saved_target = p.target_res_reduction;
+  p.max_iterations = n_iterations;
+  p.target_res_reduction = -1.0;          // a norm is never below a negative bound: the loop runs all n_iterations
+  evomg_result_t r;
+  const int rc = h->impl->evaluate(ops, n_ops, 1, 0.0, &r, nullptr, 0);
+  p.max_iterations = saved_max;
+  p.target_res_reduction = saved_target;
+  if (rc != EVOMG_OK) return rc;
+  const double its = r.n_iterations >= 1.0 ? r.n_iterations : 1.0;
+  *ms_per_iteration = r.time_ms / its;
+  if (n_done) *n_done = (int)r.n_iterations;
+  return EVOMG_OK;
+}
 int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {
   if (!h || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
   return h->impl->run_ops(ops, n_ops);

@@ -308,6 +308,7 @@
     return EVOMG_OK;
   }
 
+  evomg_problem_t& problem() override { return prob_; }
   int profile_begin(int opcode, int level) override {
     if (!level_ok(level)) return invalid("profile_begin: bad level");
     prof_opcode_ = opcode;

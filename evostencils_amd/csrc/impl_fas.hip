@@ -205,6 +205,7 @@ class FASImpl : public ImplBase {
                              op->opcode == EVOMG_OP_FAS_RESIDUAL ? "evomg_fas_residual" : "generic");
     return EVOMG_OK;
   }
+  evomg_problem_t& problem() override { return prob_; }
   int profile_begin(int, int) override { return EVOMG_OK; }
   int profile_end(evomg_bench_t* out) override { if (out) memset(out, 0, sizeof *out); return EVOMG_OK; }
 

@@ -262,12 +262,14 @@ class ConcurrentEvaluator:
 
 
 def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[object, int], Tuple[float, float, float]],
-                                  n_candidates: int, local_rank: int = 0):
+                                  n_candidates: int, local_rank: int = 0,
+                                  time_fn: Callable[[object, int, float], float] = None):
     """`evaluate_population` with this rank's share evaluated by the workers of a ConcurrentEvaluator — several
     candidates in flight on the rank's GPU (own generator, stream and fields each) — instead of one after the other.
     fn(generator, i) -> (time_ms, rho, iterations). Same split (`i % world == rank`), same single collective, same
     result table on every rank; a worker that breaks is recorded with the sentinel triple and its first exception is
-    re-raised after the collective, as in the sequential form."""
+    re-raised after the collective, as in the sequential form. `time_fn`: see below — with it the table's times are the
+    candidates' times ALONE on the GPU (the reference's time objective), without it their contended wall times."""
     rank, world = world_info()
     mine_idx = shard_indices(n_candidates, rank, world)
 
@@ -284,6 +286,14 @@ def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[
             failure = failure if failure is not None else r
             r = (FAILED, FAILED, FAILED)
         t_ms, rho, its = r
+        if time_fn is not None and failure is None and t_ms < FAILED and 1 <= its < FAILED:
+            # Contention-free time objective: the workers are idle now, so a short probe of the candidate on ONE generator
+            # measures it alone — time_fn(generator, i, iterations) -> ms (ProgramGenerator.isolated_time_ms). The wall time
+            # of the in-flight solve, which includes the neighbours, is replaced.
+            try:
+                t_ms = time_fn(evaluator.generators[0], i, its)
+            except Exception as exc:        # noqa: BLE001 — re-raised once the collective is done
+                failure = exc
         mine.append((i, float(rho), float(t_ms), float(its)))
     try:
         rows = allgather_fitness(mine, n_candidates, world, local_rank, failed=failure is not None)

@@ -259,6 +259,15 @@ int  evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops);
 /* L2 norm of the current content of a field over the inner nodes (the solver loop's norm). */
 int  evomg_norm(evomg_handle_t* h, int level, int field, double* out);
 
+/* Time objective without contention (optimization/program.py:449-451 uses time / iterations as an objective): runs exactly
+ * n_iterations solver-loop iterations of the candidate from the initial state — no convergence test — and reports the mean
+ * wall time of one iteration. With several candidates in flight on one GPU a solve's own wall time includes its neighbours;
+ * calling this while nothing else runs on the device and multiplying by the iteration count of the real evaluation gives
+ * the time the candidate needs alone (population.evaluate_population_in_flight(..., time_fn=...)). Stops early if the
+ * residual becomes NaN / Inf; n_done receives the iterations actually run (may be NULL). */
+int  evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_iterations,
+                           double* ms_per_iteration, int* n_done);
+
 /* -- measurement ------------------------------------------------------------ */
 /* Times `reps` back-to-back launches of one op on the handle's stream with HIP events. */
 int  evomg_bench_op(evomg_handle_t* h, const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out);

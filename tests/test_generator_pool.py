@@ -98,3 +98,47 @@ def test_pooled_evaluation_equals_sequential_on_the_gpu():
     pool.close()
     assert [g[1:] for g in got] == [w[1:] for w in want]
     assert all(np.isfinite(g[0]) and g[0] > 0 for g in got)
+
+
+def test_isolated_time_objective_probes_run_alone():
+    """time_objective="isolated": a probe never overlaps a solve or another probe, every evaluation returns the probe's time
+    instead of its contended wall time, rho and iterations are untouched, failed candidates are not probed."""
+    state = {"solving": 0, "probing": 0, "overlap": False, "probes": 0}
+    lock = threading.Lock()
+
+    class Gen(_FakeGenerator):
+        def evaluate_op_program(self, ops, lo, hi, solver_program, infinity, samples, gv):
+            import time
+            with lock:
+                state["solving"] += 1
+                state["overlap"] |= state["probing"] > 0
+            time.sleep(0.01 * (1 + ops[1] % 3))
+            with lock:
+                state["solving"] -= 1
+            if ops[1] == 5:
+                return (infinity, infinity, infinity)
+            return (1000.0 + ops[1], 0.5, 9.0)
+
+        def isolated_time_ms(self, ops, lo, hi, iterations, solver_program="", gv=None, probe_iterations=3):
+            import time
+            with lock:
+                state["probing"] += 1
+                state["probes"] += 1
+                state["overlap"] |= state["solving"] > 0 or state["probing"] > 1
+            time.sleep(0.002)
+            with lock:
+                state["probing"] -= 1
+            return 7.0 + ops[1]
+
+    pool = ProgramGeneratorPool(Gen, 4, time_objective="isolated")
+    with ThreadPool(4) as tp:
+        out = tp.map(lambda i: pool.generate_and_evaluate(i, None, 5, 9, "", infinity=1e100), range(14))
+    pool.close()
+    assert not state["overlap"] and state["probes"] == 13
+    for i, (t, rho, its) in enumerate(out):
+        if i == 5:
+            assert (t, rho, its) == (1e100, 1e100, 1e100)
+        else:
+            assert (t, rho, its) == (7.0 + i, 0.5, 9.0)
+    with pytest.raises(ValueError):
+        ProgramGeneratorPool(Gen, 2, time_objective="fastest")

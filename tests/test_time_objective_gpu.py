@@ -1,0 +1,73 @@
+"""A contention-free time objective for candidates in flight (the reference's second objective is time per
+iteration, optimization/program.py:449-451): evomg_time_iterations probes a candidate alone on the GPU, and the modelled
+time = probe x iterations has to rank candidates as the sequential evaluation does and agree with it."""
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, candidates, population, problems
+from helpers import context_for
+
+pytestmark = pytest.mark.gpu
+LO, HI, N = 7, 11, 16
+
+
+def _generator():
+    from evostencils_amd import native
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    g = ProgramGenerator(problem=problems.poisson_2d(LO, HI), library=native.library())
+    g.initialize_code_generation(LO, HI)
+    return g
+
+
+def _spearman(a, b):
+    ra, rb = np.argsort(np.argsort(a)).astype(float), np.argsort(np.argsort(b)).astype(float)
+    ra -= ra.mean()
+    rb -= rb.mean()
+    return float((ra * rb).sum() / np.sqrt((ra * ra).sum() * (rb * rb).sum()))
+
+
+def test_probe_runs_exactly_the_iterations_asked_for():
+    from evostencils_amd import native
+    from test_full_size_gpu import vcycle
+    pd = problems.poisson_2d(5, 9)
+    h = native.create(pd)
+    ops = vcycle(5, 9, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
+    full = h.evaluate(ops, 1, 0, 64)
+    ms, done = h.time_iterations(ops, 4)
+    assert done == 4 and 0 < ms < 50
+    again = h.evaluate(ops, 1, 0, 64)                   # the probe re-targets the stopping rule only for its own run
+    assert again.n_iterations == full.n_iterations and np.array_equal(again.history, full.history)
+    many, done = h.time_iterations(ops, 40)             # far beyond convergence: still all 40 (no convergence test)
+    assert done == 40
+    h.close()
+
+
+def test_modelled_time_ranks_candidates_like_the_sequential_pass():
+    """The 16-candidate C5 slice at 2049^2: sequential times vs (in flight) rho / iterations + isolated probes."""
+    gen = _generator()
+    pop = candidates.population(lambda: context_for(gen, LO, HI), HI - LO, 2, N, seed=2024)
+    evaluate = lambda g, i: g.generate_and_evaluate(pop[i], None, LO, HI, "", evaluation_samples=1)
+    evaluate(gen, 0)                                    # warm-up
+    seq = [evaluate(gen, i) for i in range(N)]
+    seq2 = [evaluate(gen, i) for i in range(N)]         # the sequential pass against itself: the noise floor
+    workers = population.ConcurrentEvaluator(_generator, 8)
+    try:
+        workers.map(evaluate, range(8))                 # warm-up of every worker
+        contended = population.evaluate_population_in_flight(workers, evaluate, N)
+        modelled = population.evaluate_population_in_flight(
+            workers, evaluate, N,
+            time_fn=lambda g, i, its: g.isolated_time_ms(g.generate_op_program(pop[i], LO, HI), LO, HI, its))
+    finally:
+        workers.close()
+    gen.close()
+    t_seq = np.array([s[0] for s in seq])
+    t_seq2 = np.array([s[0] for s in seq2])
+    t_con = np.array([r[2] for r in contended])
+    t_mod = np.array([r[2] for r in modelled])
+    assert [r[1] for r in modelled] == [s[1] for s in seq] and [r[3] for r in modelled] == [s[2] for s in seq]
+    rel = np.abs(t_mod - t_seq) / t_seq
+    print(f"sequential {t_seq.sum():.0f} ms; modelled/sequential: max rel diff {rel.max():.3f}, Spearman {_spearman(t_mod, t_seq):.4f}; "
+          f"contended/sequential {np.median(t_con / t_seq):.1f}x (Spearman {_spearman(t_con, t_seq):.4f}); "
+          f"sequential vs itself: max rel diff {(np.abs(t_seq2 - t_seq) / t_seq).max():.3f}")
+    assert _spearman(t_mod, t_seq) >= 0.98
+    assert rel.max() <= 0.05
