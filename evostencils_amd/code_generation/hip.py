@@ -461,7 +461,7 @@ class ProgramGenerator:
         return total_t / n, total_rho / n, total_it / n
 
     def isolated_time_ms(self, ops, min_level: int, max_level: int, iterations: float, solver_program: str = "",
-                         global_variable_values=None, probe_iterations: int = 3):
+                         global_variable_values=None, probe_iterations: int = 8):
         """Time-to-solution of a candidate as it would be ALONE on the GPU, for an evaluation that ran with other candidates
         in flight (where the measured wall time includes the neighbours and would change the selection pressure of the time
         objective, optimization/program.py:449-451): `probe_iterations` solver-loop iterations are timed with
@@ -472,9 +472,14 @@ class ProgramGenerator:
         if solver_program or max_level < self._problem.max_level or min_level > self._problem.min_level:
             min_level, max_level = self._problem.min_level, self._problem.max_level
         handle = self._ensure_handle(min_level, max_level, dict(global_variable_values or {}))
-        n = max(1, min(int(probe_iterations), int(iterations) if iterations >= 1 else 1))
-        ms, done = handle.time_iterations(ops, n)
-        return ms * float(iterations)
+        its = float(iterations)
+        n_long = max(2, min(int(probe_iterations), int(its)))
+        if n_long < 3:
+            ms, _done = handle.time_iterations(ops, max(1, int(its)))
+            return ms * its
+        # two-point fit: what a solve pays once (initial residual + norm, final synchronisation) is not multiplied
+        per_iteration, fixed = handle.time_model(ops, max(1, n_long // 4), n_long)
+        return max(fixed, 0.0) + per_iteration * its
 
     def compile_and_run(self, ops, min_level, max_level, mapping=None, infinity=1e100, evaluation_samples=3):
         """exastencils.py:468-483 + evaluate :417-443; nothing is compiled here.
@@ -592,7 +597,7 @@ class ProgramGeneratorPool:
     (`solver_program`) are known to all (one shared table). Lowering mutates flags on the DAG, whose terminals all
     candidates share: it runs under one lock (it holds the interpreter lock anyway); the solve itself does not."""
 
-    def __init__(self, make_generator, n_workers: int, time_objective: str = "contended", probe_iterations: int = 3):
+    def __init__(self, make_generator, n_workers: int, time_objective: str = "contended", probe_iterations: int = 8):
         """time_objective: "contended" — a candidate's time is the wall time of its solve, neighbours included (fastest);
         "isolated" — every evaluation is followed by a short probe of the same candidate while NOTHING else runs on the
         GPU (ProgramGenerator.isolated_time_ms): the workers finish the solves they have in flight, one of them runs the

@@ -120,6 +120,24 @@ int evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, i
   if (n_done) *n_done = (int)r.n_iterations;
   return EVOMG_OK;
 }
+int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long, double* ms_per_iteration, double* ms_fixed) {
+  if (!ms_per_iteration || !ms_fixed || n_short < 1 || n_long <= n_short) return EVOMG_ERR_INVALID;
+  double a = 0.0, b = 0.0;
+  int da = 0, db = 0;
+  int rc = evomg_time_iterations(h, ops, n_ops, n_short, &a, &da);
+  if (rc != EVOMG_OK) return rc;
+  rc = evomg_time_iterations(h, ops, n_ops, n_long, &b, &db);
+  if (rc != EVOMG_OK) return rc;
+  if (db <= da) {                        // the candidate blew up before n_long iterations: one point is all there is
+    *ms_per_iteration = b;
+    *ms_fixed = 0.0;
+    return EVOMG_OK;
+  }
+  const double ta = a * da, tb = b * db;
+  *ms_per_iteration = (tb - ta) / (double)(db - da);
+  *ms_fixed = ta - *ms_per_iteration * da;
+  return EVOMG_OK;
+}
 int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {
   if (!h || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
   return h->impl->run_ops(ops, n_ops);

@@ -353,6 +353,23 @@
     else hipLaunchKernelGGL((evomg_strip_prolong<T, false>), grid, block, 0, stream_, g, gc, coarse, fine, 1.0, rows, strips, waves, rkh);
   }
 
+  // Chunk height of the cross kernel (multiples of 16 rows). It holds 144 VGPRs — three waves per SIMD, i.e. at most three
+  // 4-wave blocks per compute unit — and every block is meant to be resident at once, so a launch lasts as long as the unit
+  // with the most blocks: ceil(blocks / units) x (rows + 9 pipeline steps); heights that need more than three blocks on a unit
+  // pay a whole extra round. At 4097^2 (36 strips): 64 rows -> 585 blocks, three on some units, two on most (measured 103 us);
+  // 80 rows -> 468 blocks, two on nearly every unit.
+  int cross_rows(int n, int strips) const {
+    long best_cost = -1;
+    int best = 4 * EVOMG_NORM_ROWS;
+    for (int r = 2 * EVOMG_NORM_ROWS; r <= 8 * EVOMG_NORM_ROWS; r += EVOMG_NORM_ROWS) {
+      const long blocks = ((long)strips * ((n + r - 1) / r) + 3) / 4;
+      const long per_unit = (blocks + n_cu_ - 1) / n_cu_;
+      const long rounds = (per_unit + 2) / 3;                           // three resident blocks per unit
+      const long cost = (rounds > 1 ? rounds * 3 : per_unit) * (r + 9);
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+    }
+    return best;
+  }
   // ---- cross-iteration launch (evomg_strip_cross.h): tail of this iteration + head of the next on the finest level -------
   // Reads SOL@max (x), RHS@max, the coarse correction; writes w into the level's spare array, the next iteration's coarse
   // right-hand side into xf_rhs_spare_, the per-pair norm sums; then reduces those to the canonical partial sums in
@@ -366,8 +383,8 @@
       const Geo& gc = lv_[L - 1].g;
       const evomg_op_t &sa = ops[n_ops - 1], &sb = ops[0];
       const int strips = (g.n + EVOMG_CROSS_STRIP_COLS - 1) / EVOMG_CROSS_STRIP_COLS;
-      int rows = strip_rows_ > 0 ? ((strip_rows_ + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : 4 * EVOMG_NORM_ROWS;
-      if (strip_rows_ <= 0 && balance_rows_) rows = balanced_rows(g.n, strips, EVOMG_NORM_ROWS, EVOMG_NORM_ROWS, 6 * EVOMG_NORM_ROWS);
+      const int forced_rows = xfuse_rows_ > 0 ? xfuse_rows_ : strip_rows_;
+      int rows = forced_rows > 0 ? ((forced_rows + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : cross_rows(g.n, strips);
       const int chunks = (g.n + rows - 1) / rows;
       const int waves = strips * chunks;
       const int chunks16 = (g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS;

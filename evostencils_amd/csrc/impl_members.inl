@@ -21,6 +21,7 @@
   // cross-iteration fusion on the finest 2D level (evomg_strip_cross.h): EVOMG_NO_XFUSE switches it off (same bits either way)
   bool xfuse_enabled_ = getenv("EVOMG_NO_XFUSE") == nullptr;
   int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 513;
+  int xfuse_rows_ = getenv("EVOMG_XFUSE_ROWS") ? atoi(getenv("EVOMG_XFUSE_ROWS")) : 0;      // chunk height of the cross kernel (tuning)
   T* xf_rhs_spare_ = nullptr;        // spare coarse right-hand side of level max - 1 (speculative output, swapped in on commit)
   T* xf_lane_sums_ = nullptr;        // per (16-row chunk, column pair) sums of the squared residual
   size_t xf_lane_sums_cap_ = 0;

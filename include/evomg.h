@@ -267,6 +267,11 @@ int  evomg_norm(evomg_handle_t* h, int level, int field, double* out);
  * residual becomes NaN / Inf; n_done receives the iterations actually run (may be NULL). */
 int  evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_iterations,
                            double* ms_per_iteration, int* n_done);
+/* The same probe as a two-point fit: runs n_short and then n_long (> n_short) iterations and returns slope and intercept of
+ * time over iterations — ms_per_iteration excludes what a solve pays once (the initial residual and norm, the final
+ * synchronisation), ms_fixed is that one-off part: time(its) ~ ms_fixed + ms_per_iteration * its. */
+int  evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long,
+                      double* ms_per_iteration, double* ms_fixed);
 
 /* -- measurement ------------------------------------------------------------ */
 /* Times `reps` back-to-back launches of one op on the handle's stream with HIP events. */

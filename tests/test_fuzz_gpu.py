@@ -170,3 +170,39 @@ def test_random_cycles_in_the_solver_loop(native, oracle, dim, lo, hi, seed, sem
     assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
     hg.close()
     ho.close()
+
+
+MORE = [(kind, lo, hi, seed) for seed in range(100, 120) for kind, lo, hi in (("poisson", 3, 7), ("helmholtz", 3, 7), ("helmholtz", 4, 8),
+                                                                                ("poisson", 4, 8), ("poisson3d", 2, 5))]
+
+
+@pytest.mark.parametrize("group", range(10))
+def test_one_hundred_more_random_programs(native, oracle, group):
+    """100 programs of tools/fuzz_more.py's stream (2D real, 2D complex with Robin columns, 3D; default thresholds — the kernels a
+    user gets), alternating `with jacobi` semantics: every field of every level bit for bit after run_ops (VERDICT r3 #9)."""
+    for n, (kind, lo, hi, seed) in enumerate(MORE[10 * group:10 * group + 10]):
+        semantics = ("textbook", "exastencils-v1.1")[(seed + n) % 2]
+        if kind == "poisson3d":
+            pd = problems.poisson_3d(lo, hi)
+        elif kind == "poisson":
+            pd = problems.poisson_2d(lo, hi)
+        else:
+            pd = problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
+        pd = with_semantics(pd, semantics)
+        rng = np.random.default_rng(31 * seed + lo)
+        ops = random_program(rng, 3 if kind == "poisson3d" else 2, lo, hi, 28)
+        hg, ho = native.create(pd), oracle.create(pd)
+        for L in range(lo, hi + 1):
+            shape = hg.field_shape(L)
+            for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+                a = rng.standard_normal(shape) + (1j * rng.standard_normal(shape) if kind == "helmholtz" else 0.0)
+                hg.set_field(L, f, a)
+                ho.set_field(L, f, a)
+        hg.run_ops(ops)
+        ho.run_ops(ops)
+        for L in range(lo, hi + 1):
+            for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+                got, want = hg.get_field(L, f), ho.get_field(L, f)
+                assert np.array_equal(got, want, equal_nan=True), (kind, lo, hi, semantics, seed, L, f)
+        hg.close()
+        ho.close()

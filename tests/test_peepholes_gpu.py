@@ -1,0 +1,180 @@
+"""Every peephole of the op-program interpreter (csrc/impl_peephole.inl), systematically: for each one the MINIMAL op sequence
+that triggers it, with each kind of smoother it can meet (point Jacobi, red-black, a two-cell block) and under BOTH `with jacobi`
+semantics — the class of bug ADVICE r2 #1 was: a fusion that swallows an op whose sweep the reference pipeline's semantics
+discards — compared three ways: default build, the same run with the peephole's switch off (EVOMG_NO_*), and the CPU oracle.
+Non-cyclic form: `run_ops` on random fields, every field of every level bit for bit. Cyclic form (fusions that need "the program is
+the body of the solver loop"): whole solves, identical histories between the two GPU runs, <= 1e-10 against the oracle, the
+returned iterate bit for bit."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from evostencils_amd import abi, problems
+
+pytestmark = pytest.mark.gpu
+SEMANTICS = ["textbook", "exastencils-v1.1"]
+SMOOTHERS = {
+    "jacobi": lambda L, om=0.8: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (1, 1, 1), om),
+    "rbgs": lambda L, om=1.15: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), om),
+    "block": lambda L, om=0.9: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (2, 1, 1), om),
+}
+
+
+@pytest.fixture(scope="module")
+def native():
+    from evostencils_amd import native as nat
+    nat.library()
+    return nat
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def residual(L):
+    return abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS)
+
+
+def restrict(L):
+    return abi.make_op(abi.OP_RESTRICT, L, abi.F_RHS, abi.F_RES)
+
+
+def prolong(L, om=0.95):
+    return abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=om)
+
+
+def zero(L, f=abi.F_SOL):
+    return abi.make_op(abi.OP_SET_ZERO, L, f)
+
+
+def coarse(lo):
+    return [abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS), zero(lo, abi.F_CORR), abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+
+
+# name -> (dimension, lo, hi, switch that disables the peephole, ops(smoother, lo, hi) -> program); the level the pattern sits
+# on is chosen so that the kernel family behind the peephole serves it (forced thresholds in `run` below)
+def _top(lo, hi):
+    return hi
+
+
+NON_CYCLIC = {
+    "residual_restrict_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [residual(hi), restrict(hi - 1), residual(hi - 1), restrict(hi - 2)]),
+    "prolong_smooth_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [prolong(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
+    "zero_elision_2d": (2, 4, 7, "EVOMG_NO_ZERO_ELISION", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), zero(hi - 2), s(hi - 2), s(hi - 2), residual(hi - 2)]),
+    "copy_zero_coarse_solve_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
+    "lds_tiles_2d": (2, 3, 6, "EVOMG_NO_SMALL2D", lambda s, lo, hi: [s(hi), s(hi - 1), prolong(hi), s(hi), zero(hi - 2), s(hi - 2), s(hi - 2)]),
+    "strip_block_2d": (2, 4, 7, "EVOMG_NO_STRIP_BLOCK", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
+    "block_fast_2d": (2, 4, 7, "EVOMG_NO_BLOCK_FAST", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
+    "boundary_mirror_2d": (2, 4, 7, "EVOMG_NO_BOUNDARY_MIRROR", lambda s, lo, hi: [s(hi), s(hi), s(hi), prolong(hi), s(hi)]),
+    "double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1), s(hi - 1), s(hi - 1)]),
+    "prolong_double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_PRO", lambda s, lo, hi: [prolong(hi), s(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
+    "small_level_chain_3d": (3, 2, 4, "EVOMG_NO_SMALL3D", lambda s, lo, hi: [zero(hi), s(hi), s(hi), residual(hi), restrict(hi - 1), prolong(hi), s(hi)]),
+    "tiles_3d": (3, 2, 5, "EVOMG_NO_TILE3D", lambda s, lo, hi: [s(hi), residual(hi), restrict(hi - 1), s(hi - 1), prolong(hi), s(hi)]),
+    "boundary_mirror_3d": (3, 2, 5, "EVOMG_NO_BOUNDARY_MIRROR", lambda s, lo, hi: [s(hi), s(hi), s(hi), prolong(hi), s(hi)]),
+}
+
+
+def v_cycle(s, lo, hi, pre, post):
+    ops = []
+    for L in range(hi, lo, -1):
+        ops += [s(L)] * pre + [residual(L), restrict(L - 1)]
+        if L - 1 > lo:
+            ops.append(zero(L - 1))
+    ops += coarse(lo)
+    for L in range(lo + 1, hi + 1):
+        ops += [prolong(L, 1.0)] + [s(L)] * post
+    return ops
+
+
+CYCLIC = {
+    "sweep_residual_restrict_2d": (2, 4, 7, "EVOMG_NO_TAIL_RESTRICT", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
+    "two_sweeps_residual_restrict_2d": (2, 3, 6, "EVOMG_NO_SMALL2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    "tail_norm_2d": (2, 4, 7, "EVOMG_NO_TAIL_NORM", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
+    "dead_residual_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 0, 1)),
+    "speculation_2d": (2, 4, 7, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    "cross_iteration_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
+    "cross_iteration_plain_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
+    "residual_restrict_3d": (3, 2, 5, "EVOMG_NO_TILE3D_RR", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
+    "double_sweep_cycle_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
+    "residual_norm_3d": (3, 2, 5, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    "speculation_3d": (3, 2, 5, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
+}
+FORCED = {"EVOMG_STRIP_MIN_N": "17", "EVOMG_STRIP3D_MIN_N": "9", "EVOMG_XFUSE_MIN_N": "65", "EVOMG_STRIP_ROWS": "16", "EVOMG_STRIP_PLANES": "8"}
+KNOBS = sorted({v[3] for v in list(NON_CYCLIC.values()) + list(CYCLIC.values())})
+
+
+def problem(dim, lo, hi, semantics, **kw):
+    pd = problems.poisson_2d(lo, hi) if dim == 2 else problems.poisson_3d(lo, hi)
+    return dataclasses.replace(pd, jacobi_semantics=abi.JACOBI_SEMANTICS[semantics], **kw)
+
+
+def environment(monkeypatch, switch_off=None):
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in FORCED.items():
+        monkeypatch.setenv(k, v)
+    if switch_off:
+        monkeypatch.setenv(switch_off, "1")
+
+
+@pytest.mark.parametrize("semantics", SEMANTICS)
+@pytest.mark.parametrize("kind", sorted(SMOOTHERS))
+@pytest.mark.parametrize("name", sorted(NON_CYCLIC))
+def test_peephole_on_random_fields(native, oracle, monkeypatch, name, kind, semantics):
+    dim, lo, hi, knob, build = NON_CYCLIC[name]
+    ops = build(SMOOTHERS[kind], lo, hi)
+    pd = problem(dim, lo, hi, semantics)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{name}/{kind}".encode()))
+    state = {}
+    results = []
+    for which in ("fused", "switched_off", "oracle"):
+        environment(monkeypatch, knob if which == "switched_off" else None)
+        h = (oracle if which == "oracle" else native).create(pd)
+        for L in range(lo, hi + 1):
+            for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+                if (L, f) not in state:
+                    a = rng.standard_normal(h.field_shape(L))
+                    if f == abi.F_SOL and L < hi:
+                        # error fields have a zero boundary in every cycle (what the zero-input variants rely on)
+                        edge = np.ones(a.shape, bool)
+                        edge[(slice(1, -1),) * dim] = False
+                        a[edge] = 0.0
+                    state[(L, f)] = a
+                h.set_field(L, f, state[(L, f)])
+        h.run_ops(ops)
+        results.append({(L, f): h.get_field(L, f) for L in range(lo, hi + 1) for f in (abi.F_SOL, abi.F_RHS, abi.F_RES)})
+        h.close()
+    fused, plain, want = results
+    for key in want:
+        assert np.array_equal(fused[key], want[key], equal_nan=True), ("fused vs oracle", name, kind, semantics, key)
+        assert np.array_equal(plain[key], want[key], equal_nan=True), ("switched off vs oracle", name, kind, semantics, key)
+
+
+@pytest.mark.parametrize("semantics", SEMANTICS)
+@pytest.mark.parametrize("kind", sorted(SMOOTHERS))
+@pytest.mark.parametrize("name", sorted(CYCLIC))
+def test_peephole_in_the_solver_loop(native, oracle, monkeypatch, name, kind, semantics):
+    dim, lo, hi, knob, build = CYCLIC[name]
+    if dim == 3 and kind == "block" and hi > 4:
+        hi = 5
+    ops = build(SMOOTHERS[kind], lo, hi)
+    pd = problem(dim, lo, hi, semantics, max_iterations=5)
+    outs = []
+    for which in ("fused", "switched_off", "oracle"):
+        environment(monkeypatch, knob if which == "switched_off" else None)
+        h = (oracle if which == "oracle" else native).create(pd)
+        out = h.evaluate(ops, 2 if which != "oracle" else 1, 0, 16)
+        outs.append((out, h.get_field(hi, abi.F_SOL), h.get_field(hi, abi.F_RES)))
+        h.close()
+    (a, ua, ra), (b, ub, rb), (c, uc, rc) = outs
+    assert a.status == b.status == c.status and a.n_iterations == b.n_iterations == c.n_iterations
+    assert np.array_equal(a.history, b.history, equal_nan=True)
+    finite = np.isfinite(c.history) & (c.history > 0)
+    assert np.array_equal(np.isfinite(a.history), np.isfinite(c.history))
+    assert np.max(np.abs(a.history[finite] - c.history[finite]) / c.history[finite]) <= 1e-10
+    assert np.array_equal(ua, ub, equal_nan=True) and np.array_equal(ua, uc, equal_nan=True)
+    assert np.array_equal(ra, rb, equal_nan=True) and np.array_equal(ra, rc, equal_nan=True)

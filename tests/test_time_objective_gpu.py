@@ -68,6 +68,8 @@ def test_modelled_time_ranks_candidates_like_the_sequential_pass():
     rel = np.abs(t_mod - t_seq) / t_seq
     print(f"sequential {t_seq.sum():.0f} ms; modelled/sequential: max rel diff {rel.max():.3f}, Spearman {_spearman(t_mod, t_seq):.4f}; "
           f"contended/sequential {np.median(t_con / t_seq):.1f}x (Spearman {_spearman(t_con, t_seq):.4f}); "
-          f"sequential vs itself: max rel diff {(np.abs(t_seq2 - t_seq) / t_seq).max():.3f}")
-    assert _spearman(t_mod, t_seq) >= 0.98
+          f"sequential vs itself: max rel diff {(np.abs(t_seq2 - t_seq) / t_seq).max():.3f}, Spearman {_spearman(t_seq2, t_seq):.4f}")
+    # the sequential pass against itself bounds what any model can reach (near-ties between candidates flip ranks)
+    assert _spearman(t_mod, t_seq) >= min(0.98, _spearman(t_seq2, t_seq) - 0.02)
     assert rel.max() <= 0.05
+    assert _spearman(t_mod, t_seq) > _spearman(t_con, t_seq)
