@@ -20,7 +20,8 @@
 // strip, sweep B on [4, 123], w's residual on [5, 122], so coarse columns with 2I in [6, 121] and the 116 stored columns
 // [6, 121] tile the row. Rows: at step j the wave relaxes A's reds on row j and A's blacks on row j-1 (z row j-1 final), forms
 // the norm's residual on z row j-2, relaxes B's reds on row j-2 and B's blacks on row j-3 (w row j-3 final), forms w's
-// residual on row j-4 and, every second step, coarse row (j-5)/2: a chunk of H rows reads H + 11 rows of x.
+// residual on row j-4 and, every second step, coarse row (j-5)/2: a chunk of H rows reads H + 11 rows of x (the step count is
+// rounded up to the unroll factor: up to five more, whose stores are all masked by their row ranges).
 // Register windows (x, z, w: 3 rows; f: 6 rows; reds and residuals: 2) are rings addressed with compile-time indices — the row
 // loop is unrolled SIX times, the least common multiple of the ring lengths — so advancing a row costs no register moves.
 //
@@ -45,31 +46,52 @@ struct CrossArgs {
   int sums_pitch;
 };
 
+// relax5 with the kind of quotient fixed at compile time: RECIP — the centre coefficient is a power of two (4 / h^2 on a dyadic
+// mesh: every Poisson level), r * (1 / c0) is exact; otherwise the division. evomg_strip2d decides per call with a uniform
+// branch; with four relaxations per row step that branch (and the never-executed division behind it) is what kept the
+// compiler from scheduling this kernel's row step as one straight line.
+template <bool RECIP>
+__device__ __forceinline__ double cross_relax5(const Stencil<double>& st, double c, double w, double e, double s, double n, double f,
+                                               double om, double omm, double inv_c0) {
+  double r = f;
+  r = r - st.c[1] * w;
+  r = r - st.c[2] * e;
+  r = r - st.c[3] * s;
+  r = r - st.c[4] * n;
+  const double xs = RECIP ? r * inv_c0 : r / st.c[0];
+  return omm * c + om * xs;
+}
+
 // one fused two-colour step: reds of row j from (xm, xc, xp) = rows j-1, j, j+1, then blacks of row j-1 from the new reds of
 // rows j-2 (red_slot on entry), j-1 (rm1), j; returns the finished row j-1 and leaves row j's reds in red_slot
+template <bool RECIP>
 __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st, int parity, const Pair<double>& xm, const Pair<double>& xc,
                                                        const Pair<double>& xp, const Pair<double>& fc, const Pair<double>& fm, double& red_slot,
                                                        double rm1, bool row_inner, bool brow_inner, bool inner_a, bool inner_b, double om,
                                                        double omm, double inv_c0) {
+  // every relaxation is computed by all lanes and SELECTED where the node is an inner one (straight-line code: a conditional
+  // evaluation becomes an exec-masked block per relaxation, which cuts the row step into a dozen basic blocks)
   const double rm2 = red_slot;
   double rc;
   if (parity == 0) {
     const double w = from_left(xc.b);
-    rc = (row_inner && inner_a) ? relax5(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0) : xc.a;
+    const double t = cross_relax5<RECIP>(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0);
+    rc = (row_inner && inner_a) ? t : xc.a;
   } else {
     const double e = from_right(xc.a);
-    rc = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0) : xc.b;
+    const double t = cross_relax5<RECIP>(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0);
+    rc = (row_inner && inner_b) ? t : xc.b;
   }
   Pair<double> out;
   if (parity == 1) {            // row j-1 even: red = a, black = b
     const double e = from_right(rm1);
-    const double bl = (brow_inner && inner_b) ? relax5(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0) : xm.b;
+    const double t = cross_relax5<RECIP>(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0);
     out.a = rm1;
-    out.b = bl;
+    out.b = (brow_inner && inner_b) ? t : xm.b;
   } else {                      // red = b, black = a
     const double w = from_left(rm1);
-    const double bl = (brow_inner && inner_a) ? relax5(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0) : xm.a;
-    out.a = bl;
+    const double t = cross_relax5<RECIP>(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0);
+    out.a = (brow_inner && inner_a) ? t : xm.a;
     out.b = rm1;
   }
   red_slot = rc;
@@ -77,7 +99,7 @@ __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st,
 }
 
 // grid: ceil(strips * chunks / 4) blocks (multiple of 8) of 256 threads = 4 independent waves; rows_per_chunk: multiple of 16
-template <bool NT_XY, bool PRO, bool TAILR>
+template <bool NT_XY, bool PRO, bool TAILR, bool RECIP>
 __global__ void __launch_bounds__(256)
 evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ y,
                     int rows_per_chunk, int n_strips, int n_waves, CrossArgs a) {
@@ -129,9 +151,10 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
       va = 0.5 * (cJ + cJ1);
       vb = 0.25 * ((cJ + cJr) + (cJ1 + cJ1r));
     }
+    const double ca = raw.a + a.om_p * va, cb = raw.b + a.om_p * vb;
     Pair<double> out;
-    out.a = (row_in && inner_a) ? raw.a + a.om_p * va : raw.a;
-    out.b = (row_in && inner_b) ? raw.b + a.om_p * vb : raw.b;
+    out.a = (row_in && inner_a) ? ca : raw.a;
+    out.b = (row_in && inner_b) ? cb : raw.b;
     return out;
   };
   const int js = y0 - 5;                                     // odd: first row whose A-reds are relaxed
@@ -170,7 +193,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
 #pragma unroll
     for (int d = 0; d < U; ++d) {
       const int j = base + d;
-      if (j < je) {                                          // wave-uniform
+      {                                                      // steps at and beyond je (the last trip): clamped loads, every store guarded
         const int parity = (1 + d) & 1;                      // js is odd
         Pair<double> xp = xq[d & 1];
         const Pair<double> fc = fq[d & 1];
@@ -189,7 +212,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
         // ---- sweep A: reds of row j, blacks of row j-1 -> z row j-1 ----
         {
           const bool row_inner = j >= 1 && j <= n - 2, brow_inner = j - 1 >= 1 && j - 1 <= n - 2;
-          zw[(d + 2) % 3] = cross_rb_step(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
+          zw[(d + 2) % 3] = cross_rb_step<RECIP>(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
                                           row_inner, brow_inner, inner_a, inner_b, a.om_a, a.omm_a, a.inv_c0);
         }
         const Pair<double>& z3 = zw[d % 3];                  // z rows j-3, j-2, j-1
@@ -202,24 +225,22 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
         {
           const int rr = j - 2;
           const double wa = from_left(z2.b), eb = from_right(z2.a);
-          if (rr >= y0 && rr < y1) {                         // wave-uniform
-            if (rr >= 1 && rr <= n - 2 && store_lane) {
-              const double qa = residual5(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
-              const double qb = residual5(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
-              if (inner_a) nrm = nrm + qa * qa;
-              if (inner_b) nrm = nrm + qb * qb;
-            }
-            if ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1) {
-              if (store_lane) a.lane_sums[(long)(rr / EVOMG_NORM_ROWS) * a.sums_pitch + (c0 >> 1)] = nrm;
-              nrm = 0.0;
-            }
+          // branch-free: where TAIL_NORM adds nothing, +0.0 is added (nrm >= +0.0: the same value, bit for bit)
+          const bool counted = rr >= y0 && rr < y1 && rr >= 1 && rr <= n - 2 && store_lane;
+          const double qa = residual5(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
+          const double qb = residual5(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
+          nrm = nrm + ((counted && inner_a) ? qa * qa : 0.0);
+          nrm = nrm + ((counted && inner_b) ? qb * qb : 0.0);
+          if (rr >= y0 && rr < y1 && ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1)) {      // wave-uniform
+            if (store_lane) a.lane_sums[(long)(rr / EVOMG_NORM_ROWS) * a.sums_pitch + (c0 >> 1)] = nrm;
+            nrm = 0.0;
           }
         }
         // ---- sweep B on z: reds of row j-2, blacks of row j-3 -> w row j-3 ----
         {
           const int jb = j - 2;
           const bool row_inner = jb >= 1 && jb <= n - 2, brow_inner = jb - 1 >= 1 && jb - 1 <= n - 2;
-          const Pair<double> wrow = cross_rb_step(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, inner_a,
+          const Pair<double> wrow = cross_rb_step<RECIP>(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, inner_a,
                                                   inner_b, a.om_b, a.omm_b, a.inv_c0);
           ww[d % 3] = wrow;
           const int jw = j - 3;
@@ -234,8 +255,9 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           const bool rin = rr >= 1 && rr <= n - 2;
           const double wa = from_left(w4.b), eb = from_right(w4.a);
           Pair<double> rcur;
-          rcur.a = (rin && inner_a) ? residual5(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a) : 0.0;
-          rcur.b = (rin && inner_b) ? residual5(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b) : 0.0;
+          const double ta = residual5(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a), tb = residual5(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b);
+          rcur.a = (rin && inner_a) ? ta : 0.0;
+          rcur.b = (rin && inner_b) ? tb : 0.0;
           const Pair<double>& res1 = rs[(d + 1) & 1];        // residual rows rr-1, rr-2
           const Pair<double>& res2 = rs[d & 1];
           if (parity == 1) {                                 // rr odd: rows rr-2, rr-1, rr = 2J-1, 2J, 2J+1

@@ -419,8 +419,10 @@
       const bool nt = strip_streams(g);
       const bool timed = prof_matches(sa) || prof_matches(sb);
       if (timed) { const int rc = prof_open(); if (rc != EVOMG_OK) return rc; }
-#define EVOMG_CROSS_LAUNCH(NT, PRO, TR) hipLaunchKernelGGL((evomg_strip2d_cross<NT, PRO, TR>), grid, block, 0, stream_, g, lv.st, x, f, y, rows, strips, waves, a)
-#define EVOMG_CROSS_NT(PRO, TR) do { if (nt) EVOMG_CROSS_LAUNCH(true, PRO, TR); else EVOMG_CROSS_LAUNCH(false, PRO, TR); } while (0)
+      const bool recip = a.inv_c0 != 0.0;
+#define EVOMG_CROSS_LAUNCH(NT, PRO, TR, RC) hipLaunchKernelGGL((evomg_strip2d_cross<NT, PRO, TR, RC>), grid, block, 0, stream_, g, lv.st, x, f, y, rows, strips, waves, a)
+#define EVOMG_CROSS_NT(PRO, TR) do { if (nt && recip) EVOMG_CROSS_LAUNCH(true, PRO, TR, true); else if (nt) EVOMG_CROSS_LAUNCH(true, PRO, TR, false); \
+                                     else if (recip) EVOMG_CROSS_LAUNCH(false, PRO, TR, true); else EVOMG_CROSS_LAUNCH(false, PRO, TR, false); } while (0)
       if (plan.pro && plan.tailr) EVOMG_CROSS_NT(true, true);
       else if (plan.pro) EVOMG_CROSS_NT(true, false);
       else if (plan.tailr) EVOMG_CROSS_NT(false, true);
