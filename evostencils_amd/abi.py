@@ -125,7 +125,7 @@ def ops_array(ops: Sequence[Op]):
 # every symbol include/evomg.h declares, without prefix
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
             "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
-            "profile_begin", "profile_end", "device_count", "time_iterations", "time_model",
+            "profile_begin", "profile_end", "device_count", "time_iterations", "time_model", "coarse_iterations",
             "comm_create", "comm_destroy", "comm_last_error", "allgather_fitness", "gather_fitness", "rccl_version"]
 FITNESS_COLUMNS = 4      # EVOMG_FITNESS_COLUMNS: (candidate index, convergence factor, time ms, iterations)
 
@@ -185,8 +185,10 @@ class Library:
             f["time_iterations"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
             f["time_iterations"].restype = C.c_int
         if "time_model" in f:
-            f["time_model"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.c_int, dp, dp]
+            f["time_model"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.c_int, dp, dp, dp]
             f["time_model"].restype = C.c_int
+            f["coarse_iterations"].argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+            f["coarse_iterations"].restype = C.c_int
         if "comm_create" in f:
             f["comm_create"].argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
             f["comm_create"].restype = C.c_int
@@ -314,12 +316,20 @@ class Handle:
         self._check(self.L.fn["time_iterations"](self._h, arr, len(ops), n_iterations, C.byref(ms), C.byref(done)), "time_iterations")
         return ms.value, done.value
 
-    def time_model(self, ops: Sequence[Op], n_short: int = 2, n_long: int = 8):
-        """(ms per iteration, one-off ms) from a two-point fit over n_short and n_long iterations (evomg_time_model)."""
+    def time_model(self, ops: Sequence[Op], n_short: int = 2, n_long: int = 6):
+        """(one-off ms, ms per solver-loop iteration, ms per coarse-solver iteration) of the candidate on an idle device
+        (evomg_time_model): time ~ fixed + per_iteration * its + per_coarse * K."""
         arr = ops_array(ops)
-        slope, fixed = C.c_double(), C.c_double()
-        self._check(self.L.fn["time_model"](self._h, arr, len(ops), n_short, n_long, C.byref(slope), C.byref(fixed)), "time_model")
-        return slope.value, fixed.value
+        fixed, per_it, per_cg = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.L.fn["time_model"](self._h, arr, len(ops), n_short, n_long, C.byref(fixed), C.byref(per_it), C.byref(per_cg)),
+                    "time_model")
+        return fixed.value, per_it.value, per_cg.value
+
+    def coarse_iterations(self) -> int:
+        """Coarse-solver iterations of all coarse solves of the last evaluate (evomg_coarse_iterations)."""
+        k = C.c_longlong()
+        self._check(self.L.fn["coarse_iterations"](self._h, C.byref(k)), "coarse_iterations")
+        return int(k.value)
 
     def norm(self, level, field) -> float:
         v = C.c_double()

@@ -133,6 +133,7 @@ class ProgramGenerator:
         self._solver_cache = {}
         self._verified = {}
         self._cycle_functions = {}       # text of a generated cycle function -> (level, window min, op program)
+        self.last_coarse_iterations = None      # coarse-solver iterations of the last evaluation (time model input)
         self._set_problem(problem)
 
     # ---- read-only attributes the optimizer reads (scripts/optimize.py:60-68) ------------------
@@ -461,25 +462,25 @@ class ProgramGenerator:
         return total_t / n, total_rho / n, total_it / n
 
     def isolated_time_ms(self, ops, min_level: int, max_level: int, iterations: float, solver_program: str = "",
-                         global_variable_values=None, probe_iterations: int = 8):
+                         global_variable_values=None, coarse_iterations=None, probe_iterations: int = 6):
         """Time-to-solution of a candidate as it would be ALONE on the GPU, for an evaluation that ran with other candidates
         in flight (where the measured wall time includes the neighbours and would change the selection pressure of the time
-        objective, optimization/program.py:449-451): `probe_iterations` solver-loop iterations are timed with
-        evomg_time_iterations — the caller makes sure nothing else runs on the device meanwhile — and scaled to the
-        `iterations` the real evaluation took. Iterations of one candidate cost the same (same launches; the coarse-grid
-        Krylov solve reduces its residual by the same factor every time), so this is within a few per cent of the
-        sequential evaluation's time (tests/test_time_objective_gpu.py)."""
+        objective, optimization/program.py:449-451). The caller makes sure nothing else runs on the device meanwhile. Three
+        short probes (evomg_time_model) give the cost of what a solve pays once, of one solver-loop iteration without its
+        coarse-grid Krylov iterations, and of one such Krylov iteration; `iterations` and `coarse_iterations` of the real
+        evaluation (the latter: `last_coarse_iterations` of the generator that ran it) scale them. The Krylov count has to
+        be part of the model: on the headline sizes the coarse solve is most of an iteration and its iteration count drifts
+        by tens of per cent along a solve and between candidates (profiles/r04_time_objective.md)."""
         if solver_program or max_level < self._problem.max_level or min_level > self._problem.min_level:
             min_level, max_level = self._problem.min_level, self._problem.max_level
         handle = self._ensure_handle(min_level, max_level, dict(global_variable_values or {}))
         its = float(iterations)
         n_long = max(2, min(int(probe_iterations), int(its)))
-        if n_long < 3:
-            ms, _done = handle.time_iterations(ops, max(1, int(its)))
+        if n_long < 3 or coarse_iterations is None:
+            ms, _done = handle.time_iterations(ops, max(1, min(int(its), max(n_long, 1))))
             return ms * its
-        # two-point fit: what a solve pays once (initial residual + norm, final synchronisation) is not multiplied
-        per_iteration, fixed = handle.time_model(ops, max(1, n_long // 4), n_long)
-        return max(fixed, 0.0) + per_iteration * its
+        fixed, per_iteration, per_coarse = handle.time_model(ops, max(1, n_long // 3), n_long)
+        return max(fixed, 0.0) + per_iteration * its + per_coarse * float(coarse_iterations)
 
     def compile_and_run(self, ops, min_level, max_level, mapping=None, infinity=1e100, evaluation_samples=3):
         """exastencils.py:468-483 + evaluate :417-443; nothing is compiled here.
@@ -494,6 +495,7 @@ class ProgramGenerator:
         rc, out = handle.try_evaluate(ops, evaluation_samples, 1e3 * float(self.timeout_evaluate), cap)
         if rc == abi.ERR_DEVICE:
             raise abi.BackendError(f"evomg_evaluate failed on device {self._device_id}: {handle.last_error()}")
+        self.last_coarse_iterations = handle.coarse_iterations() if rc == abi.OK else None
         if rc != abi.OK or out.status == abi.SOLVE_WALL_LIMIT:
             return infinity, infinity, infinity
         t, rho, its = self.interpret_outcome(out, infinity, self._solver_iteration_limit,
@@ -597,7 +599,7 @@ class ProgramGeneratorPool:
     (`solver_program`) are known to all (one shared table). Lowering mutates flags on the DAG, whose terminals all
     candidates share: it runs under one lock (it holds the interpreter lock anyway); the solve itself does not."""
 
-    def __init__(self, make_generator, n_workers: int, time_objective: str = "contended", probe_iterations: int = 8):
+    def __init__(self, make_generator, n_workers: int, time_objective: str = "contended", probe_iterations: int = 6):
         """time_objective: "contended" — a candidate's time is the wall time of its solve, neighbours included (fastest);
         "isolated" — every evaluation is followed by a short probe of the same candidate while NOTHING else runs on the
         GPU (ProgramGenerator.isolated_time_ms): the workers finish the solves they have in flight, one of them runs the
@@ -679,7 +681,8 @@ class ProgramGeneratorPool:
         solve was the last one in flight — run every queued probe alone on the GPU; otherwise wait for the worker that does."""
         request = None
         if t < infinity and its < infinity and its >= 1:
-            request = {"g": g, "args": (ops, min_level, max_level, its, solver_program, global_variable_values, self._probe_iterations),
+            request = {"g": g, "args": (ops, min_level, max_level, its, solver_program, global_variable_values,
+                                        getattr(g, "last_coarse_iterations", None), self._probe_iterations),
                        "done": False, "time": t, "error": None}
         with self._cond:
             self._active -= 1

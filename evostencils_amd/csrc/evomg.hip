@@ -120,22 +120,43 @@ int evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, i
   if (n_done) *n_done = (int)r.n_iterations;
   return EVOMG_OK;
 }
-int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long, double* ms_per_iteration, double* ms_fixed) {
-  if (!ms_per_iteration || !ms_fixed || n_short < 1 || n_long <= n_short) return EVOMG_ERR_INVALID;
-  double a = 0.0, b = 0.0;
-  int da = 0, db = 0;
-  int rc = evomg_time_iterations(h, ops, n_ops, n_short, &a, &da);
+int evomg_coarse_iterations(evomg_handle_t* h, long long* total) {
+  if (!h || !total) return EVOMG_ERR_INVALID;
+  *total = h->impl->coarse_iterations();
+  return EVOMG_OK;
+}
+int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long, double* ms_fixed,
+                     double* ms_per_iteration, double* ms_per_coarse_iteration) {
+  if (!h || !ms_fixed || !ms_per_iteration || !ms_per_coarse_iteration || n_short < 1 || n_long <= n_short) return EVOMG_ERR_INVALID;
+  evomg_problem_t& p = h->impl->problem();
+  const int saved_cgs = p.cgs_max_iterations;
+  double t[3] = {0, 0, 0};
+  long long k[3] = {0, 0, 0};
+  int done[3] = {0, 0, 0};
+  const int n[3] = {n_short, n_long, n_long};
+  int rc = EVOMG_OK;
+  for (int q = 0; q < 3 && rc == EVOMG_OK; ++q) {
+    p.cgs_max_iterations = q < 2 ? 1 : saved_cgs;
+    double ms = 0.0;
+    rc = evomg_time_iterations(h, ops, n_ops, n[q], &ms, &done[q]);
+    t[q] = ms * done[q];
+    k[q] = h->impl->coarse_iterations();
+  }
+  p.cgs_max_iterations = saved_cgs;
   if (rc != EVOMG_OK) return rc;
-  rc = evomg_time_iterations(h, ops, n_ops, n_long, &b, &db);
-  if (rc != EVOMG_OK) return rc;
-  if (db <= da) {                        // the candidate blew up before n_long iterations: one point is all there is
-    *ms_per_iteration = b;
+  if (done[0] != n_short || done[1] != n_long || done[2] != n_long) {
+    // a probe blew up before its last iteration: the plain average of the longest one is all there is
+    const int q = done[2] > 0 ? 2 : (done[1] > 0 ? 1 : 0);
     *ms_fixed = 0.0;
+    *ms_per_iteration = done[q] > 0 ? t[q] / done[q] : 0.0;
+    *ms_per_coarse_iteration = 0.0;
     return EVOMG_OK;
   }
-  const double ta = a * da, tb = b * db;
-  *ms_per_iteration = (tb - ta) / (double)(db - da);
-  *ms_fixed = ta - *ms_per_iteration * da;
+  const double c_cg = k[2] > k[1] ? (t[2] - t[1]) / (double)(k[2] - k[1]) : 0.0;
+  const double c_it = ((t[1] - t[0]) - c_cg * (double)(k[1] - k[0])) / (double)(n_long - n_short);
+  *ms_per_coarse_iteration = c_cg > 0.0 ? c_cg : 0.0;
+  *ms_per_iteration = c_it;
+  *ms_fixed = t[0] - c_it * n_short - *ms_per_coarse_iteration * (double)k[0];
   return EVOMG_OK;
 }
 int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {

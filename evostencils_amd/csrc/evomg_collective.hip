@@ -48,7 +48,22 @@ Rccl& rccl() {
   static bool tried = false;
   if (tried) return r;
   tried = true;
-  const char* names[] = {getenv("EVOMG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // The RCCL that belongs to the HIP runtime THIS process runs on: a process that imported torch first runs on the runtime
+  // torch bundles (and torch's librccl, built for it, answers to the same SONAME), any other process on /opt/rocm's. Mixing
+  // them fails in ncclCommInitRank ("unhandled cuda error": torch's RCCL 2.26 on the system's HIP 7.2, seen on the GPU box), so
+  // the library next to the loaded libamdhip64 is tried first, by path (a path is not matched against SONAMEs already loaded).
+  std::string beside_hip, beside_hip2;
+  Dl_info hip_info;
+  if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &hip_info) && hip_info.dli_fname) {
+    const std::string path(hip_info.dli_fname);
+    const size_t slash = path.rfind('/');
+    if (slash != std::string::npos) {
+      beside_hip = path.substr(0, slash) + "/librccl.so.1";
+      beside_hip2 = path.substr(0, slash) + "/librccl.so";
+    }
+  }
+  const char* names[] = {getenv("EVOMG_RCCL_LIB"), beside_hip.c_str(), beside_hip2.c_str(), "librccl.so.1", "librccl.so",
+                         "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     if (!n || !*n) continue;
     r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);

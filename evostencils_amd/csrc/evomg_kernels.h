@@ -792,3 +792,8 @@ __global__ void __launch_bounds__(256) evomg_axpy(Geo g, T* __restrict__ z, cons
   const long c = gidx<DIM>(g, i, j, k);
   z[c] = sc_add(x[c], sc_mul(a, y[c]));
 }
+
+// info[2] += *src: the launch-per-iteration Krylov solvers keep their iteration count in device state
+static __global__ void evomg_accumulate_iterations(int* __restrict__ info, const int* __restrict__ src) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { info[0] = *src; info[2] += *src; }
+}

@@ -189,7 +189,7 @@ __device__ __forceinline__ void wg_apply_bc(const Geo& g, T* __restrict__ v, dou
 }
 
 // ---- CG, vectors in global memory (L2-resident): any grid size ----------------------------------------------------
-// info[0] = iterations performed
+// info[0] = iterations performed; info[2] accumulates them over the solves of one evaluation (time model: evomg_time_model)
 template <typename T, int DIM>
 __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r,
@@ -240,7 +240,7 @@ evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict_
     rr = rrn;
     __syncthreads();
   }
-  if (threadIdx.x == 0) info[0] = it;
+  if (threadIdx.x == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
 }
 
 template <typename T, int DIM>
@@ -336,7 +336,7 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
     if (res < tol * res0) { ++it; break; }
     if (!(res == res)) { ++it; break; }
   }
-  if (threadIdx.x == 0) info[0] = it;
+  if (threadIdx.x == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
 }
 
 // ---- BiCGStab on 2D grids up to 9^2 in ONE wave ------------------------------------------------------------------------
@@ -434,7 +434,7 @@ evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restri
       if (col == m - 1) { r_out[c + 1] = sc_div(r, den); if (it > 0) x[c + 1] = sc_div(xv, den); else if (XZERO) x[c + 1] = zero; }
     }
   }
-  if (l == 0) info[0] = it;
+  if (l == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
 }
 
 // ---- CG held in registers (2D tile ownership) ------------------------------------------------------------------------
@@ -639,7 +639,7 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
         x[c] = myx[i * 512].v[e];
         r_out[c] = r[i][e];
       }
-  if (threadIdx.x == 0) info[0] = it;
+  if (threadIdx.x == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
 }
 
 // ---- CG on grids up to 33^2 in ONE wave -------------------------------------------------------------------------------
@@ -761,7 +761,7 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
       x[c] = xv[i];
       r_out[c] = r[i];
     }
-  if (l == 0) info[0] = it;
+  if (l == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
 }
 
 // ---- CG on 3D grids up to 9^3 in ONE wave ---------------------------------------------------------------------------
@@ -855,7 +855,7 @@ evomg_cg_wave3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
       x[c] = xr[i];
       r_out[c] = r[i];
     }
-  if (t == 0) info[0] = it;
+  if (t == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
 }
 
 // ---- CG on LARGE coarsest grids as a sequence of many-unit launches ------------------------------------------------------
@@ -1343,7 +1343,7 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
   // info[1] is sticky (only ever set here, cleared by the host before an evaluation): a later successful solve must not
   // hide an earlier missed rendezvous, and any group may be the one that saw it
   if (t == 0) {
-    if (w == 0) info[0] = it;
+    if (w == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
     if (!alive) info[1] = 1;
   }
 }

@@ -40,6 +40,7 @@ struct ImplBase {
   virtual int kernel_name(const evomg_op_t* op, char* buf, int len) = 0;
   virtual int profile_begin(int opcode, int level) = 0;
   virtual int profile_end(evomg_bench_t* out) = 0;
+  virtual long long coarse_iterations() { return 0; }   // Krylov iterations of all coarse solves of the last evaluate (last sample)
   virtual evomg_problem_t& problem() = 0;      // the handle's descriptor (evomg_time_iterations re-targets the loop's stopping rule)
   char err[512] = "";
 };

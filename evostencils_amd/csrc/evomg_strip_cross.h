@@ -46,20 +46,38 @@ struct CrossArgs {
   int sums_pitch;
 };
 
-// relax5 with the kind of quotient fixed at compile time: RECIP — the centre coefficient is a power of two (4 / h^2 on a dyadic
-// mesh: every Poisson level), r * (1 / c0) is exact; otherwise the division. evomg_strip2d decides per call with a uniform
-// branch; with four relaxations per row step that branch (and the never-executed division behind it) is what kept the
-// compiler from scheduling this kernel's row step as one straight line.
-template <bool RECIP>
+// relax5 / residual5 specialised at compile time. POW2: ALL five coefficients are (signed) powers of two — -1/h^2 and 4/h^2 on a
+// dyadic mesh, i.e. every level of the 2D Poisson problem (host-checked, else the general form runs). A product with a power of
+// two is exact, so `r - c * w` and fma(-c, w, r) round the same real number once: the SAME BITS with half the instructions
+// (4 fused instead of 4 + 4 in a relaxation, 4 instead of 8 in a residual; out-of-range intermediates — |values| beyond 1e300
+// or below 1e-300 — are the only place the two forms could part). Likewise om * (r * 2^-k) = (om * 2^-k) * r. The general form
+// is relax5 / residual5 of evomg_strip.h with the division (or the exact reciprocal) chosen by `inv_c0` at run time.
+template <bool POW2>
 __device__ __forceinline__ double cross_relax5(const Stencil<double>& st, double c, double w, double e, double s, double n, double f,
-                                               double om, double omm, double inv_c0) {
-  double r = f;
-  r = r - st.c[1] * w;
-  r = r - st.c[2] * e;
-  r = r - st.c[3] * s;
-  r = r - st.c[4] * n;
-  const double xs = RECIP ? r * inv_c0 : r / st.c[0];
-  return omm * c + om * xs;
+                                               double om, double omm, double inv_c0, double om_inv) {
+  if constexpr (POW2) {
+    double r = f;
+    r = __builtin_fma(-st.c[1], w, r);
+    r = __builtin_fma(-st.c[2], e, r);
+    r = __builtin_fma(-st.c[3], s, r);
+    r = __builtin_fma(-st.c[4], n, r);
+    return omm * c + om_inv * r;
+  } else {
+    return relax5(st, c, w, e, s, n, f, om, omm, inv_c0);
+  }
+}
+template <bool POW2>
+__device__ __forceinline__ double cross_residual5(const Stencil<double>& st, double c, double w, double e, double s, double n, double f) {
+  if constexpr (POW2) {
+    double a = st.c[0] * c;
+    a = __builtin_fma(st.c[1], w, a);
+    a = __builtin_fma(st.c[2], e, a);
+    a = __builtin_fma(st.c[3], s, a);
+    a = __builtin_fma(st.c[4], n, a);
+    return f - a;
+  } else {
+    return residual5(st, c, w, e, s, n, f);
+  }
 }
 
 // one fused two-colour step: reds of row j from (xm, xc, xp) = rows j-1, j, j+1, then blacks of row j-1 from the new reds of
@@ -68,29 +86,29 @@ template <bool RECIP>
 __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st, int parity, const Pair<double>& xm, const Pair<double>& xc,
                                                        const Pair<double>& xp, const Pair<double>& fc, const Pair<double>& fm, double& red_slot,
                                                        double rm1, bool row_inner, bool brow_inner, bool inner_a, bool inner_b, double om,
-                                                       double omm, double inv_c0) {
+                                                       double omm, double inv_c0, double om_inv) {
   // every relaxation is computed by all lanes and SELECTED where the node is an inner one (straight-line code: a conditional
   // evaluation becomes an exec-masked block per relaxation, which cuts the row step into a dozen basic blocks)
   const double rm2 = red_slot;
   double rc;
   if (parity == 0) {
     const double w = from_left(xc.b);
-    const double t = cross_relax5<RECIP>(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0);
+    const double t = cross_relax5<RECIP>(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0, om_inv);
     rc = (row_inner && inner_a) ? t : xc.a;
   } else {
     const double e = from_right(xc.a);
-    const double t = cross_relax5<RECIP>(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0);
+    const double t = cross_relax5<RECIP>(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0, om_inv);
     rc = (row_inner && inner_b) ? t : xc.b;
   }
   Pair<double> out;
   if (parity == 1) {            // row j-1 even: red = a, black = b
     const double e = from_right(rm1);
-    const double t = cross_relax5<RECIP>(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0);
+    const double t = cross_relax5<RECIP>(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0, om_inv);
     out.a = rm1;
     out.b = (brow_inner && inner_b) ? t : xm.b;
   } else {                      // red = b, black = a
     const double w = from_left(rm1);
-    const double t = cross_relax5<RECIP>(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0);
+    const double t = cross_relax5<RECIP>(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0, om_inv);
     out.a = (brow_inner && inner_a) ? t : xm.a;
     out.b = rm1;
   }
@@ -99,6 +117,7 @@ __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st,
 }
 
 // grid: ceil(strips * chunks / 4) blocks (multiple of 8) of 256 threads = 4 independent waves; rows_per_chunk: multiple of 16
+// RECIP: every coefficient of the stencil is a power of two (see cross_relax5)
 template <bool NT_XY, bool PRO, bool TAILR, bool RECIP>
 __global__ void __launch_bounds__(256)
 evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ y,
@@ -186,6 +205,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
     c_hi = load_coarse((r0 >> 1) + 1);
   }
   double nrm = 0.0;
+  const double om_inv_a = a.om_a * a.inv_c0, om_inv_b = a.om_b * a.inv_c0;     // POW2: exact (om times a power of two)
   const int ncr = a.gc.n;
   const int Icr = c0 >> 1;
 
@@ -213,7 +233,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
         {
           const bool row_inner = j >= 1 && j <= n - 2, brow_inner = j - 1 >= 1 && j - 1 <= n - 2;
           zw[(d + 2) % 3] = cross_rb_step<RECIP>(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
-                                          row_inner, brow_inner, inner_a, inner_b, a.om_a, a.omm_a, a.inv_c0);
+                                          row_inner, brow_inner, inner_a, inner_b, a.om_a, a.omm_a, a.inv_c0, om_inv_a);
         }
         const Pair<double>& z3 = zw[d % 3];                  // z rows j-3, j-2, j-1
         const Pair<double>& z2 = zw[(d + 1) % 3];
@@ -227,8 +247,8 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           const double wa = from_left(z2.b), eb = from_right(z2.a);
           // branch-free: where TAIL_NORM adds nothing, +0.0 is added (nrm >= +0.0: the same value, bit for bit)
           const bool counted = rr >= y0 && rr < y1 && rr >= 1 && rr <= n - 2 && store_lane;
-          const double qa = residual5(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
-          const double qb = residual5(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
+          const double qa = cross_residual5<RECIP>(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
+          const double qb = cross_residual5<RECIP>(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
           nrm = nrm + ((counted && inner_a) ? qa * qa : 0.0);
           nrm = nrm + ((counted && inner_b) ? qb * qb : 0.0);
           if (rr >= y0 && rr < y1 && ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1)) {      // wave-uniform
@@ -241,7 +261,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           const int jb = j - 2;
           const bool row_inner = jb >= 1 && jb <= n - 2, brow_inner = jb - 1 >= 1 && jb - 1 <= n - 2;
           const Pair<double> wrow = cross_rb_step<RECIP>(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, inner_a,
-                                                  inner_b, a.om_b, a.omm_b, a.inv_c0);
+                                                  inner_b, a.om_b, a.omm_b, a.inv_c0, om_inv_b);
           ww[d % 3] = wrow;
           const int jw = j - 3;
           if (store_lane && jw >= y0 && jw < y1) store_pair<NT_XY>(y + pitch * jw + c0, wrow);
@@ -255,7 +275,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           const bool rin = rr >= 1 && rr <= n - 2;
           const double wa = from_left(w4.b), eb = from_right(w4.a);
           Pair<double> rcur;
-          const double ta = residual5(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a), tb = residual5(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b);
+          const double ta = cross_residual5<RECIP>(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a), tb = cross_residual5<RECIP>(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b);
           rcur.a = (rin && inner_a) ? ta : 0.0;
           rcur.b = (rin && inner_b) ? tb : 0.0;
           const Pair<double>& res1 = rs[(d + 1) & 1];        // residual rows rr-1, rr-2
@@ -265,9 +285,9 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
             const double w = from_left(res1.b), sw = from_left(res2.b), nw = from_left(rcur.b);
             const double e4 = (w + res1.b) + (res2.a + rcur.a);
             const double q4 = (sw + res2.b) + (nw + rcur.b);
-            double v = 0.25 * res1.a;
-            v = v + 0.125 * e4;
-            v = v + 0.0625 * q4;
+            double v = 0.25 * res1.a;                        // products with 1/4, 1/8, 1/16 are exact: fma = multiply, then add
+            v = __builtin_fma(0.125, e4, v);
+            v = __builtin_fma(0.0625, q4, v);
             if (store_lane && Icr >= 1 && Icr <= ncr - 2 && J >= 1 && J <= ncr - 2 && 2 * J >= y0 && 2 * J < y1)
               a.coarse_out[(long)a.gc.pitch * J + Icr] = v;
           }

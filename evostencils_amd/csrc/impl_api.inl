@@ -201,6 +201,7 @@
       memset(&r, 0, sizeof r);
       int rc = reset_fields();
       if (rc != EVOMG_OK) return rc;
+      HIP_TRY(hipMemsetAsync(dinfo_ + 2, 0, sizeof(int), stream_));      // coarse-solver iterations of this sample
       if (prob_.outer_kind == EVOMG_OUTER_PBICGSTAB) rc = solve_pbicgstab(ops, n_ops, wall_limit_ms, &r, hist, cap);
       else rc = solve_mg(ops, n_ops, wall_limit_ms, &r, hist, cap);
       if (rc != EVOMG_OK) return rc;
@@ -210,8 +211,14 @@
     }
     *out = r;
     out->time_ms = tsum / (double)done;
+    {
+      int k = 0;                       // behind the solve's own synchronisation, outside its timer
+      HIP_TRY(hipMemcpy(&k, dinfo_ + 2, sizeof(int), hipMemcpyDeviceToHost));
+      coarse_iterations_ = k;
+    }
     return EVOMG_OK;
   }
+  long long coarse_iterations() override { return coarse_iterations_; }
 
   int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) override {
     HIP_TRY(hipSetDevice(device_));

@@ -140,7 +140,7 @@
         HIP_TRY(hipStreamSynchronize(stream_));
         if (kcg_host_->done) break;
       }
-      HIP_TRY(hipMemcpyAsync(dinfo_, &kcg_state_[k & 1].it, sizeof(int), hipMemcpyDeviceToDevice, stream_));
+      hipLaunchKernelGGL(evomg_accumulate_iterations, dim3(1), dim3(64), 0, stream_, dinfo_, (const int*)&kcg_state_[k & 1].it);
       HIP_TRY(hipGetLastError());
       return EVOMG_OK;
     }
@@ -192,7 +192,7 @@
         if (kb_host_->done) break;
         if (batch < 16) batch *= 2;
       }
-      HIP_TRY(hipMemcpyAsync(dinfo_, &kb_state_[k & 1].it, sizeof(int), hipMemcpyDeviceToDevice, stream_));
+      hipLaunchKernelGGL(evomg_accumulate_iterations, dim3(1), dim3(64), 0, stream_, dinfo_, (const int*)&kb_state_[k & 1].it);
       HIP_TRY(hipGetLastError());
       return EVOMG_OK;
     }

@@ -419,7 +419,13 @@
       const bool nt = strip_streams(g);
       const bool timed = prof_matches(sa) || prof_matches(sb);
       if (timed) { const int rc = prof_open(); if (rc != EVOMG_OK) return rc; }
-      const bool recip = a.inv_c0 != 0.0;
+      // the kernel's fused form needs EVERY coefficient to be a power of two (2D Poisson: -1/h^2, 4/h^2); else the general form
+      bool recip = a.inv_c0 != 0.0;
+      for (int e = 1; e <= 4; ++e) {
+        int ex = 0;
+        const double m = frexp(lv.st.c[e], &ex);
+        recip = recip && (m == 0.5 || m == -0.5) && ex > -900 && ex < 900;
+      }
 #define EVOMG_CROSS_LAUNCH(NT, PRO, TR, RC) hipLaunchKernelGGL((evomg_strip2d_cross<NT, PRO, TR, RC>), grid, block, 0, stream_, g, lv.st, x, f, y, rows, strips, waves, a)
 #define EVOMG_CROSS_NT(PRO, TR) do { if (nt && recip) EVOMG_CROSS_LAUNCH(true, PRO, TR, true); else if (nt) EVOMG_CROSS_LAUNCH(true, PRO, TR, false); \
                                      else if (recip) EVOMG_CROSS_LAUNCH(false, PRO, TR, true); else EVOMG_CROSS_LAUNCH(false, PRO, TR, false); } while (0)

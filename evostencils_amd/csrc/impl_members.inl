@@ -12,7 +12,8 @@
   T* partials_ = nullptr;
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
-  int* dinfo_ = nullptr;
+  int* dinfo_ = nullptr;            // [0] iterations of the last coarse solve, [1] rendezvous miss, [2] iterations of all coarse solves
+  long long coarse_iterations_ = 0;
   bool mirror_enabled_ = getenv("EVOMG_NO_BOUNDARY_MIRROR") == nullptr;
   bool x_zero_next_ = false;
   bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;

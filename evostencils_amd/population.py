@@ -263,7 +263,7 @@ class ConcurrentEvaluator:
 
 def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[object, int], Tuple[float, float, float]],
                                   n_candidates: int, local_rank: int = 0,
-                                  time_fn: Callable[[object, int, float], float] = None):
+                                  time_fn: Callable[[object, int, float, object], float] = None):
     """`evaluate_population` with this rank's share evaluated by the workers of a ConcurrentEvaluator — several
     candidates in flight on the rank's GPU (own generator, stream and fields each) — instead of one after the other.
     fn(generator, i) -> (time_ms, rho, iterations). Same split (`i % world == rank`), same single collective, same
@@ -275,7 +275,9 @@ def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[
 
     def guarded(generator, i):
         try:
-            return fn(generator, i)
+            t_ms, rho, its = fn(generator, i)
+            # the coarse-solver iteration count of THIS evaluation travels with its result (input of the time model)
+            return t_ms, rho, its, getattr(generator, "last_coarse_iterations", None)
         except Exception as exc:        # noqa: BLE001 — re-raised once the collective is done
             return exc
 
@@ -284,14 +286,15 @@ def evaluate_population_in_flight(evaluator: ConcurrentEvaluator, fn: Callable[[
     for i, r in zip(mine_idx, evaluator.map(guarded, mine_idx)):
         if isinstance(r, Exception):
             failure = failure if failure is not None else r
-            r = (FAILED, FAILED, FAILED)
-        t_ms, rho, its = r
+            r = (FAILED, FAILED, FAILED, None)
+        t_ms, rho, its, coarse_its = r
         if time_fn is not None and failure is None and t_ms < FAILED and 1 <= its < FAILED:
             # Contention-free time objective: the workers are idle now, so a short probe of the candidate on ONE generator
-            # measures it alone — time_fn(generator, i, iterations) -> ms (ProgramGenerator.isolated_time_ms). The wall time
+            # measures it alone — time_fn(generator, i, iterations, coarse_iterations) -> ms (ProgramGenerator.isolated_time_ms
+            # with the iteration counts of the in-flight evaluation). The wall time
             # of the in-flight solve, which includes the neighbours, is replaced.
             try:
-                t_ms = time_fn(evaluator.generators[0], i, its)
+                t_ms = time_fn(evaluator.generators[0], i, its, coarse_its)
             except Exception as exc:        # noqa: BLE001 — re-raised once the collective is done
                 failure = exc
         mine.append((i, float(rho), float(t_ms), float(its)))

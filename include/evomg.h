@@ -267,11 +267,17 @@ int  evomg_norm(evomg_handle_t* h, int level, int field, double* out);
  * residual becomes NaN / Inf; n_done receives the iterations actually run (may be NULL). */
 int  evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_iterations,
                            double* ms_per_iteration, int* n_done);
-/* The same probe as a two-point fit: runs n_short and then n_long (> n_short) iterations and returns slope and intercept of
- * time over iterations — ms_per_iteration excludes what a solve pays once (the initial residual and norm, the final
- * synchronisation), ms_fixed is that one-off part: time(its) ~ ms_fixed + ms_per_iteration * its. */
+/* Krylov iterations of ALL coarse-grid solves of the last evomg_evaluate (its last sample) — what varies along a solve and
+ * between candidates while every other launch of a cycle costs the same each iteration. 0 for problems whose coarse solver
+ * does not iterate to a tolerance. */
+int  evomg_coarse_iterations(evomg_handle_t* h, long long* total);
+/* Three-point fit of the candidate's time on an otherwise idle device:
+ *     time(its, K) ~ ms_fixed + ms_per_iteration * its + ms_per_coarse_iteration * K
+ * (its: solver-loop iterations, K: coarse-solver iterations, evomg_coarse_iterations). Runs n_short and n_long (> n_short)
+ * iterations with the coarse solver capped at ONE iteration, and n_long iterations as they are. Together with `its` and K of
+ * the real evaluation this is the candidate's time-to-solution ALONE on the GPU, whatever ran beside that evaluation. */
 int  evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long,
-                      double* ms_per_iteration, double* ms_fixed);
+                      double* ms_fixed, double* ms_per_iteration, double* ms_per_coarse_iteration);
 
 /* -- measurement ------------------------------------------------------------ */
 /* Times `reps` back-to-back launches of one op on the handle's stream with HIP events. */

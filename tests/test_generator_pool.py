@@ -119,7 +119,7 @@ def test_isolated_time_objective_probes_run_alone():
                 return (infinity, infinity, infinity)
             return (1000.0 + ops[1], 0.5, 9.0)
 
-        def isolated_time_ms(self, ops, lo, hi, iterations, solver_program="", gv=None, probe_iterations=3):
+        def isolated_time_ms(self, ops, lo, hi, iterations, solver_program="", gv=None, coarse_iterations=None, probe_iterations=3):
             import time
             with lock:
                 state["probing"] += 1

@@ -56,7 +56,7 @@ def test_modelled_time_ranks_candidates_like_the_sequential_pass():
         contended = population.evaluate_population_in_flight(workers, evaluate, N)
         modelled = population.evaluate_population_in_flight(
             workers, evaluate, N,
-            time_fn=lambda g, i, its: g.isolated_time_ms(g.generate_op_program(pop[i], LO, HI), LO, HI, its))
+            time_fn=lambda g, i, its, k: g.isolated_time_ms(g.generate_op_program(pop[i], LO, HI), LO, HI, its, coarse_iterations=k))
     finally:
         workers.close()
     gen.close()
