@@ -516,8 +516,16 @@ def main():
     n_nodes = ((1 << hi) + 1) ** 2
     plain_bytes = 24.0 * n_nodes
     fused = live.bytes > 1.001 * plain_bytes
-    traffic, traffic_source = measured_traffic(f"strip2d_rbgs_{'fused' if fused else 'plain'}_L{hi}")
-    if fused:
+    cross = live.bytes > 1.12 * plain_bytes        # the cross-iteration launch: 24 B/node + two coarse fields (x 1/4 each)
+    traffic, traffic_source = measured_traffic(f"strip2d_cross_L{hi}" if cross else f"strip2d_rbgs_{'fused' if fused else 'plain'}_L{hi}")
+    if cross:
+        # since round 4 one launch per iteration does the cycle's last sweep (+ prolongation, + the loop's norm) AND the next
+        # cycle's first sweep (+ residual + restriction); the first iteration's head and the last one's tail run as the
+        # round-3 fused sweeps (they are in the mean below: 2 of 13 launches per solve)
+        kname = ("evomg_strip2d_cross<true, true, true, true> (csrc/evomg_strip_cross.h): prolongation + sweep + residual norm of "
+                 "iteration k and sweep + residual + restriction of iteration k + 1 in ONE pass; replaces two launches of "
+                 f"{(24.0 * n_nodes + 8.0 * ((1 << (hi - 1)) + 1) ** 2) / 1e6:.1f} MB each")
+    elif fused:
         # inside a solve both finest-level sweeps of the V(1,1) cycle run fused with their neighbours: the
         # pre-smoother with residual + restriction, the post-smoother with prolongation and the loop's residual norm
         kname = (kname.replace(">", ", ...>") + " fused sweeps: <.., false, false, true> = smoother + residual + restriction, "
@@ -529,10 +537,15 @@ def main():
                 "bytes_per_launch": live.bytes, "ms_per_launch": live.ms, "launches_timed": live.launches,
                 "back_to_back": {"kernel": handle.kernel_name(smooth), "bytes_per_launch": plain_bytes,
                                  "ms_per_launch": b2b.ms, "achieved": b2b.gbps, "frac": b2b.gbps / 8000.0},
+                "finest_level_bytes_per_iteration": {"now": live.bytes * live.launches / (args.steps * float(last[0][2])) if cross else None,
+                                                     "round3_two_fused_launches": 2 * (24.0 * n_nodes + 8.0 * ((1 << (hi - 1)) + 1) ** 2),
+                                                     "unit": "algorithmic B per solver-loop iteration"},
                 "note": f"'achieved' = algorithmic bytes / mean duration over the {live.launches} launches that execute the "
                         f"finest-level smoothing ops inside the timed solves (HIP events on the backend stream). "
                         f"Algorithmic bytes per launch: 24 B/node x {n_nodes} nodes for a plain fused red+black sweep; "
-                        f"the fused sweeps additionally write / read the coarse level (8 B per coarse node): "
+                        f"the fused sweeps additionally write / read the coarse level (8 B per coarse node); the cross-iteration "
+                        f"launch reads x, f and the coarse correction and writes w and the coarse right-hand side "
+                        f"(24 B/node + 2 x 8 B per coarse node) for the work of TWO sweeps; mean over the timed launches: "
                         f"{live.bytes / 1e6:.1f} MB. 'back_to_back' = median of 5 batches of 100 consecutive plain ping-pong sweeps. "
                         f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC passes (profiles/pmc_traffic.json names the "
                         f"profile), null when no profile matches the launched kernel and level"}

@@ -29,10 +29,15 @@
 // the sum of its column pair per 16-row chunk (4 MB at 4097^2, 1 % of the pass), and evomg_norm_from_lane_sums replays
 // TAIL_NORM's wave tree over the canonical 120-column strips on those sums.
 #pragma once
+#include <type_traits>
+
 #include "evomg_strip.h"
 
 #define EVOMG_CROSS_STRIP_COLS 116
 #define EVOMG_CROSS_UNROLL 6
+#ifndef EVOMG_CROSS_PF
+#define EVOMG_CROSS_PF 3        // rows of x / f in flight per wave beyond the window (a divisor of the unroll factor)
+#endif
 
 struct CrossArgs {
   const double* coarse_in;   // PRO: coarse correction
@@ -158,8 +163,8 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
     return load_pair<double>(a.coarse_in + (long)a.gc.pitch * r + Ic);
   };
   // fine row `row` of x + om_p P coarse (evomg_strip2d's `corrected`, real Dirichlet case)
-  auto corrected = [&](const Pair<double>& raw, int row, bool odd, const Pair<double>& cJp, const Pair<double>& cJ1p) -> Pair<double> {
-    const bool row_in = row >= 1 && row <= n - 2;
+  auto corrected = [&](const Pair<double>& raw, int row, bool odd, const Pair<double>& cJp, const Pair<double>& cJ1p, bool edge = true) -> Pair<double> {
+    const bool row_in = !edge || (row >= 1 && row <= n - 2);
     const double cJ = cJp.a, cJr = cJp.b;
     double va, vb;
     if (!odd) {
@@ -172,14 +177,16 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
     }
     const double ca = raw.a + a.om_p * va, cb = raw.b + a.om_p * vb;
     Pair<double> out;
-    out.a = (row_in && inner_a) ? ca : raw.a;
-    out.b = (row_in && inner_b) ? cb : raw.b;
+    out.a = (row_in && (!edge || inner_a)) ? ca : raw.a;
+    out.b = (row_in && (!edge || inner_b)) ? cb : raw.b;
     return out;
   };
   const int js = y0 - 5;                                     // odd: first row whose A-reds are relaxed
   const int je = y1 + 4;                                     // one past the last
   // rings: slot of row js + k is k mod (ring length); the loop below is unrolled U = 6 times, so every index is static
-  Pair<double> xw[3], zw[3], ww[3], fw[6], xq[2], fq[2], rs[2];
+  constexpr int PF = EVOMG_CROSS_PF;
+  static_assert(EVOMG_CROSS_UNROLL % PF == 0, "the prefetch ring has to divide the unroll factor");
+  Pair<double> xw[3], zw[3], ww[3], fw[6], xq[PF], fq[PF], rs[2];
   double ra[2] = {0.0, 0.0}, rb[2] = {0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 3; ++k) xw[k] = zw[k] = ww[k] = zpair;
@@ -194,10 +201,11 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
     xw[2] = corrected(xw[2], js - 1, false, load_coarse(rm >> 1), zpair);
     xw[0] = corrected(xw[0], js, true, load_coarse(rc0 >> 1), load_coarse((rc0 >> 1) + 1));
   }
-  xq[0] = load_row(x, js + 1);
-  xq[1] = load_row(x, js + 2);
-  fq[0] = load_row_f(f, js);
-  fq[1] = load_row_f(f, js + 1);
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    xq[k] = load_row(x, js + 1 + k);
+    fq[k] = load_row_f(f, js + k);
+  }
   Pair<double> c_lo = zpair, c_hi = zpair;
   if constexpr (PRO) {
     const int r0 = js + 1;                                   // may be negative: >> floors, load_coarse clamps
@@ -209,93 +217,105 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
   const int ncr = a.gc.n;
   const int Icr = c0 >> 1;
 
-  for (int base = js; base < je; base += U) {
-#pragma unroll
-    for (int d = 0; d < U; ++d) {
-      const int j = base + d;
-      {                                                      // steps at and beyond je (the last trip): clamped loads, every store guarded
-        const int parity = (1 + d) & 1;                      // js is odd
-        Pair<double> xp = xq[d & 1];
-        const Pair<double> fc = fq[d & 1];
-        xq[d & 1] = load_row(x, j + 3);
-        fq[d & 1] = load_row_f(f, j + 2);
-        if constexpr (PRO) {
-          const bool odd_next = ((parity + 1) & 1) != 0;     // row j + 1
-          xp = corrected(xp, j + 1, odd_next, c_lo, c_hi);
-          if (odd_next) {
-            c_lo = c_hi;
-            c_hi = load_coarse(((j + 1) >> 1) + 2);
+  // The row loop exists twice: EDGE — the wave touches the domain's boundary (first / last strip, first / last chunk), every
+  // relaxation is masked to the inner nodes; interior waves (nine in ten at 4097^2) run the same steps without any of the
+  // masks: no selects, no compares (the kernel is bound by VALU issue, not by memory: profiles/r04_cross_kernel.md).
+  auto march = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    const bool in_a = !EDGE || inner_a, in_b = !EDGE || inner_b;
+    for (int base = js; base < je; base += U) {
+  #pragma unroll
+      for (int d = 0; d < U; ++d) {
+        const int j = base + d;
+        {                                                      // steps at and beyond je (the last trip): clamped loads, every store guarded
+          const int parity = (1 + d) & 1;                      // js is odd
+          Pair<double> xp = xq[d % PF];
+          const Pair<double> fc = fq[d % PF];
+          xq[d % PF] = load_row(x, j + 1 + PF);
+          fq[d % PF] = load_row_f(f, j + PF);
+          if constexpr (PRO) {
+            const bool odd_next = ((parity + 1) & 1) != 0;     // row j + 1
+            xp = corrected(xp, j + 1, odd_next, c_lo, c_hi, EDGE);
+            if (odd_next) {
+              c_lo = c_hi;
+              c_hi = load_coarse(((j + 1) >> 1) + 2);
+            }
           }
-        }
-        xw[(d + 1) % 3] = xp;
-        fw[d % 6] = fc;
-        // ---- sweep A: reds of row j, blacks of row j-1 -> z row j-1 ----
-        {
-          const bool row_inner = j >= 1 && j <= n - 2, brow_inner = j - 1 >= 1 && j - 1 <= n - 2;
-          zw[(d + 2) % 3] = cross_rb_step<RECIP>(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
-                                          row_inner, brow_inner, inner_a, inner_b, a.om_a, a.omm_a, a.inv_c0, om_inv_a);
-        }
-        const Pair<double>& z3 = zw[d % 3];                  // z rows j-3, j-2, j-1
-        const Pair<double>& z2 = zw[(d + 1) % 3];
-        const Pair<double>& z1 = zw[(d + 2) % 3];
-        const Pair<double>& f2 = fw[(d + 4) % 6];            // f rows j-2, j-3, j-4
-        const Pair<double>& f3 = fw[(d + 3) % 6];
-        const Pair<double>& f4 = fw[(d + 2) % 6];
-        // ---- the loop's norm: residual of z row j-2 (TAIL_NORM of evomg_strip2d) ----
-        {
-          const int rr = j - 2;
-          const double wa = from_left(z2.b), eb = from_right(z2.a);
-          // branch-free: where TAIL_NORM adds nothing, +0.0 is added (nrm >= +0.0: the same value, bit for bit)
-          const bool counted = rr >= y0 && rr < y1 && rr >= 1 && rr <= n - 2 && store_lane;
-          const double qa = cross_residual5<RECIP>(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
-          const double qb = cross_residual5<RECIP>(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
-          nrm = nrm + ((counted && inner_a) ? qa * qa : 0.0);
-          nrm = nrm + ((counted && inner_b) ? qb * qb : 0.0);
-          if (rr >= y0 && rr < y1 && ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1)) {      // wave-uniform
-            if (store_lane) a.lane_sums[(long)(rr / EVOMG_NORM_ROWS) * a.sums_pitch + (c0 >> 1)] = nrm;
-            nrm = 0.0;
+          xw[(d + 1) % 3] = xp;
+          fw[d % 6] = fc;
+          // ---- sweep A: reds of row j, blacks of row j-1 -> z row j-1 ----
+          {
+            const bool row_inner = !EDGE || (j >= 1 && j <= n - 2), brow_inner = !EDGE || (j - 1 >= 1 && j - 1 <= n - 2);
+            zw[(d + 2) % 3] = cross_rb_step<RECIP>(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
+                                            row_inner, brow_inner, in_a, in_b, a.om_a, a.omm_a, a.inv_c0, om_inv_a);
           }
-        }
-        // ---- sweep B on z: reds of row j-2, blacks of row j-3 -> w row j-3 ----
-        {
-          const int jb = j - 2;
-          const bool row_inner = jb >= 1 && jb <= n - 2, brow_inner = jb - 1 >= 1 && jb - 1 <= n - 2;
-          const Pair<double> wrow = cross_rb_step<RECIP>(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, inner_a,
-                                                  inner_b, a.om_b, a.omm_b, a.inv_c0, om_inv_b);
-          ww[d % 3] = wrow;
-          const int jw = j - 3;
-          if (store_lane && jw >= y0 && jw < y1) store_pair<NT_XY>(y + pitch * jw + c0, wrow);
-        }
-        if constexpr (TAILR) {
-          // ---- residual of w row j-4 and, on odd rows, one coarse row (TAIL_RESTRICT of evomg_strip2d) ----
-          const Pair<double>& w5 = ww[(d + 1) % 3];          // w rows j-5, j-4, j-3
-          const Pair<double>& w4 = ww[(d + 2) % 3];
-          const Pair<double>& w3 = ww[d % 3];
-          const int rr = j - 4;
-          const bool rin = rr >= 1 && rr <= n - 2;
-          const double wa = from_left(w4.b), eb = from_right(w4.a);
-          Pair<double> rcur;
-          const double ta = cross_residual5<RECIP>(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a), tb = cross_residual5<RECIP>(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b);
-          rcur.a = (rin && inner_a) ? ta : 0.0;
-          rcur.b = (rin && inner_b) ? tb : 0.0;
-          const Pair<double>& res1 = rs[(d + 1) & 1];        // residual rows rr-1, rr-2
-          const Pair<double>& res2 = rs[d & 1];
-          if (parity == 1) {                                 // rr odd: rows rr-2, rr-1, rr = 2J-1, 2J, 2J+1
-            const int J = (rr - 1) >> 1;
-            const double w = from_left(res1.b), sw = from_left(res2.b), nw = from_left(rcur.b);
-            const double e4 = (w + res1.b) + (res2.a + rcur.a);
-            const double q4 = (sw + res2.b) + (nw + rcur.b);
-            double v = 0.25 * res1.a;                        // products with 1/4, 1/8, 1/16 are exact: fma = multiply, then add
-            v = __builtin_fma(0.125, e4, v);
-            v = __builtin_fma(0.0625, q4, v);
-            if (store_lane && Icr >= 1 && Icr <= ncr - 2 && J >= 1 && J <= ncr - 2 && 2 * J >= y0 && 2 * J < y1)
-              a.coarse_out[(long)a.gc.pitch * J + Icr] = v;
+          const Pair<double>& z3 = zw[d % 3];                  // z rows j-3, j-2, j-1
+          const Pair<double>& z2 = zw[(d + 1) % 3];
+          const Pair<double>& z1 = zw[(d + 2) % 3];
+          const Pair<double>& f2 = fw[(d + 4) % 6];            // f rows j-2, j-3, j-4
+          const Pair<double>& f3 = fw[(d + 3) % 6];
+          const Pair<double>& f4 = fw[(d + 2) % 6];
+          // ---- the loop's norm: residual of z row j-2 (TAIL_NORM of evomg_strip2d) ----
+          {
+            const int rr = j - 2;
+            const double wa = from_left(z2.b), eb = from_right(z2.a);
+            // branch-free: where TAIL_NORM adds nothing, +0.0 is added (nrm >= +0.0: the same value, bit for bit)
+            const bool counted = rr >= y0 && rr < y1 && (!EDGE || (rr >= 1 && rr <= n - 2)) && store_lane;
+            const double qa = cross_residual5<RECIP>(st, z2.a, wa, z2.b, z3.a, z1.a, f2.a);
+            const double qb = cross_residual5<RECIP>(st, z2.b, z2.a, eb, z3.b, z1.b, f2.b);
+            nrm = nrm + ((counted && in_a) ? qa * qa : 0.0);
+            nrm = nrm + ((counted && in_b) ? qb * qb : 0.0);
+            if (rr >= y0 && rr < y1 && ((rr & (EVOMG_NORM_ROWS - 1)) == EVOMG_NORM_ROWS - 1 || rr == n - 1)) {      // wave-uniform
+              if (store_lane) a.lane_sums[(long)(rr / EVOMG_NORM_ROWS) * a.sums_pitch + (c0 >> 1)] = nrm;
+              nrm = 0.0;
+            }
           }
-          rs[d & 1] = rcur;
+          // ---- sweep B on z: reds of row j-2, blacks of row j-3 -> w row j-3 ----
+          {
+            const int jb = j - 2;
+            const bool row_inner = !EDGE || (jb >= 1 && jb <= n - 2), brow_inner = !EDGE || (jb - 1 >= 1 && jb - 1 <= n - 2);
+            const Pair<double> wrow = cross_rb_step<RECIP>(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, in_a,
+                                                    in_b, a.om_b, a.omm_b, a.inv_c0, om_inv_b);
+            ww[d % 3] = wrow;
+            const int jw = j - 3;
+            if (store_lane && jw >= y0 && jw < y1) store_pair<NT_XY>(y + pitch * jw + c0, wrow);
+          }
+          if constexpr (TAILR) {
+            // ---- residual of w row j-4 and, on odd rows, one coarse row (TAIL_RESTRICT of evomg_strip2d) ----
+            const Pair<double>& w5 = ww[(d + 1) % 3];          // w rows j-5, j-4, j-3
+            const Pair<double>& w4 = ww[(d + 2) % 3];
+            const Pair<double>& w3 = ww[d % 3];
+            const int rr = j - 4;
+            const bool rin = !EDGE || (rr >= 1 && rr <= n - 2);
+            const double wa = from_left(w4.b), eb = from_right(w4.a);
+            Pair<double> rcur;
+            const double ta = cross_residual5<RECIP>(st, w4.a, wa, w4.b, w5.a, w3.a, f4.a), tb = cross_residual5<RECIP>(st, w4.b, w4.a, eb, w5.b, w3.b, f4.b);
+            rcur.a = (rin && in_a) ? ta : 0.0;
+            rcur.b = (rin && in_b) ? tb : 0.0;
+            const Pair<double>& res1 = rs[(d + 1) & 1];        // residual rows rr-1, rr-2
+            const Pair<double>& res2 = rs[d & 1];
+            if (parity == 1) {                                 // rr odd: rows rr-2, rr-1, rr = 2J-1, 2J, 2J+1
+              const int J = (rr - 1) >> 1;
+              const double w = from_left(res1.b), sw = from_left(res2.b), nw = from_left(rcur.b);
+              const double e4 = (w + res1.b) + (res2.a + rcur.a);
+              const double q4 = (sw + res2.b) + (nw + rcur.b);
+              double v = 0.25 * res1.a;                        // products with 1/4, 1/8, 1/16 are exact: fma = multiply, then add
+              v = __builtin_fma(0.125, e4, v);
+              v = __builtin_fma(0.0625, q4, v);
+              if (store_lane && (!EDGE || (Icr >= 1 && Icr <= ncr - 2 && J >= 1 && J <= ncr - 2)) && 2 * J >= y0 && 2 * J < y1)
+                a.coarse_out[(long)a.gc.pitch * J + Icr] = v;
+            }
+            rs[d & 1] = rcur;
+          }
         }
       }
     }
-  }
+  };
+  // every row any step touches is an inner row, every column of the strip an inner column
+  const int j_last = js + ((je - js + U - 1) / U) * U - 1;
+  const bool interior = js - 1 >= 1 && j_last + 1 <= n - 2 && strip * COLS - 2 * HALO >= 1 && strip * COLS - 2 * HALO + 127 <= n - 2;
+  if (interior) march(std::false_type{});
+  else march(std::true_type{});
 }
 
 // The canonical partial sums of the squared residual norm — one per (120-column strip, 16-row chunk), wave64 tree over the
