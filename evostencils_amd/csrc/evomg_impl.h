@@ -9,6 +9,7 @@
 #include "evomg_strip_cross.h"
 #include "evomg_small2d.h"
 #include "evomg_small3d.h"
+#include "evomg_lower2d.h"
 #include "evomg_tile3d.h"
 #include "evomg_batch.h"
 #include "evomg_strip_block.h"

@@ -355,10 +355,11 @@ template <> __device__ __forceinline__ cplx lane_value<cplx>(cplx v, int src) { 
 // XZERO (the COPY to the solver's right-hand side and the SET_ZERO of x in front of the solve folded in, as in
 // evomg_cg_wave2d): f is the copy's source, the copy itself is written to copy_dst, x is not read — its inner nodes and
 // Robin columns are zero by the SET_ZERO, its Dirichlet rows by the caller's bookkeeping — so r = f.
+// (the body is a device function: evomg_lower2d.h runs it on LDS images from the first wave of its workgroup)
 template <typename T, bool ROBIN, bool XZERO = false>
-__global__ void __launch_bounds__(64)
-evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r_out, int maxit, double tol,
-                      double kh, int* __restrict__ info, T* __restrict__ copy_dst = nullptr) {
+__device__ __forceinline__ void
+evomg_bicgstab_wave2d_body(const Geo& g, const Stencil<T>& st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r_out, int maxit,
+                           double tol, double kh, int* __restrict__ info, T* __restrict__ copy_dst = nullptr) {
   const int m = g.n - 2;                         // host-checked: 1 <= m <= 7
   const int l = threadIdx.x, col = l >> 3, row = l & 7;
   const bool own = col < m && row < m;
@@ -435,6 +436,12 @@ evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restri
     }
   }
   if (l == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
+}
+template <typename T, bool ROBIN, bool XZERO = false>
+__global__ void __launch_bounds__(64)
+evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r_out, int maxit, double tol,
+                      double kh, int* __restrict__ info, T* __restrict__ copy_dst = nullptr) {
+  evomg_bicgstab_wave2d_body<T, ROBIN, XZERO>(g, st, x, f, r_out, maxit, tol, kh, info, copy_dst);
 }
 
 // ---- CG held in registers (2D tile ownership) ------------------------------------------------------------------------
@@ -664,9 +671,9 @@ __device__ __forceinline__ void scale_add_in_place(double& v, double s, double a
 __device__ __forceinline__ void scale_add_in_place(cplx& v, cplx s, cplx a) { v = sc_fma(s, v, a); }
 
 template <typename T, bool XZERO, int MASK_FROM>
-__global__ void __launch_bounds__(64)
-evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, T* __restrict__ b_copy,
-                int maxit, double tol, int* __restrict__ info) {
+__device__ __forceinline__ void
+evomg_cg_wave2d_body(const Geo& g, const Stencil<T>& st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, T* __restrict__ b_copy,
+                     int maxit, double tol, int* __restrict__ info) {
   constexpr int R = EVOMG_CG_WAVE_ROWS;
   const int l = threadIdx.x, h = l >> 5, ix = l & 31;
   const int m = g.n - 2;
@@ -762,6 +769,12 @@ evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b
       r_out[c] = r[i];
     }
   if (l == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
+}
+template <typename T, bool XZERO, int MASK_FROM>
+__global__ void __launch_bounds__(64)
+evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, T* __restrict__ b_copy,
+                int maxit, double tol, int* __restrict__ info) {
+  evomg_cg_wave2d_body<T, XZERO, MASK_FROM>(g, st, x, b, r_out, b_copy, maxit, tol, info);
 }
 
 // ---- CG on 3D grids up to 9^3 in ONE wave ---------------------------------------------------------------------------

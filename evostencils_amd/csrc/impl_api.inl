@@ -74,7 +74,7 @@
       lv.g.pitch = ((n + align - 1) / align) * align;
       lv.g.plane = (dim_ == 3) ? (long)lv.g.pitch * n : 0;
       lv.elems = (size_t)lv.g.pitch * n * (dim_ == 3 ? n : 1);
-      for (int f = 0; f < EVOMG_F_COUNT; ++f) bnd_zero_[L][f] = true;
+      for (int f = 0; f < EVOMG_F_COUNT; ++f) { bnd_zero_[L][f] = true; dirty_[L][f] = true; clean_ptr_[L][f] = nullptr; }
       for (int f : {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES}) HIP_TRY(alloc_zero(&lv.f[f], lv.elems));
       if (L == prob_.max_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_F_CORR], lv.elems));
       if (L == prob_.min_level) HIP_TRY(alloc_zero(&lv.f[EVOMG_F_CGS_RHS], lv.elems));
@@ -93,6 +93,7 @@
     if (field < 0 || !lv.f[field]) return invalid("set_initial_field: no such field on this level");
     if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
     bnd_zero_[level][field] = false;
+    dirty_[level][field] = true;
     lv.alt_mirror = nullptr;
     HIP_TRY(upload(lv, lv.init[field], host));
     HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
@@ -106,6 +107,7 @@
     T* d = fieldptr(level, field);
     if (!d) return invalid("set_field: no such field on this level");
     bnd_zero_[level][canon(level, field)] = false;
+    dirty_[level][canon(level, field)] = true;
     lv_[level].alt_mirror = nullptr;
     HIP_TRY(upload(lv_[level], d, host));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -141,6 +143,7 @@
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
     if (cg_multi_used_) HIP_TRY(hipMemsetAsync(dinfo_, 0, sizeof(int) * 4, stream_));
+    mark_written(ops, n_ops, /*loop=*/false);
     rc = exec_program(ops, n_ops, /*cyclic=*/false);
     if (rc != EVOMG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -202,6 +205,7 @@
       int rc = reset_fields();
       if (rc != EVOMG_OK) return rc;
       HIP_TRY(hipMemsetAsync(dinfo_ + 2, 0, sizeof(int), stream_));      // coarse-solver iterations of this sample
+      mark_written(ops, n_ops, /*loop=*/true);
       if (prob_.outer_kind == EVOMG_OUTER_PBICGSTAB) rc = solve_pbicgstab(ops, n_ops, wall_limit_ms, &r, hist, cap);
       else rc = solve_mg(ops, n_ops, wall_limit_ms, &r, hist, cap);
       if (rc != EVOMG_OK) return rc;

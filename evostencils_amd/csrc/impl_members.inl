@@ -18,6 +18,10 @@
   bool x_zero_next_ = false;
   bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
   bool bnd_zero_[24][EVOMG_F_COUNT];   // boundary of the field's current array is known to be all zero
+  // lazy restore of the initial fields (reset_fields): written since the last restore / which array holds the pristine content
+  bool lazy_reset_ = getenv("EVOMG_NO_LAZY_RESET") == nullptr;
+  bool dirty_[24][EVOMG_F_COUNT];
+  const T* clean_ptr_[24][EVOMG_F_COUNT];
   static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
   // cross-iteration fusion on the finest 2D level (evomg_strip_cross.h): EVOMG_NO_XFUSE switches it off (same bits either way)
   bool xfuse_enabled_ = getenv("EVOMG_NO_XFUSE") == nullptr;
@@ -62,6 +66,10 @@
   bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
+  // the lower part of a cycle in one launch (evomg_lower2d.h): levels up to this many nodes per side live in LDS together
+  bool lower2d_enabled_ = getenv("EVOMG_NO_LOWER2D") == nullptr;
+  int lower2d_max_n_ = getenv("EVOMG_LOWER2D_MAX_N") ? atoi(getenv("EVOMG_LOWER2D_MAX_N")) : (scalar_traits<T>::is_complex ? 33 : 65);
+  bool lower2d_attr_set_ = false;
   bool small3d_enabled_ = getenv("EVOMG_NO_SMALL3D") == nullptr;
   bool small3d_attr_set_ = false;
   bool small2d_enabled_ = getenv("EVOMG_NO_SMALL2D") == nullptr;

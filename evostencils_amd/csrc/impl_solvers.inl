@@ -19,21 +19,49 @@
     return EVOMG_OK;
   }
 
+  // Restores every field to its initial content before a solve — except the fields nothing has written since the last
+  // restore (dirty_): the right-hand side of the finest level and gen_error@max are never written by an MG-iteration solve, and
+  // restoring them anyway was 400 MB of the ~10 GB a C2 solve moves (with candidates in flight the GPU is bandwidth bound).
   int reset_fields() {
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
       Level<T>& lv = lv_[L];
       lv.alt_mirror = nullptr;
       for (int f = 0; f < EVOMG_F_COUNT; ++f) {
         if (!lv.f[f]) continue;
+        if (lazy_reset_ && !dirty_[L][f] && clean_ptr_[L][f] == lv.f[f]) continue;
         if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
         else {
           HIP_TRY(hipMemsetAsync(lv.f[f], 0, lv.elems * sizeof(T), stream_));
           bnd_zero_[L][f] = true;
         }
+        dirty_[L][f] = false;
+        clean_ptr_[L][f] = lv.f[f];
       }
     }
     HIP_TRY(hipStreamSynchronize(stream_));
     return EVOMG_OK;
+  }
+
+  // every field an op program may write (conservative: the destination of every op, the coarse solver's fields); `loop`: the
+  // fields the solver loop itself writes on the finest level
+  void mark_written(const evomg_op_t* ops, int n_ops, bool loop) {
+    for (int i = 0; i < n_ops; ++i) {
+      const evomg_op_t& op = ops[i];
+      if (op.level < prob_.min_level || op.level > prob_.max_level) continue;
+      const int d = canon(op.level, op.dst);
+      if (d >= 0) dirty_[op.level][d] = true;
+      if (op.opcode == EVOMG_OP_COARSE_SOLVE) {
+        dirty_[op.level][canon(op.level, EVOMG_F_CORR)] = true;
+        dirty_[op.level][EVOMG_F_RES] = true;
+        dirty_[op.level][EVOMG_F_CGS_RHS] = true;
+      }
+    }
+    if (loop) {
+      const int L = prob_.max_level;
+      dirty_[L][EVOMG_F_RES] = true;
+      if (prob_.outer_kind == EVOMG_OUTER_PBICGSTAB)
+        for (int f : {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES, EVOMG_F_CORR}) dirty_[L][f] = true;
+    }
   }
 
   int solve_mg(const evomg_op_t* ops, int n_ops, double wall_limit_ms, evomg_result_t* out, double* hist, int cap) {

@@ -69,6 +69,8 @@ NON_CYCLIC = {
     "strip_block_2d": (2, 4, 7, "EVOMG_NO_STRIP_BLOCK", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "block_fast_2d": (2, 4, 7, "EVOMG_NO_BLOCK_FAST", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "boundary_mirror_2d": (2, 4, 7, "EVOMG_NO_BOUNDARY_MIRROR", lambda s, lo, hi: [s(hi), s(hi), s(hi), prolong(hi), s(hi)]),
+    "lower_cycle_2d": (2, 3, 7, "EVOMG_NO_LOWER2D", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), restrict(hi - 2), zero(hi - 2), s(hi - 2),
+                                                                        residual(hi - 2), restrict(hi - 3), prolong(hi - 2), s(hi - 2), prolong(hi - 1), s(hi - 1)]),
     "double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1), s(hi - 1), s(hi - 1)]),
     "prolong_double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_PRO", lambda s, lo, hi: [prolong(hi), s(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
     "small_level_chain_3d": (3, 2, 4, "EVOMG_NO_SMALL3D", lambda s, lo, hi: [zero(hi), s(hi), s(hi), residual(hi), restrict(hi - 1), prolong(hi), s(hi)]),
@@ -97,6 +99,8 @@ CYCLIC = {
     "speculation_2d": (2, 4, 7, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
     "cross_iteration_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_plain_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
+    "lower_cycle_2d": (2, 3, 7, "EVOMG_NO_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    "lower_cycle_deep_2d": (2, 2, 8, "EVOMG_NO_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
     "residual_restrict_3d": (3, 2, 5, "EVOMG_NO_TILE3D_RR", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "double_sweep_cycle_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
     "residual_norm_3d": (3, 2, 5, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),

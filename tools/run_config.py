@@ -62,4 +62,7 @@ else:
 h = native.create(pd)
 out = h.evaluate(ops, 1, 0, 0)
 out = h.evaluate(ops, 1, 0, 0)
+best = min(h.evaluate(ops, 1, 0, 0).time_ms for _ in range(int(os.environ.get("RUN_CONFIG_REPEATS", "0")))) if os.environ.get("RUN_CONFIG_REPEATS") else None
+if best is not None:
+    print(cfg, "best of repeats %.3f ms" % best)
 print(cfg, "iterations", out.n_iterations, "rho %.4f" % out.conv_factor, "time %.2f ms" % out.time_ms, "status", out.status)
