@@ -1,4 +1,5 @@
-// evomg_lower2d.h — the LOWER PART of a cycle in one launch.
+// evomg_lower2d.h — the LOWER PART of a cycle in one launch. OFF by default (EVOMG_LOWER2D=1):
+// measured not faster than the pipelined launches it replaces — profiles/r04_lower_cycle.md.
 //
 // At the reference's own level ranges (Helmholtz: levels 3..7, Poisson: 5..9; example_problems/*/*.knowledge:3-4) the levels
 // below 65^2 hold a few thousand nodes: every op there is a launch of 3-6 us that does a fraction of a microsecond of work,

@@ -285,16 +285,16 @@
   // residual, restriction, prolongation, zero, copy and the one-wave coarse solver. Returns the number of ops consumed
   // (0: not worth it / not this shape — the per-op launches take over), -1 on a launch error.
   int lower2d_run(const evomg_op_t* ops, int n_ops, int i, int end) {
-    if (!lower2d_enabled_ || !fuse_enabled_ || dim_ != 2 || batch_enabled_) return 0;
+    if (!lower2d_enabled_ || !fuse_enabled_ || dim_ != 2 || batch_enabled_) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 1 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
     constexpr bool CPLX = scalar_traits<T>::is_complex;
     const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
-    if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(robin && CPLX)) return 0;
+    if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(robin && CPLX)) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 2 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
     const int lo = prob_.min_level;
     int top = -1;
     for (int L = lo; L < prob_.max_level; ++L)
       if (lv_[L].g.n <= lower2d_max_n_) top = L;
-    if (top <= lo || top - lo + 1 > EVOMG_LOWER_MAX_LEVELS) return 0;
-    if (ops[i].level < lo || ops[i].level > top) return 0;
+    if (top <= lo || top - lo + 1 > EVOMG_LOWER_MAX_LEVELS) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 3 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
+    if (ops[i].level < lo || ops[i].level > top) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 4 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
     const int n_lo = lv_[lo].g.n;
     const bool bicg = prob_.cgs_kind == EVOMG_CGS_BICGSTAB;
     const bool coarse_ok = use_reg_krylov_ && (bicg ? n_lo <= 9 : (!CPLX && prob_.cgs_kind == EVOMG_CGS_CG && krylov_own<2>(n_lo, true).wave != 0));
@@ -367,7 +367,7 @@
       P.op[P.n_ops++] = m;
     }
     const int len = p - i;
-    if (len < 4) return 0;                                    // a launch's worth of set-up and write-back has to pay
+    if (len < 4) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 5 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }                                    // a launch's worth of set-up and write-back has to pay
     // LDS layout: per level SOL, RHS, RES (+ the coarse solver's right-hand side on the coarsest, + a spare image where a
     // Jacobi sweep needs one)
     size_t elems = 0;
@@ -391,7 +391,7 @@
       if (need_alt[k]) { P.offset[k][LOWER_SLOT_ALT] = (int)elems; elems += nn; }
     }
     const size_t lds_bytes = elems * sizeof(T);
-    if (lds_bytes + 1024 > max_lds_) return 0;
+    if (lds_bytes + 1024 > max_lds_) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 6 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
     for (int q = 0; q < P.n_ops; ++q) {
       const LowerOp& m = P.op[q];
       if (m.kind == LOWER_COARSE) { P.store[0][LOWER_SLOT_SOL] = 1; P.store[0][LOWER_SLOT_RES] = 1; }
@@ -400,10 +400,10 @@
       const int refs[3] = {m.kind == LOWER_COARSE ? -1 : m.dst, (m.kind == LOWER_RESIDUAL || m.kind == LOWER_COPY) ? m.src0 : -1,
                            (m.kind == LOWER_SMOOTH || m.kind == LOWER_RESIDUAL) ? m.src1 : -1};
       for (int r : refs)
-        if (r >= 0 && P.offset[(int)m.level][r] < 0) return 0;
-      if (m.kind == LOWER_RESTRICT && P.offset[m.level + 1][(int)m.src0] < 0) return 0;
-      if ((m.kind == LOWER_PROLONG_ADD || m.kind == LOWER_PROLONG_SET) && P.offset[m.level - 1][(int)m.src0] < 0) return 0;
-      if (m.kind == LOWER_COARSE && (P.offset[0][LOWER_SLOT_CGS] < 0 || P.offset[0][LOWER_SLOT_RES] < 0)) return 0;
+        if (r >= 0 && P.offset[(int)m.level][r] < 0) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 7 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
+      if (m.kind == LOWER_RESTRICT && P.offset[m.level + 1][(int)m.src0] < 0) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 8 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
+      if ((m.kind == LOWER_PROLONG_ADD || m.kind == LOWER_PROLONG_SET) && P.offset[m.level - 1][(int)m.src0] < 0) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 9 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
+      if (m.kind == LOWER_COARSE && (P.offset[0][LOWER_SLOT_CGS] < 0 || P.offset[0][LOWER_SLOT_RES] < 0)) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 10 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
     }
     P.robin = robin ? 1 : 0;
     P.cgs_kind = prob_.cgs_kind;
@@ -411,11 +411,12 @@
     P.cgs_tol = prob_.cgs_target_res_reduction;
     P.cg_mask_full = (n_lo - 2) - EVOMG_CG_WAVE_ROWS >= EVOMG_CG_WAVE_ROWS - 1 ? 1 : 0;      // launch_cg_wave2d's choice of MASK_FROM
     P.info = dinfo_;
+    // (the kernel also holds 144 bytes of static LDS: the dynamic limit has to leave room for them)
     if (lds_bytes > 48 * 1024 && !lower2d_attr_set_) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_lower2d<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_) != hipSuccess) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_lower2d<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_ - 1024) != hipSuccess) {
         (void)hipGetLastError();
         lower2d_enabled_ = false;
-        return 0;
+        { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 11 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
       }
       lower2d_attr_set_ = true;
     }

@@ -69,7 +69,7 @@ NON_CYCLIC = {
     "strip_block_2d": (2, 4, 7, "EVOMG_NO_STRIP_BLOCK", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "block_fast_2d": (2, 4, 7, "EVOMG_NO_BLOCK_FAST", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "boundary_mirror_2d": (2, 4, 7, "EVOMG_NO_BOUNDARY_MIRROR", lambda s, lo, hi: [s(hi), s(hi), s(hi), prolong(hi), s(hi)]),
-    "lower_cycle_2d": (2, 3, 7, "EVOMG_NO_LOWER2D", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), restrict(hi - 2), zero(hi - 2), s(hi - 2),
+    "lower_cycle_2d": (2, 3, 7, "+EVOMG_LOWER2D", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), restrict(hi - 2), zero(hi - 2), s(hi - 2),
                                                                         residual(hi - 2), restrict(hi - 3), prolong(hi - 2), s(hi - 2), prolong(hi - 1), s(hi - 1)]),
     "double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1), s(hi - 1), s(hi - 1)]),
     "prolong_double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_PRO", lambda s, lo, hi: [prolong(hi), s(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
@@ -99,8 +99,8 @@ CYCLIC = {
     "speculation_2d": (2, 4, 7, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
     "cross_iteration_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_plain_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
-    "lower_cycle_2d": (2, 3, 7, "EVOMG_NO_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
-    "lower_cycle_deep_2d": (2, 2, 8, "EVOMG_NO_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
+    "lower_cycle_2d": (2, 3, 7, "+EVOMG_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    "lower_cycle_deep_2d": (2, 2, 8, "+EVOMG_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
     "residual_restrict_3d": (3, 2, 5, "EVOMG_NO_TILE3D_RR", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "double_sweep_cycle_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
     "residual_norm_3d": (3, 2, 5, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
@@ -115,13 +115,17 @@ def problem(dim, lo, hi, semantics, **kw):
     return dataclasses.replace(pd, jacobi_semantics=abi.JACOBI_SEMANTICS[semantics], **kw)
 
 
-def environment(monkeypatch, switch_off=None):
+def environment(monkeypatch, knob, fused):
+    """`knob`: EVOMG_NO_X switches a default-on peephole off; +EVOMG_X switches a default-off one on."""
     for k in KNOBS:
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delenv(k.lstrip("+"), raising=False)
     for k, v in FORCED.items():
         monkeypatch.setenv(k, v)
-    if switch_off:
-        monkeypatch.setenv(switch_off, "1")
+    if knob.startswith("+"):
+        if fused:
+            monkeypatch.setenv(knob[1:], "1")
+    elif not fused:
+        monkeypatch.setenv(knob, "1")
 
 
 @pytest.mark.parametrize("semantics", SEMANTICS)
@@ -136,7 +140,7 @@ def test_peephole_on_random_fields(native, oracle, monkeypatch, name, kind, sema
     state = {}
     results = []
     for which in ("fused", "switched_off", "oracle"):
-        environment(monkeypatch, knob if which == "switched_off" else None)
+        environment(monkeypatch, knob, which != "switched_off")
         h = (oracle if which == "oracle" else native).create(pd)
         for L in range(lo, hi + 1):
             for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
@@ -169,7 +173,7 @@ def test_peephole_in_the_solver_loop(native, oracle, monkeypatch, name, kind, se
     pd = problem(dim, lo, hi, semantics, max_iterations=5)
     outs = []
     for which in ("fused", "switched_off", "oracle"):
-        environment(monkeypatch, knob if which == "switched_off" else None)
+        environment(monkeypatch, knob, which != "switched_off")
         h = (oracle if which == "oracle" else native).create(pd)
         out = h.evaluate(ops, 2 if which != "oracle" else 1, 0, 16)
         outs.append((out, h.get_field(hi, abi.F_SOL), h.get_field(hi, abi.F_RES)))
