@@ -12,7 +12,7 @@
 // interpolate, the full-weighting expression of evomg_restrict) to the LDS images, one after the other with the boundary
 // handling the interpreter puts behind each op (Helmholtz: the Robin columns after every op that writes a field, and between
 // the colours of a red-black sweep) — the same formulas on the same values in the same order, so every field of every level
-// carries the bits the per-op launches produce (tests: EVOMG_NO_LOWER2D, and the oracle). `with jacobi` sweeps whose slot
+// carries the bits the per-op launches produce (tests: with and without EVOMG_LOWER2D=1, and the oracle). `with jacobi` sweeps whose slot
 // is never advanced (EVOMG_JACOBI_EXASTENCILS_V11) are computed into the level's spare image and dropped, as in the launches.
 // All fields of the run's levels are loaded at the start and the ones the run writes are stored at the end.
 #pragma once
