@@ -198,18 +198,24 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
         workers.map(lambda g2, i: g2.generate_and_evaluate(pop[i], None, lo, hi, "", evaluation_samples=1),
                     [(rank + j) % args.population for j in range(in_flight)])          # warm-up of every worker
     modes = {}
-    for mode in (("static", "dynamic") if world > 1 else ("static",)) + (("static_in_flight",) if in_flight else ()):
+    rows = None
+    for mode in (("static", "dynamic") if world > 1 else ("static",)) + (("static_in_flight", "static_in_flight_isolated_time") if in_flight else ()):
         busy[0] = 0.0
         fence()
         t0 = time.perf_counter()
         if mode == "static":
             rows = population.evaluate_population(evaluate, args.population, local_rank)
             mine = len(population.shard_indices(args.population, rank, world))
-        elif mode == "static_in_flight":
+        elif mode in ("static_in_flight", "static_in_flight_isolated_time"):
             tb = time.perf_counter()
+            # ..._isolated_time: the same pass followed by the time model's probes, so that the table's
+            # times are each candidate's time ALONE on the GPU — what the reference's sequential evaluation measures
+            time_fn = None
+            if mode == "static_in_flight_isolated_time":
+                time_fn = lambda g2, i, its, k: g2.isolated_time_ms(g2.generate_op_program(pop[i], lo, hi), lo, hi, its, coarse_iterations=k)
             rows_f = population.evaluate_population_in_flight(
                 workers, lambda g2, i: g2.generate_and_evaluate(pop[i], None, lo, hi, "", evaluation_samples=1),
-                args.population, local_rank)
+                args.population, local_rank, time_fn=time_fn)
             busy[0] = time.perf_counter() - tb
             mine = len(population.shard_indices(args.population, rank, world))
             # rho and iteration counts do not depend on what else runs on the GPU (reported, not asserted: a benchmark
@@ -226,9 +232,20 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
                        "busy_s_per_rank": [round(b, 4) for b in busy_all],
                        "idle_s_per_rank": [round(wall - b, 4) for b in busy_all],
                        "candidates_per_rank": [int(c) for c in count_all]}
-        if mode == "static_in_flight":
+        if mode in ("static_in_flight", "static_in_flight_isolated_time"):
             modes[mode]["candidates_in_flight_per_gpu"] = in_flight
             modes[mode]["rho_and_iterations_identical_to_sequential"] = bool(identical)
+            # the time objective of this mode against the sequential pass's (finite candidates of THIS rank's share are all
+            # candidates at N = 1; at N > 1 every rank holds the whole table)
+            pairs = [(a[2], b[2]) for a, b in zip(rows, rows_f) if a[2] < 1e99 and b[2] < 1e99 and a[2] > 0]
+            if pairs:
+                import numpy as np
+                ts, tm = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+                rank = lambda v: np.argsort(np.argsort(v)).astype(float)
+                ra, rb = rank(ts) - rank(ts).mean(), rank(tm) - rank(tm).mean()
+                modes[mode]["time_objective_vs_sequential"] = {
+                    "median_ratio": float(np.median(tm / ts)), "max_rel_deviation": float(np.max(np.abs(tm - ts) / ts)),
+                    "spearman": float((ra * rb).sum() / np.sqrt((ra * ra).sum() * (rb * rb).sum())), "candidates": len(pairs)}
         if mode == "static":
             finite = [r for r in rows if r[3] < 1e99]
             costs = sorted(r[2] for r in rows)
@@ -246,7 +263,10 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
                     "store, one all-reduce of the fitness table per generation; idle = wall - time spent inside "
                     "generate_and_evaluate on that rank. At N = 1 both modes coincide. static_in_flight = the static split with "
                     "several candidates in flight per GPU (population.ConcurrentEvaluator: own stream and fields each; rho and "
-                    "iteration counts identical — checked, see the flag — while a candidate's measured time includes its neighbours)."}
+                    "iteration counts identical — checked, see the flag — while a candidate's measured time includes its neighbours). "
+                    "static_in_flight_isolated_time = the same, then three short probes per candidate on the idle GPU (evomg_time_model) and "
+                    "the evaluation's own iteration counts give each candidate's time ALONE: time_objective_vs_sequential compares it with "
+                    "the sequential pass (static)."}
 
 
 def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):

@@ -696,6 +696,43 @@ __device__ __forceinline__ T residual7(const Stencil<T>& st, T c, T w, T e, T s,
   return sc_sub(f, a);
 }
 
+// POW2 forms (round 4): where every OFF-CENTRE coefficient is a (signed) power of two — -1/h^2 on a dyadic mesh: the 3D Poisson
+// stencil on every level (its centre 6/h^2 is not) — the product c * v is exact, so `r - c * v` and fma(-c, v, r) round the same
+// real number once: the same bits, one instruction instead of two (the 3D double sweep is VALU co-bound). Host-checked
+// (offcentre_pow2); the centre term and the quotient keep their own roundings. Out-of-range intermediates (beyond 1e300) are the
+// only place the two forms could part.
+template <bool POW2, typename T> __device__ __forceinline__ T msub(T r, T c, T v) {
+  if constexpr (POW2 && !scalar_traits<T>::is_complex) return __builtin_fma(-c, v, r);
+  else return sc_sub(r, sc_mul(c, v));
+}
+template <bool POW2, typename T> __device__ __forceinline__ T madd(T a, T c, T v) {
+  if constexpr (POW2 && !scalar_traits<T>::is_complex) return __builtin_fma(c, v, a);
+  else return sc_add(a, sc_mul(c, v));
+}
+template <bool POW2, typename T>
+__device__ __forceinline__ T relax7p(const Stencil<T>& st, const ConstDiv<T>& cd, T c, T w, T e, T s, T n, T d, T u, T f, double om, double omm) {
+  T r = f;
+  r = msub<POW2>(r, st.c[1], w);
+  r = msub<POW2>(r, st.c[2], e);
+  r = msub<POW2>(r, st.c[3], s);
+  r = msub<POW2>(r, st.c[4], n);
+  r = msub<POW2>(r, st.c[5], d);
+  r = msub<POW2>(r, st.c[6], u);
+  const T xs = const_div(r, cd);
+  return sc_add(sc_rmul(omm, c), sc_rmul(om, xs));
+}
+template <bool POW2, typename T>
+__device__ __forceinline__ T residual7p(const Stencil<T>& st, T c, T w, T e, T s, T n, T d, T u, T f) {
+  T a = sc_mul(st.c[0], c);
+  a = madd<POW2>(a, st.c[1], w);
+  a = madd<POW2>(a, st.c[2], e);
+  a = madd<POW2>(a, st.c[3], s);
+  a = madd<POW2>(a, st.c[4], n);
+  a = madd<POW2>(a, st.c[5], d);
+  a = madd<POW2>(a, st.c[6], u);
+  return sc_sub(f, a);
+}
+
 // grid: n_blocks (rounded up to a multiple of 8) blocks of 256 threads; block -> (group of 4 y tiles fastest, strip,
 // z chunk), wave w of the block = y tile 4*group + w. (Lock-stepping the four waves with a barrier per plane so that
 // shared halo rows meet in L1/L2 was measured and does not help: profiles/r01_pmc_3d.md.)

@@ -45,7 +45,7 @@ template <typename T> struct TwoCellPlan {
 #ifndef EVOMG_TILE3D_WPE
 #define EVOMG_TILE3D_WPE 0
 #endif
-template <typename T, int MODE, int NW, int NT>
+template <typename T, int MODE, int NW, int NT, bool POW2 = false>
 __global__ void __launch_bounds__(64 * NW)
 #if EVOMG_TILE3D_WPE > 0
 __attribute__((amdgpu_waves_per_eu(EVOMG_TILE3D_WPE, EVOMG_TILE3D_WPE)))
@@ -153,11 +153,11 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             const T wA = from_left(cA.b), eA = from_right(cA.a), wB = from_left(cB.b), eB = from_right(cB.a);
             auto cell = [&](T f0, T w_, T e_, T yo, T d_, T u_, bool second) -> T {
               T r = f0;
-              r = sc_sub(r, sc_mul(st.c[1], w_));
-              r = sc_sub(r, sc_mul(st.c[2], e_));
-              r = sc_sub(r, sc_mul(st.c[second ? 4 : 3], yo));
-              r = sc_sub(r, sc_mul(st.c[5], d_));
-              r = sc_sub(r, sc_mul(st.c[6], u_));
+              r = msub<POW2>(r, st.c[1], w_);
+              r = msub<POW2>(r, st.c[2], e_);
+              r = msub<POW2>(r, st.c[second ? 4 : 3], yo);
+              r = msub<POW2>(r, st.c[5], d_);
+              r = msub<POW2>(r, st.c[6], u_);
               return r;
             };
             auto solve = [&](T r0, T r1, T x0, T x1, T& o0, T& o1) {
@@ -181,8 +181,8 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
                 store_y(y + plane * k + pitch * (rA + 1) + c0, oB);
               }
             } else if (rA == n - 2) {                            // the last inner row: a one-cell tile
-              if (inner_a) oA.a = relax7(st, cd0, cA.a, wA, cA.b, sA.a, cB.a, below[tp].a, above[tp].a, fk[tp].a, om, omm);
-              if (inner_b) oA.b = relax7(st, cd0, cA.b, cA.a, eA, sA.b, cB.b, below[tp].b, above[tp].b, fk[tp].b, om, omm);
+              if (inner_a) oA.a = relax7p<POW2>(st, cd0, cA.a, wA, cA.b, sA.a, cB.a, below[tp].a, above[tp].a, fk[tp].a, om, omm);
+              if (inner_b) oA.b = relax7p<POW2>(st, cd0, cA.b, cA.a, eA, sA.b, cB.b, below[tp].b, above[tp].b, fk[tp].b, om, omm);
               if (store_lane) store_y(y + plane * k + pitch * rA + c0, oA);
             }
           }
@@ -196,17 +196,17 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
           if constexpr (MODE == TILE_BLOCK211) {
             // b as first cell of its tile (west neighbour a is outside), a as second cell (east neighbour b is outside)
             T rb0 = fk[t].b;
-            rb0 = sc_sub(rb0, sc_mul(st.c[1], c.a));
-            rb0 = sc_sub(rb0, sc_mul(st.c[3], s.b));
-            rb0 = sc_sub(rb0, sc_mul(st.c[4], nn.b));
-            rb0 = sc_sub(rb0, sc_mul(st.c[5], dn.b));
-            rb0 = sc_sub(rb0, sc_mul(st.c[6], up.b));
+            rb0 = msub<POW2>(rb0, st.c[1], c.a);
+            rb0 = msub<POW2>(rb0, st.c[3], s.b);
+            rb0 = msub<POW2>(rb0, st.c[4], nn.b);
+            rb0 = msub<POW2>(rb0, st.c[5], dn.b);
+            rb0 = msub<POW2>(rb0, st.c[6], up.b);
             T ra1 = fk[t].a;
-            ra1 = sc_sub(ra1, sc_mul(st.c[2], c.b));
-            ra1 = sc_sub(ra1, sc_mul(st.c[3], s.a));
-            ra1 = sc_sub(ra1, sc_mul(st.c[4], nn.a));
-            ra1 = sc_sub(ra1, sc_mul(st.c[5], dn.a));
-            ra1 = sc_sub(ra1, sc_mul(st.c[6], up.a));
+            ra1 = msub<POW2>(ra1, st.c[2], c.b);
+            ra1 = msub<POW2>(ra1, st.c[3], s.a);
+            ra1 = msub<POW2>(ra1, st.c[4], nn.a);
+            ra1 = msub<POW2>(ra1, st.c[5], dn.a);
+            ra1 = msub<POW2>(ra1, st.c[6], up.a);
             const T r0_left = from_left(rb0);                                      // whole wave
             // tile (left b, a): a is the second unknown
             const T xa = const_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), cdp1);
@@ -219,13 +219,13 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
               if (inner_a) out.a = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa));
               if (inner_b) out.b = sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
               // the last inner column has no partner: a one-cell tile (only the last strip has such a lane)
-              if (last_strip && c0 + 1 == n - 2) out.b = relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm);
+              if (last_strip && c0 + 1 == n - 2) out.b = relax7p<POW2>(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm);
               store_y(y + plane * k + pitch * row + c0, out);
             }
           } else if constexpr (MODE == TILE_RESNORM || MODE == TILE_RESNORM_W) {
             const bool valid = row <= n - 2 && store_lane;     // (row: wave-uniform)
-            const T ra = residual7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
-            const T rb = residual7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
+            const T ra = residual7p<POW2>(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
+            const T rb = residual7p<POW2>(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
             T sq = scalar_traits<T>::zero();
             if (valid && inner_a) sq = sc_add(sq, sc_mul(ra, ra));
             if (valid && inner_b) sq = sc_add(sq, sc_mul(rb, rb));
@@ -246,12 +246,12 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             T* dst = y + plane * k + pitch * row + c0;
             Pair<T> out;
             if constexpr (MODE == STRIP_JACOBI) {
-              out.a = inner_a ? relax7(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
-              out.b = inner_b ? relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
+              out.a = inner_a ? relax7p<POW2>(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a, om, omm) : c.a;
+              out.b = inner_b ? relax7p<POW2>(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b, om, omm) : c.b;
               store_y(dst, out);
             } else {
-              out.a = residual7(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
-              out.b = residual7(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
+              out.a = residual7p<POW2>(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk[t].a);
+              out.b = residual7p<POW2>(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk[t].b);
               if (inner_a && inner_b) store_y(dst, out);
               else if (inner_a) dst[0] = out.a;
               else dst[1] = out.b;
@@ -281,7 +281,7 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
 // Colour 0 = even index sum. c0, R0 (a multiple of H-2) and the first plane of a chunk are even, so which element of a
 // pair is red is static inside the twice-unrolled z loop. Inner nodes only are written (see evomg_tile3d).
 // Operation order = relax7 = relax_point: bit-identical to the two-pass form (evomg_rbgs_colour x 2) and to the oracle.
-template <typename T, int NW, int NT>
+template <typename T, int NW, int NT, bool POW2 = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
                   double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
@@ -378,10 +378,10 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
           // row0 even => row has the parity of t; k has the parity of d: a is red iff t + d is even
           if (((t + d) & 1) == 0) {
             const T we = from_left(c.b);
-            rc[t] = (row_inner && inner_a) ? relax7(st, cd0, c.a, we, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
+            rc[t] = (row_inner && inner_a) ? relax7p<POW2>(st, cd0, c.a, we, c.b, s.a, nn.a, dn.a, up.a, fc[t].a, om, omm) : c.a;
           } else {
             const T ea = from_right(c.a);
-            rc[t] = (row_inner && inner_b) ? relax7(st, cd0, c.b, c.a, ea, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
+            rc[t] = (row_inner && inner_b) ? relax7p<POW2>(st, cd0, c.b, c.a, ea, s.b, nn.b, dn.b, up.b, fc[t].b, om, omm) : c.b;
           }
         }
         edge_r[k & 1][w][0][lane] = rc[0];
@@ -408,10 +408,10 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
           if (a_red) {                                         // a red, b black
             const T e = from_right(red);
             out.a = red;
-            out.b = (row_inner && inner_b) ? relax7(st, cd0, old.b, red, e, rs, rn, r2[t], rc[t], fb[t].b, om, omm) : old.b;
+            out.b = (row_inner && inner_b) ? relax7p<POW2>(st, cd0, old.b, red, e, rs, rn, r2[t], rc[t], fb[t].b, om, omm) : old.b;
           } else {                                             // b red, a black
             const T we = from_left(red);
-            out.a = (row_inner && inner_a) ? relax7(st, cd0, old.a, we, red, rs, rn, r2[t], rc[t], fb[t].a, om, omm) : old.a;
+            out.a = (row_inner && inner_a) ? relax7p<POW2>(st, cd0, old.a, we, red, rs, rn, r2[t], rc[t], fb[t].a, om, omm) : old.a;
             out.b = red;
           }
           const bool row_stored = row >= 1 && row <= n - 2 && row >= R0 + 1 && (row <= R0 + H - 2 || top_group);
@@ -465,7 +465,7 @@ template <typename T> struct TwiceProlong {
   Geo gc;
   double om;
 };
-template <typename T, int MODE, int NW, int NT, bool PRO = false>
+template <typename T, int MODE, int NW, int NT, bool PRO = false, bool POW2 = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
                    double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl,
@@ -563,23 +563,23 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
     Pair<T> out = c;
     const T wa = from_left(c.b), eb = from_right(c.a);
     if constexpr (MODE == STRIP_JACOBI) {
-      const T ra = relax7(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a, om, omm);
-      const T rb = relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
+      const T ra = relax7p<POW2>(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a, om, omm);
+      const T rb = relax7p<POW2>(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
       if (node_rows_inner && inner_a) out.a = ra;
       if (node_rows_inner && inner_b) out.b = rb;
     } else {
       T rb0 = fk.b;
-      rb0 = sc_sub(rb0, sc_mul(st.c[1], c.a));
-      rb0 = sc_sub(rb0, sc_mul(st.c[3], s.b));
-      rb0 = sc_sub(rb0, sc_mul(st.c[4], nn.b));
-      rb0 = sc_sub(rb0, sc_mul(st.c[5], dn.b));
-      rb0 = sc_sub(rb0, sc_mul(st.c[6], up.b));
+      rb0 = msub<POW2>(rb0, st.c[1], c.a);
+      rb0 = msub<POW2>(rb0, st.c[3], s.b);
+      rb0 = msub<POW2>(rb0, st.c[4], nn.b);
+      rb0 = msub<POW2>(rb0, st.c[5], dn.b);
+      rb0 = msub<POW2>(rb0, st.c[6], up.b);
       T ra1 = fk.a;
-      ra1 = sc_sub(ra1, sc_mul(st.c[2], c.b));
-      ra1 = sc_sub(ra1, sc_mul(st.c[3], s.a));
-      ra1 = sc_sub(ra1, sc_mul(st.c[4], nn.a));
-      ra1 = sc_sub(ra1, sc_mul(st.c[5], dn.a));
-      ra1 = sc_sub(ra1, sc_mul(st.c[6], up.a));
+      ra1 = msub<POW2>(ra1, st.c[2], c.b);
+      ra1 = msub<POW2>(ra1, st.c[3], s.a);
+      ra1 = msub<POW2>(ra1, st.c[4], nn.a);
+      ra1 = msub<POW2>(ra1, st.c[5], dn.a);
+      ra1 = msub<POW2>(ra1, st.c[6], up.a);
       const T r0_left = from_left(rb0);
       const T xa = const_div(sc_sub(ra1, sc_mul(pl.fac, r0_left)), cdp1);
       const T x1 = from_right(xa);             // second unknown of the tile (b, right a) = the right lane's xa
@@ -587,7 +587,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
       if (node_rows_inner && inner_a) out.a = sc_add(sc_rmul(omm, c.a), sc_rmul(om, xa));
       if (node_rows_inner && inner_b) out.b = sc_add(sc_rmul(omm, c.b), sc_rmul(om, xb));
       // last inner column: a one-cell tile (only the last strip has such a lane)
-      if (last_strip && node_rows_inner && c0 + 1 == n - 2) out.b = relax7(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
+      if (last_strip && node_rows_inner && c0 + 1 == n - 2) out.b = relax7p<POW2>(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
     }
     return out;
   };
@@ -708,7 +708,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
 //     each. A chunk of C coarse planes computes the residual on 2C + 1 fine planes.
 // Summation order = evomg_restrict<T,3> (loop order dz, dy, dx; face / edge / corner sums carried across the three planes
 // in that order) on residuals computed by residual7 = evomg_apply: bit-identical to the two separate kernels.
-template <typename T, int NW, int NT>
+template <typename T, int NW, int NT, bool POW2 = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
                                T* __restrict__ coarse, int cplanes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
@@ -797,8 +797,8 @@ evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict
     for (int t = 0; t < TY; ++t) {
       const Pair<T> c = xc[t], s = (t == 0) ? hs : xc[t > 0 ? t - 1 : 0], nn = (t == TY - 1) ? hn : xc[t < TY - 1 ? t + 1 : t];
       const T wa = from_left(c.b), eb = from_right(c.a);
-      rk[t].a = residual7(st, c.a, wa, c.b, s.a, nn.a, xb[t].a, xa[t].a, fc[t].a);
-      rk[t].b = residual7(st, c.b, c.a, eb, s.b, nn.b, xb[t].b, xa[t].b, fc[t].b);
+      rk[t].a = residual7p<POW2>(st, c.a, wa, c.b, s.a, nn.a, xb[t].a, xa[t].a, fc[t].a);
+      rk[t].b = residual7p<POW2>(st, c.b, c.a, eb, s.b, nn.b, xb[t].b, xa[t].b, fc[t].b);
     }
     *reinterpret_cast<Pair<T>*>(&edge_r[k & 1][w][2 * lane]) = rk[TY - 1];
     __syncthreads();

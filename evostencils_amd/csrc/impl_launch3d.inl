@@ -42,6 +42,20 @@
     if (strip_streams3d(g)) hipLaunchKernelGGL((evomg_strip3d_rbgs<T, TY, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
     else hipLaunchKernelGGL((evomg_strip3d_rbgs<T, TY, false>), grid, block, 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
   }
+  // every off-centre coefficient of the 3D stencil is a (signed) power of two: the tile kernels' fused forms (evomg_strip.h:
+  // msub / madd) give the same bits with one instruction per neighbour term instead of two
+  bool offcentre_pow2(const Stencil<T>& st) const {
+    if constexpr (scalar_traits<T>::is_complex) return false;
+    else {
+      if (!pow2_fma_) return false;
+      for (int e = 1; e <= 6; ++e) {
+        int ex = 0;
+        const double m = frexp(st.c[e], &ex);
+        if (!(m == 0.5 || m == -0.5) || ex < -900 || ex > 900) return false;
+      }
+      return true;
+    }
+  }
   // ---- 3D tiles with LDS-shared y halo (evomg_tile3d.h): Jacobi and residual ------------------------------------------
   bool use_tile3d(const Geo& g) const {
     if (dim_ != 3 || !strip_enabled_ || !tile3d_enabled_ || scalar_traits<T>::is_complex) return false;
@@ -91,7 +105,9 @@
     const dim3 grid(((blocks + 7) / 8) * 8);
     const int nt = strip_streams3d(g) ? tile3d_nt_ : 0;
     if constexpr (!scalar_traits<T>::is_complex) {
-#define EVOMG_TILE3D_LAUNCH(NW, NT) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux)
+      const bool p2 = offcentre_pow2(st);
+#define EVOMG_TILE3D_LAUNCH(NW, NT) do { if (p2) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT, true>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux); \
+                                         else hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT, false>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux); } while (0)
 #define EVOMG_TILE3D_NT(NW) if (nt & 1) EVOMG_TILE3D_LAUNCH(NW, 1); else EVOMG_TILE3D_LAUNCH(NW, 0);
       if (nw == 8) { EVOMG_TILE3D_NT(8) } else { EVOMG_TILE3D_NT(4) }
 #undef EVOMG_TILE3D_NT
@@ -113,10 +129,11 @@
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
     if constexpr (!scalar_traits<T>::is_complex) {
-      if (coarse) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, true>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two,
-                                     TwiceProlong<T>{coarse, *gc, om_p});
-      else hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, false>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two,
-                              TwiceProlong<T>{nullptr, g, 0.0});
+      const bool p2 = offcentre_pow2(st);
+#define EVOMG_TWICE_LAUNCH(PRO, P2, PROLONG) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, PRO, P2>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, PROLONG)
+      if (coarse) { if (p2) EVOMG_TWICE_LAUNCH(true, true, (TwiceProlong<T>{coarse, *gc, om_p})); else EVOMG_TWICE_LAUNCH(true, false, (TwiceProlong<T>{coarse, *gc, om_p})); }
+      else { if (p2) EVOMG_TWICE_LAUNCH(false, true, (TwiceProlong<T>{nullptr, g, 0.0})); else EVOMG_TWICE_LAUNCH(false, false, (TwiceProlong<T>{nullptr, g, 0.0})); }
+#undef EVOMG_TWICE_LAUNCH
     }
   }
 
@@ -134,8 +151,11 @@
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
     if constexpr (!scalar_traits<T>::is_complex) {
-      if (nw == 8) hipLaunchKernelGGL((evomg_tile3d_rbgs<T, 8, 0>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
-      else hipLaunchKernelGGL((evomg_tile3d_rbgs<T, 4, 0>), grid, dim3(256), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks);
+      const bool p2 = offcentre_pow2(st);
+#define EVOMG_RBGS3D_LAUNCH(NW, P2) hipLaunchKernelGGL((evomg_tile3d_rbgs<T, NW, 0, P2>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks)
+      if (nw == 8) { if (p2) EVOMG_RBGS3D_LAUNCH(8, true); else EVOMG_RBGS3D_LAUNCH(8, false); }
+      else { if (p2) EVOMG_RBGS3D_LAUNCH(4, true); else EVOMG_RBGS3D_LAUNCH(4, false); }
+#undef EVOMG_RBGS3D_LAUNCH
     }
   }
 
@@ -154,8 +174,11 @@
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
     if constexpr (!scalar_traits<T>::is_complex) {
-      if (nw == 8) hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, 8, 0>), grid, dim3(512), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks);
-      else hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, 4, 0>), grid, dim3(256), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks);
+      const bool p2 = offcentre_pow2(lv_[L].st);
+#define EVOMG_RR3D_LAUNCH(NW, P2) hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, NW, 0, P2>), grid, dim3(64 * NW), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks)
+      if (nw == 8) { if (p2) EVOMG_RR3D_LAUNCH(8, true); else EVOMG_RR3D_LAUNCH(8, false); }
+      else { if (p2) EVOMG_RR3D_LAUNCH(4, true); else EVOMG_RR3D_LAUNCH(4, false); }
+#undef EVOMG_RR3D_LAUNCH
     }
   }
   bool strip_streams3d(const Geo& g) const { return strip_nt_ && 3.0 * (double)g.plane * g.n * sizeof(T) > 256.0 * 1024 * 1024; }
