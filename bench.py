@@ -241,8 +241,8 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
             if pairs:
                 import numpy as np
                 ts, tm = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
-                rank = lambda v: np.argsort(np.argsort(v)).astype(float)
-                ra, rb = rank(ts) - rank(ts).mean(), rank(tm) - rank(tm).mean()
+                order = lambda v: np.argsort(np.argsort(v)).astype(float)
+                ra, rb = order(ts) - order(ts).mean(), order(tm) - order(tm).mean()
                 modes[mode]["time_objective_vs_sequential"] = {
                     "median_ratio": float(np.median(tm / ts)), "max_rel_deviation": float(np.max(np.abs(tm - ts) / ts)),
                     "spearman": float((ra * rb).sum() / np.sqrt((ra * ra).sum() * (rb * rb).sum())), "candidates": len(pairs)}

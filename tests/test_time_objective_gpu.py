@@ -73,3 +73,35 @@ def test_modelled_time_ranks_candidates_like_the_sequential_pass():
     assert _spearman(t_mod, t_seq) >= min(0.98, _spearman(t_seq2, t_seq) - 0.02)
     assert rel.max() <= 0.05
     assert _spearman(t_mod, t_seq) > _spearman(t_con, t_seq)
+
+
+def test_pool_with_the_isolated_time_objective_matches_sequential_times():
+    """ProgramGeneratorPool(..., time_objective="isolated") behind a thread pool — what stands behind the optimizer's own `map`
+    (INTEGRATION.md section 3): rho and iterations of the sequential evaluation, and its TIMES within 5 % although four
+    candidates are in flight."""
+    from multiprocessing.pool import ThreadPool
+    from evostencils_amd.code_generation.hip import ProgramGeneratorPool
+    lo, hi, n = LO, HI, 12             # the C5 slice's size: solves of 50-130 ms, as in the test above
+
+    def make():
+        from evostencils_amd import native
+        from evostencils_amd.code_generation.hip import ProgramGenerator
+        g = ProgramGenerator(problem=problems.poisson_2d(lo, hi), library=native.library())
+        g.initialize_code_generation(lo, hi)
+        return g
+    single = make()
+    pop = candidates.population(lambda: context_for(single, lo, hi), hi - lo, 2, n, seed=2024)
+    evaluate = lambda g, e: g.generate_and_evaluate(e, None, lo, hi, "", evaluation_samples=1)
+    evaluate(single, pop[0])
+    want = [evaluate(single, e) for e in pop]
+    single.close()
+    pool = ProgramGeneratorPool(make, 4, time_objective="isolated")
+    with ThreadPool(4) as tp:
+        tp.map(lambda e: evaluate(pool, e), pop[:4])                # warm-up of every worker
+        got = tp.map(lambda e: evaluate(pool, e), pop)
+    pool.close()
+    assert [g[1:] for g in got] == [w[1:] for w in want]
+    usable = [(g[0], w[0]) for g, w in zip(got, want) if w[0] < 1e99]
+    rel = max(abs(a - b) / b for a, b in usable)
+    print(f"pool, isolated time objective: {len(usable)} candidates, max rel deviation from sequential {rel:.3f}")
+    assert rel <= 0.05
