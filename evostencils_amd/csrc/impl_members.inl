@@ -26,7 +26,9 @@
   bool pow2_fma_ = getenv("EVOMG_NO_POW2_FMA") == nullptr;       // 3D tiles: fused neighbour terms where the coefficients are powers of two
   // cross-iteration fusion on the finest 2D level (evomg_strip_cross.h): EVOMG_NO_XFUSE switches it off (same bits either way)
   bool xfuse_enabled_ = getenv("EVOMG_NO_XFUSE") == nullptr;
-  int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 513;
+  // from 2049^2: one long marching pass per wave is a latency chain on smaller levels (same-box A/B of whole V(1,1) solves,
+  // fused vs EVOMG_NO_XFUSE: 513^2 1.808 vs 1.747 ms, 1025^2 3.85 vs 3.79, 2049^2 11.89 vs 11.99, 4097^2 13.68 vs 14.12)
+  int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 2049;
   int xfuse_rows_ = getenv("EVOMG_XFUSE_ROWS") ? atoi(getenv("EVOMG_XFUSE_ROWS")) : 0;      // chunk height of the cross kernel (tuning)
   T* xf_rhs_spare_ = nullptr;        // spare coarse right-hand side of level max - 1 (speculative output, swapped in on commit)
   T* xf_lane_sums_ = nullptr;        // per (16-row chunk, column pair) sums of the squared residual

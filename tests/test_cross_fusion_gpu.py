@@ -108,14 +108,14 @@ def test_cross_fusion_at_the_iteration_cap_and_odd_chunk_heights(native, monkeyp
 
 @pytest.mark.parametrize("plan", ["v11_pro_tailr", "v22_plain", "v12_tailr_only"])
 def test_cross_fusion_against_the_oracle(native, monkeypatch, plan):
-    """1025^2, five levels, default thresholds (the fusion is on from 513^2): same iterations, histories to 1e-10, the
-    returned iterate bit for bit."""
+    """1025^2, five levels (the fusion's default threshold is 2049^2, where the oracle takes a minute per solve; the C2 / C5
+    tests at full size run through it by default): same iterations, histories to 1e-10, the returned iterate bit for bit."""
     from oracle import oracle
     lo, hi = 6, 10
     pre, post = PLANS[plan]
     pd = problems.poisson_2d(lo, hi)
     ops = cycle(lo, hi, pre, post)
-    a, (ua,) = solve(native, pd, ops, [(hi, abi.F_SOL)], {}, monkeypatch)
+    a, (ua,) = solve(native, pd, ops, [(hi, abi.F_SOL)], {"EVOMG_XFUSE_MIN_N": "1025"}, monkeypatch)
     ho = oracle.create(pd)
     b = ho.evaluate(ops, 1, 0, 128)
     assert a.status == b.status == abi.SOLVE_CONVERGED and a.n_iterations == b.n_iterations
