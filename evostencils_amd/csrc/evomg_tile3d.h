@@ -52,7 +52,7 @@ __attribute__((amdgpu_waves_per_eu(EVOMG_TILE3D_WPE, EVOMG_TILE3D_WPE)))
 #endif
 evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
              double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl, int order,
-             T* __restrict__ aux) {
+             T* __restrict__ aux, int xpitch) {
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RESIDUAL || MODE == TILE_BLOCK211 || MODE == TILE_BLOCK121 ||
                     MODE == TILE_RESNORM || MODE == TILE_RESNORM_W,
                 "3D tiles: Jacobi, residual (+ norm), two-cell block-Jacobi");
@@ -73,15 +73,18 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
   const bool last_strip = strip == n_strips - 1;            // uniform
   const int n = g.n;
   const long pitch = g.pitch, plane = g.plane;
-  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  // xpitch (even, <= EVOMG_STRIP_COLS): columns a strip stores — the host spreads the columns evenly over the strips
+  // (tile3d_xpitch), so that no workgroup of a launch is lighter than the others; lanes past the strip's halo lane load
+  // what that lane loads (one address: no traffic of their own)
+  const int c0 = strip * xpitch - 2 + 2 * lane;
   const bool col_ok = c0 >= 0 && c0 < n;
   const int row0 = 1 + (ygroup * NW + w) * TY;              // first row of this wave (inner rows start at 1)
   const int z0 = 1 + chunk * planes_per_chunk;              // first plane of this chunk (inner planes start at 1)
   const int z1 = min(z0 + planes_per_chunk, n - 1);         // one past the last plane computed
   const bool inner_a = c0 >= 1 && c0 <= n - 2;
   const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
-  const bool store_lane = lane >= 1 && lane <= 62 && col_ok && (inner_a || inner_b);
-  const int c_clamped = min(max(c0, 0), n - 1);
+  const bool store_lane = lane >= 1 && 2 * lane <= xpitch && col_ok && (inner_a || inner_b);
+  const int c_clamped = min(max(c0, 0), min(n - 1, strip * xpitch + xpitch));
   // branch-free clamped loads (see evomg_strip2d): whatever an out-of-domain slot delivers only feeds non-inner nodes
   auto load_x = [&](int row, int pl) -> Pair<T> {
     const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);      // wave-uniform
@@ -284,7 +287,7 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
 template <typename T, int NW, int NT, bool POW2 = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
-                  double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
+                  double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, int xpitch) {
   constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
   static_assert((H - 2) % 2 == 0 && TY % 2 == 0, "row parity must be static");
   __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x: [plane parity][wave][first | last row][column]
@@ -300,7 +303,7 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
   const int chunk = logical_block / (n_ygroups * n_strips);
   const int n = g.n;
   const long pitch = g.pitch, plane = g.plane;
-  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;
+  const int c0 = strip * xpitch - 2 + 2 * lane;               // xpitch: see evomg_tile3d
   const bool col_ok = c0 >= 0 && c0 < n;
   const int R0 = ygroup * (H - 2);                            // first red row of the workgroup (even)
   const int row0 = R0 + w * TY;
@@ -309,8 +312,8 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
   const int z1 = min(z0 + planes_per_chunk, n - 1);
   const bool inner_a = c0 >= 1 && c0 <= n - 2;
   const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
-  const bool store_lane = lane >= 1 && lane <= 62 && col_ok && (inner_a || inner_b);
-  const int c_clamped = min(max(c0, 0), n - 1);
+  const bool store_lane = lane >= 1 && 2 * lane <= xpitch && col_ok && (inner_a || inner_b);
+  const int c_clamped = min(max(c0, 0), min(n - 1, strip * xpitch + xpitch));
   const T zero = scalar_traits<T>::zero();
   auto load_x = [&](int row, int pl) -> Pair<T> {
     const int r = min(max(row, 0), n - 1), p = min(max(pl, 0), n - 1);
@@ -469,7 +472,7 @@ template <typename T, int MODE, int NW, int NT, bool PRO = false, bool POW2 = fa
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
                    double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl,
-                   TwiceProlong<T> pro) {
+                   TwiceProlong<T> pro, int xpitch) {
   static_assert(MODE == STRIP_JACOBI || MODE == TILE_BLOCK211, "two fused sweeps: point Jacobi and (2,1,1) blocks");
   constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
   __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x of the next centre plane
@@ -491,8 +494,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   // outermost lane cannot form (its own tile partner lies outside the wave)
   const bool last_strip = strip == n_strips - 1;              // uniform
   constexpr int HALO = (MODE == TILE_BLOCK211) ? 2 : 1;
-  constexpr int COLS = 128 - 4 * HALO;
-  const int c0 = strip * COLS - 2 * HALO + 2 * lane;
+  const int c0 = strip * xpitch - 2 * HALO + 2 * lane;        // xpitch <= 128 - 4 * HALO: see evomg_tile3d
   const bool col_ok = c0 >= 0 && c0 < n;
   const int R0 = ygroup * (H - 2);
   const int row0 = R0 + w * TY;
@@ -501,8 +503,8 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   const int z1 = min(z0 + planes_per_chunk, n - 1);
   const bool inner_a = c0 >= 1 && c0 <= n - 2;
   const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
-  const bool store_lane = lane >= HALO && lane <= 63 - HALO && col_ok && (inner_a || inner_b);
-  const int c_clamped = min(max(c0, 0), n - 1);
+  const bool store_lane = lane >= HALO && 2 * (lane - HALO) < xpitch && col_ok && (inner_a || inner_b);
+  const int c_clamped = min(max(c0, 0), min(n - 1, strip * xpitch + xpitch + 2 * HALO - 2));
   const T zero = scalar_traits<T>::zero();
   const Pair<T> zpair{zero, zero};
   auto load_x = [&](int row, int pl_) -> Pair<T> {
@@ -523,7 +525,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   };
   // ---- PRO: trilinear prolongation of the coarse correction onto a loaded row ----
   const int nc = PRO ? pro.gc.n : 1;
-  const int Ic = min(max(c0 >> 1, 0), nc - 1);               // coarse column of element a; b lies between Ic and Ic + 1
+  const int Ic = min(c_clamped >> 1, nc - 1);               // coarse column of element a; b lies between Ic and Ic + 1
   auto coarse_line = [&](int J, int K) -> Pair<T> {           // e[K][J][Ic], e[K][J][Ic + 1] (8-byte aligned 16-byte load)
     const int jj = min(max(J, 0), nc - 1), kk = min(max(K, 0), nc - 1);
     return load_pair<T>(pro.coarse + pro.gc.plane * kk + (long)pro.gc.pitch * jj + Ic);
@@ -699,7 +701,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
 // field ever reaching memory (24 B/node -> 16 B/node + the coarse field; the separate kernels move 24 + 8 + 1 B/node).
 // Geometry of the red-black tiles: a workgroup computes the residual on H = NW*4 rows x 128 columns and marches along z;
 //   * lane = column pair (c0 even, c0 + 1): the coarse column c0/2 sits on element a; its x neighbours are the lane's own
-//     b and the left lane's b (one DPP shift per row); lanes 1..62 produce coarse nodes (62 per strip);
+//     b and the left lane's b (one DPP shift per row); lanes 1..xpitch/2 produce coarse nodes (at most 62 per strip);
 //   * coarse rows sit on the wave's local rows 0 and 2 (row0 is even): row 2 needs the wave's rows 1..3, row 0 needs the
 //     LAST residual row of the wave below — parked in LDS, riding on the step's single barrier; the workgroup's first row
 //     has no such neighbour, so it finishes the coarse rows at local rows 2, 4, .., H-2 and consecutive workgroups overlap
@@ -711,7 +713,8 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
 template <typename T, int NW, int NT, bool POW2 = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
-                               T* __restrict__ coarse, int cplanes_per_chunk, int n_strips, int n_ygroups, int n_blocks) {
+                               T* __restrict__ coarse, int cplanes_per_chunk, int n_strips, int n_ygroups, int n_blocks,
+                               int xpitch) {
   constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
   static_assert(TY == 4 && (H - 2) % 2 == 0, "coarse rows on local rows 0 and 2 of every wave");
   __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // x: [plane parity][wave][first | last row][column]
@@ -726,13 +729,13 @@ evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict
   const int chunk = logical_block / (n_ygroups * n_strips);
   const int n = g.n, nc = gc.n;
   const long pitch = g.pitch, plane = g.plane;
-  const int c0 = strip * EVOMG_STRIP_COLS - 2 + 2 * lane;      // even
+  const int c0 = strip * xpitch - 2 + 2 * lane;                // even (xpitch: see evomg_tile3d)
   const int R0 = ygroup * (H - 2);                            // even
   const int row0 = R0 + w * TY;
   const int K0 = 1 + chunk * cplanes_per_chunk;               // coarse planes [K0, K1)
   const int K1 = min(K0 + cplanes_per_chunk, nc - 1);
   const int ks = 2 * K0 - 1, ke = 2 * K1;                     // fine planes [ks, ke): odd first and last plane
-  const int c_clamped = min(max(c0, 0), n - 1);
+  const int c_clamped = min(max(c0, 0), min(n - 1, strip * xpitch + xpitch));
   const T zero = scalar_traits<T>::zero();
   const Pair<T> zpair{zero, zero};
   auto load_x = [&](int row, int pl_) -> Pair<T> {
@@ -753,7 +756,7 @@ evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict
   };
   // the two coarse nodes of this lane: column c0 / 2, rows (row0 + 0) / 2 and (row0 + 2) / 2
   const int I = c0 >> 1;
-  const bool col_valid = lane >= 1 && lane <= 62 && I >= 1 && I <= nc - 2;
+  const bool col_valid = lane >= 1 && 2 * lane <= xpitch && I >= 1 && I <= nc - 2;
   bool valid[2];
   long cidx[2];
 #pragma unroll

@@ -56,6 +56,35 @@
       return true;
     }
   }
+  // columns a strip of a 3D tile launch stores: the n - 1 columns left of the east boundary spread evenly over the strips
+  // (even, <= cols), instead of `cols` each with a nearly empty last strip (513^3: 5 x 104 instead of 4 x 124 + 17) — with
+  // one workgroup per compute unit and a round or two per launch the heaviest workgroup IS the launch. The 3D loop norm's
+  // canonical order is defined on these strips (oracle: FN(norm_tile3d)).
+  int tile3d_xpitch(int n, int cols) const {
+    const int strips = (n + cols - 1) / cols;
+    if (!xbalance3d_) return cols;
+    const int p = 2 * ((n - 1 + 2 * strips - 1) / (2 * strips));
+    return p < cols ? p : cols;
+  }
+  // z-chunk depth by workgroup balance: one 512-thread tile workgroup is resident per compute unit (245 VGPRs), so a launch
+  // runs in ceil(workgroups / units) rounds of (depth + halo planes + prologue) plane steps each; deeper chunks re-read
+  // fewer halo planes but leave the last round partly empty. Picks the depth (a multiple of `align`, at least `lo`) with
+  // the fewest plane steps on the critical path; ties go to the shallower chunk (more workgroups in flight).
+  int balanced_planes(long tiles, int inner, int halo, int lo, int align) const {
+    long best_cost = -1;
+    int best = lo;
+    for (int c = 1; c <= inner; ++c) {
+      int p = (inner + c - 1) / c;
+      p = ((p + align - 1) / align) * align;
+      if (p < lo) break;
+      if (balance3d_cap_ > 1 && p > balance3d_cap_) continue;
+      const long chunks = (inner + p - 1) / p;
+      const long rounds = (tiles * chunks + n_cu_ - 1) / n_cu_;
+      const long cost = rounds * (p + halo + 2);
+      if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = p; }
+    }
+    return best;
+  }
   // ---- 3D tiles with LDS-shared y halo (evomg_tile3d.h): Jacobi and residual ------------------------------------------
   bool use_tile3d(const Geo& g) const {
     if (dim_ != 3 || !strip_enabled_ || !tile3d_enabled_ || scalar_traits<T>::is_complex) return false;
@@ -99,6 +128,7 @@
     // z halo: 2 planes per chunk. Measured at 513^3 (profiles/r02_pmc_3d.md): 16 planes (2560 workgroups) beat 32 and 64
     int planes = strip_planes_ > 0 ? strip_planes_ : 16;
     if (strip_planes_ <= 0) while (planes > 8 && (long)strips * ygroups * ((inner + planes - 1) / planes) < 2048) planes /= 2;
+    if (strip_planes_ <= 0 && balance3d_ && nw == 8) planes = balanced_planes((long)strips * ygroups, inner, 2, 8, 4);
     planes = (planes + 3) & ~3;
     const int chunks = (inner + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
@@ -106,8 +136,8 @@
     const int nt = strip_streams3d(g) ? tile3d_nt_ : 0;
     if constexpr (!scalar_traits<T>::is_complex) {
       const bool p2 = offcentre_pow2(st);
-#define EVOMG_TILE3D_LAUNCH(NW, NT) do { if (p2) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT, true>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux); \
-                                         else hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT, false>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux); } while (0)
+#define EVOMG_TILE3D_LAUNCH(NW, NT) do { if (p2) hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT, true>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux, tile3d_xpitch(g.n, EVOMG_STRIP_COLS)); \
+                                         else hipLaunchKernelGGL((evomg_tile3d<T, MODE, NW, NT, false>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, tile3d_order_, aux, tile3d_xpitch(g.n, EVOMG_STRIP_COLS)); } while (0)
 #define EVOMG_TILE3D_NT(NW) if (nt & 1) EVOMG_TILE3D_LAUNCH(NW, 1); else EVOMG_TILE3D_LAUNCH(NW, 0);
       if (nw == 8) { EVOMG_TILE3D_NT(8) } else { EVOMG_TILE3D_NT(4) }
 #undef EVOMG_TILE3D_NT
@@ -124,13 +154,14 @@
     const int stored = nw * TY - 2;
     const int ygroups = (g.n - 3 + stored - 1) / stored > 0 ? (g.n - 3 + stored - 1) / stored : 1;
     int planes = strip_planes_ > 0 ? strip_planes_ : twice_planes_;
+    if (strip_planes_ <= 0 && balance3d_ && !getenv("EVOMG_TWICE_PLANES")) planes = balanced_planes((long)strips * ygroups, g.n - 2, 4, 8, 4);
     planes = (planes + 3) & ~3;
     const int chunks = (g.n - 2 + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
     if constexpr (!scalar_traits<T>::is_complex) {
       const bool p2 = offcentre_pow2(st);
-#define EVOMG_TWICE_LAUNCH(PRO, P2, PROLONG) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, PRO, P2>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, PROLONG)
+#define EVOMG_TWICE_LAUNCH(PRO, P2, PROLONG) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, PRO, P2>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, PROLONG, tile3d_xpitch(g.n, cols))
       if (coarse) { if (p2) EVOMG_TWICE_LAUNCH(true, true, (TwiceProlong<T>{coarse, *gc, om_p})); else EVOMG_TWICE_LAUNCH(true, false, (TwiceProlong<T>{coarse, *gc, om_p})); }
       else { if (p2) EVOMG_TWICE_LAUNCH(false, true, (TwiceProlong<T>{nullptr, g, 0.0})); else EVOMG_TWICE_LAUNCH(false, false, (TwiceProlong<T>{nullptr, g, 0.0})); }
 #undef EVOMG_TWICE_LAUNCH
@@ -146,13 +177,14 @@
     const int ygroups = (g.n - 3 + stored - 1) / stored > 0 ? (g.n - 3 + stored - 1) / stored : 1;
     int planes = strip_planes_ > 0 ? strip_planes_ : 64;       // z halo: 3 planes per chunk
     if (strip_planes_ <= 0) while (planes > 8 && (long)strips * ygroups * ((g.n - 2 + planes - 1) / planes) < 2048) planes /= 2;
+    if (strip_planes_ <= 0 && balance3d_ && nw == 8) planes = balanced_planes((long)strips * ygroups, g.n - 2, 3, 8, 4);
     planes = (planes + 3) & ~3;
     const int chunks = (g.n - 2 + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
     if constexpr (!scalar_traits<T>::is_complex) {
       const bool p2 = offcentre_pow2(st);
-#define EVOMG_RBGS3D_LAUNCH(NW, P2) hipLaunchKernelGGL((evomg_tile3d_rbgs<T, NW, 0, P2>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks)
+#define EVOMG_RBGS3D_LAUNCH(NW, P2) hipLaunchKernelGGL((evomg_tile3d_rbgs<T, NW, 0, P2>), grid, dim3(64 * NW), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, tile3d_xpitch(g.n, EVOMG_STRIP_COLS))
       if (nw == 8) { if (p2) EVOMG_RBGS3D_LAUNCH(8, true); else EVOMG_RBGS3D_LAUNCH(8, false); }
       else { if (p2) EVOMG_RBGS3D_LAUNCH(4, true); else EVOMG_RBGS3D_LAUNCH(4, false); }
 #undef EVOMG_RBGS3D_LAUNCH
@@ -170,12 +202,13 @@
     const int per_group = (nw * TY - 2) / 2;                      // coarse rows a workgroup finishes: 15 (7 with four waves)
     const int ygroups = (rows_c + per_group - 1) / per_group;
     int cplanes = strip_planes_ > 0 ? (strip_planes_ + 1) / 2 : rr_cplanes_;   // fine planes per chunk: 2 * cplanes + 1
+    if (strip_planes_ <= 0 && balance3d_ && nw == 8 && !getenv("EVOMG_RR_CPLANES")) cplanes = balanced_planes((long)strips * ((rows_c + 14) / 15), rows_c, 1, 4, 1);
     const int chunks = (rows_c + cplanes - 1) / cplanes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);
     if constexpr (!scalar_traits<T>::is_complex) {
       const bool p2 = offcentre_pow2(lv_[L].st);
-#define EVOMG_RR3D_LAUNCH(NW, P2) hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, NW, 0, P2>), grid, dim3(64 * NW), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks)
+#define EVOMG_RR3D_LAUNCH(NW, P2) hipLaunchKernelGGL((evomg_tile3d_residual_restrict<T, NW, 0, P2>), grid, dim3(64 * NW), 0, stream_, g, gc, lv_[L].st, x, f, coarse, cplanes, strips, ygroups, blocks, tile3d_xpitch(g.n, EVOMG_STRIP_COLS))
       if (nw == 8) { if (p2) EVOMG_RR3D_LAUNCH(8, true); else EVOMG_RR3D_LAUNCH(8, false); }
       else { if (p2) EVOMG_RR3D_LAUNCH(4, true); else EVOMG_RR3D_LAUNCH(4, false); }
 #undef EVOMG_RR3D_LAUNCH

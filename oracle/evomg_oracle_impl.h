@@ -904,9 +904,10 @@ static double FN(norm_strip2d)(FN(ctx_t)* c, int level, const SC* r) {
   return sc_norm_from_dot(FN(block_tree)(th));
 }
 /* Residual norm of the solver loop on 3D levels with at least 129 nodes per dimension: the device forms it in the
- * residual pass itself (csrc/evomg_tile3d.h, TILE_RESNORM). Order: one partial sum per (plane k, row j, strip s of 124
- * stored columns): lane l of the wave holds the column pair (c0, c0+1), c0 = 124 s - 2 + 2 l (lanes 0 and 63 are halo
- * lanes), adds r(c0)^2 then r(c0+1)^2 (inner columns only), the 64 lane values go through the wave tree; the partials,
+ * residual pass itself (csrc/evomg_tile3d.h, TILE_RESNORM). Order: one partial sum per (plane k, row j, strip s of P
+ * stored columns, P even and the same for every strip: the n - 1 columns spread over ceil(n / 124) strips): lane l of the
+ * wave holds the column pair (c0, c0+1), c0 = P s - 2 + 2 l (lanes 1 .. P/2 count, the others hold zero), adds r(c0)^2
+ * then r(c0+1)^2 (inner columns only), the 64 lane values go through the wave tree; the partials,
  * indexed ((k-1) m + (j-1)) strips + s, are then summed by 1024 blocks of 256 threads striding over the array
  * (evomg_sum_stage1) and the block sums like the partials of FN(dot). */
 #define TILE_STRIP_COLS 124
@@ -916,6 +917,9 @@ static int FN(norm_is_fused3d)(FN(ctx_t)* c, int level) {
 static double FN(norm_tile3d)(FN(ctx_t)* c, int level, const SC* r) {
   const int n = c->lv[level].n, m = n - 2;
   const int strips = (n + TILE_STRIP_COLS - 1) / TILE_STRIP_COLS;
+  /* the strips store equally many columns (even, at most TILE_STRIP_COLS): csrc/impl_launch3d.inl tile3d_xpitch */
+  int xpitch = 2 * ((n - 1 + 2 * strips - 1) / (2 * strips));
+  if (xpitch > TILE_STRIP_COLS) xpitch = TILE_STRIP_COLS;
   const long count = (long)m * m * strips;
   SC* part = (SC*)malloc(sizeof(SC) * (size_t)count);
 #pragma omp parallel for schedule(static)
@@ -925,8 +929,8 @@ static double FN(norm_tile3d)(FN(ctx_t)* c, int level, const SC* r) {
         SC lane[64];
         for (int l = 0; l < 64; ++l) {
           SC acc = sc_zero();
-          const int c0 = s * TILE_STRIP_COLS - 2 + 2 * l;
-          if (l >= 1 && l <= 62 && c0 >= 0 && c0 < n)
+          const int c0 = s * xpitch - 2 + 2 * l;
+          if (l >= 1 && 2 * l <= xpitch && c0 >= 0 && c0 < n)
             for (int e = 0; e < 2; ++e) {
               const int i = c0 + e;
               if (i < 1 || i > n - 2) continue;

@@ -5,6 +5,9 @@
 //   1  relaxed agent-scope atomics only; the data store is waited for (s_waitcnt vmcnt(0)) before the flag store
 //   2  as 1, value and sequence number packed into ONE 16-byte slot written by one store? (not atomic on this ISA) -> two
 //      8-byte relaxed stores to the same 16-byte-aligned slot, flag second
+//   3  "LL" words: the value travels as two 8-byte words {32 data bits, 32-bit sequence number}, each written by ONE relaxed
+//      agent-scope 64-bit atomic store (single-copy atomic); the consumer polls the two words themselves until both carry
+//      this round's number — no flag after the data, no data load after the flag: one store trip + one poll trip
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/bench_rendezvous tools/bench_rendezvous.hip ; run: tools/bench_rendezvous
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -94,6 +97,42 @@ __global__ void __launch_bounds__(512) rendezvous(int G, int rounds, int stride,
   if (threadIdx.x == 0) { out[w] = acc; out[32 + w] = (double)xcc_id(); }
 }
 
+__global__ void __launch_bounds__(512) rendezvous_ll(int G, int rounds, int stride, unsigned long long* ll, double* out, int* fail) {
+  __shared__ double lds_part[64];
+  __shared__ int lds_flag;
+  const int w = blockIdx.x / stride;
+  if (blockIdx.x % stride != 0 || w >= G) return;
+  double acc = 1.0 + w;
+  for (int k = 1; k <= rounds; ++k) {
+    unsigned long long* slot = ll + (k & 1) * 128;       // [parity][group][2]
+    if (threadIdx.x < 2) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+      const unsigned half = threadIdx.x == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+      __hip_atomic_store(slot + 2 * w + threadIdx.x, ((unsigned long long)(unsigned)k << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) lds_flag = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+      int budget = 1 << 22;
+      unsigned long long a, b;
+      for (;;) {
+        a = __hip_atomic_load(slot + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(slot + 2 * threadIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a >> 32) == (unsigned)k && (unsigned)(b >> 32) == (unsigned)k) break;
+        if (--budget == 0) { lds_flag = 1; break; }
+      }
+      lds_part[threadIdx.x] = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+    }
+    __syncthreads();
+    if (lds_flag) { if (threadIdx.x == 0) *fail = 1; return; }
+    double s = lds_part[0];
+    for (int q = 1; q < G; ++q) s += lds_part[q];
+    acc = s * 0.125 + w;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[w] = acc; out[32 + w] = (double)xcc_id(); }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 2000;
   unsigned* flags; double *part, *out; int* fail;
@@ -103,7 +142,9 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&fail, sizeof(int)));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  for (int variant = 0; variant < 3; ++variant)
+  unsigned long long* ll;
+  CHECK(hipMalloc(&ll, 256 * sizeof(unsigned long long)));
+  for (int variant = 0; variant < 4; ++variant)
     for (int stride : {1, 8})
       for (int G : {2, 4, 8}) {
         double res[64] = {};
@@ -113,8 +154,10 @@ int main(int argc, char** argv) {
           CHECK(hipMemset(flags, 0, 64 * sizeof(unsigned)));
           CHECK(hipMemset(part, 0, 128 * sizeof(double)));
           CHECK(hipMemset(fail, 0, sizeof(int)));
+          CHECK(hipMemset(ll, 0, 256 * sizeof(unsigned long long)));
           CHECK(hipEventRecord(e0));
-          if (variant == 0) hipLaunchKernelGGL(rendezvous<0>, dim3(G * stride), dim3(512), 0, 0, G, rounds, stride, flags, part, out, fail);
+          if (variant == 3) hipLaunchKernelGGL(rendezvous_ll, dim3(G * stride), dim3(512), 0, 0, G, rounds, stride, ll, out, fail);
+          else if (variant == 0) hipLaunchKernelGGL(rendezvous<0>, dim3(G * stride), dim3(512), 0, 0, G, rounds, stride, flags, part, out, fail);
           else if (variant == 2) hipLaunchKernelGGL(rendezvous<2>, dim3(G * stride), dim3(512), 0, 0, G, rounds, stride, flags, part, out, fail);
           else hipLaunchKernelGGL(rendezvous<1>, dim3(G * stride), dim3(512), 0, 0, G, rounds, stride, flags, part, out, fail);
           CHECK(hipEventRecord(e1));
