@@ -472,7 +472,16 @@ __host__ __device__ inline long cg_reg2d_lds_elems(int rt, int e) { return 32 + 
 
 // MASK_FROM: first unrolled row that may lie outside the thread's band (needs masking); rows below it are always
 // rows of the grid for every wave (host-checked: own.R == R and the last band keeps at least MASK_FROM rows).
-template <typename T, int R, int E, int MASK_FROM>
+// POW2 (real T; host: cg_reg2d_pow2): the four off-centre coefficients are one value cc = +-2^k and the centre is
+// c0 = q0 cc with q0 = +-2^j (every Poisson level with h = 2^-L: cc = -4^L, q0 = -4). Then the stencil sum's roundings
+// commute with the scaling by cc — c0 p is exact, round(cc w + c0 p) = cc round(w + q0 p), and so on — so the pass keeps
+// t = (A p) / cc instead of A p: one fma and three additions per node instead of a product and four fmas. Everything
+// downstream scales exactly too: the partial sums of p . t are those of p . A p divided by cc (every fma and every
+// addition of the reduction tree rounds the scaled operands to the scaled result), rr / (p . t) = cc alpha is the
+// correctly rounded quotient scaled, alpha itself is recovered by one exact product per thread, and r - (cc alpha) t
+// is the very real number r - alpha (A p). Bit-identical to the general form (barring overflow / underflow of values
+// near 1e+-300, which a residual norm never reaches); 32 of ~550 vector instructions per wave and iteration fewer.
+template <typename T, int R, int E, int MASK_FROM, bool POW2 = false>
 __global__ void __launch_bounds__(512)
 evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
                double tol, int* __restrict__ info) {
@@ -545,6 +554,8 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   for (int e = 0; e < E; ++e) { p_south[e] = r_south[e]; p_north[e] = r_north[e]; }
   const double res0 = sc_norm_from_dot(rr);
   T alpha_e[E], nalpha_e[E];                       // zero step for column-less elements: their r, p and x never move
+  T q0 = zero, inv_cc = zero;
+  if constexpr (POW2) { q0 = st.c[0] / st.c[1]; inv_cc = 1.0 / st.c[1]; }      // exact: powers of two
   // A p (kept in registers) and p . A p. With UPD the two updates that use the OLD p ride along, one row ahead of the
   // stencil: x += alpha p (the LDS round trip of x hides behind the stencil's arithmetic instead of standing alone in
   // the r update: it was 30 % of the iteration there) and p = r + beta p, own rows and the neighbouring bands' seam rows.
@@ -582,11 +593,19 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
         const T pe = (e == E - 1) ? from_e : p[i][e < E - 1 ? e + 1 : e];
         const T ps = (i == 0) ? p_south[e] : p[i > 0 ? i - 1 : 0][e];
         const T pn = (i == R - 1) ? p_north[e] : p[i < R - 1 ? i + 1 : i][e];
-        T a = sc_mul(st.c[0], pc);
-        a = sc_fma(st.c[1], pw, a);
-        a = sc_fma(st.c[2], pe, a);
-        a = sc_fma(st.c[3], ps, a);
-        a = sc_fma(st.c[4], pn, a);
+        T a;
+        if constexpr (POW2) {
+          a = sc_fma(q0, pc, pw);                        // (A p) / cc, see above
+          a = sc_add(a, pe);
+          a = sc_add(a, ps);
+          a = sc_add(a, pn);
+        } else {
+          a = sc_mul(st.c[0], pc);
+          a = sc_fma(st.c[1], pw, a);
+          a = sc_fma(st.c[2], pe, a);
+          a = sc_fma(st.c[3], ps, a);
+          a = sc_fma(st.c[4], pn, a);
+        }
         if (i >= MASK_FROM) a = (i < rows) ? a : zero;   // slack row: p is zero there but the stencil sum is not
         ap[i][e] = a;
         loc = sc_fma(pc, a, loc);                        // column-less elements: p = 0, contributes exactly 0
@@ -599,8 +618,10 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
     apply_pass(std::false_type{}, zero);
     for (;;) {
       const T pap = block_sum_fast(loc, red, red_phase);
-      const T alpha = sc_div(rr, pap);
-      const T nalpha = sc_neg(alpha);
+      const T alpha_s = sc_div(rr, pap);                 // POW2: cc alpha (ap holds (A p) / cc)
+      T alpha = alpha_s;
+      if constexpr (POW2) alpha = sc_mul(alpha_s, inv_cc);
+      const T nalpha = sc_neg(alpha_s);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         alpha_e[e] = ok_e[e] ? alpha : zero;
@@ -1157,11 +1178,11 @@ __global__ void __launch_bounds__(256) kb_check(const T* __restrict__ partial_rr
 // The neighbour planes of p are never sent: p_new = r + beta p_old is recomputed from the neighbour's r plane and the
 // previous neighbour p plane with the same fused multiply-add the owner executes, so it is bit-identical — two
 // grid-wide synchronisations per iteration instead of three.
-// Synchronisation: per workgroup and exchange kind one monotonically increasing sequence flag in global memory;
-// data is published with agent-scope atomic stores, then the flag is released; consumers poll the G flags with
-// acquire loads (bounded: a workgroup that never arrives turns into status info[1] = 1, not a hang). Every workgroup
-// forms the global sums in the same order (group 0, 1, ..., G-1), so all of them take the same branch at the
-// stopping test and leave the loop together. The G workgroups must be co-resident: G = 8 of 256 CUs.
+// Synchronisation: every exchanged double travels as two "LL" words that carry their own sequence number (ll_store /
+// ll_load below); consumers poll the words themselves (bounded: a workgroup that never arrives turns into status
+// info[1] = 1, not a hang). Every workgroup forms the global sums in the same order (group 0, 1, ..., G-1), so all of
+// them take the same branch at the stopping test and leave the loop together. The G workgroups must be co-resident:
+// G = 8 of 256 CUs.
 // Reduction order restated by the oracle: FN(dot_canon) with groups (oracle/evomg_oracle_impl.h).
 #define EVOMG_CG_GROUPS 8
 template <int DIM> __host__ __device__ inline int krylov_cg_groups(int n) {
@@ -1173,6 +1194,69 @@ template <int DIM> __host__ __device__ inline int krylov_cg_groups(int n) {
 
 __device__ __forceinline__ void krylov_opaque(double& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void krylov_opaque(cplx& v) { asm volatile("" : "+v"(v.re), "+v"(v.im)); }
+
+// Exchange protocol ("LL" words, round 4; profiles/r04_rendezvous.md): a double travels as two 8-byte words
+// {32 data bits, 32-bit sequence number}, each written by ONE relaxed agent-scope 64-bit atomic store (single-copy atomic);
+// the consumer polls the two words themselves until both carry the sequence number it waits for. No flag after the data
+// (no store acknowledgement to wait for) and no data load after the flag: one store trip and one poll trip per exchange
+// instead of four (1.79 -> 1.22 us at G = 8 on eight XCDs, 0.82 us on one). Slots are double-buffered by the parity of
+// the exchange counter: a peer can overwrite a slot only two exchanges later, i.e. after it has seen everybody's next
+// publication, which everybody makes after reading this one. Sequence numbers never repeat across launches (the host
+// passes a running base), so words left by an earlier solve can never match.
+typedef unsigned long long evomg_u64;
+__device__ __forceinline__ void ll_store(evomg_u64* slot, double v, unsigned seq) {
+  const evomg_u64 bits = (evomg_u64)__double_as_longlong(v);
+  __hip_atomic_store(slot, ((evomg_u64)seq << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(slot + 1, ((evomg_u64)seq << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// bounded: false when the words never arrived (a peer that is not resident); *v is then unspecified
+__device__ __forceinline__ bool ll_load(const evomg_u64* slot, unsigned seq, double* v) {
+  int budget = 1 << 22;
+  evomg_u64 a, b;
+  for (;;) {
+    a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(a >> 32) == seq && (unsigned)(b >> 32) == seq) break;
+    if (--budget == 0) { *v = 0.0; return false; }
+  }
+  *v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+  return true;
+}
+// The same in two halves, so that the trip of the first attempt hides behind other work: ll_peek issues the two loads
+// (nothing waits for them), ll_finish looks at what they brought and only polls on if the words had not arrived yet.
+struct LLPeek { evomg_u64 a, b; };
+__device__ __forceinline__ LLPeek ll_peek(const evomg_u64* slot) {
+  LLPeek p;
+  p.a = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  p.b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return p;
+}
+__device__ __forceinline__ bool ll_finish(const LLPeek& p, const evomg_u64* slot, unsigned seq, double* v) {
+  if ((unsigned)(p.a >> 32) == seq && (unsigned)(p.b >> 32) == seq) {
+    *v = __longlong_as_double((long long)((p.a & 0xffffffffull) | (p.b << 32)));
+    return true;
+  }
+  return ll_load(slot, seq, v);
+}
+// all threads call it: threads q < groups fetch group q's partial sum of this exchange into lds_part (one buffer per
+// exchange kind: the other kind's barrier separates a buffer's readers from its next writers); after the barrier every
+// thread adds the partial sums in the order 0 .. G-1. lds_flag is sticky (set once, never cleared).
+__device__ __forceinline__ bool grid_collect_ll(const evomg_u64* slots, int groups, unsigned seq, double* lds_part, int* lds_flag,
+                                                double* sum) {
+  const int q = (int)threadIdx.x;
+  if (q < groups) {
+    double v;
+    if (!ll_load(slots + 2 * q, seq, &v)) *lds_flag = 1;
+    lds_part[q] = v;
+  }
+  __syncthreads();
+  double s = lds_part[0];
+  for (int q = 1; q < groups; ++q) s = s + lds_part[q];
+  *sum = s;
+  return *lds_flag == 0;
+}
+
+// ---- the flag-after-data protocol (evomg_fas.h still uses it: whole tiles travel there, not single doubles) ----
 __device__ __forceinline__ void xchg_store(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1181,67 +1265,49 @@ __device__ __forceinline__ double xchg_load(const double* p) {
 }
 __device__ __forceinline__ void xchg_store(cplx* p, cplx v) { xchg_store(&p->re, v.re); xchg_store(&p->im, v.im); }
 __device__ __forceinline__ cplx xchg_load(const cplx* p) { return cplx{xchg_load(&p->re), xchg_load(&p->im)}; }
-
-// Exchange protocol (all threads of the workgroup call both functions):
 //   publish: every published value has been written with an agent-scope atomic store; the workgroup barrier orders
-//            those stores before thread 0's agent-scope RELEASE store of the sequence flag;
-//   collect: thread q < G polls flag q with ACQUIRE loads (bounded), then fetches group q's partial sum with an
-//            agent-scope atomic load and parks it in LDS; after the barrier every thread adds the G partial sums in
-//            the order 0 .. G-1. Returns false when a peer did not arrive within the poll budget.
+//            those stores before thread 0's agent-scope RELEASE store of the sequence flag; consumers poll the flag with
+//            agent-scope ACQUIRE loads, then fetch the data with agent-scope atomic loads.
 __device__ __forceinline__ void grid_publish(unsigned* flags, int w, unsigned seq) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(flags + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <typename T>
-__device__ __forceinline__ bool grid_collect(const unsigned* flags, const T* part, int groups, unsigned seq,
-                                             T* lds_part, int* lds_flag, T* sum) {
-  if (threadIdx.x == 0) *lds_flag = 0;
-  __syncthreads();
-  if ((int)threadIdx.x < groups) {
-    int budget = 1 << 22;
-    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-      if (--budget == 0) { *lds_flag = 1; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    lds_part[threadIdx.x] = xchg_load(part + threadIdx.x);
-  }
-  __syncthreads();
-  T s = lds_part[0];
-  for (int q = 1; q < groups; ++q) s = sc_add(s, lds_part[q]);
-  *sum = s;
-  return *lds_flag == 0;
-}
 
-// xpart: [2][G] partial sums (A, B); xface: [G][2][1024] first / last r plane of each slab; flags: [2][G], zeroed by the host
+// ll: [2 kinds A | B][2 parities][G][2 words] partial sums, then [2 parities][G][first | last plane][1024][2 words] faces of r
+// (EVOMG_CG_LL_WORDS 8-byte words, zeroed once by the host); seq_base: sequence numbers of this launch start above it.
+// stride: only every stride-th workgroup of the grid takes part (stride 8 puts all G of them on ONE XCD — workgroups are
+// dealt to the XCDs round-robin — where a rendezvous costs 0.82 instead of 1.22 us); the others leave at once.
+#define EVOMG_CG_LL_PART_WORDS (2 * 2 * EVOMG_CG_GROUPS * 2)
+#define EVOMG_CG_LL_WORDS (EVOMG_CG_LL_PART_WORDS + 2 * EVOMG_CG_GROUPS * 2 * 1024 * 2)
 template <typename T>
 __global__ void __launch_bounds__(1024)
 evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
-                    double tol, int* __restrict__ info, T* xpart, T* xface, unsigned* flags) {
+                    double tol, int* __restrict__ info, evomg_u64* ll, unsigned seq_base, int stride) {
+  static_assert(!scalar_traits<T>::is_complex, "the LL words carry one double");
   constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
-  // G blocks land on G different XCDs (blocks are dealt round-robin); packing them onto one XCD (tried: only every
-  // eighth block of a larger grid works) is not faster, the exchanges are latency- not L2-bound
-  const int w = (int)blockIdx.x;
+  if ((int)blockIdx.x % stride != 0) return;
+  const int w = (int)blockIdx.x / stride;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* red = reinterpret_cast<T*>(lds_raw);              // 2 x 16 wave sums
   int* lds_flag = reinterpret_cast<int*>(red + 32);
-  T* lds_part = red + 34;                              // G partial sums of the current exchange
-  T* img = red + 34 + G;                               // S planes x (m+2) x (m+2), zero halo
+  T* lds_partA = red + 34;                             // G partial sums of the current exchange, one buffer per kind
+  T* lds_partB = red + 34 + G;
+  T* img = red + 34 + 2 * G;                           // S planes x (m+2) x (m+2), zero halo
   const KrylovOwn own = krylov_own<3>(g.n);
   const int m = own.m, W = m + 2, PS = W * W;
   const int zs = (w * m) / G, ze = ((w + 1) * m) / G, cnt = ze - zs;      // 1 <= cnt <= S (m >= 2 G)
   const T zero = scalar_traits<T>::zero();
   for (int i = threadIdx.x; i < S * PS; i += blockDim.x) img[i] = zero;
   const int t = threadIdx.x;
+  if (t == 0) *lds_flag = 0;
   const bool col = t < m * m;
   const int ix = col ? t % m : 0, iy = col ? t / m : 0;
   const int o0 = col ? (iy + 1) * W + ix + 1 : 0;      // column-less threads sit on the halo corner (always zero)
   const long c0 = gidx<3>(g, ix + 1, iy + 1, zs + 1);
-  unsigned* flagA = flags;
-  unsigned* flagB = flags + G;
-  T* partA = xpart;
-  T* partB = xpart + G;
-  T* face_lo = xface + (size_t)w * 2048;               // this slab's first plane of r
-  T* face_hi = face_lo + 1024;                         // ... and last plane
+  auto part_slots = [&](int kind, unsigned seq) { return ll + ((kind * 2 + (int)(seq & 1u)) * G) * 2; };
+  auto face_slot = [&](unsigned seq, int group, int which) {
+    return ll + EVOMG_CG_LL_PART_WORDS + ((((size_t)(seq & 1u) * G + group) * 2 + which) * 1024 + t) * 2;
+  };
   __syncthreads();
 
   T r[S], xr[S], pr[S], ap[S];
@@ -1269,16 +1335,18 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
     return v;
   };
   // ---- exchange B #0: r . r and the r faces ----
-  unsigned seqA = 0, seqB = 0;
+  unsigned seqA = seq_base, seqB = seq_base;
   bool alive = true;
+  bool faces_ok = true;                                 // a face that never arrived: reported (info[1]), not waited for again
   T part = block_sum_fast(loc, red, red_phase);
-  if (t == 0) xchg_store(partB + w, part);
-  if (col) { xchg_store(face_lo + t, r[0]); xchg_store(face_hi + t, last_of(r)); }
-  grid_publish(flagB, w, ++seqB);
+  ++seqB;
+  if (t == 0) ll_store(part_slots(1, seqB) + 2 * w, part, seqB);
+  if (col) { ll_store(face_slot(seqB, w, 0), r[0], seqB); ll_store(face_slot(seqB, w, 1), last_of(r), seqB); }
   T rr;
-  alive = grid_collect(flagB, partB, G, seqB, lds_part, lds_flag, &rr);
-  T rn_lo = (col && w > 0) ? xchg_load(xface + (size_t)(w - 1) * 2048 + 1024 + t) : zero;
-  T rn_hi = (col && w < G - 1) ? xchg_load(xface + (size_t)(w + 1) * 2048 + t) : zero;
+  alive = grid_collect_ll(part_slots(1, seqB), G, seqB, lds_partB, lds_flag, &rr);
+  T rn_lo = zero, rn_hi = zero;
+  if (alive && col && w > 0) faces_ok &= ll_load(face_slot(seqB, w - 1, 1), seqB, &rn_lo);
+  if (alive && col && w < G - 1) faces_ok &= ll_load(face_slot(seqB, w + 1, 0), seqB, &rn_hi);
   T p_lo = rn_lo, p_hi = rn_hi;
 #pragma unroll
   for (int i = 0; i < S; ++i) {
@@ -1310,10 +1378,10 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
         loc = sc_fma(pc, a, loc);
       }
       part = block_sum_fast(loc, red, red_phase);
-      if (t == 0) xchg_store(partA + w, part);
-      grid_publish(flagA, w, ++seqA);
+      ++seqA;
+      if (t == 0) ll_store(part_slots(0, seqA) + 2 * w, part, seqA);
       T pap;
-      if (!grid_collect(flagA, partA, G, seqA, lds_part, lds_flag, &pap)) { alive = false; break; }
+      if (!grid_collect_ll(part_slots(0, seqA), G, seqA, lds_partA, lds_flag, &pap)) { alive = false; break; }
       const T alpha = sc_div(rr, pap);
       const T nalpha = sc_neg(alpha);
       loc = zero;
@@ -1325,18 +1393,20 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
         loc = sc_fma(rv, rv, loc);
       }
       part = block_sum_fast(loc, red, red_phase);
-      if (t == 0) xchg_store(partB + w, part);
-      if (col) { xchg_store(face_lo + t, r[0]); xchg_store(face_hi + t, last_of(r)); }
-      grid_publish(flagB, w, ++seqB);
+      ++seqB;
+      if (t == 0) ll_store(part_slots(1, seqB) + 2 * w, part, seqB);
+      if (col) { ll_store(face_slot(seqB, w, 0), r[0], seqB); ll_store(face_slot(seqB, w, 1), last_of(r), seqB); }
       T rrn;
-      if (!grid_collect(flagB, partB, G, seqB, lds_part, lds_flag, &rrn)) { alive = false; break; }
-      rn_lo = (col && w > 0) ? xchg_load(xface + (size_t)(w - 1) * 2048 + 1024 + t) : zero;
-      rn_hi = (col && w < G - 1) ? xchg_load(xface + (size_t)(w + 1) * 2048 + t) : zero;
+      // (polling the faces in the same phase as the sums was slower: a thousand spinning threads delay the eight that matter)
+      if (!grid_collect_ll(part_slots(1, seqB), G, seqB, lds_partB, lds_flag, &rrn)) { alive = false; break; }
       const double res = sc_norm_from_dot(rrn);
       if (!(res > tol * res0)) { ++it; break; }
+      // the neighbouring slabs' faces of r: asked for here, looked at after this slab's own update of p (their trip, 0.4 -
+      // 0.8 us when waited for on the spot, hides behind it)
+      const evomg_u64* slot_lo = face_slot(seqB, w > 0 ? w - 1 : 0, 1);
+      const evomg_u64* slot_hi = face_slot(seqB, w < G - 1 ? w + 1 : G - 1, 0);
+      const LLPeek peek_lo = ll_peek(slot_lo), peek_hi = ll_peek(slot_hi);
       const T beta = sc_div(rrn, rr);
-      p_lo = sc_fma(beta, p_lo, rn_lo);
-      p_hi = sc_fma(beta, p_hi, rn_hi);
 #pragma unroll
       for (int i = 0; i < S; ++i) {
         pr[i] = sc_fma(beta, pr[i], r[i]);
@@ -1344,6 +1414,10 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
       }
       rr = rrn;
       __syncthreads();
+      if (col && w > 0) faces_ok &= ll_finish(peek_lo, slot_lo, seqB, &rn_lo);
+      if (col && w < G - 1) faces_ok &= ll_finish(peek_hi, slot_hi, seqB, &rn_hi);
+      p_lo = sc_fma(beta, p_lo, rn_lo);
+      p_hi = sc_fma(beta, p_hi, rn_hi);
     }
   }
 #pragma unroll
@@ -1359,4 +1433,5 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
     if (w == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
     if (!alive) info[1] = 1;
   }
+  if (!faces_ok) info[1] = 1;
 }

@@ -24,9 +24,7 @@
     if (norm_partials_) (void)hipFree(norm_partials_);
     if (xf_rhs_spare_) (void)hipFree(xf_rhs_spare_);
     if (xf_lane_sums_) (void)hipFree(xf_lane_sums_);
-    if (cg_xpart_) (void)hipFree(cg_xpart_);
-    if (cg_xface_) (void)hipFree(cg_xface_);
-    if (cg_flags_) (void)hipFree(cg_flags_);
+    if (cg_ll_) (void)hipFree(cg_ll_);
     if (kcg_state_) (void)hipFree(kcg_state_);
     if (kb_state_) (void)hipFree(kb_state_);
     if (kb_scal_) (void)hipFree(kb_scal_);
@@ -62,9 +60,8 @@
     HIP_TRY(hipMalloc(&dinfo_, sizeof(int) * 4));
     HIP_TRY(hipMemset(dinfo_, 0, sizeof(int) * 4));
     // multi-workgroup CG exchange area: [2][G] partial sums, [G][2][1024] face planes, [2][G] sequence flags
-    HIP_TRY(hipMalloc(&cg_xpart_, sizeof(T) * 2 * EVOMG_CG_GROUPS));
-    HIP_TRY(hipMalloc(&cg_xface_, sizeof(T) * EVOMG_CG_GROUPS * 2048));
-    HIP_TRY(hipMalloc(&cg_flags_, sizeof(unsigned) * 2 * EVOMG_CG_GROUPS));
+    HIP_TRY(hipMalloc(&cg_ll_, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS));
+    HIP_TRY(hipMemset(cg_ll_, 0, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS));
     HIP_TRY(hipHostMalloc(&hscalar_, sizeof(T) * 8));
     const int align = 128 / (int)sizeof(T);
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {

@@ -72,18 +72,25 @@
       // 33^3: eight co-resident workgroups (evomg_cg_multi_wg3d); the canonical reduction order of this grid is the
       // grouped one, so there is no single-workgroup alternative
       const KrylovOwn own = krylov_own<3>(lv.g.n);
-      const size_t lds_bytes = sizeof(T) * (34 + EVOMG_CG_GROUPS + (size_t)EVOMG_CG_SLAB * (own.m + 2) * (own.m + 2));
+      const size_t lds_bytes = sizeof(T) * (34 + 2 * EVOMG_CG_GROUPS + (size_t)EVOMG_CG_SLAB * (own.m + 2) * (own.m + 2));
       auto kern = evomg_cg_multi_wg3d<double>;   // complex problems are 2D only
       if (!cg_multi_attr_set_) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_));
         cg_multi_attr_set_ = true;
       }
       cg_multi_used_ = true;
-      HIP_TRY(hipMemsetAsync(cg_flags_, 0, sizeof(unsigned) * 2 * EVOMG_CG_GROUPS, stream_));
-      const int blocks = EVOMG_CG_GROUPS;
+      // sequence numbers of the exchange words: one launch uses at most max_iterations + 1 per exchange kind, above a base
+      // that only grows; before it could wrap, the words are cleared (stream-ordered) and counting starts over
+      const unsigned span = (unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u;
+      if (cg_seq_base_ > 0x7fffffffu - span) {
+        HIP_TRY(hipMemsetAsync(cg_ll_, 0, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS, stream_));
+        cg_seq_base_ = 0;
+      }
+      const int blocks = EVOMG_CG_GROUPS * cg_stride_;
       if constexpr (!scalar_traits<T>::is_complex)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
-                           prob_.cgs_target_res_reduction, dinfo_, cg_xpart_, cg_xface_, cg_flags_);
+                           prob_.cgs_target_res_reduction, dinfo_, cg_ll_, cg_seq_base_, cg_stride_);
+      cg_seq_base_ += span;
       apply_bc(L, x);
     } else if (!scalar_traits<T>::is_complex && kcg_enabled_ &&
                (dim_ == 2 ? krylov_cg_per_launch<2>(lv.g.n) : krylov_cg_per_launch<3>(lv.g.n))) {
@@ -208,6 +215,19 @@
     (void)lds_bytes;
     return EVOMG_OK;
   }
+  // evomg_cg_reg2d<.., POW2>: equal off-centre coefficients cc = +-2^k and a centre c0 = +-2^j cc
+  bool cg_reg2d_pow2(const Stencil<T>& st) const {
+    if constexpr (scalar_traits<T>::is_complex) return false;
+    else {
+      if (!pow2_fma_ || dim_ != 2) return false;
+      int ex = 0;
+      const double m1 = frexp(st.c[1], &ex);
+      if (!(m1 == 0.5 || m1 == -0.5) || ex < -400 || ex > 400) return false;
+      if (st.c[2] != st.c[1] || st.c[3] != st.c[1] || st.c[4] != st.c[1]) return false;
+      const double m0 = frexp(st.c[0], &ex);
+      return (m0 == 0.5 || m0 == -0.5) && ex > -400 && ex < 400;
+    }
+  }
   template <int RT, int E> int launch_cg_reg2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
     const size_t lds_bytes = (size_t)(cg_reg2d_lds_elems(RT, E) + 32) * sizeof(T);
     // the kernel assumes one band per wave of the 512-thread workgroup and exactly RT rows per band
@@ -217,6 +237,16 @@
     constexpr int kMaskLast = RT > 1 ? RT - 1 : 0;
     const bool nearly_full = last_rows >= kMaskLast;
     const dim3 one(1), thr(own.lanes);
+    if constexpr (RT == 16 && E == 2 && !scalar_traits<T>::is_complex) {
+      if (nearly_full && cg_reg2d_pow2(lv.st)) {           // 129^2 Poisson: the headline's coarse solve
+        auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast, true>;
+        int rc = set_lds_limit(kern, 2 * slot + 2, lds_bytes);
+        if (rc != EVOMG_OK) return rc;
+        hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+        *launched = true;
+        return EVOMG_OK;
+      }
+    }
     if (nearly_full) {
       auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast>;
       int rc = set_lds_limit(kern, 2 * slot, lds_bytes);

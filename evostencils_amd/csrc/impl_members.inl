@@ -51,9 +51,9 @@
   bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
   T* norm_partials_ = nullptr;
   size_t norm_partials_cap_ = 0;
-  T* cg_xpart_ = nullptr;
-  T* cg_xface_ = nullptr;
-  unsigned* cg_flags_ = nullptr;
+  unsigned long long* cg_ll_ = nullptr;   // exchange words of evomg_cg_multi_wg3d (EVOMG_CG_LL_WORDS, zeroed at creation)
+  unsigned cg_seq_base_ = 0;              // sequence numbers handed out so far: they never repeat between launches
+  int cg_stride_ = getenv("EVOMG_CG_SPREAD_XCDS") ? 1 : 8;   // 8: the eight workgroups on ONE XCD (every eighth block of the grid)
   bool cg_multi_attr_set_ = false;
   bool cg_multi_used_ = false;
   bool cg_lds_attr_set_[24] = {};
