@@ -372,8 +372,10 @@ def other_configs_section(local_rank):
                                                                "post-smoothing launch also folds the prolongation in)"),
                               ("residual_restrict", abi.OP_RESIDUAL, "residual + full weighting, residual never written "
                                                                      "(evomg_tile3d_residual_restrict)"),
-                              ("residual_norm", abi.PROF_LOOP_NORM, "the solver loop's residual + norm pass (evomg_tile3d<RESNORM> + "
-                                                                     "two reduction launches)"),
+                              ("residual_norm", abi.PROF_LOOP_NORM, "the solver loop's residual norm: it rides on the COMING cycle's first "
+                                                                     "double sweep, launched speculatively (evomg_tile3d_twice<NORM0>: x, f read "
+                                                                     "once for the norm and both sweeps, the swept field written) + two "
+                                                                     "reduction launches; this launch is also one of double_sweep's"),
                               ("coarse_solve", abi.OP_COARSE_SOLVE, "CG on 33^3, eight rendezvousing workgroups (evomg_cg_multi_wg3d)")):
         h.profile_begin(opcode, lo if opcode == abi.OP_COARSE_SOLVE else hi)
         solve = h.evaluate(ops, 1, 0, 0)

@@ -18,6 +18,7 @@
 // FN(apply_st3): results are bit-identical to every other 3D Jacobi / residual kernel of this library.
 #pragma once
 #include "evomg_strip.h"
+#include <type_traits>
 
 #define EVOMG_TILE3D_TY 4
 // two-cell block-Jacobi shapes as tile modes (K3): the tile's 2 x 2 local system is eliminated once on the host
@@ -468,12 +469,19 @@ template <typename T> struct TwiceProlong {
   Geo gc;
   double om;
 };
-template <typename T, int MODE, int NW, int NT, bool PRO = false, bool POW2 = false>
+// NORM0 (round 4): the kernel also leaves the canonical partial sums of || f - A x ||^2 of its INPUT x in norm_aux (the
+// layout and order of evomg_tile3d<TILE_RESNORM>: one wave sum per strip, row and plane; every inner node counted once, by the
+// workgroup that stores it) — the solver loop's residual norm of the iterate rides on the first (double) sweep of the NEXT
+// cycle, launched speculatively (impl_solvers.inl: norm_on_head), instead of a pass of its own over x and f. The residual
+// comes from the rows the first sweep holds anyway (residual7p: the arithmetic of the residual kernels), seven more
+// multiply-adds per node on a launch that waits for memory.
+template <typename T, int MODE, int NW, int NT, bool PRO = false, bool POW2 = false, bool NORM0 = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
                    double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl,
-                   TwiceProlong<T> pro, int xpitch) {
+                   TwiceProlong<T> pro, int xpitch, T* __restrict__ norm_aux) {
   static_assert(MODE == STRIP_JACOBI || MODE == TILE_BLOCK211, "two fused sweeps: point Jacobi and (2,1,1) blocks");
+  static_assert(!(PRO && NORM0), "the norm is that of the sweeps' input as it lies in memory");
   constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
   __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x of the next centre plane
   __shared__ __attribute__((aligned(16))) T edge_y[2][NW][2][128];   // y1 of the current centre plane
@@ -561,9 +569,13 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   // one sweep at one row: centre pair c with its south / north / down / up pairs and right-hand side; non-inner nodes keep
   // their value. Whole wave (DPP shifts inside).
   auto sweep = [&](const Pair<T>& c, const Pair<T>& s, const Pair<T>& nn, const Pair<T>& dn, const Pair<T>& up,
-                   const Pair<T>& fk, bool node_rows_inner) -> Pair<T> {
+                   const Pair<T>& fk, bool node_rows_inner, auto want_residual, Pair<T>& res) -> Pair<T> {
     Pair<T> out = c;
     const T wa = from_left(c.b), eb = from_right(c.a);
+    if constexpr (decltype(want_residual)::value) {
+      res.a = residual7p<POW2>(st, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a);
+      res.b = residual7p<POW2>(st, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b);
+    }
     if constexpr (MODE == STRIP_JACOBI) {
       const T ra = relax7p<POW2>(st, cd0, c.a, wa, c.b, s.a, nn.a, dn.a, up.a, fk.a, om, omm);
       const T rb = relax7p<POW2>(st, cd0, c.b, c.a, eb, s.b, nn.b, dn.b, up.b, fk.b, om, omm);
@@ -657,7 +669,22 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
     for (int t = 0; t < TY; ++t) {
       const int row = row0 + t;
       const Pair<T> s = (t == 0) ? hs : xc[t > 0 ? t - 1 : 0], nn = (t == TY - 1) ? hn : xc[t < TY - 1 ? t + 1 : t];
-      pc[t] = sweep(xc[t], s, nn, xb[t], xa[t], fc[t], plane_inner && row >= 1 && row <= n - 2);
+      Pair<T> res = zpair;
+      pc[t] = sweep(xc[t], s, nn, xb[t], xa[t], fc[t], plane_inner && row >= 1 && row <= n - 2, std::integral_constant<bool, NORM0>{}, res);
+      if constexpr (NORM0) {
+        // (row, plane) counted by this workgroup: the ones it stores (wave-uniform)
+        const bool counts = k >= z0 && k < z1 && row >= 1 && row <= n - 2 && row >= R0 + 1 && (row <= R0 + H - 2 || top_group);
+        if (counts) {
+          T sq = zero;
+          if (store_lane && inner_a) sq = sc_add(sq, sc_mul(res.a, res.a));
+          if (store_lane && inner_b) sq = sc_add(sq, sc_mul(res.b, res.b));
+          // the canonical wave holds column pair c0 = strip * xpitch - 2 + 2 l in lane l: with two halo lanes this wave's
+          // lanes sit one to the right of it
+          if constexpr (HALO == 2) sq = from_right(sq);
+          sq = wave_sum(sq);
+          if (lane == 0) norm_aux[((long)(k - 1) * (n - 2) + (row - 1)) * n_strips + strip] = sq;
+        }
+      }
     }
     park(edge_y, k & 1, pc[0], pc[TY - 1]);
     // ---- second sweep: y2 on plane k-1, own rows, from y1 on the planes k-2, k-1, k ----
@@ -670,7 +697,8 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
       const Pair<T> s = (t == 0) ? ys1 : p1[t > 0 ? t - 1 : 0];
       // the boundary row above the topmost workgroup: y1 = x there
       const Pair<T> nn = (t == TY - 1) ? ((w == NW - 1 && top_group) ? hn_prev : yn1) : p1[t < TY - 1 ? t + 1 : t];
-      const Pair<T> out = sweep(p1[t], s, nn, p2[t], pc[t], fb[t], bplane_inner && row >= 1 && row <= n - 2);
+      Pair<T> unused;
+      const Pair<T> out = sweep(p1[t], s, nn, p2[t], pc[t], fb[t], bplane_inner && row >= 1 && row <= n - 2, std::false_type{}, unused);
       const bool row_stored = row >= 1 && row <= n - 2 && row >= R0 + 1 && (row <= R0 + H - 2 || top_group);
       if (store_lane && bplane_stored && row_stored) store_pair(y + plane * kb2 + pitch * row + c0, out);
     }

@@ -195,7 +195,7 @@
     return EVOMG_OK;
   }
 
-  int exec_twice(const evomg_op_t& sm, const evomg_op_t* pr = nullptr) {
+  int exec_twice(const evomg_op_t& sm, const evomg_op_t* pr = nullptr, T* norm_aux = nullptr) {
     const int L = sm.level;
     Level<T>& lv = lv_[L];
     T* x = fieldptr(L, sm.dst);
@@ -208,11 +208,11 @@
         const BlockPlan<T> pl = make_block_plan<T, 3>(lv.st, 2, 1, 1);
         const T* cz = pr ? fieldptr(L - 1, pr->src0) : nullptr;
         launch_tile3d_twice<TILE_BLOCK211>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{pl.fac[1][0], pl.upper[0][1], pl.pivot[0], pl.pivot[1]},
-                                           cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g, pr ? pr->omega : 0.0);
+                                           cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g, pr ? pr->omega : 0.0, norm_aux);
       } else {
         const T* cz = pr ? fieldptr(L - 1, pr->src0) : nullptr;
         launch_tile3d_twice<STRIP_JACOBI>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{}, cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g,
-                                          pr ? pr->omega : 0.0);
+                                          pr ? pr->omega : 0.0, norm_aux);
       }
     }
     advance(lv, L, sm, x, y);      // two sweeps, one pass: the result lives in the spare array -> ONE swap

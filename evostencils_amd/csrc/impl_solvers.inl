@@ -71,7 +71,8 @@
     const double t0 = wall_ms();
     T d;
     if (!norm_event_) HIP_TRY(hipEventCreateWithFlags(&norm_event_, hipEventDisableTiming));
-    bool ahead = false, res_stale = false;
+    int ahead = 0;                // ops of the coming iteration that have already been launched (speculatively)
+    bool res_stale = false;
     // residual + norm of the current iterate: launched, the scalar copied back asynchronously, an event recorded
     auto residual_norm_launch_all = [&]() -> int {
       int rc = EVOMG_OK;
@@ -105,8 +106,8 @@
     // first sweep (+ residual + restriction) on the finest level as ONE speculative launch per iteration
     const CrossPlan xplan = cross_plan(ops, n_ops);
     bool head_done = false;       // ops[0 .. head_len) of the coming iteration ran inside the previous iteration's cross launch
-    auto speculate = [&](bool* launched) -> int {
-      *launched = false;
+    auto speculate = [&](int* launched) -> int {
+      *launched = 0;
       if (xplan.ok) return EVOMG_OK;
       if (!speculate_ || n_ops < 1 || !smoother_is_out_of_place(ops[0])) return EVOMG_OK;
       // a sweep that fuses with the residual + restriction behind it is worth more than the overlap (and the fused
@@ -118,8 +119,42 @@
       saved_mirror = lv_[l0].alt_mirror;
       saved_x = fieldptr(l0, ops[0].dst);
       const int rc = exec(ops[0]);
-      *launched = rc == EVOMG_OK;
+      *launched = rc == EVOMG_OK ? 1 : 0;
       return rc;
+    };
+    // 3D, a cycle that opens with a double sweep on the iterate (C4: V(2,2)): the norm of the CURRENT iterate rides on that
+    // double sweep of the COMING cycle (evomg_tile3d_twice<.., NORM0>), launched speculatively like the sweep above — x and f
+    // are read once for both instead of once by the norm pass (439 us at 513^3) and once by the sweeps. Should the norm
+    // say "stop", the pointer swap is undone; the iterate was only read.
+    auto norm_on_head = [&](int* launched) -> int {
+      *launched = 0;
+      if (!head_norm_ || xplan.ok || n_ops < 2 || !norm_fused3d(lv.g) || !fuse_enabled_ || !fusable_twice(ops, n_ops, 0)) return EVOMG_OK;
+      const evomg_op_t& sm = ops[0];
+      if (sm.level != L || canon(L, sm.dst) != EVOMG_F_SOL || canon(L, sm.src1) != EVOMG_F_RHS) return EVOMG_OK;
+      if (!loop_residual_is_dead(ops, n_ops) || !twice_strips_canonical(lv.g, sm.block[0] == 2)) return EVOMG_OK;
+      const Geo& g = lv.g;
+      const int strips = (g.n + EVOMG_STRIP_COLS - 1) / EVOMG_STRIP_COLS;
+      const long count = (long)(g.n - 2) * (g.n - 2) * strips;
+      int rc = ensure_norm_partials((size_t)count + kDotBlocks);
+      if (rc != EVOMG_OK) return rc;
+      // profiling: the launch counts as the loop's norm pass under EVOMG_PROF_LOOP_NORM (with its two reduction launches) and
+      // as a smoothing launch under the sweeps' opcode; it reads x and f and writes the swept field either way
+      const bool timed_norm = prof_opcode_ == EVOMG_PROF_LOOP_NORM && prof_level_ == L;
+      const bool timed_sm = !timed_norm && prof_matches(sm);
+      saved_alt = lv.alt;
+      saved_mirror = lv.alt_mirror;
+      saved_x = fieldptr(L, sm.dst);
+      if ((timed_norm || timed_sm) && (rc = prof_open()) != EVOMG_OK) return rc;
+      if ((rc = exec_twice(sm, nullptr, norm_partials_)) != EVOMG_OK) return rc;
+      if (timed_sm && (rc = prof_close(algorithmic_bytes(sm))) != EVOMG_OK) return rc;
+      hipLaunchKernelGGL((evomg_sum_stage1<T>), dim3(kDotBlocks), dim3(256), 0, stream_, norm_partials_, count, norm_partials_ + count);
+      hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_ + count, kDotBlocks, dscalar_);
+      if (timed_norm && (rc = prof_close(3.0 * sizeof(T) * pow((double)g.n, dim_))) != EVOMG_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+      HIP_TRY(hipEventRecord(norm_event_, stream_));
+      res_stale = true;
+      *launched = 2;
+      return EVOMG_OK;
     };
     auto undo_speculation = [&]() {
       const int l0 = ops[0].level;
@@ -132,9 +167,12 @@
       d = hscalar_[0];
       return EVOMG_OK;
     };
-    int rc = residual_norm_launch_all();
+    int rc = prob_.max_iterations >= 1 ? norm_on_head(&ahead) : EVOMG_OK;
     if (rc != EVOMG_OK) return rc;
-    if ((rc = speculate(&ahead)) != EVOMG_OK) return rc;
+    if (!ahead) {
+      if ((rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
+      if ((rc = speculate(&ahead)) != EVOMG_OK) return rc;
+    }
     if ((rc = wait_norm()) != EVOMG_OK) return rc;
     const double res0 = sc_norm_from_dot(d);
     if (hist && nh < cap) hist[nh] = res0;
@@ -147,14 +185,14 @@
         bool norm_rode_along = false;
         // not in the last iteration the loop may run: there is no next cycle to start
         const bool cross = xplan.ok && it < prob_.max_iterations;
-        const int first = head_done ? xplan.head_len : (ahead ? 1 : 0);
+        const int first = head_done ? xplan.head_len : ahead;
         head_done = false;
         if (cross) {
           if ((rc = exec_program(ops, n_ops, /*cyclic=*/true, first, nullptr, n_ops - xplan.tail_len)) != EVOMG_OK) return rc;
           if ((rc = launch_cross(ops, n_ops, xplan)) != EVOMG_OK) return rc;
           norm_rode_along = true;
         } else rc = exec_program(ops, n_ops, /*cyclic=*/true, first, &norm_rode_along);
-        ahead = false;
+        ahead = 0;
         if (rc != EVOMG_OK) return rc;
         if (norm_rode_along) {
           // the last sweep left the canonical partial sums behind: reduce them, no residual sweep
@@ -164,8 +202,12 @@
           hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, dscalar_);
           HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
           HIP_TRY(hipEventRecord(norm_event_, stream_));
-        } else if ((rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
-        if (it < prob_.max_iterations && (rc = speculate(&ahead)) != EVOMG_OK) return rc;
+        } else {
+          // not after the last iteration the loop may run: there is no coming cycle for the norm to ride on
+          if (it < prob_.max_iterations && (rc = norm_on_head(&ahead)) != EVOMG_OK) return rc;
+          if (!ahead && (rc = residual_norm_launch_all()) != EVOMG_OK) return rc;
+        }
+        if (!ahead && it < prob_.max_iterations && (rc = speculate(&ahead)) != EVOMG_OK) return rc;
         if ((rc = wait_norm()) != EVOMG_OK) return rc;
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;

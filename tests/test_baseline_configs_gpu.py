@@ -165,6 +165,42 @@ def test_c4_cycle_at_129_both_semantics_against_the_oracle(native, semantics):
     ho.close()
 
 
+@pytest.mark.parametrize("smoother", ["block211", "jacobi"])
+def test_c4_launch_plan_at_129_against_the_oracle(native, monkeypatch, smoother):
+    """C4's launch plan — double sweeps in one pass, the prolongation folded into the post-smoothing pair, residual +
+    restriction in one pass, and the loop's residual norm riding on the COMING cycle's first double sweep (round 4:
+    evomg_tile3d_twice<NORM0>, launched speculatively) — runs from 257^3 by default; forced onto 129^3 here, where the oracle
+    answers in seconds. Histories bit-identical to the oracle's and to the plan with a norm pass of its own."""
+    from oracle import oracle
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "129")
+    lo, hi = 5, 7
+    pd = dataclasses.replace(problems.poisson_3d(lo, hi), max_iterations=20)
+    ops = vcycle(lo, hi, 2, 2, _block211 if smoother == "block211" else _jacobi)
+    hg = native.create(pd, jacobi_semantics="textbook")
+    ho = oracle.create(pd, jacobi_semantics="textbook")
+    # the plan is the one meant: the loop norm is timed as ONE pass that also writes the swept field (3 fields, not 2)
+    hg.profile_begin(abi.PROF_LOOP_NORM, hi)
+    a = hg.evaluate(ops, 1, 0, 128)
+    prof = hg.profile_end()
+    n = (1 << hi) + 1
+    # (one norm per iteration + the initial one; the norm after the last iteration the loop may run has no coming cycle)
+    fields = prof.bytes * prof.launches / (8.0 * n ** 3)
+    assert prof.launches == a.n_iterations + 1 and abs(fields - (3.0 * a.n_iterations + 2.0)) < 1e-6
+    b = ho.evaluate(ops, 1, 0, 128)
+    assert a.status == b.status and a.n_iterations == b.n_iterations
+    assert np.array_equal(a.history, b.history)
+    assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+    assert np.array_equal(hg.get_field(hi, abi.F_RES), ho.get_field(hi, abi.F_RES))
+    hg.close()
+    monkeypatch.setenv("EVOMG_NO_HEAD_NORM", "1")
+    hp = native.create(pd, jacobi_semantics="textbook")
+    c = hp.evaluate(ops, 1, 0, 128)
+    assert np.array_equal(a.history, c.history) and a.n_iterations == c.n_iterations
+    assert np.array_equal(hp.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+    hp.close()
+    ho.close()
+
+
 def test_c4_full_size_in_the_reference_pipelines_semantics(native):
     """configs[3] at 513^3 under `exastencils-v1.1`: every block-Jacobi sweep is launched (and timed) but never advanced,
     so the residual history is bit for bit the history of the same cycle with the smoothers removed; the candidate does not
