@@ -233,7 +233,7 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
             T sq = scalar_traits<T>::zero();
             if (valid && inner_a) sq = sc_add(sq, sc_mul(ra, ra));
             if (valid && inner_b) sq = sc_add(sq, sc_mul(rb, rb));
-            sq = wave_sum(sq);                                  // whole wave
+            sq = wave_sum_fast(sq);                                  // whole wave
             if (row <= n - 2) {
               if (lane == 0) aux[((long)(k - 1) * (n - 2) + (row - 1)) * n_strips + strip] = sq;
               if constexpr (MODE == TILE_RESNORM_W) {
@@ -681,7 +681,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
           // the canonical wave holds column pair c0 = strip * xpitch - 2 + 2 l in lane l: with two halo lanes this wave's
           // lanes sit one to the right of it
           if constexpr (HALO == 2) sq = from_right(sq);
-          sq = wave_sum(sq);
+          sq = wave_sum_fast(sq);
           if (lane == 0) norm_aux[((long)(k - 1) * (n - 2) + (row - 1)) * n_strips + strip] = sq;
         }
       }
