@@ -201,6 +201,40 @@ def test_c4_launch_plan_at_129_against_the_oracle(native, monkeypatch, smoother)
     ho.close()
 
 
+GEOMETRIES = {
+    "balanced": {},
+    "depth_12": {"EVOMG_STRIP_PLANES": "12"},
+    "depth_44": {"EVOMG_STRIP_PLANES": "44"},
+    "depth_capped_20": {"EVOMG_BALANCE3D": "20"},
+    "fixed_16_planes": {"EVOMG_NO_BALANCE3D": "1"},
+}
+
+
+@pytest.mark.parametrize("geometry", sorted(GEOMETRIES))
+@pytest.mark.parametrize("smoother", ["rbgs", "block211"])
+def test_3d_tile_geometries_are_bit_identical_to_the_oracle(native, monkeypatch, smoother, geometry):
+    """The launch geometry of the 3D tiles (round 4: z-chunk depth picked by workgroup balance, strips of equal width) must
+    not show in a single bit: the eight-wave tiles 513^3 runs on, forced onto 129^3 with several chunk depths, against the
+    oracle — V(2,1) cycles, so that single sweeps, double sweeps, fused residual + restriction, the folded prolongation and
+    the loop norm all take part."""
+    from oracle import oracle
+    monkeypatch.setenv("EVOMG_STRIP3D_MIN_N", "65")
+    monkeypatch.setenv("EVOMG_TILE3D_WAVES", "8")
+    for k, v in GEOMETRIES[geometry].items():
+        monkeypatch.setenv(k, v)
+    lo, hi = 5, 7
+    pd = dataclasses.replace(problems.poisson_3d(lo, hi), max_iterations=6)
+    rb = lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.15)
+    ops = vcycle(lo, hi, 2, 1, rb if smoother == "rbgs" else _block211)
+    hg = native.create(pd, jacobi_semantics="textbook")
+    ho = oracle.create(pd, jacobi_semantics="textbook")
+    a, b = hg.evaluate(ops, 1, 0, 16), ho.evaluate(ops, 1, 0, 16)
+    assert a.n_iterations == b.n_iterations and np.array_equal(a.history, b.history)
+    assert np.array_equal(hg.get_field(hi, abi.F_SOL), ho.get_field(hi, abi.F_SOL))
+    hg.close()
+    ho.close()
+
+
 def test_c4_full_size_in_the_reference_pipelines_semantics(native):
     """configs[3] at 513^3 under `exastencils-v1.1`: every block-Jacobi sweep is launched (and timed) but never advanced,
     so the residual history is bit for bit the history of the same cycle with the smoothers removed; the candidate does not
