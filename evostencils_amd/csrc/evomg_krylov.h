@@ -481,10 +481,13 @@ __host__ __device__ inline long cg_reg2d_lds_elems(int rt, int e) { return 32 + 
 // correctly rounded quotient scaled, alpha itself is recovered by one exact product per thread, and r - (cc alpha) t
 // is the very real number r - alpha (A p). Bit-identical to the general form (barring overflow / underflow of values
 // near 1e+-300, which a residual norm never reaches); 32 of ~550 vector instructions per wave and iteration fewer.
-template <typename T, int R, int E, int MASK_FROM, bool POW2 = false>
+// XZERO / b_copy (round 4): the COPY `gen_rhs = RHS` and the SET_ZERO of the solution in front of the solve, folded in as in
+// the one-wave kernels below — b is the copy's source, the workgroup writes the copy (the whole array, padding included),
+// the solve starts from x = 0 without reading x (r = b): two launches per cycle fewer.
+template <typename T, int R, int E, int MASK_FROM, bool POW2 = false, bool XZERO = false>
 __global__ void __launch_bounds__(512)
 evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
-               double tol, int* __restrict__ info) {
+               double tol, int* __restrict__ info, T* __restrict__ b_copy = nullptr) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
   T* row_seam = red + 32;                          // [wave][0: first row, 1: row R-1][element][lane]
@@ -510,6 +513,10 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
   XRow* const myx = reinterpret_cast<XRow*>(xs) + tid;     // [row][thread]
   const long c0 = gidx<2>(g, min(ix0, own.m - 1) + 1, min(iy0, own.m - 1) + 1, 0);
 
+  if (b_copy) {
+    const long elems = (long)g.pitch * g.n;
+    for (long q = tid; q < elems; q += 512) b_copy[q] = b[q];
+  }
   T r[R][E], p[R][E], ap[R][E];
   T loc = zero;
   // branch-free: slots that are not nodes of this thread read a clamped (valid) address and are masked to zero
@@ -519,10 +526,16 @@ evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b,
     for (int e = 0; e < E; ++e) {
       const bool ok = ok_e[e] && i < rows;
       const long c = c0 + (long)g.pitch * (i < rows ? i : 0) + (ok_e[e] ? e : 0);
-      const T v = ok ? sc_sub(b[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
+      T v;
+      if constexpr (XZERO) {
+        v = ok ? b[c] : zero;
+        myx[i * 512].v[e] = zero;
+      } else {
+        v = ok ? sc_sub(b[c], apply_stencil_fma<T, 2>(st, x, g, c)) : zero;
+        myx[i * 512].v[e] = x[c];
+      }
       r[i][e] = v;
       p[i][e] = v;
-      myx[i * 512].v[e] = x[c];
       loc = sc_fma(v, v, loc);
     }
     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);

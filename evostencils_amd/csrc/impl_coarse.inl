@@ -28,7 +28,13 @@
       if constexpr (!scalar_traits<T>::is_complex) {
         const T* src = fieldptr(L, copy_op->src0);
         T* cgs = fieldptr(L, EVOMG_F_CGS_RHS);
-        launch_cg_wave2d<true>(lv, x, src, r, cgs);
+        if (krylov_own<2>(lv.g.n, true).wave) launch_cg_wave2d<true>(lv, x, src, r, cgs);
+        else {
+          bool launched = false;
+          const int rc = launch_cg_reg2d_folded(lv, x, src, r, cgs, &launched);
+          if (rc != EVOMG_OK) return rc;
+          if (!launched) return invalid("coarse_solve: no folded form for this grid");
+        }
         bnd_zero_[L][canon(L, copy_op->dst)] = bnd_zero_[L][canon(L, copy_op->src0)];     // the COPY's bookkeeping
         lv.alt_mirror = nullptr;
         apply_bc(L, x);
@@ -228,7 +234,10 @@
       return (m0 == 0.5 || m0 == -0.5) && ex > -400 && ex < 400;
     }
   }
-  template <int RT, int E> int launch_cg_reg2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched) {
+  // b_copy != nullptr: the folded form (fusable_copy_zero_solve) — b is the COPY's source, the solve starts from x = 0; only
+  // the variants for nearly full last bands exist in that form (every 2^k + 1 grid), `launched` stays false otherwise
+  template <int RT, int E> int launch_cg_reg2d(const Level<T>& lv, T* x, const T* b, T* r, const KrylovOwn& own, int slot, bool* launched,
+                                               T* b_copy = nullptr) {
     const size_t lds_bytes = (size_t)(cg_reg2d_lds_elems(RT, E) + 32) * sizeof(T);
     // the kernel assumes one band per wave of the 512-thread workgroup and exactly RT rows per band
     if (lds_bytes > max_lds_ || own.lanes != 512 || own.bands != 8 || own.R != RT || E != (own.pair ? 2 : 1)) return EVOMG_OK;
@@ -239,24 +248,40 @@
     const dim3 one(1), thr(own.lanes);
     if constexpr (RT == 16 && E == 2 && !scalar_traits<T>::is_complex) {
       if (nearly_full && cg_reg2d_pow2(lv.st)) {           // 129^2 Poisson: the headline's coarse solve
-        auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast, true>;
-        int rc = set_lds_limit(kern, 2 * slot + 2, lds_bytes);
-        if (rc != EVOMG_OK) return rc;
-        hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+        if (b_copy) {
+          auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast, true, true>;
+          int rc = set_lds_limit(kern, 12 + 2 * slot + 1, lds_bytes);
+          if (rc != EVOMG_OK) return rc;
+          hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, b_copy);
+        } else {
+          auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast, true>;
+          int rc = set_lds_limit(kern, 2 * slot + 2, lds_bytes);
+          if (rc != EVOMG_OK) return rc;
+          hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, (T*)nullptr);
+        }
         *launched = true;
         return EVOMG_OK;
       }
+    }
+    if (b_copy) {
+      if (!nearly_full) return EVOMG_OK;
+      auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast, false, true>;
+      int rc = set_lds_limit(kern, 12 + 2 * slot, lds_bytes);
+      if (rc != EVOMG_OK) return rc;
+      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, b_copy);
+      *launched = true;
+      return EVOMG_OK;
     }
     if (nearly_full) {
       auto kern = evomg_cg_reg2d<T, RT, E, kMaskLast>;
       int rc = set_lds_limit(kern, 2 * slot, lds_bytes);
       if (rc != EVOMG_OK) return rc;
-      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, (T*)nullptr);
     } else {
       auto kern = evomg_cg_reg2d<T, RT, E, 0>;
       int rc = set_lds_limit(kern, 2 * slot + 1, lds_bytes);
       if (rc != EVOMG_OK) return rc;
-      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      hipLaunchKernelGGL(kern, one, thr, lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, (T*)nullptr);
     }
     *launched = true;
     return EVOMG_OK;
@@ -272,6 +297,31 @@
         hipLaunchKernelGGL((evomg_cg_wave2d<T, XZERO, 0>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, b_copy,
                            prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
     }
+  }
+  // the register CG in its folded form (COPY + SET_ZERO inside the launch): which grids have it, and the launch
+  bool cg_reg2d_folds(const Geo& g) const {
+    if (scalar_traits<T>::is_complex || dim_ != 2 || !use_reg_krylov_) return false;
+    const KrylovOwn own = krylov_own<2>(g.n, true);
+    if (own.wave || !own.tile || own.lanes != 512 || own.bands != 8) return false;
+    const int e = own.pair ? 2 : 1;
+    if (own.pair ? own.R != 16 : (own.R != 1 && own.R != 2 && own.R != 4 && own.R != 8)) return false;
+    if ((size_t)(cg_reg2d_lds_elems(own.R, e) + 32) * sizeof(T) > max_lds_) return false;
+    return own.m - (own.bands - 1) * own.R >= (own.R > 1 ? own.R - 1 : 0);
+  }
+  int launch_cg_reg2d_folded(const Level<T>& lv, T* x, const T* src, T* r, T* cgs, bool* launched) {
+    *launched = false;
+    if constexpr (!scalar_traits<T>::is_complex) {
+      const KrylovOwn own = krylov_own<2>(lv.g.n, true);
+      if (!own.pair) {
+        if (own.R == 1) return launch_cg_reg2d<1, 1>(lv, x, src, r, own, 0, launched, cgs);
+        if (own.R == 2) return launch_cg_reg2d<2, 1>(lv, x, src, r, own, 1, launched, cgs);
+        if (own.R == 4) return launch_cg_reg2d<4, 1>(lv, x, src, r, own, 2, launched, cgs);
+        if (own.R == 8) return launch_cg_reg2d<8, 1>(lv, x, src, r, own, 3, launched, cgs);
+        return EVOMG_OK;
+      }
+      if (own.R == 16) return launch_cg_reg2d<16, 2>(lv, x, src, r, own, 4, launched, cgs);
+    }
+    return EVOMG_OK;
   }
   template <int DIM> int launch_cg_reg(const Level<T>& lv, T* x, const T* b, T* r, bool* launched) {
     *launched = false;

@@ -45,7 +45,7 @@
   bool fusable_copy_zero_solve(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || !use_reg_krylov_ || i + 2 >= n_ops || dim_ != 2) return false;
     const int L = prob_.min_level;
-    // the one-wave CG (real, Dirichlet) or the one-wave BiCGStab (up to 9^2, real or complex with its Robin columns)
+    // the one-wave or the register CG (real, Dirichlet) or the one-wave BiCGStab (up to 9^2, real or complex with its Robin columns)
     const bool cg_case = !scalar_traits<T>::is_complex && prob_.cgs_kind == EVOMG_CGS_CG && prob_.bc_kind == EVOMG_BC_DIRICHLET;
     const bool bicg_case = prob_.cgs_kind == EVOMG_CGS_BICGSTAB && lv_[L].g.n <= 9 &&
                            (prob_.bc_kind == EVOMG_BC_DIRICHLET || (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && scalar_traits<T>::is_complex));
@@ -59,7 +59,7 @@
     // "x = 0, so r = b" needs the boundary values of x to be zero as well (SET_ZERO leaves them alone); true for every
     // error field of a cycle, not for a field a test filled with random numbers
     if (!bnd_zero_[L][canon(L, EVOMG_F_CORR)]) return false;
-    return bicg_case || krylov_own<2>(lv_[L].g.n, true).wave != 0;
+    return bicg_case || krylov_own<2>(lv_[L].g.n, true).wave != 0 || (cg_fold_reg_ && cg_reg2d_folds(lv_[L].g));
   }
   bool fusable_residual_restrict(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || i + 1 >= n_ops) return false;

@@ -65,6 +65,8 @@ NON_CYCLIC = {
     "prolong_smooth_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [prolong(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
     "zero_elision_2d": (2, 4, 7, "EVOMG_NO_ZERO_ELISION", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), zero(hi - 2), s(hi - 2), s(hi - 2), residual(hi - 2)]),
     "copy_zero_coarse_solve_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
+    "copy_zero_register_cg_65_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
+    "copy_zero_register_cg_129_2d": (2, 7, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
     "lds_tiles_2d": (2, 3, 6, "EVOMG_NO_SMALL2D", lambda s, lo, hi: [s(hi), s(hi - 1), prolong(hi), s(hi), zero(hi - 2), s(hi - 2), s(hi - 2)]),
     "strip_block_2d": (2, 4, 7, "EVOMG_NO_STRIP_BLOCK", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "block_fast_2d": (2, 4, 7, "EVOMG_NO_BLOCK_FAST", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
@@ -97,6 +99,7 @@ CYCLIC = {
     "tail_norm_2d": (2, 4, 7, "EVOMG_NO_TAIL_NORM", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
     "dead_residual_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 0, 1)),
     "speculation_2d": (2, 4, 7, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    "register_cg_fold_cycle_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_plain_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
     "lower_cycle_2d": (2, 3, 7, "+EVOMG_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
