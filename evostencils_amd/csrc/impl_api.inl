@@ -279,6 +279,10 @@
           else snprintf(buf, len, "evomg_strip3d<%s, %d, 4, %s>", type_name<T>::get(), STRIP_JACOBI, strip_streams3d(lv_[op->level].g) ? "true" : "false");
           return EVOMG_OK;
         }
+        if (cells == 1 && op->partitioning == EVOMG_PART_RED_BLACK && rbgs3d_block_ok(lv_[op->level].g)) {
+          snprintf(buf, len, "evomg_rbgs3d_block");
+          return EVOMG_OK;
+        }
         break;
       }
       case EVOMG_OP_RESIDUAL:

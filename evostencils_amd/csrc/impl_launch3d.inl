@@ -85,6 +85,11 @@
     }
     return best;
   }
+  // 3D red-black sweeps on the levels no marching kernel serves (below 129^3): one launch for both colours (evomg_rbgs3d_block)
+  bool rbgs3d_block_ok(const Geo& g) const {
+    return rbgs3d_block_ && dim_ == 3 && std::is_same<T, double>::value && prob_.bc_kind == EVOMG_BC_DIRICHLET && g.n >= 5 &&
+           !use_strip3d(g, true) && !(use_tile3d(g) && tile3d_rbgs_);
+  }
   // ---- 3D tiles with LDS-shared y halo (evomg_tile3d.h): Jacobi and residual ------------------------------------------
   bool use_tile3d(const Geo& g) const {
     if (dim_ != 3 || !strip_enabled_ || !tile3d_enabled_ || scalar_traits<T>::is_complex) return false;

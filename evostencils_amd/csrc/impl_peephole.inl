@@ -204,7 +204,7 @@
     const Geo& g = lv_[op.level].g;
     const int cells = op.block[0] * op.block[1] * (dim_ == 3 ? op.block[2] : 1);
     const bool rb = op.partitioning == EVOMG_PART_RED_BLACK;
-    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || (rb && use_tile3d(g) && tile3d_rbgs_) || !rb;
+    return cells > 1 || use_strip(g) || use_strip3d(g, rb) || (rb && use_tile3d(g) && tile3d_rbgs_) || (rb && rbgs3d_block_ok(g)) || !rb;
   }
 
   // COPY gen_rhs@min = ..., SET_ZERO gen_error@min, COARSE_SOLVE@min (what every cycle emits around gen_mgCycle@min,
