@@ -189,3 +189,34 @@ def test_peephole_in_the_solver_loop(native, oracle, monkeypatch, name, kind, se
     assert np.max(np.abs(a.history[finite] - c.history[finite]) / c.history[finite]) <= 1e-10
     assert np.array_equal(ua, ub, equal_nan=True) and np.array_equal(ua, uc, equal_nan=True)
     assert np.array_equal(ra, rb, equal_nan=True) and np.array_equal(ra, rc, equal_nan=True)
+
+
+@pytest.mark.parametrize("level", [3, 4, 5, 6])
+def test_one_launch_red_black_sweep_on_small_3d_levels(native, oracle, monkeypatch, level):
+    """3D levels below the tile threshold (9^3 .. 65^3, DEFAULT thresholds — the forced ones above hand these sizes to the
+    tiles): both colours of a red-black sweep in one launch (evomg_rbgs3d_block: blocks of 16 x 8 x 8 with recomputed halo
+    reds; 63 and 31 inner nodes are not multiples of the block edges) vs two thread-per-node launches vs the oracle, on random
+    fields with a non-zero boundary, three sweeps with different weights, a residual behind them."""
+    for k in list(FORCED) + KNOBS:
+        monkeypatch.delenv(k.lstrip("+"), raising=False)
+    pd = problem(3, level - 1, level, "textbook")
+    rb = lambda om: abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), om)
+    ops = [rb(1.0), rb(1.25), rb(0.7), residual(level)]
+    rng = np.random.default_rng(level)
+    fields = None
+    got = []
+    for which in ("fused", "switched_off", "oracle"):
+        if which == "switched_off":
+            monkeypatch.setenv("EVOMG_NO_RBGS3D_BLOCK", "1")
+        h = (oracle if which == "oracle" else native).create(pd)
+        if fields is None:
+            fields = {f: rng.standard_normal(h.field_shape(level)) for f in (abi.F_SOL, abi.F_RHS)}
+        for f, a in fields.items():
+            h.set_field(level, f, a)
+        if which == "fused":
+            assert h.kernel_name(ops[0]) == "evomg_rbgs3d_block"
+        h.run_ops(ops)
+        got.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
+        h.close()
+    for u, r in got[:2]:
+        assert np.array_equal(u, got[2][0]) and np.array_equal(r, got[2][1])
