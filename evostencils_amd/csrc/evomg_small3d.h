@@ -107,13 +107,14 @@ evomg_small3d_chain(Geo g, Stencil<double> st, double* __restrict__ x, const dou
 // bits), then the blacks of the block from those reds, and writes the block to the spare array (a pointer swap makes it
 // current, as for every out-of-place smoother; the boundary faces: ensure_faces). Red work 1.76x, one launch instead of two.
 // Arithmetic = relax_point (the quotient by the centre as const_div, as in evomg_small3d_chain and the tiles): bit-identical.
+// The SET_ZERO or the PROLONG_ADD in front of the sweep ride on the block's load (zero_first / coarse_in): one more launch less.
 #define EVOMG_RB3D_BX 16
 #define EVOMG_RB3D_BY 8
 #define EVOMG_RB3D_BZ 8
 #define EVOMG_RB3D_THREADS 1024
 static __global__ void __launch_bounds__(EVOMG_RB3D_THREADS)
 evomg_rbgs3d_block(Geo g, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ y,
-                   double om, double omm, int nbx, int nby) {
+                   double om, double omm, int nbx, int nby, int zero_first, const double* __restrict__ coarse_in, Geo gc, double om_p) {
   constexpr int BX = EVOMG_RB3D_BX, BY = EVOMG_RB3D_BY, BZ = EVOMG_RB3D_BZ;
   constexpr int TX = BX + 4, TY = BY + 4, TZ = BZ + 4;
   __shared__ double U[TZ * TY * TX];
@@ -123,7 +124,12 @@ evomg_rbgs3d_block(Geo g, Stencil<double> st, const double* __restrict__ x, cons
   for (int q = tid; q < TX * TY * TZ; q += EVOMG_RB3D_THREADS) {
     const int gi = i0 - 2 + q % TX, gj = j0 - 2 + (q / TX) % TY, gk = k0 - 2 + q / (TX * TY);
     const bool in = gi >= 0 && gi < n && gj >= 0 && gj < n && gk >= 0 && gk < n;
-    U[q] = in ? x[gidx<3>(g, gi, gj, gk)] : 0.0;
+    const bool inner = gi >= 1 && gi <= n - 2 && gj >= 1 && gj <= n - 2 && gk >= 1 && gk <= n - 2;
+    // zero_first: the SET_ZERO in front of the sweep, elided (the field's boundary is zero as well: host-checked);
+    // coarse_in: the PROLONG_ADD in front of the sweep, folded in as evomg_small3d_chain folds it (u + w P(coarse) on inner nodes)
+    double v = (in && !zero_first) ? x[gidx<3>(g, gi, gj, gk)] : 0.0;
+    if (coarse_in && inner) v = v + om_p * interpolate<double, 3>(gc, coarse_in, gi, gj, gk);
+    U[q] = v;
   }
   __syncthreads();
   const ConstDiv<double> cd0 = const_div_make(st.c[0]);

@@ -112,15 +112,8 @@
           advance(lv, L, op, x, y);
         } else if (op.partitioning == EVOMG_PART_RED_BLACK && rbgs3d_block_ok(g)) {
           // 3D below the tile threshold: both colours in one launch (evomg_small3d.h: evomg_rbgs3d_block), out of place
-          T* y = lv.alt;
-          ensure_faces(lv, x, y);
-          if constexpr (std::is_same<T, double>::value) {
-            const int inner = g.n - 2;
-            const int nbx = (inner + EVOMG_RB3D_BX - 1) / EVOMG_RB3D_BX, nby = (inner + EVOMG_RB3D_BY - 1) / EVOMG_RB3D_BY,
-                      nbz = (inner + EVOMG_RB3D_BZ - 1) / EVOMG_RB3D_BZ;
-            hipLaunchKernelGGL(evomg_rbgs3d_block, dim3(nbx * nby * nbz), dim3(EVOMG_RB3D_THREADS), 0, stream_, g, lv.st, (const T*)x, f, y, om, omm, nbx, nby);
-          }
-          advance(lv, L, op, x, y);
+          launch_rbgs3d_block(lv, x, f, om, omm, take_x_zero(), nullptr, g, 0.0);
+          advance(lv, L, op, x, lv.alt);
         } else if (op.partitioning == EVOMG_PART_RED_BLACK) {
           const dim3 hgrd((g.n / 2 + 1 + 63) / 64, grd.y, grd.z);
           for (int colour = 0; colour < 2; ++colour) {

@@ -90,6 +90,19 @@
     return rbgs3d_block_ && dim_ == 3 && std::is_same<T, double>::value && prob_.bc_kind == EVOMG_BC_DIRICHLET && g.n >= 5 &&
            !use_strip3d(g, true) && !(use_tile3d(g) && tile3d_rbgs_);
   }
+  // x -> lv.alt (the caller advances); zero_first / coarse: the SET_ZERO or PROLONG_ADD in front of the sweep, folded in
+  void launch_rbgs3d_block(Level<T>& lv, const T* x, const T* f, double om, double omm, int zero_first, const T* coarse, const Geo& gc, double om_p) {
+    T* y = lv.alt;
+    ensure_faces(lv, x, y);
+    if constexpr (std::is_same<T, double>::value) {
+      const Geo& g = lv.g;
+      const int inner = g.n - 2;
+      const int nbx = (inner + EVOMG_RB3D_BX - 1) / EVOMG_RB3D_BX, nby = (inner + EVOMG_RB3D_BY - 1) / EVOMG_RB3D_BY,
+                nbz = (inner + EVOMG_RB3D_BZ - 1) / EVOMG_RB3D_BZ;
+      hipLaunchKernelGGL(evomg_rbgs3d_block, dim3(nbx * nby * nbz), dim3(EVOMG_RB3D_THREADS), 0, stream_, g, lv.st, x, f, y, om, omm, nbx, nby,
+                         zero_first, coarse, gc, om_p);
+    }
+  }
   // ---- 3D tiles with LDS-shared y halo (evomg_tile3d.h): Jacobi and residual ------------------------------------------
   bool use_tile3d(const Geo& g) const {
     if (dim_ != 3 || !strip_enabled_ || !tile3d_enabled_ || scalar_traits<T>::is_complex) return false;

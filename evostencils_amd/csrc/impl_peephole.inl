@@ -77,7 +77,7 @@
   // SET_ZERO(L, X) immediately followed by a strip point smoother on X whose boundary is known to be zero: the zero
   // launch is skipped and the sweep reads no x at all (same arithmetic on literal zeros => same bits)
   bool elidable_zero(const evomg_op_t* ops, int n_ops, int i) const {
-    if (!fuse_enabled_ || !zero_elision_ || dim_ != 2 || i + 1 >= n_ops) return false;
+    if (!fuse_enabled_ || !zero_elision_ || i + 1 >= n_ops) return false;
     const evomg_op_t &z = ops[i], &sm = ops[i + 1];
     if (z.opcode != EVOMG_OP_SET_ZERO || sm.opcode != EVOMG_OP_SMOOTH || z.level != sm.level) return false;
     if (canon(z.level, z.dst) != canon(sm.level, sm.dst)) return false;
@@ -88,8 +88,15 @@
   // ops[i] is a sweep that can run as the zero-input variant of its strip kernel (its field is zero everywhere, boundary
   // included; the variant loads nothing of it and writes every node of the output)
   bool zero_input_sweep(const evomg_op_t* ops, int n_ops, int i) const {
-    if (!fuse_enabled_ || !zero_elision_ || dim_ != 2 || i >= n_ops) return false;
+    if (!fuse_enabled_ || !zero_elision_ || i >= n_ops) return false;
     const evomg_op_t& sm = ops[i];
+    if (dim_ == 3) {
+      // small 3D levels: the one-launch red-black sweep takes the zero on its load (evomg_rbgs3d_block: zero_first)
+      // (levels up to 17^3 belong to evomg_small3d_chain, which takes the SET_ZERO itself)
+      return sm.opcode == EVOMG_OP_SMOOTH && sm.partitioning == EVOMG_PART_RED_BLACK && sm.block[0] * sm.block[1] * sm.block[2] == 1 &&
+             canon(sm.level, sm.src1) != canon(sm.level, sm.dst) && !prof_matches(sm) && lv_[sm.level].g.n > 17 &&
+             rbgs3d_block_ok(lv_[sm.level].g);
+    }
     if (sm.opcode != EVOMG_OP_SMOOTH || sm.block[0] * sm.block[1] != 1) return false;
     if (jacobi_lost(sm)) return false;        // the sweep's output is discarded: the field has to be zeroed for real
     if (canon(sm.level, sm.src1) == canon(sm.level, sm.dst)) return false;
@@ -153,6 +160,17 @@
     return use_strip(lv_[a.level].g);
   }
 
+  // PROLONG_ADD@L, red-black SMOOTH on a small 3D level: the correction folded into the one-launch sweep's load
+  bool fusable_prolong_rbgs3d(const evomg_op_t* ops, int n_ops, int i) const {
+    if (!fuse_enabled_ || dim_ != 3 || i + 1 >= n_ops) return false;
+    const evomg_op_t &a = ops[i], &b = ops[i + 1];
+    if (a.opcode != EVOMG_OP_PROLONG_ADD || b.opcode != EVOMG_OP_SMOOTH || a.level != b.level || a.level <= prob_.min_level) return false;
+    if (b.partitioning != EVOMG_PART_RED_BLACK || b.block[0] * b.block[1] * b.block[2] != 1) return false;
+    if (canon(a.level, a.dst) != canon(b.level, b.dst) || canon(b.level, b.src1) == canon(b.level, b.dst)) return false;
+    if (prof_matches(a) || prof_matches(b)) return false;
+    const int cs = canon(a.level - 1, a.src0);
+    return cs >= 0 && lv_[a.level - 1].f[cs] != nullptr && rbgs3d_block_ok(lv_[a.level].g);
+  }
   // PROLONG_ADD@L, SMOOTH, SMOOTH: the coarse-grid correction folded into the double sweep's loads (evomg_tile3d_twice<PRO>)
   bool fusable_prolong_twice(const evomg_op_t* ops, int n_ops, int i) const {
     if (!tile3d_pro_ || i + 2 >= n_ops || ops[i].opcode != EVOMG_OP_PROLONG_ADD || !fusable_twice(ops, n_ops, i + 1)) return false;
@@ -582,6 +600,17 @@
           if (write_r) apply_bc(L, fieldptr(L, ops[i].dst));
           apply_bc(L - 1, fieldptr(L - 1, ops[i + 1].dst));
         }
+        HIP_TRY(hipGetLastError());
+        ++i;
+        continue;
+      }
+      if (fusable_prolong_rbgs3d(ops, n_ops, i)) {
+        const evomg_op_t &pr = ops[i], &sm = ops[i + 1];
+        const int L = pr.level;
+        Level<T>& lv = lv_[L];
+        T* x = fieldptr(L, sm.dst);
+        launch_rbgs3d_block(lv, x, fieldptr(L, sm.src1), sm.omega, 1.0 - sm.omega, 0, fieldptr(L - 1, pr.src0), lv_[L - 1].g, pr.omega);
+        advance(lv, L, sm, x, lv.alt);
         HIP_TRY(hipGetLastError());
         ++i;
         continue;

@@ -220,3 +220,37 @@ def test_one_launch_red_black_sweep_on_small_3d_levels(native, oracle, monkeypat
         h.close()
     for u, r in got[:2]:
         assert np.array_equal(u, got[2][0]) and np.array_equal(r, got[2][1])
+
+
+@pytest.mark.parametrize("level", [5, 6])
+def test_zero_and_prolongation_ride_on_the_small_3d_sweep(native, oracle, monkeypatch, level):
+    """SET_ZERO + sweep and PROLONG_ADD + sweep on 33^3 / 65^3 at default thresholds: the zero is elided and the correction is
+    formed on the one-launch sweep's load (evomg_rbgs3d_block: zero_first / coarse_in) — against the same ops as separate
+    launches (EVOMG_NO_FUSE) and against the oracle, on fields with a zero boundary (what an error field of a cycle has)."""
+    for k in list(FORCED) + KNOBS:
+        monkeypatch.delenv(k.lstrip("+"), raising=False)
+    pd = problem(3, level - 1, level, "textbook")
+    rb = lambda om: abi.make_op(abi.OP_SMOOTH, level, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), om)
+    ops = [zero(level), rb(1.25), rb(1.25), residual(level), prolong(level, 0.9), rb(1.0), residual(level)]
+    rng = np.random.default_rng(100 + level)
+    fields = {}
+    got = []
+    for which in ("fused", "switched_off", "oracle"):
+        if which == "switched_off":
+            monkeypatch.setenv("EVOMG_NO_FUSE", "1")
+        h = (oracle if which == "oracle" else native).create(pd)
+        for L in (level - 1, level):
+            for f in (abi.F_SOL, abi.F_RHS):
+                if (L, f) not in fields:
+                    a = rng.standard_normal(h.field_shape(L))
+                    if f == abi.F_SOL:
+                        edge = np.ones(a.shape, bool)
+                        edge[(slice(1, -1),) * 3] = False
+                        a[edge] = 0.0
+                    fields[(L, f)] = a
+                h.set_field(L, f, fields[(L, f)])
+        h.run_ops(ops)
+        got.append((h.get_field(level, abi.F_SOL), h.get_field(level, abi.F_RES)))
+        h.close()
+    for u, r in got[:2]:
+        assert np.array_equal(u, got[2][0]) and np.array_equal(r, got[2][1])
