@@ -290,7 +290,10 @@
     if constexpr (!scalar_traits<T>::is_complex) {
       // rows every lane is guaranteed to own: the upper half's share (33^2: 15 of 16)
       const int m = lv.g.n - 2, upper = m - EVOMG_CG_WAVE_ROWS;
-      if (upper >= EVOMG_CG_WAVE_ROWS - 1)
+      if (upper >= EVOMG_CG_WAVE_ROWS - 1 && cg_reg2d_pow2(lv.st))       // 33^2 Poisson: the tutorial's coarse solve
+        hipLaunchKernelGGL((evomg_cg_wave2d<T, XZERO, EVOMG_CG_WAVE_ROWS - 1, true>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, b_copy,
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
+      else if (upper >= EVOMG_CG_WAVE_ROWS - 1)
         hipLaunchKernelGGL((evomg_cg_wave2d<T, XZERO, EVOMG_CG_WAVE_ROWS - 1>), dim3(1), dim3(64), 0, stream_, lv.g, lv.st, x, b, r, b_copy,
                            prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_);
       else
