@@ -235,6 +235,31 @@ def test_3d_tile_geometries_are_bit_identical_to_the_oracle(native, monkeypatch,
     ho.close()
 
 
+@pytest.mark.parametrize("top,iterations,smoother", [(8, 4, "block211"), (9, 3, "block211"), (9, 1, "rbgs"), (9, 1, "jacobi")])
+def test_c4_first_cycles_at_full_size_against_the_oracle(native, top, iterations, smoother):
+    """C4 itself (textbook semantics, default thresholds and launch geometry: nothing forced) for its first cycle(s) against the
+    oracle — at 257^3 (two cycles) and at 513^3 (one cycle: the 172-plane chunks, the 104-column strips, the norm riding on
+    the first double sweep, the 33^3 CG with its exchange words): norms and the whole solution field bit-identical. One cycle
+    each with the fused red-black tiles (V(2,1)) and point Jacobi in C4's place."""
+    from oracle import oracle
+    lo = 5
+    pd = dataclasses.replace(problems.poisson_3d(lo, top), max_iterations=iterations)
+    if smoother == "rbgs":
+        ops = vcycle(lo, top, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.15))
+    else:
+        ops = vcycle(lo, top, 2, 2, _block211 if smoother == "block211" else _jacobi)
+    hg = native.create(pd, jacobi_semantics="textbook")
+    a = hg.evaluate(ops, 1, 0, 8)
+    ug = hg.get_field(top, abi.F_SOL)
+    hg.close()
+    ho = oracle.create(pd, jacobi_semantics="textbook")
+    b = ho.evaluate(ops, 1, 0, 8)
+    assert a.n_iterations == b.n_iterations == iterations
+    assert np.array_equal(a.history, b.history)
+    assert np.array_equal(ug, ho.get_field(top, abi.F_SOL))
+    ho.close()
+
+
 def test_c4_full_size_in_the_reference_pipelines_semantics(native):
     """configs[3] at 513^3 under `exastencils-v1.1`: every block-Jacobi sweep is launched (and timed) but never advanced,
     so the residual history is bit for bit the history of the same cycle with the smoothers removed; the candidate does not
