@@ -107,6 +107,27 @@ def test_c3_helmholtz_2048_evolved_cycle(native):
     print(f"C3 evolved: 60 outer iterations in {out.time_ms:.0f} ms ({out.time_ms / 60:.2f} ms per iteration = 4 MG cycles + 5 dots)")
 
 
+def test_c3_thirty_outer_iterations_at_full_size_against_the_oracle(native):
+    """C3 at 2049^2 (complex, k h = 0.625, the evolved double cycle as preconditioner) for the thirty outer BiCGStab iterations
+    `bench.py`'s `configs.c3` times, against the oracle: every norm of the history within 1e-10 (north_star's tolerance), the iterate within 1e-10 of its scale."""
+    from oracle import oracle
+    from test_helmholtz_oracle import evolved_double_cycle_ops
+    lo, hi = 7, 11
+    gen, ops = evolved_double_cycle_ops(lo, hi, 0.625 * (1 << hi))
+    pd = dataclasses.replace(gen.problem, max_iterations=30)
+    hg = native.create(pd)
+    a = hg.evaluate(ops, 1, 600e3, 40)
+    ug = hg.get_field(hi, abi.F_CORR)
+    hg.close()
+    ho = oracle.create(pd)
+    b = ho.evaluate(ops, 1, 600e3, 40)
+    uo = ho.get_field(hi, abi.F_CORR)
+    ho.close()
+    assert a.n_iterations == b.n_iterations == 30 and len(a.history) == len(b.history) == 31
+    assert np.max(np.abs(a.history - b.history) / np.abs(b.history)) <= 1e-10
+    assert np.max(np.abs(ug - uo)) <= 1e-10 * np.max(np.abs(uo))
+
+
 # ---- C1 / C4 in both `with jacobi` semantics ------------------------------------------------------------------------------
 def _jacobi(L, omega=0.8):
     return abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_SINGLE, (1, 1, 1), omega)
