@@ -475,13 +475,16 @@ template <typename T> struct TwiceProlong {
 // cycle, launched speculatively (impl_solvers.inl: norm_on_head), instead of a pass of its own over x and f. The residual
 // comes from the rows the first sweep holds anyway (residual7p: the arithmetic of the residual kernels), seven more
 // multiply-adds per node on a launch that waits for memory.
-template <typename T, int MODE, int NW, int NT, bool PRO = false, bool POW2 = false, bool NORM0 = false>
+// XZ (round 4): the sweeps' input is the zero field (the SET_ZERO in front of them, elided: boundary zero as well, host-checked)
+// — nothing of x is loaded; the arithmetic is the general form's on literal zeros.
+template <typename T, int MODE, int NW, int NT, bool PRO = false, bool POW2 = false, bool NORM0 = false, bool XZ = false>
 __global__ void __launch_bounds__(64 * NW)
 evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om,
                    double omm, int planes_per_chunk, int n_strips, int n_ygroups, int n_blocks, TwoCellPlan<T> pl,
                    TwiceProlong<T> pro, int xpitch, T* __restrict__ norm_aux) {
   static_assert(MODE == STRIP_JACOBI || MODE == TILE_BLOCK211, "two fused sweeps: point Jacobi and (2,1,1) blocks");
   static_assert(!(PRO && NORM0), "the norm is that of the sweeps' input as it lies in memory");
+  static_assert(!(XZ && (PRO || NORM0)), "zero input: plain double sweep only");
   constexpr int TY = EVOMG_TILE3D_TY, H = NW * TY;
   __shared__ __attribute__((aligned(16))) T edge_x[2][NW][2][128];   // old x of the next centre plane
   __shared__ __attribute__((aligned(16))) T edge_y[2][NW][2][128];   // y1 of the current centre plane
@@ -516,6 +519,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   const T zero = scalar_traits<T>::zero();
   const Pair<T> zpair{zero, zero};
   auto load_x = [&](int row, int pl_) -> Pair<T> {
+    if constexpr (XZ) return zpair;
     const int r = min(max(row, 0), n - 1), p = min(max(pl_, 0), n - 1);
     return load_pair<T>(x + plane * p + pitch * r + c_clamped);
   };

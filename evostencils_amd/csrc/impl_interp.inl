@@ -206,17 +206,18 @@
     const T* f = fieldptr(L, sm.src1);
     T* y = lv.alt;
     const double om = sm.omega, omm = 1.0 - sm.omega;
+    const bool xzero = take_x_zero() != 0 && !pr && !norm_aux;      // the SET_ZERO in front of the sweeps, elided (zero_input_sweep)
     ensure_faces(lv, x, y);
     if constexpr (!scalar_traits<T>::is_complex) {
       if (sm.block[0] == 2) {
         const BlockPlan<T> pl = make_block_plan<T, 3>(lv.st, 2, 1, 1);
         const T* cz = pr ? fieldptr(L - 1, pr->src0) : nullptr;
         launch_tile3d_twice<TILE_BLOCK211>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{pl.fac[1][0], pl.upper[0][1], pl.pivot[0], pl.pivot[1]},
-                                           cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g, pr ? pr->omega : 0.0, norm_aux);
+                                           cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g, pr ? pr->omega : 0.0, norm_aux, xzero);
       } else {
         const T* cz = pr ? fieldptr(L - 1, pr->src0) : nullptr;
         launch_tile3d_twice<STRIP_JACOBI>(lv.g, lv.st, x, f, y, om, omm, TwoCellPlan<T>{}, cz, &lv_[L - 1 >= prob_.min_level ? L - 1 : L].g,
-                                          pr ? pr->omega : 0.0, norm_aux);
+                                          pr ? pr->omega : 0.0, norm_aux, xzero);
       }
     }
     advance(lv, L, sm, x, y);      // two sweeps, one pass: the result lives in the spare array -> ONE swap

@@ -171,7 +171,7 @@
   // two identical Jacobi-type sweeps in a row on one field (evomg_tile3d_twice): same geometry as the red-black tiles
   template <int MODE> void launch_tile3d_twice(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm,
                                                TwoCellPlan<T> two, const T* coarse = nullptr, const Geo* gc = nullptr, double om_p = 0.0,
-                                               T* norm_aux = nullptr) {
+                                               T* norm_aux = nullptr, bool xzero = false) {
     constexpr int TY = EVOMG_TILE3D_TY;
     constexpr int cols = (MODE == TILE_BLOCK211) ? 120 : EVOMG_STRIP_COLS;      // two halo lanes per side for the blocks
     const int strips = (g.n + cols - 1) / cols;
@@ -188,11 +188,14 @@
       const bool p2 = offcentre_pow2(st);
 #define EVOMG_TWICE_LAUNCH(PRO, P2, PROLONG) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, PRO, P2>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, PROLONG, tile3d_xpitch(g.n, cols), (T*)nullptr)
 #define EVOMG_TWICE_NORM_LAUNCH(P2) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, false, P2, true>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, (TwiceProlong<T>{nullptr, g, 0.0}), tile3d_xpitch(g.n, cols), norm_aux)
-      if (norm_aux && !coarse) { if (p2) EVOMG_TWICE_NORM_LAUNCH(true); else EVOMG_TWICE_NORM_LAUNCH(false); }
+#define EVOMG_TWICE_XZ_LAUNCH(P2) hipLaunchKernelGGL((evomg_tile3d_twice<T, MODE, 8, 0, false, P2, false, true>), grid, dim3(512), 0, stream_, g, st, x, f, y, om, omm, planes, strips, ygroups, blocks, two, (TwiceProlong<T>{nullptr, g, 0.0}), tile3d_xpitch(g.n, cols), (T*)nullptr)
+      if (xzero && !coarse && !norm_aux) { if (p2) EVOMG_TWICE_XZ_LAUNCH(true); else EVOMG_TWICE_XZ_LAUNCH(false); }
+      else if (norm_aux && !coarse) { if (p2) EVOMG_TWICE_NORM_LAUNCH(true); else EVOMG_TWICE_NORM_LAUNCH(false); }
       else if (coarse) { if (p2) EVOMG_TWICE_LAUNCH(true, true, (TwiceProlong<T>{coarse, *gc, om_p})); else EVOMG_TWICE_LAUNCH(true, false, (TwiceProlong<T>{coarse, *gc, om_p})); }
       else { if (p2) EVOMG_TWICE_LAUNCH(false, true, (TwiceProlong<T>{nullptr, g, 0.0})); else EVOMG_TWICE_LAUNCH(false, false, (TwiceProlong<T>{nullptr, g, 0.0})); }
 #undef EVOMG_TWICE_LAUNCH
 #undef EVOMG_TWICE_NORM_LAUNCH
+#undef EVOMG_TWICE_XZ_LAUNCH
     }
   }
 

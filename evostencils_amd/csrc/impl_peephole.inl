@@ -91,6 +91,8 @@
     if (!fuse_enabled_ || !zero_elision_ || i >= n_ops) return false;
     const evomg_op_t& sm = ops[i];
     if (dim_ == 3) {
+      // a double sweep of the tiles on a zero field loads nothing of it (evomg_tile3d_twice<.., XZ>)
+      if (twice_xzero_ && fusable_twice(ops, n_ops, i) && !prof_matches(sm) && !prof_matches(ops[i + 1])) return true;
       // small 3D levels: the one-launch red-black sweep takes the zero on its load (evomg_rbgs3d_block: zero_first)
       // (levels up to 17^3 belong to evomg_small3d_chain, which takes the SET_ZERO itself)
       return sm.opcode == EVOMG_OP_SMOOTH && sm.partitioning == EVOMG_PART_RED_BLACK && sm.block[0] * sm.block[1] * sm.block[2] == 1 &&

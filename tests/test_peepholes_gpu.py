@@ -74,6 +74,8 @@ NON_CYCLIC = {
     "lower_cycle_2d": (2, 3, 7, "+EVOMG_LOWER2D", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), restrict(hi - 2), zero(hi - 2), s(hi - 2),
                                                                         residual(hi - 2), restrict(hi - 3), prolong(hi - 2), s(hi - 2), prolong(hi - 1), s(hi - 1)]),
     "double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1), s(hi - 1), s(hi - 1)]),
+    "zero_double_sweep_3d": (3, 2, 5, "EVOMG_NO_TWICE_XZERO", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), s(hi - 1), zero(hi - 2), s(hi - 2), s(hi - 2),
+                                                                                  s(hi - 2), residual(hi - 2)]),
     "prolong_double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_PRO", lambda s, lo, hi: [prolong(hi), s(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
     "small_level_chain_3d": (3, 2, 4, "EVOMG_NO_SMALL3D", lambda s, lo, hi: [zero(hi), s(hi), s(hi), residual(hi), restrict(hi - 1), prolong(hi), s(hi)]),
     "tiles_3d": (3, 2, 5, "EVOMG_NO_TILE3D", lambda s, lo, hi: [s(hi), residual(hi), restrict(hi - 1), s(hi - 1), prolong(hi), s(hi)]),
