@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -10,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/evomg.h"

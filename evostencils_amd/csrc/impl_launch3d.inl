@@ -71,6 +71,9 @@
   // fewer halo planes but leave the last round partly empty. Picks the depth (a multiple of `align`, at least `lo`) with
   // the fewest plane steps on the critical path; ties go to the shallower chunk (more workgroups in flight).
   int balanced_planes(long tiles, int inner, int halo, int lo, int align) const {
+    // (a handful of distinct questions per handle, asked once per launch: remembered)
+    for (const auto& e : balance_cache_)
+      if (e.tiles == tiles && e.inner == inner && e.halo == halo && e.lo == lo && e.align == align) return e.planes;
     long best_cost = -1;
     int best = lo;
     for (int c = 1; c <= inner; ++c) {
@@ -83,6 +86,7 @@
       const long cost = rounds * (p + halo + 2);
       if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = p; }
     }
+    balance_cache_[balance_cache_next_++ % balance_cache_.size()] = BalanceEntry{tiles, inner, halo, lo, align, best};
     return best;
   }
   // 3D red-black sweeps on the levels no marching kernel serves (below 129^3): one launch for both colours (evomg_rbgs3d_block)
@@ -179,7 +183,7 @@
     const int stored = nw * TY - 2;
     const int ygroups = (g.n - 3 + stored - 1) / stored > 0 ? (g.n - 3 + stored - 1) / stored : 1;
     int planes = strip_planes_ > 0 ? strip_planes_ : twice_planes_;
-    if (strip_planes_ <= 0 && balance3d_ && !getenv("EVOMG_TWICE_PLANES")) planes = balanced_planes((long)strips * ygroups, g.n - 2, 4, 8, 4);
+    if (strip_planes_ <= 0 && balance3d_ && !twice_planes_forced_) planes = balanced_planes((long)strips * ygroups, g.n - 2, 4, 8, 4);
     planes = (planes + 3) & ~3;
     const int chunks = (g.n - 2 + planes - 1) / planes;
     const int blocks = strips * ygroups * chunks;
@@ -233,7 +237,7 @@
     const int per_group = (nw * TY - 2) / 2;                      // coarse rows a workgroup finishes: 15 (7 with four waves)
     const int ygroups = (rows_c + per_group - 1) / per_group;
     int cplanes = strip_planes_ > 0 ? (strip_planes_ + 1) / 2 : rr_cplanes_;   // fine planes per chunk: 2 * cplanes + 1
-    if (strip_planes_ <= 0 && balance3d_ && nw == 8 && !getenv("EVOMG_RR_CPLANES")) cplanes = balanced_planes((long)strips * ((rows_c + 14) / 15), rows_c, 1, 4, 1);
+    if (strip_planes_ <= 0 && balance3d_ && nw == 8 && !rr_cplanes_forced_) cplanes = balanced_planes((long)strips * ((rows_c + 14) / 15), rows_c, 1, 4, 1);
     const int chunks = (rows_c + cplanes - 1) / cplanes;
     const int blocks = strips * ygroups * chunks;
     const dim3 grid(((blocks + 7) / 8) * 8);

@@ -96,6 +96,10 @@
   bool cg_fold_reg_ = getenv("EVOMG_NO_CG_FOLD") == nullptr;     // COPY + SET_ZERO folded into the register CG too (65^2 .. 129^2)
   bool twice_xzero_ = getenv("EVOMG_NO_TWICE_XZERO") == nullptr;   // SET_ZERO + 3D double sweep: the zero field is not loaded
   bool head_norm_ = getenv("EVOMG_NO_HEAD_NORM") == nullptr;   // 3D: the loop norm rides on the coming cycle's first double sweep (solve_mg: norm_on_head)
+  bool twice_planes_forced_ = getenv("EVOMG_TWICE_PLANES") != nullptr, rr_cplanes_forced_ = getenv("EVOMG_RR_CPLANES") != nullptr;
+  struct BalanceEntry { long tiles; int inner, halo, lo, align, planes; };
+  mutable std::array<BalanceEntry, 16> balance_cache_{};      // balanced_planes: answers already worked out
+  mutable unsigned balance_cache_next_ = 0;
   bool xbalance3d_ = getenv("EVOMG_NO_XBALANCE3D") == nullptr;   // 3D tile strips of equal width (launch3d: tile3d_xpitch)
   int balance3d_cap_ = getenv("EVOMG_BALANCE3D") ? atoi(getenv("EVOMG_BALANCE3D")) : 0;   // > 1: deepest chunk it may pick
   int rr_cplanes_ = getenv("EVOMG_RR_CPLANES") ? atoi(getenv("EVOMG_RR_CPLANES")) : 8;
