@@ -264,7 +264,7 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
                     "generate_and_evaluate on that rank. At N = 1 both modes coincide. static_in_flight = the static split with "
                     "several candidates in flight per GPU (population.ConcurrentEvaluator: own stream and fields each; rho and "
                     "iteration counts identical — checked, see the flag — while a candidate's measured time includes its neighbours). "
-                    "static_in_flight_isolated_time = the same, then three short probes per candidate on the idle GPU (evomg_time_model) and "
+                    "static_in_flight_isolated_time = the same, then short probes per candidate on the idle GPU (evomg_time_model for a worker's first three candidates, evomg_time_model_known_coarse after them: what one coarse-solver iteration costs does not depend on the candidate) and "
                     "the evaluation's own iteration counts give each candidate's time ALONE: time_objective_vs_sequential compares it with "
                     "the sequential pass (static)."}
 

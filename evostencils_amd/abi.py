@@ -125,7 +125,7 @@ def ops_array(ops: Sequence[Op]):
 # every symbol include/evomg.h declares, without prefix
 EXPORTED = ["create", "destroy", "last_error", "abi_version", "set_initial_field", "get_field",
             "set_field", "set_operators", "evaluate", "run_ops", "norm", "bench_op", "kernel_name",
-            "profile_begin", "profile_end", "device_count", "time_iterations", "time_model", "coarse_iterations",
+            "profile_begin", "profile_end", "device_count", "time_iterations", "time_model", "time_model_known_coarse", "coarse_iterations",
             "comm_create", "comm_destroy", "comm_last_error", "allgather_fitness", "gather_fitness", "rccl_version"]
 FITNESS_COLUMNS = 4      # EVOMG_FITNESS_COLUMNS: (candidate index, convergence factor, time ms, iterations)
 
@@ -187,6 +187,9 @@ class Library:
         if "time_model" in f:
             f["time_model"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.c_int, dp, dp, dp]
             f["time_model"].restype = C.c_int
+        if "time_model_known_coarse" in f:
+            f["time_model_known_coarse"].argtypes = [C.c_void_p, C.POINTER(Op), C.c_int, C.c_int, C.c_int, C.c_double, dp, dp]
+            f["time_model_known_coarse"].restype = C.c_int
             f["coarse_iterations"].argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
             f["coarse_iterations"].restype = C.c_int
         if "comm_create" in f:
@@ -316,11 +319,16 @@ class Handle:
         self._check(self.L.fn["time_iterations"](self._h, arr, len(ops), n_iterations, C.byref(ms), C.byref(done)), "time_iterations")
         return ms.value, done.value
 
-    def time_model(self, ops: Sequence[Op], n_short: int = 2, n_long: int = 6):
+    def time_model(self, ops: Sequence[Op], n_short: int = 2, n_long: int = 6, per_coarse: Optional[float] = None):
         """(one-off ms, ms per solver-loop iteration, ms per coarse-solver iteration) of the candidate on an idle device
-        (evomg_time_model): time ~ fixed + per_iteration * its + per_coarse * K."""
+        (evomg_time_model): time ~ fixed + per_iteration * its + per_coarse * K. `per_coarse` given: taken as known, the
+        expensive third probe is skipped (evomg_time_model_known_coarse)."""
         arr = ops_array(ops)
         fixed, per_it, per_cg = C.c_double(), C.c_double(), C.c_double()
+        if per_coarse is not None:
+            self._check(self.L.fn["time_model_known_coarse"](self._h, arr, len(ops), n_short, n_long, float(per_coarse), C.byref(fixed),
+                                                             C.byref(per_it)), "time_model_known_coarse")
+            return fixed.value, per_it.value, float(per_coarse)
         self._check(self.L.fn["time_model"](self._h, arr, len(ops), n_short, n_long, C.byref(fixed), C.byref(per_it), C.byref(per_cg)),
                     "time_model")
         return fixed.value, per_it.value, per_cg.value

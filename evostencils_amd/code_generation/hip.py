@@ -59,6 +59,8 @@ class ProgramGenerator:
           fires: the one numeric the reference records (notebooks/tutorial.ipynb:3373) is reproduced to the last
           printed digit this way and under no other convention (oracle/APPB_MATRIX.md).
       "textbook"  the sweep's result becomes the field (the IR / LFA meaning, and what that patch intends)."""
+    COARSE_COST_SAMPLES = 3      # full three-probe time models a generator runs before it takes the coarse-iteration cost as known
+
 
     def __init__(self, absolute_compiler_path: Optional[str] = None, base_path: Optional[str] = None,
                  settings_path: Optional[str] = None, knowledge_path: Optional[str] = None,
@@ -134,6 +136,7 @@ class ProgramGenerator:
         self._verified = {}
         self._cycle_functions = {}       # text of a generated cycle function -> (level, window min, op program)
         self.last_coarse_iterations = None      # coarse-solver iterations of the last evaluation (time model input)
+        self._coarse_iteration_ms = {}           # (min_level, max_level) -> samples so far | the settled cost of one coarse-solver iteration
         self._set_problem(problem)
 
     # ---- read-only attributes the optimizer reads (scripts/optimize.py:60-68) ------------------
@@ -479,7 +482,21 @@ class ProgramGenerator:
         if n_long < 3 or coarse_iterations is None:
             ms, _done = handle.time_iterations(ops, max(1, min(int(its), max(n_long, 1))))
             return ms * its
-        fixed, per_iteration, per_coarse = handle.time_model(ops, max(1, n_long // 3), n_long)
+        # what ONE iteration of the coarse-grid solver costs belongs to the problem and its coarsest level, not to the candidate:
+        # the first few candidates measure it (three probes each), every later one runs the two cheap probes only
+        key = (min_level, max_level)
+        known = self._coarse_iteration_ms.get(key)
+        if isinstance(known, float):
+            fixed, per_iteration, per_coarse = handle.time_model(ops, max(1, n_long // 3), n_long, per_coarse=known)
+        else:
+            fixed, per_iteration, per_coarse = handle.time_model(ops, max(1, n_long // 3), n_long)
+            samples = self._coarse_iteration_ms.setdefault(key, [])
+            samples.append(per_coarse)
+            positive = sorted(v for v in samples if v > 0.0)
+            if len(positive) >= self.COARSE_COST_SAMPLES:
+                self._coarse_iteration_ms[key] = float(positive[len(positive) // 2])
+            elif len(samples) >= 4 * self.COARSE_COST_SAMPLES:
+                self._coarse_iteration_ms[key] = 0.0      # a coarse solver that does not iterate: nothing to scale
         return max(fixed, 0.0) + per_iteration * its + per_coarse * float(coarse_iterations)
 
     def compile_and_run(self, ops, min_level, max_level, mapping=None, infinity=1e100, evaluation_samples=3):

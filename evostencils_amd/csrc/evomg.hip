@@ -125,17 +125,12 @@ int evomg_coarse_iterations(evomg_handle_t* h, long long* total) {
   *total = h->impl->coarse_iterations();
   return EVOMG_OK;
 }
-int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long, double* ms_fixed,
-                     double* ms_per_iteration, double* ms_per_coarse_iteration) {
-  if (!h || !ms_fixed || !ms_per_iteration || !ms_per_coarse_iteration || n_short < 1 || n_long <= n_short) return EVOMG_ERR_INVALID;
+// the probes of the time model: `count` runs of evomg_time_iterations, the first two with the coarse solver capped at one iteration
+static int time_model_probes(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, const int* n, int count, double* t, long long* k, int* done) {
   evomg_problem_t& p = h->impl->problem();
   const int saved_cgs = p.cgs_max_iterations;
-  double t[3] = {0, 0, 0};
-  long long k[3] = {0, 0, 0};
-  int done[3] = {0, 0, 0};
-  const int n[3] = {n_short, n_long, n_long};
   int rc = EVOMG_OK;
-  for (int q = 0; q < 3 && rc == EVOMG_OK; ++q) {
+  for (int q = 0; q < count && rc == EVOMG_OK; ++q) {
     p.cgs_max_iterations = q < 2 ? 1 : saved_cgs;
     double ms = 0.0;
     rc = evomg_time_iterations(h, ops, n_ops, n[q], &ms, &done[q]);
@@ -143,6 +138,16 @@ int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_
     k[q] = h->impl->coarse_iterations();
   }
   p.cgs_max_iterations = saved_cgs;
+  return rc;
+}
+int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long, double* ms_fixed,
+                     double* ms_per_iteration, double* ms_per_coarse_iteration) {
+  if (!h || !ms_fixed || !ms_per_iteration || !ms_per_coarse_iteration || n_short < 1 || n_long <= n_short) return EVOMG_ERR_INVALID;
+  double t[3] = {0, 0, 0};
+  long long k[3] = {0, 0, 0};
+  int done[3] = {0, 0, 0};
+  const int n[3] = {n_short, n_long, n_long};
+  const int rc = time_model_probes(h, ops, n_ops, n, 3, t, k, done);
   if (rc != EVOMG_OK) return rc;
   if (done[0] != n_short || done[1] != n_long || done[2] != n_long) {
     // a probe blew up before its last iteration: the plain average of the longest one is all there is
@@ -157,6 +162,26 @@ int evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_
   *ms_per_coarse_iteration = c_cg > 0.0 ? c_cg : 0.0;
   *ms_per_iteration = c_it;
   *ms_fixed = t[0] - c_it * n_short - *ms_per_coarse_iteration * (double)k[0];
+  return EVOMG_OK;
+}
+int evomg_time_model_known_coarse(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long,
+                                  double ms_per_coarse_iteration, double* ms_fixed, double* ms_per_iteration) {
+  if (!h || !ms_fixed || !ms_per_iteration || n_short < 1 || n_long <= n_short || !(ms_per_coarse_iteration >= 0.0)) return EVOMG_ERR_INVALID;
+  double t[2] = {0, 0};
+  long long k[2] = {0, 0};
+  int done[2] = {0, 0};
+  const int n[2] = {n_short, n_long};
+  const int rc = time_model_probes(h, ops, n_ops, n, 2, t, k, done);
+  if (rc != EVOMG_OK) return rc;
+  if (done[0] != n_short || done[1] != n_long) {
+    const int q = done[1] > 0 ? 1 : 0;
+    *ms_fixed = 0.0;
+    *ms_per_iteration = done[q] > 0 ? (t[q] - ms_per_coarse_iteration * (double)k[q]) / done[q] : 0.0;
+    return EVOMG_OK;
+  }
+  const double c_it = ((t[1] - t[0]) - ms_per_coarse_iteration * (double)(k[1] - k[0])) / (double)(n_long - n_short);
+  *ms_per_iteration = c_it;
+  *ms_fixed = t[0] - c_it * n_short - ms_per_coarse_iteration * (double)k[0];
   return EVOMG_OK;
 }
 int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {

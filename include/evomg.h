@@ -278,6 +278,12 @@ int  evomg_coarse_iterations(evomg_handle_t* h, long long* total);
  * the real evaluation this is the candidate's time-to-solution ALONE on the GPU, whatever ran beside that evaluation. */
 int  evomg_time_model(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long,
                       double* ms_fixed, double* ms_per_iteration, double* ms_per_coarse_iteration);
+/* The same fit with ms_per_coarse_iteration KNOWN: what one iteration of the coarse-grid solver costs depends on the problem
+ * and its coarsest level, not on the candidate, so a population measures it on its first few candidates (evomg_time_model)
+ * and every later candidate pays for the two cheap probes only (the third one, n_long iterations with the coarse solver
+ * uncapped, is four fifths of a model's cost on the headline sizes). */
+int  evomg_time_model_known_coarse(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_short, int n_long,
+                                   double ms_per_coarse_iteration, double* ms_fixed, double* ms_per_iteration);
 
 /* -- measurement ------------------------------------------------------------ */
 /* Times `reps` back-to-back launches of one op on the handle's stream with HIP events. */
