@@ -39,7 +39,7 @@ pdh = dataclasses.replace(problems.helmholtz_2d(lo, hi, k=20.0), max_iterations=
 gen = ProgramGenerator(problem=pdh, library=native.library())
 gen.initialize_code_generation(lo, hi)
 pop = candidates.population(lambda: context_for(gen, lo, hi), hi - lo, 2, nh, seed=seed + 1)
-ref = oracle.create(pdh)
+ref = oracle.create(gen.problem)        # the generator's descriptor: its `with jacobi` semantics (default exastencils-v1.1), not the bare problem's
 for k, expression in enumerate(pop):
     ops = gen.generate_op_program(expression, lo, hi)
     got = gen._ensure_handle(lo, hi, None).evaluate(ops, 1, 0, 64)
