@@ -1,6 +1,7 @@
 """Developer tool: more seeds of tests/test_fuzz_gpu.py's random op programs than the suite runs, real (Poisson) and complex
 (Helmholtz with its Robin columns) 2D problems, HIP backend vs CPU oracle bit for bit on every field of every level.
-usage: python tools/fuzz_more.py [first_seed] [count] [3d]   (3d: random programs on 3D Poisson hierarchies instead)"""
+usage: python tools/fuzz_more.py [first_seed] [count] [3d | 3dbig]   (3d: random programs on 3D Poisson hierarchies instead;
+3dbig: hierarchies that end on 129^3 and 257^3, where the marching tiles with their launch geometry run by default)"""
 import os, sys
 os.environ.setdefault("OMP_NUM_THREADS", "4")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,10 +13,11 @@ from test_fuzz_gpu import random_program, with_semantics
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-three_d = len(sys.argv) > 3 and sys.argv[3] == "3d"
+three_d = len(sys.argv) > 3 and sys.argv[3] in ("3d", "3dbig")
+big = len(sys.argv) > 3 and sys.argv[3] == "3dbig"
 bad = 0
 for seed in range(first, first + count):
-    for kind, lo, hi in ((("poisson3d", 2, 5), ("poisson3d", 1, 4), ("poisson3d", 3, 6)) if three_d else
+    for kind, lo, hi in ((("poisson3d", 5, 7), ("poisson3d", 6, 8)) if big else (("poisson3d", 2, 5), ("poisson3d", 1, 4), ("poisson3d", 3, 6)) if three_d else
                          (("poisson", 3, 7), ("helmholtz", 3, 7), ("helmholtz", 4, 8), ("poisson", 4, 8))):
         for semantics in ("textbook", "exastencils-v1.1"):
             if kind == "poisson3d":
