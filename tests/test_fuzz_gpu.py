@@ -112,6 +112,26 @@ def test_random_programs_are_bit_exact(native, oracle, dim, lo, hi, seed, semant
     ho.close()
 
 
+@pytest.mark.parametrize("lo,hi,seed,semantics", [(5, 7, 40, "textbook"), (5, 7, 41, "exastencils-v1.1"), (6, 8, 42, "textbook")])
+def test_random_3d_programs_at_default_thresholds_are_bit_exact(native, oracle, lo, hi, seed, semantics):
+    """Random op programs on 3D hierarchies that end on 129^3 / 257^3 with NOTHING forced: the marching tiles with their
+    round-4 launch geometry (chunk depth by workgroup balance, strips of equal width), the double sweeps and the one-launch
+    red-black sweeps of the levels below them as a candidate gets them by default (tools/fuzz_more.py 3dbig runs more seeds)."""
+    pd = with_semantics(problems.poisson_3d(lo, hi), semantics)
+    rng = np.random.default_rng(3000 + seed)
+    hg, ho = native.create(pd), oracle.create(pd)
+    ops = random_program(rng, 3, lo, hi, 28)
+    load_random(hg, ho, pd, rng)
+    hg.run_ops(ops)
+    ho.run_ops(ops)
+    for L in range(lo, hi + 1):
+        for f in (abi.F_SOL, abi.F_RHS, abi.F_RES):
+            got, want = hg.get_field(L, f), ho.get_field(L, f)
+            assert np.array_equal(got, want, equal_nan=True), (seed, L, f, np.nanmax(np.abs(got - want)))
+    hg.close()
+    ho.close()
+
+
 @pytest.mark.parametrize("lo,hi,seed,semantics", [(3, 7, s, "textbook") for s in range(4)] + [(4, 8, s, "exastencils-v1.1") for s in range(4, 7)])
 def test_random_programs_on_helmholtz_are_bit_exact(native, oracle, lo, hi, seed, semantics):
     """The same random programs on the complex Helmholtz problem: Robin columns after every op that writes a field, the
