@@ -245,6 +245,9 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
                 ra, rb = order(ts) - order(ts).mean(), order(tm) - order(tm).mean()
                 modes[mode]["time_objective_vs_sequential"] = {
                     "median_ratio": float(np.median(tm / ts)), "max_rel_deviation": float(np.max(np.abs(tm - ts) / ts)),
+                    # (the sequential pass measures every candidate ONCE: a single disturbed solve there shows up as the maximum)
+                    "p99_rel_deviation": float(np.percentile(np.abs(tm - ts) / ts, 99)),
+                    "candidates_beyond_5_percent": int(np.sum(np.abs(tm - ts) / ts > 0.05)),
                     "spearman": float((ra * rb).sum() / np.sqrt((ra * ra).sum() * (rb * rb).sum())), "candidates": len(pairs)}
         if mode == "static":
             finite = [r for r in rows if r[3] < 1e99]
