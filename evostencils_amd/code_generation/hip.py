@@ -609,7 +609,8 @@ class ProgramGeneratorPool:
     Why it pays: a candidate's coarse-grid Krylov solve is a 1 ms latency chain on one of 256 compute units; the sweeps of
     the other candidates use the rest of the GPU meanwhile (5.5x on BASELINE's 256-candidate population at 2048^2,
     profiles/r03_throughput_queues.md). Convergence factors and iteration counts are those of the sequential evaluation;
-    a candidate's measured time includes its neighbours, so keep one worker when the time objective must be isolated.
+    a candidate's measured time includes its neighbours unless time_objective="isolated" is asked for (below: short probes on
+    the idle GPU give every candidate the time a sequential evaluation would have measured, at 41.7 instead of 46.7 solves/s).
 
     Everything that is not an evaluation — attributes, generate_storage, generate_cycle_function ... — is answered by the
     first generator; level-range set-up calls go to all of them; the cycle functions of earlier optimisation runs
