@@ -175,3 +175,73 @@ evomg_rbgs3d_block(Geo g, Stencil<double> st, const double* __restrict__ x, cons
     if (gi <= n - 2 && gj <= n - 2 && gk <= n - 2) y[gidx<3>(g, gi, gj, gk)] = U[(lk * TY + lj) * TX + li];
   }
 }
+
+// ---- residual + full weighting in ONE launch on the 3D levels below the tile threshold (round 4) ---------------------------
+// RESIDUAL@L, RESTRICT@(L-1) with the residual field dead afterwards were two thread-per-node launches there. Here a 1024-thread
+// workgroup owns a block of 8 x 4 x 4 coarse nodes: it loads the 19 x 11 x 11 fine values of u around them into LDS, forms the
+// residual on the 17 x 9 x 9 fine nodes the weighting reads (evomg_apply's arithmetic: f - apply_stencil) and then the 27-point
+// sums in evomg_restrict<3>'s order (as evomg_small3d_chain does for a whole level): bit-identical, fields and all.
+#define EVOMG_RR3D_CX 8
+#define EVOMG_RR3D_CY 4
+#define EVOMG_RR3D_CZ 4
+static __global__ void __launch_bounds__(1024)
+evomg_residual_restrict3d_block(Geo g, Geo gc, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f,
+                                double* __restrict__ res_out, double* __restrict__ coarse, int nbx, int nby, int nbz) {
+  constexpr int CX = EVOMG_RR3D_CX, CY = EVOMG_RR3D_CY, CZ = EVOMG_RR3D_CZ;
+  constexpr int FX = 2 * CX + 1, FY = 2 * CY + 1, FZ = 2 * CZ + 1;        // fine nodes whose residual is needed
+  constexpr int UX = FX + 2, UY = FY + 2, UZ = FZ + 2;                    // ... and the values of u around them
+  __shared__ double U[UZ * UY * UX];
+  __shared__ double R[FZ * FY * FX];
+  const int n = g.n, nc = gc.n, tid = (int)threadIdx.x;
+  const int bi = (int)blockIdx.x % nbx, bj = ((int)blockIdx.x / nbx) % nby, bk = (int)blockIdx.x / (nbx * nby);
+  const int I0 = 1 + bi * CX, J0 = 1 + bj * CY, K0 = 1 + bk * CZ;         // first inner coarse node of the block
+  const int i0 = 2 * I0 - 1, j0 = 2 * J0 - 1, k0 = 2 * K0 - 1;            // fine node of R[0]; U[0] sits one further out
+  for (int q = tid; q < UX * UY * UZ; q += 1024) {
+    const int gi = i0 - 1 + q % UX, gj = j0 - 1 + (q / UX) % UY, gk = k0 - 1 + q / (UX * UY);
+    const bool in = gi >= 0 && gi < n && gj >= 0 && gj < n && gk >= 0 && gk < n;
+    U[q] = in ? x[gidx<3>(g, gi, gj, gk)] : 0.0;
+  }
+  __syncthreads();
+  Geo gl;                                                                   // the LDS image of u: rows and planes packed
+  gl.n = UX;
+  gl.pitch = UX;
+  gl.plane = UX * UY;
+  for (int q = tid; q < FX * FY * FZ; q += 1024) {
+    const int li = q % FX, lj = (q / FX) % FY, lk = q / (FX * FY);
+    const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+    double r = 0.0;
+    if (gi >= 1 && gi <= n - 2 && gj >= 1 && gj <= n - 2 && gk >= 1 && gk <= n - 2) {
+      r = f[gidx<3>(g, gi, gj, gk)] - apply_stencil<double, 3>(st, U, gl, gidx<3>(gl, li + 1, lj + 1, lk + 1));
+      // the residual field as the separate launch leaves it (evomg_small3d_chain writes it too): every fine node by ONE block —
+      // the first 2 C layers of its region, the last block of a direction also the layer behind them
+      if (res_out && (li < 2 * CX || bi == nbx - 1) && (lj < 2 * CY || bj == nby - 1) && (lk < 2 * CZ || bk == nbz - 1))
+        res_out[gidx<3>(g, gi, gj, gk)] = r;
+    }
+    R[q] = r;
+  }
+  __syncthreads();
+  for (int qc = tid; qc < CX * CY * CZ; qc += 1024) {
+    const int I = I0 + qc % CX, J = J0 + (qc / CX) % CY, K = K0 + qc / (CX * CY);
+    if (I > nc - 2 || J > nc - 2 || K > nc - 2) continue;
+    const int li = 2 * (I - I0) + 1, lj = 2 * (J - J0) + 1, lk = 2 * (K - K0) + 1;     // the coarse node's fine node in R
+    double face = 0.0, edge = 0.0, corner = 0.0;
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+          if (nz == 0) continue;
+          const double v = R[((lk + dz) * FY + (lj + dy)) * FX + li + dx];
+          if (nz == 1) face = face + v;
+          else if (nz == 2) edge = edge + v;
+          else corner = corner + v;
+        }
+    double v = 0.125 * R[(lk * FY + lj) * FX + li];
+    v = v + 0.0625 * face;
+    v = v + 0.03125 * edge;
+    v = v + 0.015625 * corner;
+    coarse[gidx<3>(gc, I, J, K)] = v;
+  }
+}

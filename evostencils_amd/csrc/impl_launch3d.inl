@@ -94,6 +94,19 @@
     return rbgs3d_block_ && dim_ == 3 && std::is_same<T, double>::value && prob_.bc_kind == EVOMG_BC_DIRICHLET && g.n >= 5 &&
            !use_strip3d(g, true) && !(use_tile3d(g) && tile3d_rbgs_);
   }
+  // residual + restriction on those levels in one launch (evomg_residual_restrict3d_block), the residual field dead
+  bool rr3d_block_ok(const Geo& g) const {
+    return rr3d_block_ && dim_ == 3 && std::is_same<T, double>::value && prob_.bc_kind == EVOMG_BC_DIRICHLET && g.n >= 5 && !use_tile3d(g);
+  }
+  void launch_rr3d_block(int L, const T* x, const T* f, T* res, T* coarse) {
+    if constexpr (std::is_same<T, double>::value) {
+      const Geo &g = lv_[L].g, &gc = lv_[L - 1].g;
+      const int inner = gc.n - 2;
+      const int nbx = (inner + EVOMG_RR3D_CX - 1) / EVOMG_RR3D_CX, nby = (inner + EVOMG_RR3D_CY - 1) / EVOMG_RR3D_CY,
+                nbz = (inner + EVOMG_RR3D_CZ - 1) / EVOMG_RR3D_CZ;
+      hipLaunchKernelGGL(evomg_residual_restrict3d_block, dim3(nbx * nby * nbz), dim3(1024), 0, stream_, g, gc, lv_[L].st, x, f, res, coarse, nbx, nby, nbz);
+    }
+  }
   // x -> lv.alt (the caller advances); zero_first / coarse: the SET_ZERO or PROLONG_ADD in front of the sweep, folded in
   void launch_rbgs3d_block(Level<T>& lv, const T* x, const T* f, double om, double omm, int zero_first, const T* coarse, const Geo& gc, double om_p) {
     T* y = lv.alt;

@@ -211,8 +211,8 @@
     if (a.opcode != EVOMG_OP_RESIDUAL || b.opcode != EVOMG_OP_RESTRICT) return false;
     if (b.level != a.level - 1 || canon(a.level, b.src0) != canon(a.level, a.dst)) return false;
     if (canon(a.level, a.dst) == canon(a.level, a.src0) || canon(a.level, a.dst) == canon(a.level, a.src1)) return false;
-    if (prob_.bc_kind != EVOMG_BC_DIRICHLET || !use_tile3d(lv_[a.level].g)) return false;
-    if (prof_matches(b)) return false;
+    if (prob_.bc_kind != EVOMG_BC_DIRICHLET || !(use_tile3d(lv_[a.level].g) || rr3d_block_ok(lv_[a.level].g))) return false;
+    if (a.level <= prob_.min_level || prof_matches(b)) return false;
     return residual_dead_after(ops, n_ops, i);
   }
 
@@ -582,7 +582,8 @@
         const int L = ops[i].level;
         const bool timed = prof_matches(ops[i]);
         if (timed) { const int rc = prof_open(); if (rc != EVOMG_OK) return rc; }
-        launch_tile3d_residual_restrict(L, fieldptr(L, ops[i].src0), fieldptr(L, ops[i].src1), fieldptr(L - 1, ops[i + 1].dst));
+        if (use_tile3d(lv_[L].g)) launch_tile3d_residual_restrict(L, fieldptr(L, ops[i].src0), fieldptr(L, ops[i].src1), fieldptr(L - 1, ops[i + 1].dst));
+        else launch_rr3d_block(L, fieldptr(L, ops[i].src0), fieldptr(L, ops[i].src1), fieldptr(L, ops[i].dst), fieldptr(L - 1, ops[i + 1].dst));
         // x, f read + the coarse right-hand side written; the residual field is never written
         if (timed) { const int rc = prof_close(2.0 * sizeof(T) * pow((double)lv_[L].g.n, dim_) + (double)sizeof(T) * pow((double)lv_[L - 1].g.n, dim_)); if (rc != EVOMG_OK) return rc; }
         apply_bc(L - 1, fieldptr(L - 1, ops[i + 1].dst));

@@ -256,3 +256,28 @@ def test_zero_and_prolongation_ride_on_the_small_3d_sweep(native, oracle, monkey
         h.close()
     for u, r in got[:2]:
         assert np.array_equal(u, got[2][0]) and np.array_equal(r, got[2][1])
+
+
+@pytest.mark.parametrize("knob", ["EVOMG_NO_RBGS3D_BLOCK", "EVOMG_NO_RR3D_BLOCK"])
+@pytest.mark.parametrize("kind", ["rbgs", "jacobi"])
+def test_small_3d_levels_in_the_solver_loop_at_default_thresholds(native, oracle, monkeypatch, kind, knob):
+    """The reference's 3D example (levels 2..6, 65^3) with nothing forced: the one-launch red-black sweeps (with the zero and the
+    prolongation riding on them) and the one-launch residual + restriction of the levels below the tile threshold, as the body
+    of the solver loop — with each of them switched off, and against the oracle."""
+    for k in list(FORCED) + KNOBS:
+        monkeypatch.delenv(k.lstrip("+"), raising=False)
+    lo, hi = 2, 6
+    ops = v_cycle(SMOOTHERS[kind], lo, hi, 2, 1)
+    pd = problem(3, lo, hi, "textbook", max_iterations=4)
+    outs = []
+    for which in ("fused", "switched_off", "oracle"):
+        if which == "switched_off":
+            monkeypatch.setenv(knob, "1")
+        h = (oracle if which == "oracle" else native).create(pd)
+        out = h.evaluate(ops, 1, 0, 16)
+        outs.append((out, h.get_field(hi, abi.F_SOL), h.get_field(hi, abi.F_RES)))
+        h.close()
+    (a, ua, ra), (b, ub, rb), (c, uc, rc) = outs
+    assert a.n_iterations == b.n_iterations == c.n_iterations
+    assert np.array_equal(a.history, b.history) and np.array_equal(a.history, c.history)
+    assert np.array_equal(ua, ub) and np.array_equal(ua, uc) and np.array_equal(ra, rb) and np.array_equal(ra, rc)
