@@ -604,6 +604,29 @@ __global__ void __launch_bounds__(256) evomg_dot_partial(Geo g, const T* __restr
   s = block_sum(s, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+// The solver loop's residual + r . r on the levels no norm-carrying kernel serves (round 4): evomg_apply<.., true>'s residual of
+// every inner node (written) and, in the same pass, its square added up in evomg_dot_partial's order — one launch instead of two,
+// the same bits (the residual of a node is the value the dot kernel would have read back).
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) evomg_residual_dot_partial(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f,
+                                                                  T* __restrict__ r_out, T* __restrict__ partial) {
+  __shared__ T red[17];
+  const int m = g.n - 2;
+  const long rows = (DIM == 2) ? m : (long)m * m;
+  T s = scalar_traits<T>::zero();
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int j = 1 + (int)(r % m), k = (DIM == 3) ? 1 + (int)(r / m) : 0;
+    const long base = gidx<DIM>(g, 0, j, k);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
+      const long c = base + i;
+      const T v = sc_sub(f[c], apply_stencil<T, DIM>(st, x, g, c));
+      r_out[c] = v;
+      s = sc_add(s, sc_mul(v, v));
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
 // pass 2: one block sums the partials in a fixed order
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_dot_final(const T* __restrict__ partial, int count, T* __restrict__ out) {

@@ -86,6 +86,14 @@
         if (dead) res_stale = true;
         wrote_r = !dead;
         rc = residual_norm_launch3d(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), !dead);
+      } else if (residual_dot_fused_ && prob_.bc_kind == EVOMG_BC_DIRICHLET && !use_strip(lv.g) && !use_tile3d(lv.g) && !use_strip3d(lv.g, false)) {
+        // small finest levels (the reference's 3D example: 65^3): residual and r . r in one pass (evomg_residual_dot_partial)
+        const int m = lv.g.n - 2;
+        const long rows = dim_ == 2 ? m : (long)m * m;
+        const int blocks = (int)(rows < kDotBlocks ? rows : kDotBlocks);
+        if (dim_ == 2) hipLaunchKernelGGL((evomg_residual_dot_partial<T, 2>), dim3(blocks), dim3(256), 0, stream_, lv.g, lv.st, (const T*)fieldptr(L, EVOMG_F_SOL), (const T*)fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), partials_);
+        else hipLaunchKernelGGL((evomg_residual_dot_partial<T, 3>), dim3(blocks), dim3(256), 0, stream_, lv.g, lv.st, (const T*)fieldptr(L, EVOMG_F_SOL), (const T*)fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), partials_);
+        hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dscalar_);
       } else {
         residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
         dot_async(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), dscalar_);
