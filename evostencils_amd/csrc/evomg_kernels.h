@@ -458,6 +458,22 @@ __global__ void __launch_bounds__(256) evomg_zero_inner(Geo g, T* __restrict__ x
   x[gidx<DIM>(g, i, j, k)] = scalar_traits<T>::zero();
 }
 
+// ---- restoring the initial fields before a solve: every SMALL field in one launch (round 4) ---------------------------------
+// A level range of five or six levels has two dozen fields to zero or to copy from their initial image; one hipMemsetAsync /
+// hipMemcpyAsync each was two dozen launches per candidate (a tenth of a 513^2 evaluation's wall time, and launches are what
+// candidates in flight compete for). Segments are 16-byte multiples (rows are padded to 128 bytes).
+#define EVOMG_RESET_MAX 40
+struct ResetSeg { void* dst; const void* src; unsigned long long n16; };
+struct ResetBatch { int n; ResetSeg seg[EVOMG_RESET_MAX]; };
+static __global__ void __launch_bounds__(256) evomg_reset_batch(ResetBatch b) {
+  const ResetSeg s = b.seg[blockIdx.y];
+  uint4* __restrict__ d = reinterpret_cast<uint4*>(s.dst);
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(s.src);
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < s.n16; i += (unsigned long long)gridDim.x * 256)
+    d[i] = src ? src[i] : zero;
+}
+
 // ---- K8: Helmholtz Robin boundary at x = 0, 1:  x_b = x_in / (1 - i k h)  (2D complex only) ----------------
 // (static: the header is part of several translation units)
 static __global__ void __launch_bounds__(256) evomg_robin_bc(Geo g, cplx* __restrict__ x, double kh) {

@@ -78,6 +78,7 @@
   int lower2d_max_n_ = getenv("EVOMG_LOWER2D_MAX_N") ? atoi(getenv("EVOMG_LOWER2D_MAX_N")) : (scalar_traits<T>::is_complex ? 33 : 65);
   bool lower2d_attr_set_ = false;
   bool lower2d_trace_ = getenv("EVOMG_TRACE_LOWER2D") != nullptr;
+  bool reset_batch_ = getenv("EVOMG_NO_RESET_BATCH") == nullptr;     // restoring the initial fields: the small ones in one launch
   bool residual_dot_fused_ = getenv("EVOMG_NO_RESIDUAL_DOT") == nullptr;   // generic loop norm: residual and r . r in one launch
   bool rr3d_block_ = getenv("EVOMG_NO_RR3D_BLOCK") == nullptr;       // small 3D levels: residual + restriction in one launch
   bool rbgs3d_block_ = getenv("EVOMG_NO_RBGS3D_BLOCK") == nullptr;   // small 3D levels: both colours of a red-black sweep in one launch

@@ -23,21 +23,41 @@
   // restore (dirty_): the right-hand side of the finest level and gen_error@max are never written by an MG-iteration solve, and
   // restoring them anyway was 400 MB of the ~10 GB a C2 solve moves (with candidates in flight the GPU is bandwidth bound).
   int reset_fields() {
+    // fields of up to 16 MiB go through ONE launch (evomg_reset_batch), larger ones through the copy / fill engines' kernels
+    ResetBatch batch;
+    batch.n = 0;
+    unsigned long long longest = 0;
+    auto flush = [&]() {
+      if (batch.n == 0) return;
+      unsigned long long bx = (longest + 255) / 256;
+      if (bx > 256) bx = 256;
+      hipLaunchKernelGGL(evomg_reset_batch, dim3((unsigned)bx, (unsigned)batch.n), dim3(256), 0, stream_, batch);
+      batch.n = 0;
+      longest = 0;
+    };
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
       Level<T>& lv = lv_[L];
       lv.alt_mirror = nullptr;
       for (int f = 0; f < EVOMG_F_COUNT; ++f) {
         if (!lv.f[f]) continue;
         if (lazy_reset_ && !dirty_[L][f] && clean_ptr_[L][f] == lv.f[f]) continue;
-        if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        const size_t bytes = lv.elems * sizeof(T);
+        if (reset_batch_ && bytes <= (16u << 20) && bytes % 16 == 0) {
+          if (batch.n == EVOMG_RESET_MAX) flush();
+          batch.seg[batch.n++] = ResetSeg{lv.f[f], lv.init[f], (unsigned long long)(bytes / 16)};
+          if (bytes / 16 > longest) longest = bytes / 16;
+          if (!lv.init[f]) bnd_zero_[L][f] = true;
+        } else if (lv.init[f]) HIP_TRY(hipMemcpyAsync(lv.f[f], lv.init[f], bytes, hipMemcpyDeviceToDevice, stream_));
         else {
-          HIP_TRY(hipMemsetAsync(lv.f[f], 0, lv.elems * sizeof(T), stream_));
+          HIP_TRY(hipMemsetAsync(lv.f[f], 0, bytes, stream_));
           bnd_zero_[L][f] = true;
         }
         dirty_[L][f] = false;
         clean_ptr_[L][f] = lv.f[f];
       }
     }
+    flush();
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream_));
     return EVOMG_OK;
   }

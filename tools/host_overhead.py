@@ -5,7 +5,7 @@ sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
 import bench
 from evostencils_amd import native, problems
 from evostencils_amd.code_generation.hip import ProgramGenerator
-lo, hi = 7, 12
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (7, 12)
 gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), library=native.library())
 gen.initialize_code_generation(lo, hi)
 e = bench.build_candidate(gen, lo, hi)
