@@ -31,6 +31,7 @@
     if (kb_host_) (void)hipHostFree(kb_host_);
     if (kcg_host_) (void)hipHostFree(kcg_host_);
     if (hscalar_) (void)hipHostFree(hscalar_);
+    if (hnorm_) (void)hipHostFree(hnorm_);
     for (auto e : prof_events_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -63,6 +64,8 @@
     HIP_TRY(hipMalloc(&cg_ll_, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS));
     HIP_TRY(hipMemset(cg_ll_, 0, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS));
     HIP_TRY(hipHostMalloc(&hscalar_, sizeof(T) * 8));
+    HIP_TRY(hipHostMalloc(&hnorm_, sizeof(T) * 8, hipHostMallocMapped));
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&hnorm_dev_), hnorm_, 0) != hipSuccess || !hnorm_dev_) host_norm_ = false;
     const int align = 128 / (int)sizeof(T);
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
       Level<T>& lv = lv_[L];

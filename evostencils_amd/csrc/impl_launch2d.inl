@@ -281,6 +281,8 @@
   // costs no second pass. The summation order — per (strip, 16-row chunk) wave, lane = column pair, rows ascending —
   // is canonical for 2D levels of at least 33 nodes (the oracle's FN(norm_strip2d)) and does NOT depend on
   // EVOMG_NO_STRIP or the tuning knobs.
+  // where the solver loop's final reduction writes the norm: straight into pinned host memory (no copy launch behind it), or the device scalar
+  T* norm_out() { return host_norm_ ? hnorm_dev_ : dscalar_; }
   bool norm_fused(const Geo& g) const { return dim_ == 2 && g.n >= 33; }
   // 3D from 129^3 up: residual + norm in ONE tile pass (evomg_tile3d<.., TILE_RESNORM>): canonical order of the solver
   // loop's norm there, whatever kernels the ops themselves run on (oracle: FN(norm_tile3d))
@@ -296,7 +298,7 @@
     if (write_r) launch_tile3d<TILE_RESNORM_W>(g, st, x, f, r, 0.0, 0.0, TwoCellPlan<T>{}, norm_partials_);
     else launch_tile3d<TILE_RESNORM>(g, st, x, f, r, 0.0, 0.0, TwoCellPlan<T>{}, norm_partials_);
     hipLaunchKernelGGL((evomg_sum_stage1<T>), dim3(kDotBlocks), dim3(256), 0, stream_, norm_partials_, count, norm_partials_ + count);
-    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_ + count, kDotBlocks, dscalar_);
+    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_ + count, kDotBlocks, norm_out());
     return EVOMG_OK;
   }
   int residual_norm_launch(int L, const Stencil<T>& st, const T* x, const T* f, T* r) {
@@ -311,7 +313,7 @@
     const dim3 grid((((waves + 3) / 4 + 7) / 8) * 8), block(256);
     if (strip_streams(g)) hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, true>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
     else hipLaunchKernelGGL((evomg_strip2d<T, STRIP_RESNORM, 2, false>), grid, block, 0, stream_, g, st, x, f, r, 0.0, 0.0, EVOMG_NORM_ROWS, strips, waves, 0.0, norm_partials_, 0, ProlongIn<T>{nullptr, g, 0.0, nullptr, inv_c0(st), 0.0});
-    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, dscalar_);
+    hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, waves, norm_out());
     return EVOMG_OK;
   }
 

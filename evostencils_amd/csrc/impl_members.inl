@@ -12,6 +12,9 @@
   T* partials_ = nullptr;
   T* dscalar_ = nullptr;
   T* hscalar_ = nullptr;
+  T* hnorm_ = nullptr;             // pinned host scalar the solver loop's final reduction writes directly (host_norm_)
+  T* hnorm_dev_ = nullptr;         // ... its device address
+  bool host_norm_ = getenv("EVOMG_NO_HOST_NORM") == nullptr;
   int* dinfo_ = nullptr;            // [0] iterations of the last coarse solve, [1] rendezvous miss, [2] iterations of all coarse solves
   long long coarse_iterations_ = 0;
   bool mirror_enabled_ = getenv("EVOMG_NO_BOUNDARY_MIRROR") == nullptr;

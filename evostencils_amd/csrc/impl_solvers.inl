@@ -113,15 +113,15 @@
         const int blocks = (int)(rows < kDotBlocks ? rows : kDotBlocks);
         if (dim_ == 2) hipLaunchKernelGGL((evomg_residual_dot_partial<T, 2>), dim3(blocks), dim3(256), 0, stream_, lv.g, lv.st, (const T*)fieldptr(L, EVOMG_F_SOL), (const T*)fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), partials_);
         else hipLaunchKernelGGL((evomg_residual_dot_partial<T, 3>), dim3(blocks), dim3(256), 0, stream_, lv.g, lv.st, (const T*)fieldptr(L, EVOMG_F_SOL), (const T*)fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES), partials_);
-        hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dscalar_);
+        hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, partials_, blocks, norm_out());
       } else {
         residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
-        dot_async(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), dscalar_);
+        dot_async(L, fieldptr(L, EVOMG_F_RES), fieldptr(L, EVOMG_F_RES), norm_out());
       }
       if (rc != EVOMG_OK) return rc;
       // x, f read (+ the residual field written where the cycle reads it); the reduction launches behind it are included
       if (timed && (rc = prof_close((wrote_r ? 3.0 : 2.0) * sizeof(T) * pow((double)lv.g.n, dim_))) != EVOMG_OK) return rc;
-      HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+      if (!host_norm_) HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
       HIP_TRY(hipEventRecord(norm_event_, stream_));
       return EVOMG_OK;
     };
@@ -176,9 +176,9 @@
       if ((rc = exec_twice(sm, nullptr, norm_partials_)) != EVOMG_OK) return rc;
       if (timed_sm && (rc = prof_close(algorithmic_bytes(sm))) != EVOMG_OK) return rc;
       hipLaunchKernelGGL((evomg_sum_stage1<T>), dim3(kDotBlocks), dim3(256), 0, stream_, norm_partials_, count, norm_partials_ + count);
-      hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_ + count, kDotBlocks, dscalar_);
+      hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_ + count, kDotBlocks, norm_out());
       if (timed_norm && (rc = prof_close(3.0 * sizeof(T) * pow((double)g.n, dim_))) != EVOMG_OK) return rc;
-      HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+      if (!host_norm_) HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
       HIP_TRY(hipEventRecord(norm_event_, stream_));
       res_stale = true;
       *launched = 2;
@@ -192,7 +192,7 @@
     };
     auto wait_norm = [&]() -> int {
       HIP_TRY(hipEventSynchronize(norm_event_));
-      d = hscalar_[0];
+      d = host_norm_ ? hnorm_[0] : hscalar_[0];
       return EVOMG_OK;
     };
     int rc = prob_.max_iterations >= 1 ? norm_on_head(&ahead) : EVOMG_OK;
@@ -227,8 +227,8 @@
           res_stale = true;
           const Geo& g = lv.g;
           const int parts = ((g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS) * ((g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS);
-          hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, dscalar_);
-          HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+          hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, norm_out());
+          if (!host_norm_) HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
           HIP_TRY(hipEventRecord(norm_event_, stream_));
         } else {
           // not after the last iteration the loop may run: there is no coming cycle for the norm to ride on
