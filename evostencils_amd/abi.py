@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
@@ -21,7 +21,7 @@ SOLVE_CONVERGED, SOLVE_MAXITER, SOLVE_DIVERGED, SOLVE_WALL_LIMIT = 0, 1, 2, 3
 REAL_F64, COMPLEX_F64 = 0, 1
 BC_DIRICHLET, BC_HELMHOLTZ_ROBIN = 0, 1
 OUTER_MG_ITERATION, OUTER_PBICGSTAB = 0, 1
-CGS_CG, CGS_BICGSTAB, CGS_FAS_SMOOTHER = 0, 1, 2
+CGS_CG, CGS_BICGSTAB, CGS_FAS_SMOOTHER, CGS_CG_CLASSICAL = 0, 1, 2, 3
 NONLINEAR_NONE, NONLINEAR_GAM_U_EXP_U = 0, 1
 # `with jacobi` slot handling (include/evomg.h EVOMG_JACOBI_*): TEXTBOOK = the sweep's result becomes the field;
 # EXASTENCILS_V11 = the next slot is never advanced, as in the reference's pipeline (notebooks/tutorial.ipynb:3373)

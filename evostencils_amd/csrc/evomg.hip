@@ -21,6 +21,7 @@ int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (p->outer_kind == EVOMG_OUTER_PBICGSTAB && p->dimension != 2) { snprintf(err, len, "PBiCGStab outer solver is 2D only"); return EVOMG_ERR_UNSUPPORTED; }
   if (p->max_iterations < 1 || p->cgs_max_iterations < 1) { snprintf(err, len, "iteration limits must be positive"); return EVOMG_ERR_INVALID; }
   if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) { snprintf(err, len, "jacobi_semantics must be EVOMG_JACOBI_TEXTBOOK or EVOMG_JACOBI_EXASTENCILS_V11"); return EVOMG_ERR_INVALID; }
+  if (p->cgs_kind != EVOMG_CGS_CG && p->cgs_kind != EVOMG_CGS_BICGSTAB && p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER && p->cgs_kind != EVOMG_CGS_CG_CLASSICAL) { snprintf(err, len, "bad coarse-grid solver kind"); return EVOMG_ERR_INVALID; }
   if (p->nonlinear_kind != EVOMG_NONLINEAR_NONE) {
     if (p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
         p->bc_kind != EVOMG_BC_DIRICHLET || p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER ||

@@ -1,0 +1,413 @@
+// evomg_cg1.h — the coarse-grid CG with ONE reduction per iteration (Chronopoulos & Gear 1989), 2D real grids up to 129^2.
+//
+// gen_mgCycle@minLevel with solver_cgs = "CG" (example_problems/Poisson/2D_FD_Poisson_fromL2.exa3:12-14: at most 1000
+// iterations, reduction 1e-12). Classical CG (evomg_krylov.h: evomg_cg_reg2d and friends) has two dependent
+// reduce -> divide chains per iteration (p . A p, then r . r), which is what bounded it: 2.05 us per iteration at 129^2 on
+// ONE compute unit — more units did not pay, two grid rendezvous of 0.6-0.8 us each cost what they saved. The recurrence
+// below needs both inner products at the SAME point of the iteration, so one exchange carries everything that crosses
+// waves:
+//     r0 = b - A x0, w0 = A r0, g = (r0, r0), d = (w0, r0), den = d, alpha = g / den, beta = 0, p = s = 0
+//     repeat:  p = r + beta p;  s = w + beta s  (= A p);  x += alpha p;  r -= alpha s
+//              w = A r;  g' = (r, r);  d = (w, r)                 <- the one reduction
+//              stop when sqrt(g') <= tol * sqrt(g0) or at the iteration cap
+//              beta = g' / g;  den = d - beta^2 den;  alpha = g' / den;  g = g'
+// (den_k = d_k - beta_k g_k / alpha_{k-1} with alpha_{k-1} = g_{k-1} / den_{k-1}: the same real number as in the paper,
+// with two divisions on the scalar chain instead of three.) Same iterates as classical CG in exact arithmetic, same
+// stopping rule on the recursively updated residual; iteration counts on the Poisson levels agree with the classical form
+// (tests/test_cg_variants*.py). The oracle restates exactly this recurrence and summation order (oracle/evomg_oracle_impl.h:
+// coarse_cg1); the classical form stays available on both sides as cgs_kind = EVOMG_CGS_CG_CLASSICAL.
+//
+// Ownership ("bands"): band k owns the R inner rows k R .. k R + R - 1. A wave holds H bands side by side (H = 1: 64 lanes
+// per band; narrow grids: H = 2, 4, ... bands of C = 64 / H lanes, whose last lane never has a column — the zero it holds is
+// the halo between two bands of a wave), lane (h, c) of global wave gw works on band gw H + h and owns the E columns
+// E c .. E c + E - 1 of each of its rows; x, r, p, s and w of these nodes live in registers for the whole solve. West / east
+// neighbours are the lane's other element or one DPP wave shift away. South / north neighbours: every lane ALSO carries r
+// and s of the row below its first and above its last row (ghost rows) and updates them with the very operations their
+// owner executes; the only thing it needs from the neighbouring band for that is that band's edge row of w = A r, which
+// travels with the exchange of the sums — so an iteration has exactly one synchronisation.
+// Waves are grouped into workgroups of WAVES waves; MULTI: `groups` co-resident workgroups share the grid (129^2: the five
+// vectors are 645 KB, more than one unit's registers hold), otherwise one workgroup runs the solve out of one unit.
+//   within a workgroup: wave sums and edge rows through LDS (double-buffered by the parity of the exchange), one barrier;
+//   across workgroups:  every wave publishes its two sums, edge waves their edge row of w, as "LL" words (evomg_krylov.h:
+//                       ll_store / ll_load); wave 0 of every workgroup collects all wave sums before the barrier.
+// Reduction order (restated by the oracle): fused multiply-add accumulation over a lane's nodes (rows ascending, elements
+// ascending), wave64 tree (offsets 32 .. 1), then the tree with offsets 16 .. 1 over the <= 32 wave sums — the same for
+// every grouping of the waves into workgroups, so `groups` and WAVES are tuning parameters, not part of the arithmetic
+// (R, E and H are). Both inner products share ONE tree: after the first step (one v_permlane32_swap of the two registers)
+// lanes 0..31 carry (r, r), lanes 32..63 (w, r).
+// Scalars: 1 / g is formed while the exchange is under way, so the chain behind the sums is two products, one fused
+// multiply-add and ONE division: beta = g' (1 / g), den = d - beta^2 den, alpha = g' / den.
+#pragma once
+#include "evomg_krylov.h"
+
+// developer builds (tools/bench_cg1.hip -DEVOMG_CG1_PROFILE): clock ticks of wave 0 of workgroup 0 per phase of an iteration
+#ifdef EVOMG_CG1_PROFILE
+#define PROF(k) do { if (gw == 0) { const long long t_ = clock64(); prof_acc[k] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
+
+#ifndef EVOMG_CG1_POLL
+#define EVOMG_CG1_POLL 0
+#endif
+#ifndef EVOMG_CG1_SLEEP0
+#define EVOMG_CG1_SLEEP0 8
+#endif
+#ifndef EVOMG_CG1_SLEEP1
+#define EVOMG_CG1_SLEEP1 2
+#endif
+#define EVOMG_CG1_MAX_WAVES 32    // all wave sums of both inner products fit one wave64: (r, r) in lanes 0..31, (w, r) in 32..63
+#define EVOMG_CG1_MAX_GROUPS 16
+#define EVOMG_CG1_MAX_E 2
+// exchange words across workgroups: [parity][quantity][wave][2 words] sums, then [parity][group][edge][element][lane][2 words]
+#define EVOMG_CG1_LL_SUM_WORDS (2 * 2 * EVOMG_CG1_MAX_WAVES * 2)
+#define EVOMG_CG1_LL_WORDS (EVOMG_CG1_LL_SUM_WORDS + 2 * EVOMG_CG1_MAX_GROUPS * 2 * EVOMG_CG1_MAX_E * 64 * 2)
+
+// the band layout of a grid: rows per band, columns per lane, bands per wave, waves in total; waves == 0: no banded form
+struct Cg1Plan {
+  int R, E, H, waves, mask_from;
+};
+__host__ __device__ inline Cg1Plan cg1_plan(int n) {
+  const int m = n - 2;
+  Cg1Plan p{0, 0, 0, 0, 0};
+  if (m < 1 || m > 64 * EVOMG_CG1_MAX_E) return p;
+  p.E = m > 64 ? 2 : 1;
+  p.H = m >= 32 ? 1 : m >= 16 ? 2 : m >= 8 ? 4 : m >= 4 ? 8 : 16;     // a band of a narrow grid keeps one lane without a column
+  // rows per band, by measurement (tools/bench_cg1.hip): 129^2 32 waves of 4 rows, 65^2 4 waves of 16, 33^2 4 waves of 2 x 4
+  p.R = m >= 64 ? 4 : m >= 32 ? 16 : m >= 16 ? 4 : m >= 8 ? 2 : 1;
+  const int bands = (m + p.R - 1) / p.R;
+  p.waves = (bands + p.H - 1) / p.H;
+  if (p.waves > EVOMG_CG1_MAX_WAVES) { p.waves = 0; return p; }
+  // rows from mask_from on may lie outside the grid in the last band that has rows (2^k + 1 grids: it owns R - 1 rows); a
+  // wave with bands that own no row at all masks every row
+  const int last = m - (bands - 1) * p.R;
+  p.mask_from = (bands == p.waves * p.H && last >= p.R - 1) ? p.R - 1 : 0;
+  return p;
+}
+
+__device__ __forceinline__ double cg1_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// wave sums of two quantities in one tree: the first step (offset 32) is one v_permlane32_swap per 32-bit half — afterwards
+// lanes 0..31 hold a[l] + a[l + 32], lanes 32..63 hold b[l - 32] + b[l] — then offsets 16, 8, 4, 2, 1 inside each half.
+// Lane 0 ends up with the sum of a, lane 32 with the sum of b; summation order = wave_sum_fast's.
+__device__ __forceinline__ double cg1_wave_sums(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  double t = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  t += lanes_plus16(t);
+  return row_tree(t);
+}
+// the tree over the wave sums: lane q < 32 holds quantity 0 of wave q, lane 32 + q quantity 1 (zeros beyond the last wave:
+// the steps that would only add them are left out, NW = number of waves rounded up to a power of two)
+template <int NW> __device__ __forceinline__ double cg1_cross_tree(double t) {
+  if constexpr (NW > 16) t += lanes_plus16(t);
+  if constexpr (NW > 8) t += row_plus<8>(t);
+  if constexpr (NW > 4) t += row_plus<4>(t);
+  if constexpr (NW > 2) t += row_plus<2>(t);
+  if constexpr (NW > 1) t += row_plus<1>(t);
+  return t;
+}
+__host__ __device__ constexpr int cg1_pow2_ceil(int v) { return v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 4 : v <= 8 ? 8 : v <= 16 ? 16 : 32; }
+
+// WAVES: waves per workgroup; waves beyond cg1_plan().waves (workgroup padding) own no rows and add zeros.
+// MASK_FROM: first unrolled row that may lie outside the grid (cg1_plan().mask_from, or 0 when padding waves exist).
+// XZERO / b_copy: the SET_ZERO of the solution and the COPY `gen_rhs = RHS` in front of the solve folded in, as in
+// evomg_cg_reg2d: b is the copy's source, the copy (whole array) is written to b_copy, x is not read.
+template <int R, int E, int H, int WAVES, bool MULTI, bool XZERO, int MASK_FROM>
+__global__ void __launch_bounds__(64 * WAVES)
+evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
+                 double* __restrict__ b_copy, int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll,
+                 unsigned seq_base, int groups, int stride) {
+  static_assert(E >= 1 && E <= EVOMG_CG1_MAX_E && (E == 1 || H == 1), "columns per lane");
+  static_assert(!MULTI || H == 1, "several workgroups: full-width bands only");
+  constexpr int C = 64 / H;                          // lanes per band
+  int group = 0;
+  if constexpr (MULTI) {
+    if ((int)blockIdx.x % stride != 0) return;
+    group = (int)blockIdx.x / stride;
+  } else {
+    groups = 1;
+  }
+  __shared__ double sums_lds[2][64];
+  __shared__ double seam_lds[2][2][E][WAVES * 64];  // [parity][edge: first / last row][element][band slot = thread]
+  __shared__ int lds_fail[2];                        // sticky; [parity of the exchange whose barrier publishes it]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int gw = group * WAVES + w;
+  const int m = g.n - 2;
+  const int band = gw * H + l / C;
+  const int iy0 = band * R;
+  const int rows = max(0, min(R, m - iy0));
+  const int ix0 = E * (l % C);
+  bool ok_e[E];
+  double sl[E][5];                                   // this element's coefficients: zero where it has no column
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    ok_e[e] = ix0 + e < m;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sl[e][k] = ok_e[e] ? st.c[k] : 0.0;
+  }
+  const bool has_south = band > 0 && rows > 0, has_north = iy0 + R < m;
+  // where the neighbouring bands' edge rows come from: this workgroup's LDS, or (MULTI) the neighbouring workgroup
+  const bool south_lds = tid >= C, north_lds = tid + C < WAVES * 64;
+  if (tid < 64) { sums_lds[0][tid] = 0.0; sums_lds[1][tid] = 0.0; }
+  if (tid == 0) { lds_fail[0] = 0; lds_fail[1] = 0; }
+  if (b_copy) {
+    const long elems = (long)g.pitch * g.n;
+    for (long q = (long)group * blockDim.x + tid; q < elems; q += (long)groups * blockDim.x) b_copy[q] = b[q];
+  }
+  auto sum_slot = [&](int par, int quantity, int wave) { return ll + ((size_t)(par * 2 + quantity) * EVOMG_CG1_MAX_WAVES + wave) * 2; };
+  auto seam_slot = [&](int par, int grp, int edge, int e) {
+    return ll + EVOMG_CG1_LL_SUM_WORDS + (((((size_t)par * EVOMG_CG1_MAX_GROUPS + grp) * 2 + edge) * EVOMG_CG1_MAX_E + e) * 64 + l) * 2;
+  };
+  // the initial residual of one node (row iy may be a ghost row or lie outside the grid: then zero)
+  auto r_init = [&](int iy, int e, double* xval) -> double {
+    const bool ok = ok_e[e] && iy >= 0 && iy < m;
+    const long c = gidx<2>(g, min(ix0 + e, m - 1) + 1, min(max(iy, 0), m - 1) + 1, 0);
+    if constexpr (XZERO) {
+      if (xval) *xval = 0.0;
+      return ok ? b[c] : 0.0;
+    } else {
+      if (xval) *xval = x[c];
+      return ok ? sc_sub(b[c], apply_stencil_fma<double, 2>(st, x, g, c)) : 0.0;
+    }
+  };
+  double r[R][E], p[R][E], s[R][E], wv[R][E], xv[R][E];
+  double r_gs[E], r_gn[E], s_gs[E], s_gn[E], w_gs[E], w_gn[E];
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      r[i][e] = r_init(iy0 + i, e, &xv[i][e]);
+      p[i][e] = 0.0;
+      s[i][e] = 0.0;
+    }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    r_gs[e] = has_south ? r_init(iy0 - 1, e, nullptr) : 0.0;
+    r_gn[e] = has_north ? r_init(iy0 + R, e, nullptr) : 0.0;
+    s_gs[e] = 0.0;
+    s_gn[e] = 0.0;
+  }
+  __syncthreads();                                   // the zeroed LDS slots
+
+  double gam, del, gn = 0.0, dl = 0.0;
+#ifdef EVOMG_CG1_PROFILE
+  long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = clock64();
+#endif
+  // w = A r on the lane's rows, partial sums of (r, r) and (w, r); operation order of apply_stencil_fma
+  auto apply = [&]() {
+    gam = 0.0;
+    del = 0.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const double from_w = from_left(r[i][E - 1]);  // west of the lane's first element
+      const double from_e = from_right(r[i][0]);     // east of the lane's last element
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const double rc = r[i][e];
+        const double rw = (e == 0) ? from_w : r[i][e > 0 ? e - 1 : 0];
+        const double re = (e == E - 1) ? from_e : r[i][e < E - 1 ? e + 1 : e];
+        const double rs = (i == 0) ? r_gs[e] : r[i > 0 ? i - 1 : 0][e];
+        const double rn = (i == R - 1) ? r_gn[e] : r[i < R - 1 ? i + 1 : i][e];
+        double a = sc_mul(sl[e][0], rc);
+        a = sc_fma(sl[e][1], rw, a);
+        a = sc_fma(sl[e][2], re, a);
+        a = sc_fma(sl[e][3], rs, a);
+        a = sc_fma(sl[e][4], rn, a);
+        if (i >= MASK_FROM) a = (i < rows) ? a : 0.0;      // a row outside the grid: r is zero there, the stencil sum is not
+        wv[i][e] = a;
+        gam = sc_fma(rc, rc, gam);
+        del = sc_fma(a, rc, del);
+      }
+    }
+  };
+  // the one synchronisation of an iteration: sums of both inner products over all waves (gn, dl) and the neighbouring
+  // bands' edge rows of w (w_gs, w_gn). false: a workgroup never arrived (not co-resident) — reported, not waited for again.
+  auto exchange = [&](unsigned seq) -> bool {
+    const int par = (int)(seq & 1u);
+    PROF(0);
+    const double ws = cg1_wave_sums(gam, del);       // lane 0: the wave's (r, r), lane 32: its (w, r)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      seam_lds[par][0][e][tid] = wv[0][e];
+      seam_lds[par][1][e][tid] = wv[R - 1][e];
+    }
+    PROF(1);
+    double ll_gs[E], ll_gn[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { ll_gs[e] = 0.0; ll_gn[e] = 0.0; }
+    if constexpr (!MULTI) {
+      if ((l & 31) == 0) sums_lds[par][(l & 32) + w] = ws;
+    } else {
+      if ((l & 31) == 0) ll_store(sum_slot(par, l >> 5, gw), ws, seq);
+      if (w == 0 && group > 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) ll_store(seam_slot(par, group, 0, e), wv[0][e], seq);
+      }
+      if (w == WAVES - 1 && group < groups - 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) ll_store(seam_slot(par, group, 1, e), wv[R - 1][e], seq);
+      }
+      // wave 0 collects the sums of all waves (lane = (quantity, wave)); the edge waves fetch the neighbouring workgroups'
+      // edge rows. Everything a lane waits for is asked for in one go and polled together: one round trip, not one per word.
+      constexpr int K = 1 + 2 * E;
+      const evomg_u64* slot[K];
+      bool need[K];
+      slot[0] = sum_slot(par, l >> 5, l & 31);
+      need[0] = w == 0 && (l & 31) < groups * WAVES;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        slot[1 + e] = seam_slot(par, group > 0 ? group - 1 : 0, 1, e);
+        need[1 + e] = w == 0 && group > 0;
+        slot[1 + E + e] = seam_slot(par, group < groups - 1 ? group + 1 : group, 0, e);
+        need[1 + E + e] = w == WAVES - 1 && group < groups - 1;
+      }
+      if (w == 0 || w == WAVES - 1) {
+        evomg_u64 a[K], c[K];
+        int budget = 1 << 22;
+        bool all = false;
+#if EVOMG_CG1_POLL == 1
+        // two requests under way, half a trip apart: what a request that left just before the words landed would cost (a
+        // whole further trip) becomes half a trip
+        evomg_u64 a2[K], c2[K];
+        auto ask = [&](evomg_u64 (&u)[K], evomg_u64 (&v)[K]) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (need[k]) {
+              u[k] = __hip_atomic_load(slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              v[k] = __hip_atomic_load(slot[k] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        auto here = [&](const evomg_u64 (&u)[K], const evomg_u64 (&v)[K]) {
+          bool ok_ = true;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (need[k]) ok_ = ok_ && (unsigned)(u[k] >> 32) == seq && (unsigned)(v[k] >> 32) == seq;
+          return ok_;
+        };
+        __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);
+        ask(a, c);
+        for (;;) {
+          __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP1);
+          ask(a2, c2);
+          if (here(a, c)) { all = true; break; }
+          __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP1);
+          ask(a, c);
+          if (here(a2, c2)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { a[k] = a2[k]; c[k] = c2[k]; }
+            all = true;
+            break;
+          }
+          if (--budget == 0) break;
+        }
+#else
+        __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);
+        while (!all) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (need[k]) {
+              a[k] = __hip_atomic_load(slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              c[k] = __hip_atomic_load(slot[k] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          all = true;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (need[k]) all = all && (unsigned)(a[k] >> 32) == seq && (unsigned)(c[k] >> 32) == seq;
+          if (!all && --budget == 0) break;
+        }
+#endif
+        auto value = [&](int k) { return __longlong_as_double((long long)((a[k] & 0xffffffffull) | (c[k] << 32))); };
+        // a missing sum is seen by everybody behind THIS barrier, a missing edge row behind the next one
+        if (!all) lds_fail[need[0] ? par : par ^ 1] = 1;
+        if (w == 0) sums_lds[par][l] = (need[0] && all) ? value(0) : 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (need[1 + e] && all) ll_gs[e] = value(1 + e);
+          if (need[1 + E + e] && all) ll_gn[e] = value(1 + E + e);
+        }
+      }
+    }
+    PROF(2);
+    __syncthreads();
+    PROF(3);
+    double t = sums_lds[par][l];
+    double vs[E], vn[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      vs[e] = south_lds ? seam_lds[par][1][e][south_lds ? tid - C : tid] : ll_gs[e];
+      vn[e] = north_lds ? seam_lds[par][0][e][north_lds ? tid + C : tid] : ll_gn[e];
+    }
+    t = cg1_cross_tree<MULTI ? 32 : cg1_pow2_ceil(WAVES)>(t);
+    gn = cg1_lane(t, 0);
+    dl = cg1_lane(t, 32);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      w_gs[e] = has_south ? vs[e] : 0.0;
+      w_gn[e] = has_north ? vn[e] : 0.0;
+    }
+    // failures seen before this barrier (a missing sum) or after the previous one (a missing edge row): the same answer in
+    // every wave of the workgroup, so all of them leave the loop together
+    bool ok = true;
+    if constexpr (MULTI) ok = lds_fail[par] == 0;
+    PROF(4);
+    return ok;
+  };
+
+  unsigned seq = seq_base;
+  apply();
+  bool alive = exchange(++seq);
+  const double res0 = sc_norm_from_dot(gn);
+  int it = 0;
+  if (alive && res0 != 0.0 && maxit > 0) {
+    double den = dl, alpha = sc_div(gn, dl), beta = 0.0;
+    for (;;) {
+      const double inv_g = sc_div(1.0, gn);          // for the next beta: formed while the exchange is under way
+      const double nalpha = sc_neg(alpha);
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          p[i][e] = sc_fma(beta, p[i][e], r[i][e]);
+          s[i][e] = sc_fma(beta, s[i][e], wv[i][e]);
+          xv[i][e] = sc_fma(alpha, p[i][e], xv[i][e]);
+          r[i][e] = sc_fma(nalpha, s[i][e], r[i][e]);
+        }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {                  // the ghost rows: what their owners do to them
+        s_gs[e] = sc_fma(beta, s_gs[e], w_gs[e]);
+        r_gs[e] = sc_fma(nalpha, s_gs[e], r_gs[e]);
+        s_gn[e] = sc_fma(beta, s_gn[e], w_gn[e]);
+        r_gn[e] = sc_fma(nalpha, s_gn[e], r_gn[e]);
+      }
+      apply();
+      alive = exchange(++seq);
+      ++it;
+      if (!alive) break;
+      const double res = sc_norm_from_dot(gn);
+      if (!(res > tol * res0) || it >= maxit) break;
+      beta = sc_mul(gn, inv_g);
+      den = sc_fma(sc_neg(sc_mul(beta, beta)), den, dl);
+      alpha = sc_div(gn, den);
+      PROF(5);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (ok_e[e] && i < rows) {
+        const long c = gidx<2>(g, ix0 + e + 1, iy0 + i + 1, 0);
+        x[c] = xv[i][e];
+        r_out[c] = r[i][e];
+      }
+#ifdef EVOMG_CG1_PROFILE
+  if (gw == 0 && l == 0) for (int k = 0; k < 6; ++k) reinterpret_cast<long long*>(info + 4)[k] = prof_acc[k];
+#endif
+  // info[1] is sticky (cleared by the host before an evaluation): any workgroup may be the one that saw a missed rendezvous
+  if (tid == 0) {
+    if (group == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
+    if (!alive) info[1] = 1;
+  }
+}

@@ -5,11 +5,11 @@
 #include "evomg_runtime.h"
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"
+#include "evomg_cg1.h"
 #include "evomg_strip.h"
 #include "evomg_strip_cross.h"
 #include "evomg_small2d.h"
 #include "evomg_small3d.h"
-#include "evomg_lower2d.h"
 #include "evomg_tile3d.h"
 #include "evomg_batch.h"
 #include "evomg_strip_block.h"

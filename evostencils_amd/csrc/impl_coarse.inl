@@ -28,7 +28,10 @@
       if constexpr (!scalar_traits<T>::is_complex) {
         const T* src = fieldptr(L, copy_op->src0);
         T* cgs = fieldptr(L, EVOMG_F_CGS_RHS);
-        if (krylov_own<2>(lv.g.n, true).wave) launch_cg_wave2d<true>(lv, x, src, r, cgs);
+        if (cg1_serves(lv.g)) {
+          const int rc = launch_cg1(lv, x, src, r, cgs);
+          if (rc != EVOMG_OK) return rc;
+        } else if (krylov_own<2>(lv.g.n, true).wave) launch_cg_wave2d<true>(lv, x, src, r, cgs);
         else {
           bool launched = false;
           const int rc = launch_cg_reg2d_folded(lv, x, src, r, cgs, &launched);
@@ -74,6 +77,11 @@
         if (dim_ == 2) hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 2, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
         else hipLaunchKernelGGL((evomg_bicgstab_single_wg<T, 3, false>), one, thr, 0, stream_, lv.g, lv.st, x, b, r, w[0], w[1], w[2], w[3], w[4], w[5], prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, 0.0, dinfo_);
       }
+    } else if (cg1_serves(lv.g)) {
+      // real 2D grids up to 129^2: the single-reduction recurrence (evomg_cg1.h)
+      const int rc = launch_cg1(lv, x, b, r, nullptr);
+      if (rc != EVOMG_OK) return rc;
+      apply_bc(L, x);
     } else if (!scalar_traits<T>::is_complex && dim_ == 3 && krylov_cg_groups<3>(lv.g.n) > 1) {
       // 33^3: eight co-resident workgroups (evomg_cg_multi_wg3d); the canonical reduction order of this grid is the
       // grouped one, so there is no single-workgroup alternative
@@ -85,18 +93,13 @@
         cg_multi_attr_set_ = true;
       }
       cg_multi_used_ = true;
-      // sequence numbers of the exchange words: one launch uses at most max_iterations + 1 per exchange kind, above a base
-      // that only grows; before it could wrap, the words are cleared (stream-ordered) and counting starts over
-      const unsigned span = (unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u;
-      if (cg_seq_base_ > 0x7fffffffu - span) {
-        HIP_TRY(hipMemsetAsync(cg_ll_, 0, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS, stream_));
-        cg_seq_base_ = 0;
-      }
+        unsigned seq_base = 0;
+      const int rc_seq = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u, &seq_base);
+      if (rc_seq != EVOMG_OK) return rc_seq;
       const int blocks = EVOMG_CG_GROUPS * cg_stride_;
       if constexpr (!scalar_traits<T>::is_complex)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
-                           prob_.cgs_target_res_reduction, dinfo_, cg_ll_, cg_seq_base_, cg_stride_);
-      cg_seq_base_ += span;
+                           prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
       apply_bc(L, x);
     } else if (!scalar_traits<T>::is_complex && kcg_enabled_ &&
                (dim_ == 2 ? krylov_cg_per_launch<2>(lv.g.n) : krylov_cg_per_launch<3>(lv.g.n))) {
@@ -116,6 +119,63 @@
     }
     HIP_TRY(hipGetLastError());
     return EVOMG_OK;
+  }
+
+  // ---- the single-reduction CG (evomg_cg1.h): which grids it serves, and the launch ------------------------------------
+  bool cgs_is_cg() const { return prob_.cgs_kind == EVOMG_CGS_CG || prob_.cgs_kind == EVOMG_CGS_CG_CLASSICAL; }
+  bool cg1_serves(const Geo& g) const {
+    if (scalar_traits<T>::is_complex || dim_ != 2 || prob_.cgs_kind != EVOMG_CGS_CG || !use_reg_krylov_) return false;
+    const int m = g.n - 2;
+    return m == 1 || m == 3 || m == 7 || m == 15 || m == 31 || m == 63 || m == 127;     // the level grids 3^2 .. 129^2
+  }
+  // sequence numbers of the exchange words: one launch uses at most `span` per exchange kind, above a base that only
+  // grows; before it could wrap, the words are cleared (stream-ordered) and counting starts over
+  int take_ll_sequence(unsigned span, unsigned* base) {
+    if (cg_seq_base_ > 0x7fffffffu - span) {
+      HIP_TRY(hipMemsetAsync(cg_ll_, 0, sizeof(unsigned long long) * EVOMG_CG_LL_WORDS, stream_));
+      cg_seq_base_ = 0;
+    }
+    *base = cg_seq_base_;
+    cg_seq_base_ += span;
+    return EVOMG_OK;
+  }
+  // b_copy != nullptr: the folded form — b is the COPY's source, the solve starts from x = 0 (fusable_copy_zero_solve)
+  template <int R, int E, int H, int WAVES, bool MULTI, int MASK>
+  int launch_cg1_as(const Level<T>& lv, T* x, const T* b, T* r, T* b_copy, int groups) {
+    static_assert(EVOMG_CG1_LL_WORDS <= EVOMG_CG_LL_WORDS, "the exchange area is shared with evomg_cg_multi_wg3d");
+    if constexpr (scalar_traits<T>::is_complex) return invalid("launch_cg1: real problems only");
+    else {
+      unsigned base = 0;
+      int stride = 1;
+      if (MULTI) {
+        const int rc = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u, &base);
+        if (rc != EVOMG_OK) return rc;
+        stride = cg_stride_;
+        cg_multi_used_ = true;
+      }
+      const dim3 grid(MULTI ? groups * stride : 1), block(64 * WAVES);
+      if (b_copy)
+        hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, true, MASK>), grid, block, 0, stream_, lv.g, lv.st, x, b, r, b_copy,
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, cg_ll_, base, groups, stride);
+      else
+        hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, false, MASK>), grid, block, 0, stream_, lv.g, lv.st, x, b, r, (T*)nullptr,
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, cg_ll_, base, groups, stride);
+      return EVOMG_OK;
+    }
+  }
+  // one instantiation per level grid: the band layout is cg1_plan()'s (the oracle restates it), the grouping of the waves
+  // into workgroups is free
+  int launch_cg1(const Level<T>& lv, T* x, const T* b, T* r, T* b_copy) {
+    switch (lv.g.n - 2) {
+      case 127: return launch_cg1_as<4, 2, 1, 4, true, 3>(lv, x, b, r, b_copy, 8);     // 32 waves on eight compute units
+      case 63: return launch_cg1_as<16, 1, 1, 4, false, 15>(lv, x, b, r, b_copy, 1);
+      case 31: return launch_cg1_as<4, 1, 2, 4, false, 3>(lv, x, b, r, b_copy, 1);
+      case 15: return launch_cg1_as<2, 1, 4, 2, false, 1>(lv, x, b, r, b_copy, 1);
+      case 7: return launch_cg1_as<1, 1, 8, 1, false, 0>(lv, x, b, r, b_copy, 1);
+      case 3:
+      case 1: return launch_cg1_as<1, 1, 16, 1, false, 0>(lv, x, b, r, b_copy, 1);
+    }
+    return invalid("launch_cg1: no banded form for this grid");
   }
 
   // CG as a sequence of launches (large coarsest grids): batches of 16 iterations are queued, the done flag is read between

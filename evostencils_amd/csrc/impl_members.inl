@@ -72,15 +72,6 @@
   bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
-  // the lower part of a cycle in one launch (evomg_lower2d.h): levels up to this many nodes per side live in LDS together.
-  // OFF by default — built, bit-identical, measured (profiles/r04_lower_cycle.md) and not faster: one workgroup interpreting
-  // 17 micro-ops takes what the five pipelined launches it replaces take (Helmholtz levels 3..7: 121.3 vs 120.2 ms), and
-  // with the one-wave CG inlined into a 1024-thread workgroup (128 VGPRs per thread) the solver spills (tutorial size 2.77 vs
-  // 1.82 ms). EVOMG_LOWER2D=1 enables it (tests)
-  bool lower2d_enabled_ = getenv("EVOMG_LOWER2D") != nullptr;
-  int lower2d_max_n_ = getenv("EVOMG_LOWER2D_MAX_N") ? atoi(getenv("EVOMG_LOWER2D_MAX_N")) : (scalar_traits<T>::is_complex ? 33 : 65);
-  bool lower2d_attr_set_ = false;
-  bool lower2d_trace_ = getenv("EVOMG_TRACE_LOWER2D") != nullptr;
   bool reset_batch_ = getenv("EVOMG_NO_RESET_BATCH") == nullptr;     // restoring the initial fields: the small ones in one launch
   bool residual_dot_fused_ = getenv("EVOMG_NO_RESIDUAL_DOT") == nullptr;   // generic loop norm: residual and r . r in one launch
   bool rr3d_block_ = getenv("EVOMG_NO_RR3D_BLOCK") == nullptr;       // small 3D levels: residual + restriction in one launch

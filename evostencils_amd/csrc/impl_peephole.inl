@@ -46,7 +46,7 @@
     if (!fuse_enabled_ || !use_reg_krylov_ || i + 2 >= n_ops || dim_ != 2) return false;
     const int L = prob_.min_level;
     // the one-wave or the register CG (real, Dirichlet) or the one-wave BiCGStab (up to 9^2, real or complex with its Robin columns)
-    const bool cg_case = !scalar_traits<T>::is_complex && prob_.cgs_kind == EVOMG_CGS_CG && prob_.bc_kind == EVOMG_BC_DIRICHLET;
+    const bool cg_case = !scalar_traits<T>::is_complex && cgs_is_cg() && prob_.bc_kind == EVOMG_BC_DIRICHLET;
     const bool bicg_case = prob_.cgs_kind == EVOMG_CGS_BICGSTAB && lv_[L].g.n <= 9 &&
                            (prob_.bc_kind == EVOMG_BC_DIRICHLET || (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && scalar_traits<T>::is_complex));
     if (!cg_case && !bicg_case) return false;
@@ -59,7 +59,7 @@
     // "x = 0, so r = b" needs the boundary values of x to be zero as well (SET_ZERO leaves them alone); true for every
     // error field of a cycle, not for a field a test filled with random numbers
     if (!bnd_zero_[L][canon(L, EVOMG_F_CORR)]) return false;
-    return bicg_case || krylov_own<2>(lv_[L].g.n, true).wave != 0 || (cg_fold_reg_ && cg_reg2d_folds(lv_[L].g));
+    return bicg_case || cg1_serves(lv_[L].g) || krylov_own<2>(lv_[L].g.n, true).wave != 0 || (cg_fold_reg_ && cg_reg2d_folds(lv_[L].g));
   }
   bool fusable_residual_restrict(const evomg_op_t* ops, int n_ops, int i) const {
     if (!fuse_enabled_ || i + 1 >= n_ops) return false;
@@ -299,158 +299,6 @@
     }
   }
 
-  // ---- the lower part of a cycle in one launch (evomg_lower2d.h) --------------------------------------------------------
-  // The longest run of ops starting at i that lives entirely on the levels whose fields fit LDS together (all levels up to
-  // lower2d_max_n_ nodes per side, below the finest) and consists of what the device-side interpreter knows: point smoothers,
-  // residual, restriction, prolongation, zero, copy and the one-wave coarse solver. Returns the number of ops consumed
-  // (0: not worth it / not this shape — the per-op launches take over), -1 on a launch error.
-  int lower2d_run(const evomg_op_t* ops, int n_ops, int i, int end) {
-    if (!lower2d_enabled_ || !fuse_enabled_ || dim_ != 2 || batch_enabled_) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 1 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-    constexpr bool CPLX = scalar_traits<T>::is_complex;
-    const bool robin = prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN;
-    if (prob_.bc_kind != EVOMG_BC_DIRICHLET && !(robin && CPLX)) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 2 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-    const int lo = prob_.min_level;
-    int top = -1;
-    for (int L = lo; L < prob_.max_level; ++L)
-      if (lv_[L].g.n <= lower2d_max_n_) top = L;
-    if (top <= lo || top - lo + 1 > EVOMG_LOWER_MAX_LEVELS) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 3 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-    if (ops[i].level < lo || ops[i].level > top) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 4 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-    const int n_lo = lv_[lo].g.n;
-    const bool bicg = prob_.cgs_kind == EVOMG_CGS_BICGSTAB;
-    const bool coarse_ok = use_reg_krylov_ && (bicg ? n_lo <= 9 : (!CPLX && prob_.cgs_kind == EVOMG_CGS_CG && krylov_own<2>(n_lo, true).wave != 0));
-    auto slot_of = [&](int level, int field) -> int {
-      const int c = canon(level, field);
-      if (c == EVOMG_F_SOL) return LOWER_SLOT_SOL;
-      if (c == EVOMG_F_RHS) return LOWER_SLOT_RHS;
-      if (c == EVOMG_F_RES) return LOWER_SLOT_RES;
-      if (c == EVOMG_F_CGS_RHS && level == lo) return LOWER_SLOT_CGS;
-      return -1;
-    };
-    LowerProgram<T> P;
-    memset(&P, 0, sizeof P);
-    bool need_alt[EVOMG_LOWER_MAX_LEVELS] = {};
-    int p = i;
-    for (; p < end && P.n_ops < EVOMG_LOWER_MAX_OPS; ++p) {
-      const evomg_op_t& op = ops[p];
-      if (op.level < lo || op.level > top || prof_matches(op)) break;
-      LowerOp m{};
-      m.level = (signed char)(op.level - lo);
-      m.om = op.omega;
-      bool ok = true;
-      switch (op.opcode) {
-        case EVOMG_OP_SMOOTH:
-          m.kind = LOWER_SMOOTH;
-          m.dst = (signed char)slot_of(op.level, op.dst);
-          m.src1 = (signed char)slot_of(op.level, op.src1);
-          m.part = (signed char)op.partitioning;
-          m.lost = jacobi_lost(op) ? 1 : 0;
-          ok = op.block[0] * op.block[1] == 1 && m.dst >= 0 && m.src1 >= 0 && m.dst != m.src1;
-          if (ok && op.partitioning != EVOMG_PART_RED_BLACK) need_alt[op.level - lo] = true;
-          break;
-        case EVOMG_OP_RESIDUAL:
-          m.kind = LOWER_RESIDUAL;
-          m.dst = (signed char)slot_of(op.level, op.dst);
-          m.src0 = (signed char)slot_of(op.level, op.src0);
-          m.src1 = (signed char)slot_of(op.level, op.src1);
-          ok = m.dst >= 0 && m.src0 >= 0 && m.src1 >= 0 && m.dst != m.src0 && m.dst != m.src1;
-          break;
-        case EVOMG_OP_RESTRICT:
-          m.kind = LOWER_RESTRICT;
-          m.dst = (signed char)slot_of(op.level, op.dst);
-          m.src0 = (signed char)(op.level + 1 <= top ? slot_of(op.level + 1, op.src0) : -1);
-          ok = m.dst >= 0 && m.src0 >= 0;
-          break;
-        case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET:
-          m.kind = op.opcode == EVOMG_OP_PROLONG_ADD ? LOWER_PROLONG_ADD : LOWER_PROLONG_SET;
-          m.dst = (signed char)slot_of(op.level, op.dst);
-          m.src0 = (signed char)(op.level - 1 >= lo ? slot_of(op.level - 1, op.src0) : -1);
-          ok = m.dst >= 0 && m.src0 >= 0;
-          break;
-        case EVOMG_OP_SET_ZERO:
-          m.kind = LOWER_ZERO;
-          m.dst = (signed char)slot_of(op.level, op.dst);
-          ok = m.dst >= 0;
-          break;
-        case EVOMG_OP_COPY:
-          m.kind = LOWER_COPY;
-          m.dst = (signed char)slot_of(op.level, op.dst);
-          m.src0 = (signed char)slot_of(op.level, op.src0);
-          ok = m.dst >= 0 && m.src0 >= 0;
-          break;
-        case EVOMG_OP_COARSE_SOLVE:
-          m.kind = LOWER_COARSE;
-          ok = coarse_ok && op.level == lo;
-          break;
-        default: ok = false;
-      }
-      if (!ok) break;
-      P.op[P.n_ops++] = m;
-    }
-    const int len = p - i;
-    if (len < 4) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 5 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }                                    // a launch's worth of set-up and write-back has to pay
-    // LDS layout: per level SOL, RHS, RES (+ the coarse solver's right-hand side on the coarsest, + a spare image where a
-    // Jacobi sweep needs one)
-    size_t elems = 0;
-    P.n_levels = top - lo + 1;
-    for (int L = lo; L <= top; ++L) {
-      const int k = L - lo;
-      const size_t nn = (size_t)lv_[L].g.n * lv_[L].g.n;
-      P.g[k] = lv_[L].g;
-      P.st[k] = lv_[L].st;
-      P.kh[k] = robin ? kh(L) : 0.0;
-      for (int s2 = 0; s2 < LOWER_SLOTS; ++s2) P.offset[k][s2] = -1;
-      const int fields[LOWER_SLOT_ALT] = {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES, EVOMG_F_CGS_RHS};
-      for (int s2 = 0; s2 < LOWER_SLOT_ALT; ++s2) {
-        if (s2 == LOWER_SLOT_CGS && L != lo) continue;
-        T* ptr = lv_[L].f[fields[s2]];
-        if (!ptr) continue;
-        P.field[k][s2] = ptr;
-        P.offset[k][s2] = (int)elems;
-        elems += nn;
-      }
-      if (need_alt[k]) { P.offset[k][LOWER_SLOT_ALT] = (int)elems; elems += nn; }
-    }
-    const size_t lds_bytes = elems * sizeof(T);
-    if (lds_bytes + 1024 > max_lds_) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 6 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-    for (int q = 0; q < P.n_ops; ++q) {
-      const LowerOp& m = P.op[q];
-      if (m.kind == LOWER_COARSE) { P.store[0][LOWER_SLOT_SOL] = 1; P.store[0][LOWER_SLOT_RES] = 1; }
-      else if (!(m.kind == LOWER_SMOOTH && m.lost)) P.store[(int)m.level][(int)m.dst] = 1;
-      // every slot an op names has to have an image (a level without that field: not this shape)
-      const int refs[3] = {m.kind == LOWER_COARSE ? -1 : m.dst, (m.kind == LOWER_RESIDUAL || m.kind == LOWER_COPY) ? m.src0 : -1,
-                           (m.kind == LOWER_SMOOTH || m.kind == LOWER_RESIDUAL) ? m.src1 : -1};
-      for (int r : refs)
-        if (r >= 0 && P.offset[(int)m.level][r] < 0) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 7 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-      if (m.kind == LOWER_RESTRICT && P.offset[m.level + 1][(int)m.src0] < 0) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 8 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-      if ((m.kind == LOWER_PROLONG_ADD || m.kind == LOWER_PROLONG_SET) && P.offset[m.level - 1][(int)m.src0] < 0) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 9 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-      if (m.kind == LOWER_COARSE && (P.offset[0][LOWER_SLOT_CGS] < 0 || P.offset[0][LOWER_SLOT_RES] < 0)) { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 10 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-    }
-    P.robin = robin ? 1 : 0;
-    P.cgs_kind = prob_.cgs_kind;
-    P.cgs_maxit = prob_.cgs_max_iterations;
-    P.cgs_tol = prob_.cgs_target_res_reduction;
-    P.cg_mask_full = (n_lo - 2) - EVOMG_CG_WAVE_ROWS >= EVOMG_CG_WAVE_ROWS - 1 ? 1 : 0;      // launch_cg_wave2d's choice of MASK_FROM
-    P.info = dinfo_;
-    // (the kernel also holds 144 bytes of static LDS: the dynamic limit has to leave room for them)
-    if (lds_bytes > 48 * 1024 && !lower2d_attr_set_) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_lower2d<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_ - 1024) != hipSuccess) {
-        (void)hipGetLastError();
-        lower2d_enabled_ = false;
-        { if (lower2d_trace_) fprintf(stderr, "lower2d: reason 11 at op %d (level %d, opcode %d)\n", i, ops[i].level, ops[i].opcode); return 0; }
-      }
-      lower2d_attr_set_ = true;
-    }
-    hipLaunchKernelGGL((evomg_lower2d<T>), dim3(1), dim3(1024), lds_bytes, stream_, P);
-    if (hipGetLastError() != hipSuccess) { snprintf(err, sizeof err, "evomg_lower2d: launch failed"); return -1; }
-    // host-side bookkeeping of the ops the launch stood for
-    for (int q = i; q < p; ++q) {
-      const evomg_op_t& op = ops[q];
-      if (op.opcode == EVOMG_OP_COPY) bnd_zero_[op.level][canon(op.level, op.dst)] = bnd_zero_[op.level][canon(op.level, op.src0)];
-      lv_[op.level].alt_mirror = nullptr;
-    }
-    return len;
-  }
-
   // ---- cross-iteration fusion (evomg_strip_cross.h) ------------------------------------------------------------------
   // The cycle ends with [PROLONG_ADD +] a red-black point sweep on SOL@max and starts with one, (normally) followed by
   // RESIDUAL + RESTRICT of a residual nobody else reads: the solver loop then runs tail and head of consecutive iterations
@@ -501,14 +349,6 @@
         continue;
       }
       flush_batch();
-      {
-        const int len = lower2d_run(ops, n_ops, i, end);
-        if (len < 0) return EVOMG_ERR_DEVICE;
-        if (len > 0) {
-          i += len - 1;
-          continue;
-        }
-      }
       if (i + 1 < end && elidable_zero(ops, n_ops, i)) {
         x_zero_next_ = true;          // consumed by the sweep launched for ops[i + 1] (plain or fused)
         continue;

@@ -19,6 +19,9 @@ def library() -> abi.Library:
             _library = abi.Library(LIB_PATH)
         except OSError as exc:
             raise RuntimeError(f"HIP backend failed to load ({LIB_PATH}): {exc}") from exc
+        except AttributeError as exc:     # a library built before a symbol of the current header existed
+            raise RuntimeError(f"HIP backend {LIB_PATH} lacks a symbol of include/evomg.h ({exc}); "
+                               f"rebuild with `python -m evostencils_amd.build`") from exc
         if _library.fn["abi_version"]() != abi.ABI_VERSION:
             raise RuntimeError("HIP backend ABI version mismatch; rebuild with `python -m evostencils_amd.build`")
     return _library

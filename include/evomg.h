@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EVOMG_ABI_VERSION 4
+#define EVOMG_ABI_VERSION 5
 #define EVOMG_MAX_LEVELS 24       /* levels are absolute: grid level L has 2^L+1 nodes per dimension */
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
@@ -69,10 +69,19 @@ enum {
 
 /* coarse-grid solver = gen_mgCycle@minLevel */
 enum {
-  EVOMG_CGS_CG = 0,       /* solver_cgs = "CG" (Poisson/2D_FD_Poisson_fromL2.exa3:12-14) */
+  EVOMG_CGS_CG = 0,       /* solver_cgs = "CG" (Poisson/2D_FD_Poisson_fromL2.exa3:12-14: at most cgs_max_iterations,
+                             reduction cgs_target_res_reduction). ABI 5: where a single-reduction form of the recurrence
+                             exists (Chronopoulos & Gear: both inner products of an iteration in ONE reduction, the same
+                             iterates in exact arithmetic, the same stopping rule) the solve runs in that form — real 2D
+                             grids up to 129^2 (csrc/evomg_cg1.h), real 3D grids of 33^3 (evomg_cg1_slab3d) — otherwise as
+                             EVOMG_CGS_CG_CLASSICAL. The reference's one recorded number does not depend on the coarse
+                             solver's arithmetic (oracle/APPB_MATRIX.md, row "coarse=exact") */
   EVOMG_CGS_BICGSTAB = 1, /* explicit BiCGStab text, Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 */
-  EVOMG_CGS_FAS_SMOOTHER = 2  /* non-linear FAS problems: cgs_max_iterations Newton-Jacobi sweeps with weight fas_cgs_omega
+  EVOMG_CGS_FAS_SMOOTHER = 2, /* non-linear FAS problems: cgs_max_iterations Newton-Jacobi sweeps with weight fas_cgs_omega
                                  (`Function CGS@coarsest`: repeat 200 times Smoother, FAS_2D_Basic_template.exa4:56-61,63-71) */
+  EVOMG_CGS_CG_CLASSICAL = 3  /* ABI 5: "CG" as the textbook two-reduction recurrence on every grid (p . A p, then r . r):
+                                 what EVOMG_CGS_CG was up to ABI 4; kept as the second mode the single-reduction form is
+                                 checked against */
 };
 
 /* Non-linear term N(u) of a FAS problem -Lap u + N(u) = f, SURVEY 8f N4 (exastencils_FAS.py; FAS_2D_Basic_template.exa4) */

@@ -145,6 +145,9 @@ static int check_problem(const evomg_problem_t* p) {
   if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) {
     snprintf(g_err, sizeof g_err, "jacobi_semantics must be chosen"); return EVOMG_ERR_INVALID;
   }
+  if (p->cgs_kind != EVOMG_CGS_CG && p->cgs_kind != EVOMG_CGS_BICGSTAB && p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER && p->cgs_kind != EVOMG_CGS_CG_CLASSICAL) {
+    snprintf(g_err, sizeof g_err, "bad coarse-grid solver kind"); return EVOMG_ERR_INVALID;
+  }
   if (p->nonlinear_kind != EVOMG_NONLINEAR_NONE) {
     if (p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
         p->bc_kind != EVOMG_BC_DIRICHLET || p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER ||

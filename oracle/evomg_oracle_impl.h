@@ -693,6 +693,111 @@ static int FN(coarse_cg)(FN(ctx_t)* c) {
   return it;
 }
 
+/* ---- K9a': CG in its single-reduction form (Chronopoulos & Gear) — what cgs_kind = EVOMG_CGS_CG runs on real 2D grids up to
+ * 129^2 (csrc/evomg_cg1.h: evomg_cg1_band2d). Same configuration as the classical form (Poisson/2D_FD_Poisson_fromL2.exa3:12-14),
+ * same stopping rule; both inner products of an iteration are needed at the same point of the recurrence:
+ *     r0 = b - A x0, w0 = A r0, g = (r0, r0), d = (w0, r0), den = d, alpha = g / den, beta = 0, p = s = 0
+ *     repeat:  p = r + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  w = A r;  g' = (r, r);  d = (w, r)
+ *              stop when sqrt(g') <= tol sqrt(g0) or at the iteration cap
+ *              beta = g' (1 / g);  den = d - beta^2 den;  alpha = g' / den;  g = g'
+ * Summation order = the device's band ownership (csrc/evomg_cg1.h: cg1_plan): band k owns the R rows k R .. k R + R - 1; a
+ * wave holds H bands of C = 64 / H lanes, lane (h, c) of wave gw accumulates the E columns E c .. of band gw H + h (rows
+ * ascending, elements ascending, fused multiply-add), then the wave64 tree, then the tree with offsets 16 .. 1 over the
+ * (at most 32) wave sums. */
+typedef struct { int R, E, H, waves; } FN(cg1_plan_t);
+static FN(cg1_plan_t) FN(cg1_plan)(int n) {
+  const int m = n - 2;
+  FN(cg1_plan_t) p = {0, 0, 0, 0};
+  if (m < 1 || m > 128) return p;
+  p.E = m > 64 ? 2 : 1;
+  p.H = m >= 32 ? 1 : m >= 16 ? 2 : m >= 8 ? 4 : m >= 4 ? 8 : 16;
+  p.R = m >= 64 ? 4 : m >= 32 ? 16 : m >= 16 ? 4 : m >= 8 ? 2 : 1;
+  const int bands = (m + p.R - 1) / p.R;
+  p.waves = (bands + p.H - 1) / p.H;
+  if (p.waves > 32) p.waves = 0;
+  return p;
+}
+/* which coarsest grids the single-reduction form serves (csrc/impl_coarse.inl: cg1_serves): the level grids 3^2 .. 129^2 */
+static int FN(cg1_serves)(FN(ctx_t)* c, int level) {
+  const int m = c->lv[level].n - 2;
+  if (SC_IS_COMPLEX || c->dim != 2 || c->prob.cgs_kind != EVOMG_CGS_CG) return 0;
+  return m == 1 || m == 3 || m == 7 || m == 15 || m == 31 || m == 63 || m == 127;
+}
+static SC FN(dot_bands)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
+  const int n = c->lv[level].n, m = n - 2;
+  const FN(cg1_plan_t) pl = FN(cg1_plan)(n);
+  const int C = 64 / pl.H;
+  SC waves[64];
+  for (int w = 0; w < 64; ++w) waves[w] = sc_zero();
+  for (int gw = 0; gw < pl.waves; ++gw) {
+    SC lanes[64];
+    for (int l = 0; l < 64; ++l) {
+      SC s = sc_zero();
+      for (int i = 0; i < pl.R; ++i)
+        for (int e = 0; e < pl.E; ++e) {
+          const int ix = pl.E * (l % C) + e, iy = (gw * pl.H + l / C) * pl.R + i;
+          if (ix < m && iy < m) {
+            const size_t idx = IDX2(n, ix + 1, iy + 1);
+            s = sc_fma(a[idx], b[idx], s);
+          }
+        }
+      lanes[l] = s;
+    }
+    waves[gw] = FN(tree64)(lanes);
+  }
+  /* the device's tree runs over 32 slots (offsets 16 .. 1): tree64's first step only adds the zeros of slots 32 .. 63 */
+  return FN(tree64)(waves);
+}
+static int FN(coarse_cg1)(FN(ctx_t)* c) {
+  const int L = c->prob.min_level;
+  FN(level_t)* lv = &c->lv[L];
+  const int n = lv->n;
+  SC* x = FN(field)(c, L, EVOMG_F_CORR);
+  const SC* b = FN(field)(c, L, EVOMG_F_CGS_RHS);
+  SC* rout = FN(field)(c, L, EVOMG_F_RES);
+  /* r, p, s, w are vectors of the solver with a homogeneous boundary (the device keeps them in registers): work arrays
+   * whose boundary entries stay zero; the residual field receives the inner nodes of r at the end */
+  SC* r = FN(tmpvec)(c, L, 0);
+  SC* p = FN(tmpvec)(c, L, 1);
+  SC* s = FN(tmpvec)(c, L, 2);
+  SC* w = FN(tmpvec)(c, L, 3);
+  memset(r, 0, lv->count * sizeof(SC));
+  memset(p, 0, lv->count * sizeof(SC));
+  memset(s, 0, lv->count * sizeof(SC));
+  memset(w, 0, lv->count * sizeof(SC));
+  FN(krylov_apply)(c, L, lv->st, x, b, r, 1);
+  FN(krylov_apply)(c, L, lv->st, r, NULL, w, 0);
+  SC g = FN(dot_bands)(c, L, r, r);
+  SC d = FN(dot_bands)(c, L, w, r);
+  const double res0 = sc_norm_from_dot(g);
+  int it = 0;
+  if (res0 != 0.0 && c->prob.cgs_max_iterations > 0) {
+    SC den = d, alpha = sc_div(g, d), beta = sc_zero();
+    for (;;) {
+      const SC inv_g = sc_div(sc_from_real(1.0), g);
+      FN(krylov_axpy)(c, L, p, beta, p, r);                 /* p = beta p + r */
+      FN(krylov_axpy)(c, L, s, beta, s, w);                 /* s = beta s + w */
+      FN(krylov_axpy)(c, L, x, alpha, p, x);                /* x = alpha p + x */
+      FN(krylov_axpy)(c, L, r, sc_neg(alpha), s, r);        /* r = -alpha s + r */
+      FN(krylov_apply)(c, L, lv->st, r, NULL, w, 0);
+      const SC gn = FN(dot_bands)(c, L, r, r);
+      d = FN(dot_bands)(c, L, w, r);
+      ++it;
+      const double res = sc_norm_from_dot(gn);
+      if (!(res > c->prob.cgs_target_res_reduction * res0) || it >= c->prob.cgs_max_iterations) break;
+      beta = sc_mul(gn, inv_g);
+      den = sc_fma(sc_neg(sc_mul(beta, beta)), den, d);
+      alpha = sc_div(gn, den);
+      g = gn;
+    }
+  }
+  for (int j = 1; j < n - 1; ++j)
+    for (int i = 1; i < n - 1; ++i) rout[IDX2(n, i, j)] = r[IDX2(n, i, j)];
+  FN(apply_bc)(c, L, x);
+  if (getenv("EVOMG_ORACLE_DEBUG")) fprintf(stderr, "[oracle] coarse CG (single reduction): %d iterations (cap %d)\n", it, c->prob.cgs_max_iterations);
+  return it;
+}
+
 /* ---- K9b: BiCGStab coarse-grid solver: literal restatement of
  * example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3:396-433 (the DSL text IS the spec). */
 static int FN(coarse_bicgstab)(FN(ctx_t)* c) {
@@ -830,6 +935,7 @@ static int FN(exec_op)(FN(ctx_t)* c, const evomg_op_t* op) {
     }
     case EVOMG_OP_COARSE_SOLVE:
       if (c->prob.cgs_kind == EVOMG_CGS_BICGSTAB) FN(coarse_bicgstab)(c);
+      else if (FN(cg1_serves)(c, c->prob.min_level)) FN(coarse_cg1)(c);
       else FN(coarse_cg)(c);
       return EVOMG_OK;
   }

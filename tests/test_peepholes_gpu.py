@@ -71,8 +71,6 @@ NON_CYCLIC = {
     "strip_block_2d": (2, 4, 7, "EVOMG_NO_STRIP_BLOCK", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "block_fast_2d": (2, 4, 7, "EVOMG_NO_BLOCK_FAST", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "boundary_mirror_2d": (2, 4, 7, "EVOMG_NO_BOUNDARY_MIRROR", lambda s, lo, hi: [s(hi), s(hi), s(hi), prolong(hi), s(hi)]),
-    "lower_cycle_2d": (2, 3, 7, "+EVOMG_LOWER2D", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), restrict(hi - 2), zero(hi - 2), s(hi - 2),
-                                                                        residual(hi - 2), restrict(hi - 3), prolong(hi - 2), s(hi - 2), prolong(hi - 1), s(hi - 1)]),
     "double_sweep_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1), s(hi - 1), s(hi - 1)]),
     "zero_double_sweep_3d": (3, 2, 5, "EVOMG_NO_TWICE_XZERO", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), s(hi - 1), residual(hi - 1), s(hi - 1), zero(hi - 2), s(hi - 2), s(hi - 2),
                                                                                   s(hi - 2), residual(hi - 2)]),
@@ -104,8 +102,6 @@ CYCLIC = {
     "register_cg_fold_cycle_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_plain_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
-    "lower_cycle_2d": (2, 3, 7, "+EVOMG_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
-    "lower_cycle_deep_2d": (2, 2, 8, "+EVOMG_LOWER2D", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
     "residual_restrict_3d": (3, 2, 5, "EVOMG_NO_TILE3D_RR", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "double_sweep_cycle_3d": (3, 2, 5, "EVOMG_NO_TILE3D_TWICE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
     "residual_norm_3d": (3, 2, 5, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
