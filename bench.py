@@ -32,6 +32,8 @@ import time
 # hardware queues for the candidates-in-flight modes: must be in the environment before the HIP runtime initialises
 # (evostencils_amd/__init__.py explains; ranks started by the launcher inherit it)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# A/B of the coarse-grid CG's two forms (ProgramGenerator(coarse_cg=...)); the default is the product's default
+COARSE_CG = os.environ.get("EVOMG_BENCH_COARSE_CG", "single-reduction")
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
@@ -162,7 +164,7 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
     from helpers import context_for
     hi = args.population_level
     lo = hi - 4
-    gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library())
+    gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library(), coarse_cg=COARSE_CG)
     gen.initialize_code_generation(lo, hi)
     pop = candidates.population(lambda: context_for(gen, lo, hi), hi - lo, 2, args.population, seed=2024)
     busy = [0.0]
@@ -191,7 +193,7 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
     workers = None
     if in_flight:
         def make():
-            g2 = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library())
+            g2 = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library(), coarse_cg=COARSE_CG)
             g2.initialize_code_generation(lo, hi)
             return g2
         workers = population.ConcurrentEvaluator(make, in_flight)
@@ -279,7 +281,7 @@ def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):
     from evostencils_amd import native, problems
     from evostencils_amd.code_generation.hip import ProgramGenerator
     lo, hi = 5, 9
-    gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library())
+    gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library(), coarse_cg=COARSE_CG)
     gen.initialize_code_generation(lo, hi)
     storages = gen.generate_storage(lo, hi, gen.finest_grid)
     expression = build_candidate(gen, lo, hi)
@@ -297,7 +299,7 @@ def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):
         from evostencils_amd import population
 
         def make():
-            g = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library())
+            g = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank, library=native.library(), coarse_cg=COARSE_CG)
             g.initialize_code_generation(lo, hi)
             return g
         workers = population.ConcurrentEvaluator(make, in_flight)
@@ -453,7 +455,7 @@ def main():
 
     lo, hi = args.min_level, args.max_level
     gen = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank,
-                           library=native.library())
+                           library=native.library(), coarse_cg=COARSE_CG)
     gen.initialize_code_generation(lo, hi)
     storages = gen.generate_storage(lo, hi, gen.finest_grid)
     expression = build_candidate(gen, lo, hi)
@@ -463,7 +465,7 @@ def main():
     if n_extra > 0:
         def make():
             g2 = ProgramGenerator(problem=problems.poisson_2d(lo, hi), device_id=local_rank, mpi_rank=rank,
-                                  library=native.library())
+                                  library=native.library(), coarse_cg=COARSE_CG)
             g2.initialize_code_generation(lo, hi)
             return g2
         workers = population.ConcurrentEvaluator(make, n_extra)

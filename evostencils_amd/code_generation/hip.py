@@ -58,7 +58,11 @@ class ProgramGenerator:
           layer 4 for "[next]"; with the ExaStencils version the reference pins (README.md:19-21) it evidently never
           fires: the one numeric the reference records (notebooks/tutorial.ipynb:3373) is reproduced to the last
           printed digit this way and under no other convention (oracle/APPB_MATRIX.md).
-      "textbook"  the sweep's result becomes the field (the IR / LFA meaning, and what that patch intends)."""
+      "textbook"  the sweep's result becomes the field (the IR / LFA meaning, and what that patch intends).
+
+    `coarse_cg`: how `solver_cgs = "CG"` runs — "single-reduction" (default: include/evomg.h EVOMG_CGS_CG, both inner
+    products of an iteration in one reduction where such a kernel exists) or "classical" (EVOMG_CGS_CG_CLASSICAL, the textbook
+    recurrence everywhere). The same Krylov process either way; no number the reference records depends on it."""
     COARSE_COST_SAMPLES = 3      # full three-probe time models a generator runs before it takes the coarse-iteration cost as known
 
 
@@ -68,7 +72,8 @@ class ProgramGenerator:
                  cycle_name="gen_mgCycle", model_based_estimation=False, evaluation_timeout=300,
                  code_generation_timeout=300, c_compiler_timeout=120, solver_iteration_limit=None, *,
                  problem: Optional[problems.ProblemDescription] = None, device_id: Optional[int] = None,
-                 library: Optional[abi.Library] = None, jacobi_semantics: str = "exastencils-v1.1"):
+                 library: Optional[abi.Library] = None, jacobi_semantics: str = "exastencils-v1.1",
+                 coarse_cg: str = "single-reduction"):
         if isinstance(solution_equations, str):
             solution_equations = [solution_equations]
         self._average_generation_time = 0
@@ -117,9 +122,13 @@ class ProgramGenerator:
                 raise RuntimeError("dimensionality mismatch between knowledge file and problem")
         if jacobi_semantics not in abi.JACOBI_SEMANTICS:
             raise ValueError(f"jacobi_semantics must be one of {sorted(abi.JACOBI_SEMANTICS)}")
+        if coarse_cg not in ("single-reduction", "classical"):
+            raise ValueError("coarse_cg must be 'single-reduction' or 'classical'")
         import dataclasses
         problem = dataclasses.replace(problem, jacobi_semantics=abi.JACOBI_SEMANTICS[jacobi_semantics],
                                       parameters=dict(problem.parameters))
+        if problem.cgs_kind in (abi.CGS_CG, abi.CGS_CG_CLASSICAL):
+            problem = dataclasses.replace(problem, cgs_kind=abi.CGS_CG if coarse_cg == "single-reduction" else abi.CGS_CG_CLASSICAL)
         self._jacobi_semantics = jacobi_semantics
         self._problem = problem
         self._original_min_level = problem.min_level

@@ -1,3 +1,4 @@
+#include <atomic>
 // evomg.hip — the C-ABI of include/evomg.h: descriptor checks, the handle, dispatch to one of four implementation classes
 // (impl_real.hip / impl_complex.hip: evomg_impl.h, the tuned scalar path; impl_system.hip; impl_fas.hip).
 //
@@ -9,6 +10,13 @@
 namespace evomg_detail {
 
 thread_local char g_create_error[512] = "";
+
+std::atomic<int> g_evaluations_in_flight{0};
+int evaluations_in_flight() { return g_evaluations_in_flight.load(std::memory_order_relaxed); }
+struct InFlight {
+  InFlight() { g_evaluations_in_flight.fetch_add(1, std::memory_order_relaxed); }
+  ~InFlight() { g_evaluations_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+};
 
 int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (!p) { snprintf(err, len, "null problem"); return EVOMG_ERR_INVALID; }
@@ -101,6 +109,7 @@ int evomg_set_operators(evomg_handle_t* h, const evomg_problem_t* problem) {
 }
 int evomg_evaluate(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int evaluation_samples, double wall_limit_ms,
                    evomg_result_t* out, double* res_history, int history_capacity) {
+  const InFlight in_flight;
   return h ? h->impl->evaluate(ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity)
            : EVOMG_ERR_INVALID;
 }

@@ -124,6 +124,9 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   constexpr int C = 64 / H;                          // lanes per band
   int group = 0;
   if constexpr (MULTI) {
+    // only every stride-th block takes part: workgroups are dealt to the XCDs round-robin, so stride 8 puts the solve on ONE
+    // XCD (a rendezvous is cheaper there: isolated solves), stride 1 one workgroup on each (candidates in flight: their
+    // solves then do not pile onto one XCD's 32 compute units — the host chooses, impl_coarse.inl)
     if ((int)blockIdx.x % stride != 0) return;
     group = (int)blockIdx.x / stride;
   } else {
@@ -140,13 +143,14 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   const int rows = max(0, min(R, m - iy0));
   const int ix0 = E * (l % C);
   bool ok_e[E];
-  double sl[E][5];                                   // this element's coefficients: zero where it has no column
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    ok_e[e] = ix0 + e < m;
+  for (int e = 0; e < E; ++e) ok_e[e] = ix0 + e < m;
+  // Only a lane's LAST element can be without a column (host-checked for E = 2: m = 127, element 0 is column 2 l <= 126):
+  // it gets its own coefficients, zero where the column is missing — its stencil sum is then zero by construction, no mask
+  // in the loop; the other elements use the stencil as it is (scalar registers).
+  double sl[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sl[e][k] = ok_e[e] ? st.c[k] : 0.0;
-  }
+  for (int k = 0; k < 5; ++k) sl[k] = ok_e[E - 1] ? st.c[k] : 0.0;
   const bool has_south = band > 0 && rows > 0, has_north = iy0 + R < m;
   // where the neighbouring bands' edge rows come from: this workgroup's LDS, or (MULTI) the neighbouring workgroup
   const bool south_lds = tid >= C, north_lds = tid + C < WAVES * 64;
@@ -210,11 +214,20 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
         const double re = (e == E - 1) ? from_e : r[i][e < E - 1 ? e + 1 : e];
         const double rs = (i == 0) ? r_gs[e] : r[i > 0 ? i - 1 : 0][e];
         const double rn = (i == R - 1) ? r_gn[e] : r[i < R - 1 ? i + 1 : i][e];
-        double a = sc_mul(sl[e][0], rc);
-        a = sc_fma(sl[e][1], rw, a);
-        a = sc_fma(sl[e][2], re, a);
-        a = sc_fma(sl[e][3], rs, a);
-        a = sc_fma(sl[e][4], rn, a);
+        double a;
+        if (e == E - 1) {
+          a = sc_mul(sl[0], rc);
+          a = sc_fma(sl[1], rw, a);
+          a = sc_fma(sl[2], re, a);
+          a = sc_fma(sl[3], rs, a);
+          a = sc_fma(sl[4], rn, a);
+        } else {
+          a = sc_mul(st.c[0], rc);
+          a = sc_fma(st.c[1], rw, a);
+          a = sc_fma(st.c[2], re, a);
+          a = sc_fma(st.c[3], rs, a);
+          a = sc_fma(st.c[4], rn, a);
+        }
         if (i >= MASK_FROM) a = (i < rows) ? a : 0.0;      // a row outside the grid: r is zero there, the stencil sum is not
         wv[i][e] = a;
         gam = sc_fma(rc, rc, gam);

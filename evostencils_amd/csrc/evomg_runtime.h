@@ -21,6 +21,9 @@
 namespace evomg_detail {
 
 extern thread_local char g_create_error[512];
+// evomg_evaluate calls of this process under way right now (defined in evomg.hip): more than one means candidates in
+// flight on the device
+int evaluations_in_flight();
 
 inline double wall_ms() {
   using namespace std::chrono;

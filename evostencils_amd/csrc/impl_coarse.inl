@@ -124,7 +124,8 @@
   // ---- the single-reduction CG (evomg_cg1.h): which grids it serves, and the launch ------------------------------------
   bool cgs_is_cg() const { return prob_.cgs_kind == EVOMG_CGS_CG || prob_.cgs_kind == EVOMG_CGS_CG_CLASSICAL; }
   bool cg1_serves(const Geo& g) const {
-    if (scalar_traits<T>::is_complex || dim_ != 2 || prob_.cgs_kind != EVOMG_CGS_CG || !use_reg_krylov_) return false;
+    // (EVOMG_NO_REG_KRYLOV does not reach here: it chooses among kernels of ONE arithmetic form, this form has one kernel)
+    if (scalar_traits<T>::is_complex || dim_ != 2 || prob_.cgs_kind != EVOMG_CGS_CG) return false;
     const int m = g.n - 2;
     return m == 1 || m == 3 || m == 7 || m == 15 || m == 31 || m == 63 || m == 127;     // the level grids 3^2 .. 129^2
   }
@@ -150,7 +151,10 @@
       if (MULTI) {
         const int rc = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u, &base);
         if (rc != EVOMG_OK) return rc;
-        stride = cg_stride_;
+        // alone on the device: all workgroups on one XCD (92 against 86 solves/s isolated); while other evaluations of this
+        // process are under way — candidates in flight — one workgroup per XCD (throughput_mode 335 against 290 solves/s,
+        // profiles/r05_cg1_placement_raw.txt)
+        stride = (cg_stride_ > 1 && evaluations_in_flight() > 1) ? 1 : cg_stride_;
         cg_multi_used_ = true;
       }
       const dim3 grid(MULTI ? groups * stride : 1), block(64 * WAVES);
@@ -167,7 +171,9 @@
   // into workgroups is free
   int launch_cg1(const Level<T>& lv, T* x, const T* b, T* r, T* b_copy) {
     switch (lv.g.n - 2) {
-      case 127: return launch_cg1_as<4, 2, 1, 4, true, 3>(lv, x, b, r, b_copy, 8);     // 32 waves on eight compute units
+      case 127:                                    // 32 waves: on eight compute units, or on four (same bits)
+        if (cg1_groups_ == 4) return launch_cg1_as<4, 2, 1, 8, true, 3>(lv, x, b, r, b_copy, 4);
+        return launch_cg1_as<4, 2, 1, 4, true, 3>(lv, x, b, r, b_copy, 8);
       case 63: return launch_cg1_as<16, 1, 1, 4, false, 15>(lv, x, b, r, b_copy, 1);
       case 31: return launch_cg1_as<4, 1, 2, 4, false, 3>(lv, x, b, r, b_copy, 1);
       case 15: return launch_cg1_as<2, 1, 4, 2, false, 1>(lv, x, b, r, b_copy, 1);

@@ -59,6 +59,9 @@
   int cg_stride_ = getenv("EVOMG_CG_SPREAD_XCDS") ? 1 : 8;   // 8: the eight workgroups on ONE XCD (every eighth block of the grid)
   bool cg_multi_attr_set_ = false;
   bool cg_multi_used_ = false;
+  // the 129^2 single-reduction CG (evomg_cg1.h): its 32 waves as eight workgroups of four or four of eight — a tuning
+  // choice, the summation order does not depend on it
+  int cg1_groups_ = getenv("EVOMG_CG1_GROUPS") ? atoi(getenv("EVOMG_CG1_GROUPS")) : 8;
   bool cg_lds_attr_set_[24] = {};
   int prof_opcode_ = -1, prof_level_ = -1;
   size_t prof_used_ = 0;

@@ -8,6 +8,7 @@ Bars
    wave-shuffle tree and the oracle's row-wise sum -> relative tolerance 1e-10 on residual norms (the
    tolerance north_star states), identical iteration counts.
 """
+import dataclasses
 import numpy as np
 import pytest
 
@@ -321,11 +322,12 @@ def test_rejects_malformed_programs(native):
 
 @pytest.mark.parametrize("lo", [1, 2, 3, 4, 5])
 def test_one_wave_cg_and_its_folded_copy_and_zero(native, oracle, lo, monkeypatch):
-    """2D grids up to 33^2: the whole CG in one wave (evomg_cg_wave2d), and `gen_rhs = RHS; gen_error = 0; gen_mgCycle@min()`
+    """The classical form of the coarse CG (cgs_kind CGS_CG_CLASSICAL; the default kind's kernels: tests/test_cg_variants_gpu.py).
+    2D grids up to 33^2: the whole CG in one wave (evomg_cg_wave2d), and `gen_rhs = RHS; gen_error = 0; gen_mgCycle@min()`
     as ONE launch (the kernel copies the right-hand side and starts from x = 0 without reading x) — against the three
     separate ops, the global-memory kernel and the oracle: solution, residual and the copied right-hand side bit for bit.
     With a non-zero BOUNDARY on x (a test-only state) the fold must not happen: r = b - A x then sees those values."""
-    pd = problems.poisson_2d(lo, lo + 1)
+    pd = dataclasses.replace(problems.poisson_2d(lo, lo + 1), cgs_kind=abi.CGS_CG_CLASSICAL)
     n = (1 << lo) + 1
     rng = np.random.default_rng(50 + lo)
     rhs = rng.standard_normal((n, n))
@@ -387,8 +389,10 @@ def test_large_coarsest_grids_run_cg_as_launches(native, oracle, dim, lo):
 @pytest.mark.parametrize("dim,lo", [(2, 3), (2, 5), (2, 6), (2, 7), (3, 2), (3, 3), (3, 4), (3, 5)])
 def test_coarse_cg_variants_are_bit_identical(native, oracle, dim, lo, monkeypatch):
     """The register-resident CG (2D) / the eight-workgroup CG (33^3), the global-memory single-workgroup CG
-    and the oracle follow one summation order: all three give the same bits (129^2 = the C2 coarsest grid)."""
+    and the oracle follow one summation order: all three give the same bits (129^2 = the C2 coarsest grid up to round 4).
+    The classical form: cgs_kind CGS_CG_CLASSICAL (the default kind's single-reduction kernels: tests/test_cg_variants_gpu.py)."""
     pd = problems.poisson_2d(lo, lo + 1) if dim == 2 else problems.poisson_3d(lo, lo + 1)
+    pd = dataclasses.replace(pd, cgs_kind=abi.CGS_CG_CLASSICAL)
     rng = np.random.default_rng(lo * 10 + dim)
     shape = ((1 << lo) + 1,) * dim
     rhs = rng.standard_normal(shape)

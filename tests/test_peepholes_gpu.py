@@ -60,13 +60,20 @@ def _top(lo, hi):
     return hi
 
 
+CLASSICAL_CG = {"cgs_kind": abi.CGS_CG_CLASSICAL}      # optional sixth entry of a case: fields of the problem descriptor
+
 NON_CYCLIC = {
     "residual_restrict_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [residual(hi), restrict(hi - 1), residual(hi - 1), restrict(hi - 2)]),
     "prolong_smooth_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [prolong(hi), s(hi), prolong(hi - 1), s(hi - 1), s(hi - 1)]),
     "zero_elision_2d": (2, 4, 7, "EVOMG_NO_ZERO_ELISION", lambda s, lo, hi: [zero(hi - 1), s(hi - 1), zero(hi - 2), s(hi - 2), s(hi - 2), residual(hi - 2)]),
     "copy_zero_coarse_solve_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
-    "copy_zero_register_cg_65_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
-    "copy_zero_register_cg_129_2d": (2, 7, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
+    # the classical register CG (cgs_kind CGS_CG_CLASSICAL) and its own switch; the single-reduction form (the default kind)
+    # folds wherever anything folds: EVOMG_NO_FUSE
+    "copy_zero_register_cg_65_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)], CLASSICAL_CG),
+    "copy_zero_register_cg_129_2d": (2, 7, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)], CLASSICAL_CG),
+    "copy_zero_one_wave_cg_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)], CLASSICAL_CG),
+    "copy_zero_single_reduction_cg_65_2d": (2, 6, 8, "EVOMG_NO_FUSE", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
+    "copy_zero_single_reduction_cg_129_2d": (2, 7, 8, "EVOMG_NO_FUSE", lambda s, lo, hi: [s(lo + 1), residual(lo + 1), restrict(lo)] + coarse(lo) + [prolong(lo + 1), s(lo + 1)]),
     "lds_tiles_2d": (2, 3, 6, "EVOMG_NO_SMALL2D", lambda s, lo, hi: [s(hi), s(hi - 1), prolong(hi), s(hi), zero(hi - 2), s(hi - 2), s(hi - 2)]),
     "strip_block_2d": (2, 4, 7, "EVOMG_NO_STRIP_BLOCK", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
     "block_fast_2d": (2, 4, 7, "EVOMG_NO_BLOCK_FAST", lambda s, lo, hi: [s(hi), s(hi), residual(hi), s(hi - 1)]),
@@ -99,7 +106,8 @@ CYCLIC = {
     "tail_norm_2d": (2, 4, 7, "EVOMG_NO_TAIL_NORM", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
     "dead_residual_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 0, 1)),
     "speculation_2d": (2, 4, 7, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
-    "register_cg_fold_cycle_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
+    "register_cg_fold_cycle_2d": (2, 6, 8, "EVOMG_NO_CG_FOLD", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1), CLASSICAL_CG),
+    "single_reduction_cg_fold_cycle_2d": (2, 7, 9, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "cross_iteration_plain_2d": (2, 4, 8, "EVOMG_NO_XFUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 2)),
     "residual_restrict_3d": (3, 2, 5, "EVOMG_NO_TILE3D_RR", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
@@ -133,9 +141,9 @@ def environment(monkeypatch, knob, fused):
 @pytest.mark.parametrize("kind", sorted(SMOOTHERS))
 @pytest.mark.parametrize("name", sorted(NON_CYCLIC))
 def test_peephole_on_random_fields(native, oracle, monkeypatch, name, kind, semantics):
-    dim, lo, hi, knob, build = NON_CYCLIC[name]
+    dim, lo, hi, knob, build = NON_CYCLIC[name][:5]
     ops = build(SMOOTHERS[kind], lo, hi)
-    pd = problem(dim, lo, hi, semantics)
+    pd = problem(dim, lo, hi, semantics, **(NON_CYCLIC[name][5] if len(NON_CYCLIC[name]) > 5 else {}))
     import zlib
     rng = np.random.default_rng(zlib.crc32(f"{name}/{kind}".encode()))
     state = {}
@@ -167,11 +175,11 @@ def test_peephole_on_random_fields(native, oracle, monkeypatch, name, kind, sema
 @pytest.mark.parametrize("kind", sorted(SMOOTHERS))
 @pytest.mark.parametrize("name", sorted(CYCLIC))
 def test_peephole_in_the_solver_loop(native, oracle, monkeypatch, name, kind, semantics):
-    dim, lo, hi, knob, build = CYCLIC[name]
+    dim, lo, hi, knob, build = CYCLIC[name][:5]
     if dim == 3 and kind == "block" and hi > 4:
         hi = 5
     ops = build(SMOOTHERS[kind], lo, hi)
-    pd = problem(dim, lo, hi, semantics, max_iterations=5)
+    pd = problem(dim, lo, hi, semantics, max_iterations=5, **(CYCLIC[name][5] if len(CYCLIC[name]) > 5 else {}))
     outs = []
     for which in ("fused", "switched_off", "oracle"):
         environment(monkeypatch, knob, which != "switched_off")
