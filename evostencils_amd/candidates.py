@@ -8,8 +8,108 @@ from typing import List
 
 import numpy as np
 
+from evostencils_amd import abi
+from evostencils_amd.grammar import productions
+from evostencils_amd.ir import base, system
+
 SMOOTHERS_2D = ["jacobi", "rbgs", ("block", (2, 1)), ("block", (1, 2)), ("block", (2, 2))]
 SMOOTHERS_3D = ["jacobi", "rbgs", ("block", (2, 1, 1)), ("block", (1, 2, 1)), ("block", (2, 2, 1))]
+
+
+def production_context(gen, min_level: int, max_level: int):
+    """A fresh production context (name -> production / terminal) of `gen`'s problem over the levels min..max, as the
+    optimizer builds it for a run (optimization/program.py:786-830): approximation, right-hand side and the operators of
+    every level. One context = one individual (productions share and mutate DAG nodes)."""
+    finest = gen.finest_grid
+    approximation = system.Approximation("x", [base.Approximation(f.name, g) for f, g in zip(gen.fields, finest)])
+    top = [eq for eq in gen.equations if eq.level == max_level]
+    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, g) for eq, g in zip(top, finest)])
+    return productions.generate_context(approximation, rhs, gen.dimension, gen.coarsening_factor, max_level,
+                                        gen.equations, gen.operators, gen.fields, depth=max_level - min_level)
+
+
+def smooth(P, depth, cycle, spec):
+    """One smoothing step on `depth` levels below the finest. spec: ('jacobi', idx) | ('rbgs', idx) | ('block', idx, shape);
+    on systems of PDEs also ('blocks', idx, shapes) | ('decoupled', idx) | ('decoupled_rb', idx). idx: index into
+    np.linspace(0.1, 1.9, 37), the grammar's relaxation factors (grammar/multigrid.py:428)."""
+    kind = spec[0]
+    if kind == "jacobi":
+        return P[f"collective_jacobi_{depth}"](spec[1], P["single"], cycle)
+    if kind == "rbgs":
+        return P[f"collective_jacobi_{depth}"](spec[1], P["red_black"], cycle)
+    if kind == "block":
+        return P[f"collective_block_jacobi_{depth}"](spec[1], (tuple(spec[2]),), cycle)
+    if kind == "blocks":                       # one block shape per unknown
+        return P[f"collective_block_jacobi_{depth}"](spec[1], tuple(tuple(b) for b in spec[2]), cycle)
+    if kind == "decoupled":
+        return P[f"decoupled_jacobi_{depth}"](spec[1], P["single"], cycle)
+    if kind == "decoupled_rb":
+        return P[f"decoupled_jacobi_{depth}"](spec[1], P["red_black"], cycle)
+    raise ValueError(kind)
+
+
+def v_cycle(P, depth, pre, post, cgc_index=18, state=None):
+    """A V-cycle over `depth`+1 levels built with the grammar's productions; pre / post: per level (finest first) a list of
+    smoother specs (see `smooth`). Returns the state (cycle expression, rhs). `state`: continue from the result of an
+    earlier cycle (several coarse-grid corrections in a row, as the grammar allows) instead of from the initial (u, f)."""
+    state = P["u_and_f"] if state is None else state
+    cycle = P["residual_0"](state)
+    for d in range(depth):
+        for spec in pre[d]:
+            state = smooth(P, d, cycle, spec)
+            cycle = P[f"residual_{d}"](state)
+        if d < depth - 1:
+            cycle = P[f"coarsening_{d}"](P[f"A_{d + 1}"], P[f"zero_{d + 1}"], P[f"R_{d}"], cycle)
+        else:
+            state = P[f"correct_with_coarse_grid_solver_{d}"](cgc_index, P[f"P_{d + 1}"], P[f"CGS_{d + 1}"],
+                                                              P[f"R_{d}"], cycle)
+    for d in range(depth - 1, -1, -1):
+        if d < depth - 1:
+            state = P[f"update_with_coarse_grid_correction_{d}"](cgc_index, P[f"P_{d + 1}"], state)
+        for spec in post[d]:
+            cycle = P[f"residual_{d}"](state)
+            state = smooth(P, d, cycle, spec)
+    return state
+
+
+def v_cycle_ops(lo: int, hi: int, pre: int, post: int, smoother=None, omega: float = 1.0):
+    """A hand-written V(pre, post) cycle over the levels lo..hi as an op program — the statements `generate_multigrid` emits
+    for such a cycle (exastencils.py:684-925), without going through the IR. `smoother(L)` returns the SMOOTH op of level
+    L; default: a red-black point sweep with weight `omega` (omega = 0.6, pre = 2, post = 1: gen_mgCycle of
+    example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3:202-272)."""
+    if smoother is None:
+        smoother = lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), omega)
+    ops = []
+    for L in range(hi, lo, -1):
+        ops += [smoother(L) for _ in range(pre)]
+        ops.append(abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS))
+        ops.append(abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES))
+        if L - 1 > lo:
+            ops.append(abi.make_op(abi.OP_SET_ZERO, L - 1, abi.F_SOL))
+    ops.append(abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS))
+    ops.append(abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR))
+    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, lo))
+    for L in range(lo + 1, hi + 1):
+        ops.append(abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=1.0))
+        ops += [smoother(L) for _ in range(post)]
+    return ops
+
+
+def evolved_helmholtz_double_cycle(lo: int, hi: int, k: float):
+    """The frozen "evolved" Helmholtz preconditioner of this repository (BASELINE.json configs[2]: "evolved cycle"): TWO
+    complete V(2,1) RB-GS w = 0.6 corrections per application, built with the grammar's own productions (several
+    coarse-grid corrections in a row are ordinary members of the search space). It halves the outer iteration count of the
+    reference's hand-written cycle (tools/helmholtz_multi_vcycle.py: 1825 -> 1211 at 257^2, k h = 0.625).
+    Returns (generator, op program); the generator is built without a library (lowering only)."""
+    from evostencils_amd import problems
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    gen = ProgramGenerator(problem=problems.helmholtz_2d(lo, hi, k=k), library=object())
+    P = production_context(gen, lo, hi)
+    d = hi - lo
+    rb = [("rbgs", 10)]                      # linspace(0.1, 1.9, 37)[10] = 0.6
+    first = v_cycle(P, d, [rb * 2] * d, [rb] * d)
+    second = v_cycle(P, d, [rb * 2] * d, [rb] * d, state=first)
+    return gen, gen.generate_op_program(second[0], lo, hi)
 
 
 def _smooth(ctx, depth, cycle, kind, omega_index):

@@ -64,6 +64,7 @@ class ProgramGenerator:
     products of an iteration in one reduction where such a kernel exists) or "classical" (EVOMG_CGS_CG_CLASSICAL, the textbook
     recurrence everywhere). The same Krylov process either way; no number the reference records depends on it."""
     COARSE_COST_SAMPLES = 3      # full three-probe time models a generator runs before it takes the coarse-iteration cost as known
+    COARSE_COST_REFRESH = 32     # ... and after how many two-probe models it measures that cost again (median of the last five)
 
 
     def __init__(self, absolute_compiler_path: Optional[str] = None, base_path: Optional[str] = None,
@@ -145,7 +146,7 @@ class ProgramGenerator:
         self._verified = {}
         self._cycle_functions = {}       # text of a generated cycle function -> (level, window min, op program)
         self.last_coarse_iterations = None      # coarse-solver iterations of the last evaluation (time model input)
-        self._coarse_iteration_ms = {}           # (min_level, max_level) -> samples so far | the settled cost of one coarse-solver iteration
+        self._coarse_iteration_ms = {}           # (min_level, max_level) -> {samples, the settled cost of one coarse-solver iteration, uses since}
         self._set_problem(problem)
 
     # ---- read-only attributes the optimizer reads (scripts/optimize.py:60-68) ------------------
@@ -473,6 +474,12 @@ class ProgramGenerator:
                 mapping["k"] *= 2
         return total_t / n, total_rho / n, total_it / n
 
+    def coarse_iteration_cost_ms(self, min_level: int, max_level: int):
+        """What one iteration of the coarse-grid solver costs on this level range, as far as `isolated_time_ms` has settled
+        it (None: not yet)."""
+        state = self._coarse_iteration_ms.get((min_level, max_level))
+        return None if state is None else state["known"]
+
     def isolated_time_ms(self, ops, min_level: int, max_level: int, iterations: float, solver_program: str = "",
                          global_variable_values=None, coarse_iterations=None, probe_iterations: int = 6):
         """Time-to-solution of a candidate as it would be ALONE on the GPU, for an evaluation that ran with other candidates
@@ -494,18 +501,23 @@ class ProgramGenerator:
         # what ONE iteration of the coarse-grid solver costs belongs to the problem and its coarsest level, not to the candidate:
         # the first few candidates measure it (three probes each), every later one runs the two cheap probes only
         key = (min_level, max_level)
-        known = self._coarse_iteration_ms.get(key)
-        if isinstance(known, float):
+        state = self._coarse_iteration_ms.setdefault(key, {"samples": [], "known": None, "uses": 0})
+        known = state["known"]
+        if known is not None and state["uses"] < self.COARSE_COST_REFRESH:
+            state["uses"] += 1
             fixed, per_iteration, per_coarse = handle.time_model(ops, max(1, n_long // 3), n_long, per_coarse=known)
         else:
+            # not known yet, or due for another look: clocks and what shares the device drift over a long optimisation
             fixed, per_iteration, per_coarse = handle.time_model(ops, max(1, n_long // 3), n_long)
-            samples = self._coarse_iteration_ms.setdefault(key, [])
+            samples = state["samples"]
             samples.append(per_coarse)
-            positive = sorted(v for v in samples if v > 0.0)
-            if len(positive) >= self.COARSE_COST_SAMPLES:
-                self._coarse_iteration_ms[key] = float(positive[len(positive) // 2])
+            positive = sorted(v for v in samples[-5:] if v > 0.0)
+            if len(positive) >= (self.COARSE_COST_SAMPLES if known is None else 1):
+                state["known"], state["uses"] = float(positive[len(positive) // 2]), 0
             elif len(samples) >= 4 * self.COARSE_COST_SAMPLES:
-                self._coarse_iteration_ms[key] = 0.0      # a coarse solver that does not iterate: nothing to scale
+                state["known"], state["uses"] = 0.0, 0      # a coarse solver that does not iterate: nothing to scale
+            if known is not None:
+                per_coarse = state["known"]
         return max(fixed, 0.0) + per_iteration * its + per_coarse * float(coarse_iterations)
 
     def compile_and_run(self, ops, min_level, max_level, mapping=None, infinity=1e100, evaluation_samples=3):
@@ -695,9 +707,9 @@ class ProgramGeneratorPool:
                 t, rho, its = g.evaluate_op_program(ops, min_level, max_level, solver_program, infinity, evaluation_samples,
                                                     global_variable_values)
             except BaseException:
-                with self._cond:
-                    self._active -= 1
-                    self._cond.notify_all()
+                # this solve may have been the last one in flight while other workers are parked behind their probe
+                # requests: somebody has to run those probes — the same hand-over as in _probe, then the error goes up
+                self._leave(None)
                 raise
             return self._probe(g, ops, min_level, max_level, solver_program, global_variable_values, t, rho, its, infinity)
         finally:
@@ -711,6 +723,19 @@ class ProgramGeneratorPool:
             request = {"g": g, "args": (ops, min_level, max_level, its, solver_program, global_variable_values,
                                         getattr(g, "last_coarse_iterations", None), self._probe_iterations),
                        "done": False, "time": t, "error": None}
+        self._leave(request)
+        if request is None:
+            return t, rho, its
+        with self._cond:
+            while not request["done"]:
+                self._cond.wait()
+        if request["error"] is not None:
+            raise request["error"]
+        return request["time"], rho, its
+
+    def _leave(self, request):
+        """A worker's solve is over (with a probe request, without one, or with an exception): one solve less in flight; the
+        worker whose solve was the LAST one in flight runs every queued probe, alone on the GPU, and wakes the others."""
         with self._cond:
             self._active -= 1
             if request is not None:
@@ -721,25 +746,20 @@ class ProgramGeneratorPool:
             else:
                 batch = None
                 self._cond.notify_all()
-        if batch is not None:
+        if batch is None:
+            return
+        try:
             for r in batch:                     # nothing else is in flight: the wall time of the probe is the candidate's own
                 try:
                     r["time"] = r["g"].isolated_time_ms(*r["args"])
                 except Exception as exc:        # noqa: BLE001 — handed to the worker that owns the request
                     r["error"] = exc
+        finally:
             with self._cond:
                 for r in batch:
-                    r["done"] = True
+                    r["done"] = True            # (a request a BaseException cut short keeps its contended time)
                 self._probing = False
                 self._cond.notify_all()
-        if request is None:
-            return t, rho, its
-        with self._cond:
-            while not request["done"]:
-                self._cond.wait()
-        if request["error"] is not None:
-            raise request["error"]
-        return request["time"], rho, its
 
     def close(self):
         for g in self._generators:

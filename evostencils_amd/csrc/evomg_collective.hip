@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <ctime>
 #include <unistd.h>
 
 #include <chrono>
@@ -43,11 +45,14 @@ struct Rccl {
   std::string error;
 };
 
+Rccl load_rccl();
+// loaded once, by whichever thread asks first (a function-local static is initialised under the runtime's own guard)
 Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+  static Rccl r = load_rccl();
+  return r;
+}
+Rccl load_rccl() {
+  Rccl r;
   // The RCCL that belongs to the HIP runtime THIS process runs on: a process that imported torch first runs on the runtime
   // torch bundles (and torch's librccl, built for it, answers to the same SONAME), any other process on /opt/rocm's. Mixing
   // them fails in ncclCommInitRank ("unhandled cuda error": torch's RCCL 2.26 on the system's HIP 7.2, seen on the GPU box), so
@@ -64,13 +69,18 @@ Rccl& rccl() {
   }
   const char* names[] = {getenv("EVOMG_RCCL_LIB"), beside_hip.c_str(), beside_hip2.c_str(), "librccl.so.1", "librccl.so",
                          "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    if (!n || !*n) continue;
-    r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.lib) break;
-  }
+  // EVOMG_RCCL_ONLY=<path>: that library or none (a deployment that pins its RCCL; the test of the not-found path)
+  const char* only = getenv("EVOMG_RCCL_ONLY");
+  if (only && *only) r.lib = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+  else
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
   if (!r.lib) {
-    r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+    const char* why = dlerror();                   // one call: it hands the message over and clears it
+    r.error = std::string("librccl not found: ") + (why ? why : "");
     return r;
   }
   auto sym = [&](const char* name) -> void* {
@@ -90,6 +100,11 @@ Rccl& rccl() {
 thread_local char g_comm_error[512] = "";
 
 constexpr char kMagic[8] = {'E', 'V', 'O', 'M', 'G', 'I', 'D', '1'};
+// An id file that is older than this process (minus a grace period for ranks that start late) was left by another job —
+// a crashed one, or one whose rank 0 failed before evomg_comm_destroy: readers take it as absent and keep waiting for
+// rank 0's (a stale id would send them into ncclCommInitRank with nobody on the other side, which has no timeout).
+const time_t g_loaded_at = time(nullptr);
+constexpr time_t kStaleGraceSeconds = 60;
 
 }  // namespace
 
@@ -155,6 +170,7 @@ int evomg_comm_create(int rank, int world, int device_id, const char* id_path, i
   memset(&id, 0, sizeof id);
   const std::string path(id_path);
   if (rank == 0) {
+    (void)unlink(path.c_str());                    // whatever an earlier job left under this name
     if (r.GetUniqueId(&id) != 0) {
       snprintf(g_comm_error, sizeof g_comm_error, "ncclGetUniqueId failed");
       return EVOMG_ERR_DEVICE;
@@ -179,7 +195,9 @@ int evomg_comm_create(int rank, int world, int device_id, const char* id_path, i
       FILE* f = fopen(path.c_str(), "rb");
       if (f) {
         char magic[sizeof kMagic];
-        have = fread(magic, 1, sizeof magic, f) == sizeof magic && memcmp(magic, kMagic, sizeof magic) == 0 &&
+        struct stat st;
+        const bool fresh = fstat(fileno(f), &st) == 0 && st.st_mtime + kStaleGraceSeconds >= g_loaded_at;
+        have = fresh && fread(magic, 1, sizeof magic, f) == sizeof magic && memcmp(magic, kMagic, sizeof magic) == 0 &&
                fread(&id, 1, sizeof id, f) == sizeof id;
         fclose(f);
       }
@@ -200,6 +218,7 @@ int evomg_comm_create(int rank, int world, int device_id, const char* id_path, i
   auto fail = [&](int rc) {
     snprintf(g_comm_error, sizeof g_comm_error, "%s", c->err);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (rank == 0) (void)unlink(path.c_str());     // nobody may join an id whose root never came up
     delete c;
     return rc;
   };

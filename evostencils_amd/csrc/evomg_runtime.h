@@ -46,6 +46,9 @@ struct ImplBase {
   virtual int profile_begin(int opcode, int level) = 0;
   virtual int profile_end(evomg_bench_t* out) = 0;
   virtual long long coarse_iterations() { return 0; }   // Krylov iterations of all coarse solves of the last evaluate (last sample)
+  // false: coarse_iterations() is always 0 (systems of PDEs, FAS): the time model must not cap the coarse solver then —
+  // nothing would add its cost back (evomg_time_model)
+  virtual bool counts_coarse_iterations() const { return false; }
   virtual evomg_problem_t& problem() = 0;      // the handle's descriptor (evomg_time_iterations re-targets the loop's stopping rule)
   char err[512] = "";
 };

@@ -223,6 +223,7 @@
     return EVOMG_OK;
   }
   long long coarse_iterations() override { return coarse_iterations_; }
+  bool counts_coarse_iterations() const override { return true; }
 
   int bench_op(const evomg_op_t* op, int warmup, int reps, evomg_bench_t* out) override {
     HIP_TRY(hipSetDevice(device_));

@@ -1,0 +1,59 @@
+"""Preflight of the one-process-per-GPU path: what a rank can check about its environment before (and with) its first HIP
+call — used by tools/preflight_8gpu.py under the real launcher and by bench.py at start-up (the report goes on the bench
+line, `config.collectives.preflight`).
+
+Checks: GPU_MAX_HW_QUEUES in the environment before the runtime initialises (evostencils_amd/__init__.py);
+HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: RCCL across processes needs it on this pool); evomg_device_count() >= ranks on the
+node; LOCAL_RANK -> device as ProgramGenerator resolves it, one distinct device per local rank; librccl opens
+(evomg_rccl_version); with collective=True: the C-ABI communicator is built across all ranks and one evomg_allgather_fitness
+round trip returns every rank's row (optimization/program.py:582 is one such exchange per generation)."""
+import os
+import sys
+
+
+def id_path(tag="preflight"):
+    """A rendezvous file name unique per launch: the ranks of one torchrun share MASTER_PORT and their parent (the launcher's
+    agent); a rerun after a crash gets another name, so no rank can pick up a stale id."""
+    return f"/dev/shm/evomg_{tag}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+
+
+def report(collective=False, torch_imported_before=None):
+    rep = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+           "world": int(os.environ.get("WORLD_SIZE", "1")),
+           "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))}
+    failures = []
+    rep["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES")
+    if torch_imported_before is None:
+        torch_imported_before = False
+    if torch_imported_before:
+        failures.append("torch was imported before evostencils_amd: the hardware-queue setting may be too late")
+    rep["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if rep["world"] > 1 and rep["HSA_ENABLE_IPC_MODE_LEGACY"] != "0":
+        failures.append("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for multi-process RCCL on this pool")
+    from evostencils_amd import native
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    lib = native.library()
+    rep["rccl_version"] = lib.fn["rccl_version"]()       # dlopen only: nothing touches the GPU yet
+    if rep["rccl_version"] <= 0:
+        failures.append("librccl could not be opened")
+    count = lib.fn["device_count"]()                     # possibly the first HIP call of this process
+    rep["device_count"] = count
+    if count < rep["local_world"]:
+        failures.append(f"{rep['local_world']} ranks on this node but {count} visible GPUs")
+    device = ProgramGenerator._default_device(rep["rank"], lib)
+    rep["device"] = device
+    if count >= rep["local_world"] and device != rep["local_rank"] % max(count, 1):
+        failures.append(f"local rank {rep['local_rank']} resolved to device {device}")
+    if collective and not failures:
+        import numpy as np
+        comm = native.communicator(rep["rank"], rep["world"], device, id_path(), timeout_ms=30000)
+        table = comm.allgather(np.array([[rep["rank"], device, os.getpid(), 1.0]]))
+        comm.close()
+        rep["allgather"] = table.tolist()
+        if [int(r[0]) for r in table] != list(range(rep["world"])):
+            failures.append("evomg_allgather_fitness returned the wrong rows")
+        if len({int(r[1]) for r in table}) != min(rep["world"], count):
+            failures.append("ranks share devices")
+    rep["ok"] = not failures
+    rep["failures"] = failures
+    return rep

@@ -1,7 +1,7 @@
 """Shared test plumbing: contexts, generators and op programs for the cases in tests/cycles.py."""
 import os
 
-from evostencils_amd import abi, problems
+from evostencils_amd import abi, candidates, problems
 from evostencils_amd.code_generation.hip import ProgramGenerator
 from evostencils_amd.grammar import productions
 from evostencils_amd.ir import base, system
@@ -25,13 +25,7 @@ def generator_for(problem_name, min_level, max_level, library=None, **kw):
 
 
 def context_for(gen: ProgramGenerator, min_level, max_level):
-    fields, equations = gen.fields, gen.equations
-    finest = gen.finest_grid
-    approximation = system.Approximation("x", [base.Approximation(f.name, g) for f, g in zip(fields, finest)])
-    top = [eq for eq in equations if eq.level == max_level]
-    rhs = system.RightHandSide("b", [base.RightHandSide(eq.rhs_name, g) for eq, g in zip(top, finest)])
-    return productions.generate_context(approximation, rhs, gen.dimension, gen.coarsening_factor, max_level,
-                                        equations, gen.operators, fields, depth=max_level - min_level)
+    return candidates.production_context(gen, min_level, max_level)
 
 
 def window_context(gen: ProgramGenerator, min_level, max_level):

@@ -112,3 +112,39 @@ def test_constructing_a_generator_does_not_touch_the_hip_runtime(monkeypatch):
     assert gen._device_id is None and not called
     explicit = ProgramGenerator(problem=problems.poisson_2d(3, 5), library=Lib(), device_id=5)
     assert explicit._device_id == 5 and not called
+
+
+def _run_python(code, **env):
+    full = dict(os.environ, **env)
+    return subprocess.run(["python", "-c", code], capture_output=True, text=True, env=full, cwd=REPO, timeout=120)
+
+
+def test_a_host_without_rccl_is_reported_not_crashed(libpath):
+    """include/evomg.h: evomg_rccl_version() is 0 and evomg_comm_create() EVOMG_ERR_UNSUPPORTED where librccl cannot be opened
+    (the message was built from two dlerror() calls, the second of which returns NULL)."""
+    code = ("import ctypes as C\n"
+            f"lib = C.CDLL({libpath!r})\n"
+            "lib.evomg_rccl_version.restype = C.c_int\n"
+            "print('version', lib.evomg_rccl_version())\n"
+            "comm = C.c_void_p()\n"
+            "rc = lib.evomg_comm_create(0, 1, 0, b'/tmp/evomg_test_no_rccl.id', 100, C.byref(comm))\n"
+            "lib.evomg_comm_last_error.restype = C.c_char_p\n"
+            "lib.evomg_comm_last_error.argtypes = [C.c_void_p]\n"
+            "print('rc', rc, lib.evomg_comm_last_error(None).decode())\n")
+    out = _run_python(code, EVOMG_RCCL_ONLY="/nonexistent/librccl.so.1")
+    assert out.returncode == 0, out.stderr
+    assert "version 0" in out.stdout
+    assert f"rc {abi.ERR_UNSUPPORTED} librccl not found" in out.stdout
+
+
+def test_a_library_from_before_a_symbol_existed_asks_for_a_rebuild():
+    """native.library() turns the AttributeError of a missing export into the readable 'rebuild' message."""
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "old.c")
+        open(c, "w").write("int evomg_abi_version(void) { return 1; }\nint evomg_create(void) { return 1; }\n")
+        so = os.path.join(d, "libold.so")
+        subprocess.run(["gcc", "-shared", "-fPIC", c, "-o", so], check=True)
+        out = _run_python("from evostencils_amd import native\n"
+                          "try:\n    native.library()\nexcept RuntimeError as exc:\n    print('RuntimeError:', exc)\n", EVOMG_LIB=so)
+    assert out.returncode == 0, out.stderr
+    assert "RuntimeError:" in out.stdout and "rebuild with `python -m evostencils_amd.build`" in out.stdout

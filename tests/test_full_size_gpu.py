@@ -4,7 +4,7 @@ consistency of the Robin boundary — plus repeatability (two evaluations give i
 import numpy as np
 import pytest
 
-from evostencils_amd import abi, problems
+from evostencils_amd import abi, candidates, problems
 
 pytestmark = pytest.mark.gpu
 
@@ -17,20 +17,7 @@ def native():
 
 
 def vcycle(lo, hi, pre, post, smoother):
-    ops = []
-    for L in range(hi, lo, -1):
-        ops += [smoother(L) for _ in range(pre)]
-        ops.append(abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS))
-        ops.append(abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES))
-        if L - 1 > lo:
-            ops.append(abi.make_op(abi.OP_SET_ZERO, L - 1, abi.F_SOL))
-    ops.append(abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS))
-    ops.append(abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR))
-    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, lo))
-    for L in range(lo + 1, hi + 1):
-        ops.append(abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=1.0))
-        ops += [smoother(L) for _ in range(post)]
-    return ops
+    return candidates.v_cycle_ops(lo, hi, pre, post, smoother)
 
 
 def test_c2_poisson2d_4096_six_level_rbgs(native):

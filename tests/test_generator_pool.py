@@ -142,3 +142,43 @@ def test_isolated_time_objective_probes_run_alone():
             assert (t, rho, its) == (7.0 + i, 0.5, 9.0)
     with pytest.raises(ValueError):
         ProgramGeneratorPool(Gen, 2, time_objective="fastest")
+
+
+def test_a_solve_that_raises_last_still_hands_the_probes_over():
+    """time_objective="isolated": worker A finishes its solve and parks behind its probe request while worker B is still
+    solving; B's solve raises (a device error, a missed coarse-grid rendezvous). B was the last solve in flight, so B has to run
+    A's probe on its way out — otherwise A waits for ever and the pool hangs instead of failing."""
+    a_parked = threading.Event()
+
+    class Gen(_FakeGenerator):
+        def evaluate_op_program(self, ops, lo, hi, solver_program, infinity, samples, gv):
+            if ops[1] == "raises":
+                assert a_parked.wait(timeout=30)          # A's request is queued (or about to be: _leave sorts that out)
+                import time
+                time.sleep(0.05)
+                raise RuntimeError("device error")
+            return (1000.0, 0.5, 9.0)
+
+        def isolated_time_ms(self, *args, **kw):
+            return 7.0
+
+    pool = ProgramGeneratorPool(Gen, 2, time_objective="isolated")
+    results = {}
+
+    def run(name):
+        try:
+            if name == "parks":
+                threading.Timer(0.02, a_parked.set).start()
+            results[name] = pool.generate_and_evaluate(name, None, 5, 9, "", infinity=1e100)
+        except RuntimeError as exc:
+            results[name] = exc
+
+    threads = [threading.Thread(target=run, args=(name,), daemon=True) for name in ("raises", "parks")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=20)
+    assert not any(t.is_alive() for t in threads), "a worker is still parked behind its probe request"
+    assert isinstance(results["raises"], RuntimeError)
+    assert results["parks"] == (7.0, 0.5, 9.0)
+    pool.close()

@@ -3,30 +3,14 @@ example_problems/Helmholtz/2D_FD_Helmholtz_fromL3.exa3 (V(2,1) RB-GS w=0.6 on th
 preconditioner of BiCGStab on A, BiCGStab coarse solver) restated as an op program."""
 import numpy as np
 
-from evostencils_amd import abi, problems
+from evostencils_amd import abi, candidates, problems
 from oracle import oracle
 
 
 def reference_vcycle_ops(lo, hi, omega=0.6, pre=2, post=1):
     """gen_mgCycle@(coarsest+1 .. finest) of exa3:202-272 as ops. On the finest level the cycle's unknown
     is `u` (SOL) and its right-hand side `f` (RHS)."""
-    one = (1, 1, 1)
-    ops = []
-    for L in range(hi, lo, -1):
-        for _ in range(pre):
-            ops.append(abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, omega))
-        ops.append(abi.make_op(abi.OP_RESIDUAL, L, abi.F_RES, abi.F_SOL, abi.F_RHS))
-        ops.append(abi.make_op(abi.OP_RESTRICT, L - 1, abi.F_RHS, abi.F_RES))
-        if L - 1 > lo:
-            ops.append(abi.make_op(abi.OP_SET_ZERO, L - 1, abi.F_SOL))
-    ops.append(abi.make_op(abi.OP_COPY, lo, abi.F_CGS_RHS, abi.F_RHS))
-    ops.append(abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR))
-    ops.append(abi.make_op(abi.OP_COARSE_SOLVE, lo))
-    for L in range(lo + 1, hi + 1):
-        ops.append(abi.make_op(abi.OP_PROLONG_ADD, L, abi.F_SOL, abi.F_SOL, omega=1.0))
-        for _ in range(post):
-            ops.append(abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, one, omega))
-    return ops
+    return candidates.v_cycle_ops(lo, hi, pre, post, omega=omega)
 
 
 def test_reference_helmholtz_solver_converges():
@@ -66,20 +50,7 @@ def test_wavenumber_retargeting_changes_the_operator():
 
 
 def evolved_double_cycle_ops(lo, hi, k):
-    """The frozen "evolved" Helmholtz preconditioner of this repo (SURVEY 8d asks for one): TWO complete V(2,1) RB-GS
-    w = 0.6 corrections per application, built with the grammar's own productions (several coarse-grid corrections in a
-    row are ordinary members of the search space). It halves the outer iteration count of the hand-written cycle
-    (tools/helmholtz_multi_vcycle.py: 1825 -> 1211 at 257^2, k h = 0.625). Returns (generator, op program)."""
-    import cycles
-    from evostencils_amd.code_generation.hip import ProgramGenerator
-    from helpers import context_for
-    gen = ProgramGenerator(problem=problems.helmholtz_2d(lo, hi, k=k), library=object())
-    P = context_for(gen, lo, hi)
-    d = hi - lo
-    rb = [("rbgs", 10)]                      # linspace(0.1, 1.9, 37)[10] = 0.6
-    first = cycles.v_cycle(P, d, [rb * 2] * d, [rb] * d)
-    second = cycles.v_cycle(P, d, [rb * 2] * d, [rb] * d, state=first)
-    return gen, gen.generate_op_program(second[0], lo, hi)
+    return candidates.evolved_helmholtz_double_cycle(lo, hi, k)
 
 
 def test_evolved_double_cycle_fixture():

@@ -36,7 +36,7 @@ def test_three_full_models_then_the_coarse_cost_is_known():
     times = [g.isolated_time_ms([], 7, 11, 100.0, coarse_iterations=40000) for _ in range(5)]
     assert [c[2] for c in h.calls] == [None, None, None, 2.2e-3, 2.2e-3]
     assert all(c[:2] == (2, 6) for c in h.calls)
-    assert g._coarse_iteration_ms[(7, 11)] == 2.2e-3
+    assert g.coarse_iteration_cost_ms(7, 11) == 2.2e-3
     assert times[3] == pytest.approx(0.5 + 0.2 * 100 + 2.2e-3 * 40000)
     assert times[1] == pytest.approx(0.5 + 0.2 * 100 + 9.0e-3 * 40000)      # before settling: the candidate's own fit
 
@@ -54,7 +54,21 @@ def test_a_coarse_solver_that_never_iterates_settles_on_zero():
     g = _generator(h)
     for _ in range(13):
         g.isolated_time_ms([], 7, 11, 50.0, coarse_iterations=0)
-    assert h.calls[-1][2] == 0.0 and g._coarse_iteration_ms[(7, 11)] == 0.0
+    assert h.calls[-1][2] == 0.0 and g.coarse_iteration_cost_ms(7, 11) == 0.0
+
+
+def test_the_coarse_cost_is_measured_again_every_so_often():
+    """After COARSE_COST_REFRESH two-probe models the next candidate runs the full model again; the settled cost becomes the
+    median of the last five positive samples (the stale first ones drop out one by one)."""
+    h = _Handle([2.0e-3, 2.0e-3, 2.0e-3, 3.0e-3, 3.0e-3, 3.0e-3])
+    g = _generator(h)
+    n = 3 + 3 * (g.COARSE_COST_REFRESH + 1)
+    for _ in range(n):
+        g.isolated_time_ms([], 7, 11, 100.0, coarse_iterations=1000)
+    full = [i for i, c in enumerate(h.calls) if c[2] is None]
+    assert full == [0, 1, 2, 3 + g.COARSE_COST_REFRESH, 4 + 2 * g.COARSE_COST_REFRESH, 5 + 3 * g.COARSE_COST_REFRESH]
+    assert g.coarse_iteration_cost_ms(7, 11) == 3.0e-3          # samples 2, 2, 3, 3, 3 of the last five
+    assert h.calls[3][2] == 2.0e-3 and h.calls[-1][2] is None
 
 
 def test_short_solves_and_missing_counts_fall_back_to_the_plain_probe():

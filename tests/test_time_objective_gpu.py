@@ -93,10 +93,10 @@ def test_the_coarse_iteration_cost_is_measured_once_and_then_known():
         counts.append(gen.last_coarse_iterations)
     modelled = []
     for i in range(N):
-        settled_before = isinstance(gen._coarse_iteration_ms.get((LO, HI)), float)
+        settled_before = gen.coarse_iteration_cost_ms(LO, HI) is not None
         assert settled_before == (i >= gen.COARSE_COST_SAMPLES)
         modelled.append(gen.isolated_time_ms(gen.generate_op_program(pop[i], LO, HI), LO, HI, seq[i][2], coarse_iterations=counts[i]))
-    per_cg = gen._coarse_iteration_ms[(LO, HI)]
+    per_cg = gen.coarse_iteration_cost_ms(LO, HI)
     gen.close()
     t_seq, t_mod = np.array([s[0] for s in seq]), np.array(modelled)
     rel = np.abs(t_mod - t_seq) / t_seq
