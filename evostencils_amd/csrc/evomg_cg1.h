@@ -424,3 +424,187 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     if (!alive) info[1] = 1;
   }
 }
+
+// ---- the single-reduction CG on 33^3: eight co-resident workgroups, one slab of z planes each ----------------------------
+// The 3D counterpart of evomg_cg1_band2d and the successor of evomg_cg_multi_wg3d (evomg_krylov.h) for cgs_kind =
+// EVOMG_CGS_CG: same slabs, same column ownership (thread t of a workgroup owns the column (t % m, t / m) of its slab, up
+// to four nodes, all vectors in registers, r additionally as a zero-haloed image in LDS for the in-plane neighbours), same
+// summation order (fused accumulation along the column, wave64 tree, tree over the 16 wave sums, the eight slab sums added
+// in the order 0 .. 7 — oracle: dot_canon_grouped) — but ONE exchange per iteration instead of two: the slab sums of
+// (r, r) and (w, r) and the slab's first and last plane of w = A r. The planes of r and s next to the slab (ghost planes)
+// are kept in registers and updated with the operations their owner executes, as the ghost rows of the 2D kernel.
+// Per iteration: three workgroup barriers (image of r; wave sums; slab sums) and one grid rendezvous, where the classical
+// form has five and two.
+// ll: [parity][quantity][group][2 words] sums, then [parity][group][first | last plane][1024][2 words] faces of w — inside
+// the exchange area of evomg_cg_multi_wg3d (EVOMG_CG_LL_WORDS).
+// (static: the header is part of several translation units)
+static __global__ void __launch_bounds__(1024)
+evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
+                 int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll, unsigned seq_base, int stride) {
+  constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
+  if ((int)blockIdx.x % stride != 0) return;
+  const int grp = (int)blockIdx.x / stride;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double* wave_sums = reinterpret_cast<double*>(lds_raw);       // [parity][64]: (r, r) of wave q at q, (w, r) at 32 + q
+  double* slab_sums = wave_sums + 128;                           // [parity][64]: (r, r) of slab q at q, (w, r) at 32 + q
+  int* lds_fail = reinterpret_cast<int*>(slab_sums + 128);       // [2], sticky
+  double* img = slab_sums + 128 + 2;                             // S planes x (m+2) x (m+2), zero halo
+  const KrylovOwn own = krylov_own<3>(g.n);
+  const int m = own.m, W = m + 2, PS = W * W;
+  const int zs = (grp * m) / G, ze = ((grp + 1) * m) / G, cnt = ze - zs;      // 1 <= cnt <= S (m >= 2 G)
+  const int t = threadIdx.x, wv_id = t >> 6, l = t & 63;
+  for (int i = t; i < S * PS; i += blockDim.x) img[i] = 0.0;
+  if (t < 128) { wave_sums[t] = 0.0; slab_sums[t] = 0.0; }
+  if (t == 0) { lds_fail[0] = 0; lds_fail[1] = 0; }
+  const bool col = t < m * m;
+  const int ix = col ? t % m : 0, iy = col ? t / m : 0;
+  const int o0 = col ? (iy + 1) * W + ix + 1 : 0;      // column-less threads sit on the halo corner (always zero)
+  const long c0 = gidx<3>(g, ix + 1, iy + 1, zs + 1);
+  auto sum_slot = [&](int par, int quantity, int group) { return ll + ((size_t)(par * 2 + quantity) * G + group) * 2; };
+  auto face_slot = [&](int par, int group, int which) {
+    return ll + EVOMG_CG_LL_PART_WORDS + ((((size_t)par * G + group) * 2 + which) * 1024 + t) * 2;
+  };
+  __syncthreads();
+
+  double r[S], xr[S], p[S], s[S], wv[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const bool ok = col && i < cnt;
+    const long c = c0 + g.plane * (i < cnt ? i : 0);
+    r[i] = ok ? sc_sub(b[c], apply_stencil_fma<double, 3>(st, x, g, c)) : 0.0;
+    xr[i] = x[c];
+    p[i] = 0.0;
+    s[i] = 0.0;
+    if (ok) img[i * PS + o0] = r[i];
+  }
+  // the planes of r below and above the slab (the neighbouring slabs' last / first plane): formed here as their owners
+  // form them, updated below as their owners update them
+  double r_lo = 0.0, r_hi = 0.0, s_lo = 0.0, s_hi = 0.0, w_lo = 0.0, w_hi = 0.0;
+  if (col && grp > 0) { const long c = c0 - g.plane; r_lo = sc_sub(b[c], apply_stencil_fma<double, 3>(st, x, g, c)); }
+  if (col && grp < G - 1) { const long c = c0 + g.plane * cnt; r_hi = sc_sub(b[c], apply_stencil_fma<double, 3>(st, x, g, c)); }
+  auto last_of = [&](const double (&a)[S]) -> double {       // a[cnt - 1] without a dynamically indexed (scratch) array
+    double v = a[0];
+#pragma unroll
+    for (int i = 1; i < S; ++i) {
+      double cand = a[i];
+      krylov_opaque(cand);
+      v = (i < cnt) ? cand : v;
+    }
+    return v;
+  };
+  double gam, del, gn = 0.0, dl = 0.0;
+  auto apply = [&]() {
+    gam = 0.0;
+    del = 0.0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const bool ok = col && i < cnt;
+      const double* q = img + i * PS + o0;
+      const double rc = r[i];
+      const double rd = (i == 0) ? r_lo : r[i > 0 ? i - 1 : 0];
+      const double ru = (i + 1 < cnt) ? r[(i + 1 < S) ? i + 1 : i] : r_hi;
+      double a = sc_mul(st.c[0], rc);
+      a = sc_fma(st.c[1], q[-1], a);
+      a = sc_fma(st.c[2], q[1], a);
+      a = sc_fma(st.c[3], q[-W], a);
+      a = sc_fma(st.c[4], q[W], a);
+      a = sc_fma(st.c[5], rd, a);
+      a = sc_fma(st.c[6], ru, a);
+      a = ok ? a : 0.0;
+      wv[i] = a;
+      gam = sc_fma(rc, rc, gam);
+      del = sc_fma(a, rc, del);
+    }
+  };
+  LLPeek peek_lo{0, 0}, peek_hi{0, 0};
+  const evomg_u64 *slot_lo = nullptr, *slot_hi = nullptr;
+  // sums over the whole grid (gn, dl); the neighbouring slabs' faces of w are asked for (peek_lo / peek_hi) and looked at by
+  // faces() once the caller has done what does not need them
+  auto exchange = [&](unsigned seq) -> bool {
+    const int par = (int)(seq & 1u);
+    const double ws = cg1_wave_sums(gam, del);
+    if ((l & 31) == 0) wave_sums[par * 64 + (l & 32) + wv_id] = ws;
+    if (col && grp > 0) ll_store(face_slot(par, grp, 0), wv[0], seq);
+    if (col && grp < G - 1) ll_store(face_slot(par, grp, 1), last_of(wv), seq);
+    __syncthreads();
+    if (wv_id == 0) {
+      double v = wave_sums[par * 64 + l];            // lanes 0..15: (r, r) of the 16 waves, lanes 32..47: (w, r)
+      v = cg1_cross_tree<16>(v);
+      if ((l & 31) == 0) ll_store(sum_slot(par, l >> 5, grp), v, seq);
+      const int q = l & 31;
+      double got = 0.0;
+      if (q < G && !ll_load(sum_slot(par, l >> 5, q), seq, &got)) lds_fail[par] = 1;
+      slab_sums[par * 64 + l] = got;
+    }
+    __syncthreads();
+    double a = slab_sums[par * 64], d = slab_sums[par * 64 + 32];
+#pragma unroll
+    for (int q = 1; q < G; ++q) {
+      a = a + slab_sums[par * 64 + q];
+      d = d + slab_sums[par * 64 + 32 + q];
+    }
+    gn = a;
+    dl = d;
+    slot_lo = face_slot(par, grp > 0 ? grp - 1 : 0, 1);
+    slot_hi = face_slot(par, grp < G - 1 ? grp + 1 : G - 1, 0);
+    peek_lo = ll_peek(slot_lo);
+    peek_hi = ll_peek(slot_hi);
+    return lds_fail[par] == 0;
+  };
+  bool faces_ok = true;
+  auto faces = [&](unsigned seq) {
+    w_lo = 0.0;
+    w_hi = 0.0;
+    if (col && grp > 0) faces_ok &= ll_finish(peek_lo, slot_lo, seq, &w_lo);
+    if (col && grp < G - 1) faces_ok &= ll_finish(peek_hi, slot_hi, seq, &w_hi);
+  };
+
+  unsigned seq = seq_base;
+  __syncthreads();                                   // the image of r
+  apply();
+  bool alive = exchange(++seq);
+  const double res0 = sc_norm_from_dot(gn);
+  int it = 0;
+  if (alive && res0 != 0.0 && maxit > 0) {
+    double den = dl, alpha = sc_div(gn, dl), beta = 0.0;
+    for (;;) {
+      const double inv_g = sc_div(1.0, gn);
+      const double nalpha = sc_neg(alpha);
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        p[i] = sc_fma(beta, p[i], r[i]);
+        s[i] = sc_fma(beta, s[i], wv[i]);
+        xr[i] = sc_fma(alpha, p[i], xr[i]);
+        r[i] = sc_fma(nalpha, s[i], r[i]);
+        if (col && i < cnt) img[i * PS + o0] = r[i];
+      }
+      faces(seq);                                    // their trip hid behind the update
+      s_lo = sc_fma(beta, s_lo, w_lo);
+      r_lo = sc_fma(nalpha, s_lo, r_lo);
+      s_hi = sc_fma(beta, s_hi, w_hi);
+      r_hi = sc_fma(nalpha, s_hi, r_hi);
+      __syncthreads();                               // the image of r
+      apply();
+      alive = exchange(++seq);
+      ++it;
+      if (!alive) break;
+      const double res = sc_norm_from_dot(gn);
+      if (!(res > tol * res0) || it >= maxit) break;
+      beta = sc_mul(gn, inv_g);
+      den = sc_fma(sc_neg(sc_mul(beta, beta)), den, dl);
+      alpha = sc_div(gn, den);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+    if (col && i < cnt) {
+      const long c = c0 + g.plane * i;
+      x[c] = xr[i];
+      r_out[c] = r[i];
+    }
+  if (t == 0) {
+    if (grp == 0) { info[0] = it; info[2] += it; }      // [2]: iterations of all coarse solves since the host last cleared it
+    if (!alive) info[1] = 1;
+  }
+  if (!faces_ok) info[1] = 1;
+}

@@ -83,23 +83,31 @@
       if (rc != EVOMG_OK) return rc;
       apply_bc(L, x);
     } else if (!scalar_traits<T>::is_complex && dim_ == 3 && krylov_cg_groups<3>(lv.g.n) > 1) {
-      // 33^3: eight co-resident workgroups (evomg_cg_multi_wg3d); the canonical reduction order of this grid is the
-      // grouped one, so there is no single-workgroup alternative
+      // 33^3: eight co-resident workgroups, one slab of planes each — the single-reduction form (evomg_cg1.h: evomg_cg1_slab3d)
+      // or the classical one (evomg_cg_multi_wg3d); the canonical reduction order of this grid is the grouped one either way, so
+      // there is no single-workgroup alternative
       const KrylovOwn own = krylov_own<3>(lv.g.n);
-      const size_t lds_bytes = sizeof(T) * (34 + 2 * EVOMG_CG_GROUPS + (size_t)EVOMG_CG_SLAB * (own.m + 2) * (own.m + 2));
-      auto kern = evomg_cg_multi_wg3d<double>;   // complex problems are 2D only
+      const bool single_reduction = prob_.cgs_kind == EVOMG_CGS_CG;       // evomg_cg1_slab3d; else the classical evomg_cg_multi_wg3d
+      const size_t lds_bytes = single_reduction ? sizeof(double) * (258 + (size_t)EVOMG_CG_SLAB * (own.m + 2) * (own.m + 2))
+                                                : sizeof(T) * (34 + 2 * EVOMG_CG_GROUPS + (size_t)EVOMG_CG_SLAB * (own.m + 2) * (own.m + 2));
       if (!cg_multi_attr_set_) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_cg_multi_wg3d<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(evomg_cg1_slab3d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_));
         cg_multi_attr_set_ = true;
       }
       cg_multi_used_ = true;
-        unsigned seq_base = 0;
+      unsigned seq_base = 0;
       const int rc_seq = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u, &seq_base);
       if (rc_seq != EVOMG_OK) return rc_seq;
       const int blocks = EVOMG_CG_GROUPS * cg_stride_;
-      if constexpr (!scalar_traits<T>::is_complex)
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
-                           prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
+      if constexpr (!scalar_traits<T>::is_complex) {       // complex problems are 2D only
+        if (single_reduction)
+          hipLaunchKernelGGL(evomg_cg1_slab3d, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
+                             prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
+        else
+          hipLaunchKernelGGL(evomg_cg_multi_wg3d<double>, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
+                             prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
+      }
       apply_bc(L, x);
     } else if (!scalar_traits<T>::is_complex && kcg_enabled_ &&
                (dim_ == 2 ? krylov_cg_per_launch<2>(lv.g.n) : krylov_cg_per_launch<3>(lv.g.n))) {

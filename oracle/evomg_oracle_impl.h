@@ -717,10 +717,14 @@ static FN(cg1_plan_t) FN(cg1_plan)(int n) {
   if (p.waves > 32) p.waves = 0;
   return p;
 }
-/* which coarsest grids the single-reduction form serves (csrc/impl_coarse.inl: cg1_serves): the level grids 3^2 .. 129^2 */
+static int FN(cg_groups)(FN(ctx_t)* c, int level);
+/* which coarsest grids the single-reduction form serves (csrc/impl_coarse.inl): the 2D level grids 3^2 .. 129^2 (bands,
+ * evomg_cg1_band2d) and the 3D grid that runs as eight slabs, 33^3 (evomg_cg1_slab3d: the grouped summation order of the
+ * classical form, dot_canon_grouped) */
 static int FN(cg1_serves)(FN(ctx_t)* c, int level) {
   const int m = c->lv[level].n - 2;
-  if (SC_IS_COMPLEX || c->dim != 2 || c->prob.cgs_kind != EVOMG_CGS_CG) return 0;
+  if (SC_IS_COMPLEX || c->prob.cgs_kind != EVOMG_CGS_CG) return 0;
+  if (c->dim == 3) return FN(cg_groups)(c, level) > 1;
   return m == 1 || m == 3 || m == 7 || m == 15 || m == 31 || m == 63 || m == 127;
 }
 static SC FN(dot_bands)(FN(ctx_t)* c, int level, const SC* a, const SC* b) {
@@ -765,10 +769,11 @@ static int FN(coarse_cg1)(FN(ctx_t)* c) {
   memset(p, 0, lv->count * sizeof(SC));
   memset(s, 0, lv->count * sizeof(SC));
   memset(w, 0, lv->count * sizeof(SC));
+#define CG1_DOT(u, v) (c->dim == 3 ? FN(dot_canon_grouped)(c, L, u, v) : FN(dot_bands)(c, L, u, v))
   FN(krylov_apply)(c, L, lv->st, x, b, r, 1);
   FN(krylov_apply)(c, L, lv->st, r, NULL, w, 0);
-  SC g = FN(dot_bands)(c, L, r, r);
-  SC d = FN(dot_bands)(c, L, w, r);
+  SC g = CG1_DOT(r, r);
+  SC d = CG1_DOT(w, r);
   const double res0 = sc_norm_from_dot(g);
   int it = 0;
   if (res0 != 0.0 && c->prob.cgs_max_iterations > 0) {
@@ -780,8 +785,8 @@ static int FN(coarse_cg1)(FN(ctx_t)* c) {
       FN(krylov_axpy)(c, L, x, alpha, p, x);                /* x = alpha p + x */
       FN(krylov_axpy)(c, L, r, sc_neg(alpha), s, r);        /* r = -alpha s + r */
       FN(krylov_apply)(c, L, lv->st, r, NULL, w, 0);
-      const SC gn = FN(dot_bands)(c, L, r, r);
-      d = FN(dot_bands)(c, L, w, r);
+      const SC gn = CG1_DOT(r, r);
+      d = CG1_DOT(w, r);
       ++it;
       const double res = sc_norm_from_dot(gn);
       if (!(res > c->prob.cgs_target_res_reduction * res0) || it >= c->prob.cgs_max_iterations) break;
@@ -791,8 +796,15 @@ static int FN(coarse_cg1)(FN(ctx_t)* c) {
       g = gn;
     }
   }
-  for (int j = 1; j < n - 1; ++j)
-    for (int i = 1; i < n - 1; ++i) rout[IDX2(n, i, j)] = r[IDX2(n, i, j)];
+#undef CG1_DOT
+  if (c->dim == 2) {
+    for (int j = 1; j < n - 1; ++j)
+      for (int i = 1; i < n - 1; ++i) rout[IDX2(n, i, j)] = r[IDX2(n, i, j)];
+  } else {
+    for (int k = 1; k < n - 1; ++k)
+      for (int j = 1; j < n - 1; ++j)
+        for (int i = 1; i < n - 1; ++i) rout[IDX3(n, i, j, k)] = r[IDX3(n, i, j, k)];
+  }
   FN(apply_bc)(c, L, x);
   if (getenv("EVOMG_ORACLE_DEBUG")) fprintf(stderr, "[oracle] coarse CG (single reduction): %d iterations (cap %d)\n", it, c->prob.cgs_max_iterations);
   return it;

@@ -77,20 +77,44 @@ def test_zero_right_hand_side_is_left_alone():
         assert not x.any() and not r.any()
 
 
-def test_three_dimensional_and_large_grids_keep_the_classical_form():
-    """cgs_kind = CGS_CG on grids the single-reduction form does not serve is the classical recurrence, bit for bit."""
-    lo = 3
-    pd3 = problems.poisson_3d(lo, lo + 1)
+def coarse_solve_3d(lib_create, lo, kind, rhs, **kw):
+    h = lib_create(dataclasses.replace(problems.poisson_3d(lo, lo + 1), cgs_kind=kind, **kw))
+    h.set_field(lo, abi.F_CGS_RHS, rhs)
+    h.run_ops([abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR), abi.make_op(abi.OP_COARSE_SOLVE, lo)])
+    return h.get_field(lo, abi.F_CORR), h.get_field(lo, abi.F_RES)
+
+
+def random_rhs_3d(lo, seed=0):
     n = (1 << lo) + 1
     rhs = np.zeros((n, n, n))
-    rhs[1:-1, 1:-1, 1:-1] = np.random.default_rng(3).standard_normal((n - 2,) * 3)
-    out = []
-    for kind in (abi.CGS_CG, abi.CGS_CG_CLASSICAL):
-        h = oracle.create(dataclasses.replace(pd3, cgs_kind=kind))
-        h.set_field(lo, abi.F_CGS_RHS, rhs)
-        h.run_ops([abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR), abi.make_op(abi.OP_COARSE_SOLVE, lo)])
-        out.append(h.get_field(lo, abi.F_CORR))
-    assert np.array_equal(out[0], out[1])
+    rhs[1:-1, 1:-1, 1:-1] = np.random.default_rng(300 * lo + seed).standard_normal((n - 2,) * 3)
+    return rhs
+
+
+def test_grids_without_a_single_reduction_kernel_keep_the_classical_form():
+    """cgs_kind = CGS_CG on grids the single-reduction form does not serve (3D other than 33^3, 2D beyond 129^2) is the
+    classical recurrence, bit for bit."""
+    for lo in (2, 3, 4):
+        rhs = random_rhs_3d(lo)
+        a, _ = coarse_solve_3d(oracle.create, lo, abi.CGS_CG, rhs)
+        b, _ = coarse_solve_3d(oracle.create, lo, abi.CGS_CG_CLASSICAL, rhs)
+        assert np.array_equal(a, b)
+    rhs = random_rhs(8)
+    a, _ = coarse_solve(oracle.create, 8, abi.CGS_CG, rhs, cgs_max_iterations=20)
+    b, _ = coarse_solve(oracle.create, 8, abi.CGS_CG_CLASSICAL, rhs, cgs_max_iterations=20)
+    assert np.array_equal(a, b)
+
+
+def test_single_reduction_form_on_the_3d_grid_of_eight_slabs():
+    """33^3 (the coarsest grid of BASELINE config C4): the two forms solve the same system to the same tolerance."""
+    lo = 5
+    rhs = random_rhs_3d(lo)
+    x1, r1 = coarse_solve_3d(oracle.create, lo, abi.CGS_CG, rhs)
+    x0, r0 = coarse_solve_3d(oracle.create, lo, abi.CGS_CG_CLASSICAL, rhs)
+    assert not np.array_equal(x1, x0)
+    assert np.abs(x1 - x0).max() <= 1e-10 * np.abs(x0).max()
+    for r in (r1, r0):
+        assert np.linalg.norm(r[1:-1, 1:-1, 1:-1]) <= 1e-12 * np.linalg.norm(rhs)
 
 
 def test_unknown_solver_kind_is_rejected():

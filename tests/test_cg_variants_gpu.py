@@ -10,7 +10,7 @@ import pytest
 from evostencils_amd import abi, native, problems
 from oracle import oracle
 
-from test_cg_variants import coarse_solve, random_rhs
+from test_cg_variants import coarse_solve, coarse_solve_3d, random_rhs, random_rhs_3d
 
 pytestmark = pytest.mark.gpu
 KINDS = {"single-reduction": abi.CGS_CG, "classical": abi.CGS_CG_CLASSICAL}
@@ -57,6 +57,23 @@ def test_folded_copy_zero_solve(lo, kind):
     for a, b in zip(*out):
         assert np.array_equal(a[1:-1, 1:-1], b[1:-1, 1:-1])
     assert np.array_equal(out[0][2], rhs)
+
+
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_coarse_solve_on_33_cubed_bit_identical_to_the_oracle(kind):
+    """The coarsest grid of BASELINE config C4 on eight workgroups (evomg_cg1_slab3d / evomg_cg_multi_wg3d): solution and
+    residual bit-identical to the oracle, also under an iteration cap; many solves in a row keep their exchange words apart."""
+    lo = 5
+    rhs = random_rhs_3d(lo, 1)
+    for kw in ({}, {"cgs_max_iterations": 1}, {"cgs_max_iterations": 7}):
+        xg, rg = coarse_solve_3d(native.create, lo, KINDS[kind], rhs, **kw)
+        xo, ro = coarse_solve_3d(oracle.create, lo, KINDS[kind], rhs, **kw)
+        assert np.array_equal(xg, xo) and np.array_equal(rg[1:-1, 1:-1, 1:-1], ro[1:-1, 1:-1, 1:-1]), kw
+    h = native.create(dataclasses.replace(problems.poisson_3d(lo, lo + 1), cgs_kind=KINDS[kind]))
+    h.set_field(lo, abi.F_CGS_RHS, rhs)
+    ops = [abi.make_op(abi.OP_SET_ZERO, lo, abi.F_CORR), abi.make_op(abi.OP_COARSE_SOLVE, lo)]
+    h.run_ops(ops * 40)
+    assert np.array_equal(h.get_field(lo, abi.F_CORR), xo if not kw else coarse_solve_3d(oracle.create, lo, KINDS[kind], rhs)[0])
 
 
 def test_zero_right_hand_side():
