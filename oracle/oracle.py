@@ -55,3 +55,36 @@ def create(problem_description, parameters=None, jacobi_semantics=None, lib=None
     h = abi.Handle(lib or library(), problem_description.to_c(parameters, jacobi_semantics), 0)
     problem_description.upload_initial_fields(h)
     return h
+
+
+_tuned_lib = None
+TUNED_LIB_PATH = os.path.join(_HERE, "libevomg_cpu_tuned.so")
+
+
+def tuned_poisson2d(lo, hi, u0, rhs, pre=1, post=1, omega=1.0, tol=1e-12, maxit=100, cgs_maxit=1000, cgs_tol=1e-12):
+    """The TUNED CPU solver (oracle/evomg_cpu_tuned.c: plain OpenMP, not bit-comparable) on the 2D Poisson problem with
+    initial guess / boundary values `u0` and right-hand side `rhs` on level `hi`: V(pre, post) red-black cycle, CG on level
+    `lo`. Built on this host on first use. Returns (solution, residual history, coarse-solver iterations, seconds)."""
+    import ctypes as C
+    import time
+    import numpy as np
+    global _tuned_lib
+    if _tuned_lib is None:
+        subprocess.run(["make", "-s", "-B", "-C", _HERE, "libevomg_cpu_tuned.so"], check=True)
+        _tuned_lib = C.CDLL(TUNED_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        _tuned_lib.evomg_cpu_tuned_poisson2d.argtypes = [C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                          C.c_int, C.c_double, dp, C.c_int, C.POINTER(C.c_longlong)]
+        _tuned_lib.evomg_cpu_tuned_poisson2d.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    u = np.ascontiguousarray(u0, dtype=np.float64).copy()
+    f = np.ascontiguousarray(rhs, dtype=np.float64)
+    hist = np.zeros(maxit + 1)
+    k = C.c_longlong()
+    t0 = time.time()
+    its = _tuned_lib.evomg_cpu_tuned_poisson2d(lo, hi, u.ctypes.data_as(dp), f.ctypes.data_as(dp), pre, post, omega, tol, maxit,
+                                               cgs_maxit, cgs_tol, hist.ctypes.data_as(dp), len(hist), C.byref(k))
+    seconds = time.time() - t0
+    if its < 0:
+        raise RuntimeError("evomg_cpu_tuned_poisson2d: bad arguments")
+    return u, hist[:its + 1], int(k.value), seconds
