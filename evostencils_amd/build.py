@@ -72,3 +72,39 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+
+
+def kernel_resources(unit="impl_real"):
+    """Register and LDS use of every kernel of one translation unit AS BUILT: {mangled name: {"vgpr", "agpr", "sgpr",
+    "vgpr_spill", "sgpr_spill", "lds", "scratch"}} from the metadata notes of the gfx950 code object inside csrc/obj/<unit>.o
+    (llvm-objcopy dumps the fat binary, clang-offload-bundler takes the device part out, llvm-readelf prints the notes).
+    What the documentation says about occupancy is checked against this (tests/test_abi.py)."""
+    import re
+    import tempfile
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    obj = _obj(unit + ".hip")
+    if not os.path.exists(obj):
+        build()
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "device.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", obj], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    keys = {".vgpr_count": "vgpr", ".agpr_count": "agpr", ".sgpr_count": "sgpr", ".vgpr_spill_count": "vgpr_spill",
+            ".sgpr_spill_count": "sgpr_spill", ".group_segment_fixed_size": "lds", ".private_segment_fixed_size": "scratch"}
+    out, current = {}, {}
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*(\.[a-z_]+):\s*(\S+)", line)
+        if not m:
+            continue
+        key, value = m.group(1), m.group(2)
+        if key == ".name" and "name" not in current:           # (arguments carry a .name too: they come before the kernel's own keys end)
+            current["name"] = value
+        elif key in keys:
+            current[keys[key]] = int(value)
+        elif key == ".wavefront_size":                          # last key of a kernel's map
+            if "name" in current:
+                out[current["name"]] = {k: v for k, v in current.items() if k != "name"}
+            current = {}
+    return out

@@ -516,10 +516,8 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
       del = sc_fma(a, rc, del);
     }
   };
-  LLPeek peek_lo{0, 0}, peek_hi{0, 0};
-  const evomg_u64 *slot_lo = nullptr, *slot_hi = nullptr;
-  // sums over the whole grid (gn, dl); the neighbouring slabs' faces of w are asked for (peek_lo / peek_hi) and looked at by
-  // faces() once the caller has done what does not need them
+  // sums over the whole grid (gn, dl); the neighbouring slabs' faces of w are fetched by faces() once the caller has done what
+  // does not need them (they were published before the sums: by then they have landed)
   auto exchange = [&](unsigned seq) -> bool {
     const int par = (int)(seq & 1u);
     const double ws = cg1_wave_sums(gam, del);
@@ -545,18 +543,15 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     }
     gn = a;
     dl = d;
-    slot_lo = face_slot(par, grp > 0 ? grp - 1 : 0, 1);
-    slot_hi = face_slot(par, grp < G - 1 ? grp + 1 : G - 1, 0);
-    peek_lo = ll_peek(slot_lo);
-    peek_hi = ll_peek(slot_hi);
     return lds_fail[par] == 0;
   };
   bool faces_ok = true;
   auto faces = [&](unsigned seq) {
+    const int par = (int)(seq & 1u);
     w_lo = 0.0;
     w_hi = 0.0;
-    if (col && grp > 0) faces_ok &= ll_finish(peek_lo, slot_lo, seq, &w_lo);
-    if (col && grp < G - 1) faces_ok &= ll_finish(peek_hi, slot_hi, seq, &w_hi);
+    if (col && grp > 0) faces_ok &= ll_load(face_slot(par, grp - 1, 1), seq, &w_lo);
+    if (col && grp < G - 1) faces_ok &= ll_load(face_slot(par, grp + 1, 0), seq, &w_hi);
   };
 
   unsigned seq = seq_base;

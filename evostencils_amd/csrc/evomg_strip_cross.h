@@ -36,7 +36,7 @@
 #define EVOMG_CROSS_STRIP_COLS 116
 #define EVOMG_CROSS_UNROLL 6
 #ifndef EVOMG_CROSS_PF
-#define EVOMG_CROSS_PF 3        // rows of x / f in flight per wave beyond the window (a divisor of the unroll factor)
+#define EVOMG_CROSS_PF 2        // rows of x / f in flight per wave beyond the window (a divisor of the unroll factor); 3: 176 VGPRs, 2: 158 — same speed (profiles/r05_cross_kernel.md)
 #endif
 
 struct CrossArgs {

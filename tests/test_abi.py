@@ -148,3 +148,26 @@ def test_a_library_from_before_a_symbol_existed_asks_for_a_rebuild():
                           "try:\n    native.library()\nexcept RuntimeError as exc:\n    print('RuntimeError:', exc)\n", EVOMG_LIB=so)
     assert out.returncode == 0, out.stderr
     assert "RuntimeError:" in out.stdout and "rebuild with `python -m evostencils_amd.build`" in out.stdout
+
+
+def test_register_budgets_the_documentation_states_hold_in_the_built_code_object():
+    """DESIGN.md quotes occupancy figures; they are read off the gfx950 code object that ships (build.kernel_resources), not
+    off a build somebody remembers (the cross kernel was documented at 161 VGPRs and shipped with 176)."""
+    res = build.kernel_resources("impl_real")
+    cross = {k: v for k, v in res.items() if "evomg_strip2d_cross" in k}
+    assert len(cross) == 16
+    # the variants a Poisson cycle launches (power-of-two stencil, <.., RECIP = true>): at most 168 VGPRs = three waves per SIMD
+    for name, r in cross.items():
+        if name.split("EEv3Geo")[0].endswith("Lb1"):
+            assert r["vgpr"] + r["agpr"] <= 168 and r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
+    headline = next(v for k, v in cross.items() if "ILb1ELb1ELb1ELb1E" in k)
+    assert headline["vgpr"] == 158
+    # the single-reduction CG kernels: nothing spills (a spill inside a latency chain is a round trip to memory per iteration)
+    cg1 = {k: v for k, v in res.items() if "evomg_cg1_" in k}
+    assert len(cg1) >= 14
+    for name, r in cg1.items():
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
+    band129 = [v for k, v in cg1.items() if "band2dILi4ELi2ELi1ELi4E" in k]
+    assert band129 and all(v["vgpr"] <= 192 for v in band129)
+    slab = next(v for k, v in cg1.items() if "slab3d" in k)
+    assert slab["vgpr"] <= 128                       # 1024 threads per workgroup
