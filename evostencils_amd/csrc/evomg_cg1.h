@@ -47,14 +47,8 @@
 #define PROF(k) do { } while (0)
 #endif
 
-#ifndef EVOMG_CG1_POLL
-#define EVOMG_CG1_POLL 0
-#endif
 #ifndef EVOMG_CG1_SLEEP0
 #define EVOMG_CG1_SLEEP0 8
-#endif
-#ifndef EVOMG_CG1_SLEEP1
-#define EVOMG_CG1_SLEEP1 2
 #endif
 #define EVOMG_CG1_MAX_WAVES 32    // all wave sums of both inner products fit one wave64: (r, r) in lanes 0..31, (w, r) in 32..63
 #define EVOMG_CG1_MAX_GROUPS 16
@@ -253,14 +247,14 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     if constexpr (!MULTI) {
       if ((l & 31) == 0) sums_lds[par][(l & 32) + w] = ws;
     } else {
-      if ((l & 31) == 0) ll_store(sum_slot(par, l >> 5, gw), ws, seq);
+      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, gw), ws, seq);
       if (w == 0 && group > 0) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) ll_store(seam_slot(par, group, 0, e), wv[0][e], seq);
+        for (int e = 0; e < E; ++e) ll_store16(seam_slot(par, group, 0, e), wv[0][e], seq);
       }
       if (w == WAVES - 1 && group < groups - 1) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) ll_store(seam_slot(par, group, 1, e), wv[R - 1][e], seq);
+        for (int e = 0; e < E; ++e) ll_store16(seam_slot(par, group, 1, e), wv[R - 1][e], seq);
       }
       // wave 0 collects the sums of all waves (lane = (quantity, wave)); the edge waves fetch the neighbouring workgroups'
       // edge rows. Everything a lane waits for is asked for in one go and polled together: one round trip, not one per word.
@@ -277,68 +271,20 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
         need[1 + E + e] = w == WAVES - 1 && group < groups - 1;
       }
       if (w == 0 || w == WAVES - 1) {
-        evomg_u64 a[K], c[K];
-        int budget = 1 << 22;
-        bool all = false;
-#if EVOMG_CG1_POLL == 1
-        // two requests under way, half a trip apart: what a request that left just before the words landed would cost (a
-        // whole further trip) becomes half a trip
-        evomg_u64 a2[K], c2[K];
-        auto ask = [&](evomg_u64 (&u)[K], evomg_u64 (&v)[K]) {
+        // (a slot this lane does not need: any readable word will do — its own sum slot)
 #pragma unroll
-          for (int k = 0; k < K; ++k)
-            if (need[k]) {
-              u[k] = __hip_atomic_load(slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              v[k] = __hip_atomic_load(slot[k] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        auto here = [&](const evomg_u64 (&u)[K], const evomg_u64 (&v)[K]) {
-          bool ok_ = true;
-#pragma unroll
-          for (int k = 0; k < K; ++k)
-            if (need[k]) ok_ = ok_ && (unsigned)(u[k] >> 32) == seq && (unsigned)(v[k] >> 32) == seq;
-          return ok_;
-        };
-        __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);
-        ask(a, c);
-        for (;;) {
-          __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP1);
-          ask(a2, c2);
-          if (here(a, c)) { all = true; break; }
-          __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP1);
-          ask(a, c);
-          if (here(a2, c2)) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) { a[k] = a2[k]; c[k] = c2[k]; }
-            all = true;
-            break;
-          }
-          if (--budget == 0) break;
-        }
-#else
-        __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);
-        while (!all) {
-#pragma unroll
-          for (int k = 0; k < K; ++k)
-            if (need[k]) {
-              a[k] = __hip_atomic_load(slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              c[k] = __hip_atomic_load(slot[k] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          all = true;
-#pragma unroll
-          for (int k = 0; k < K; ++k)
-            if (need[k]) all = all && (unsigned)(a[k] >> 32) == seq && (unsigned)(c[k] >> 32) == seq;
-          if (!all && --budget == 0) break;
-        }
-#endif
-        auto value = [&](int k) { return __longlong_as_double((long long)((a[k] & 0xffffffffull) | (c[k] << 32))); };
+        for (int k = 0; k < K; ++k)
+          if (!need[k]) slot[k] = sum_slot(par, 0, gw);
+        double got[K];
+        __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);       // the words cannot have landed yet: do not load the fabric with a poll that must fail
+        const bool all = ll_poll16<K>(slot, need, seq, got);
         // a missing sum is seen by everybody behind THIS barrier, a missing edge row behind the next one
         if (!all) lds_fail[need[0] ? par : par ^ 1] = 1;
-        if (w == 0) sums_lds[par][l] = (need[0] && all) ? value(0) : 0.0;
+        if (w == 0) sums_lds[par][l] = (need[0] && all) ? got[0] : 0.0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          if (need[1 + e] && all) ll_gs[e] = value(1 + e);
-          if (need[1 + E + e] && all) ll_gn[e] = value(1 + E + e);
+          if (need[1 + e] && all) ll_gs[e] = got[1 + e];
+          if (need[1 + E + e] && all) ll_gn[e] = got[1 + E + e];
         }
       }
     }
@@ -522,17 +468,19 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     const int par = (int)(seq & 1u);
     const double ws = cg1_wave_sums(gam, del);
     if ((l & 31) == 0) wave_sums[par * 64 + (l & 32) + wv_id] = ws;
-    if (col && grp > 0) ll_store(face_slot(par, grp, 0), wv[0], seq);
-    if (col && grp < G - 1) ll_store(face_slot(par, grp, 1), last_of(wv), seq);
+    if (col && grp > 0) ll_store16(face_slot(par, grp, 0), wv[0], seq);
+    if (col && grp < G - 1) ll_store16(face_slot(par, grp, 1), last_of(wv), seq);
     __syncthreads();
     if (wv_id == 0) {
       double v = wave_sums[par * 64 + l];            // lanes 0..15: (r, r) of the 16 waves, lanes 32..47: (w, r)
       v = cg1_cross_tree<16>(v);
-      if ((l & 31) == 0) ll_store(sum_slot(par, l >> 5, grp), v, seq);
+      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, grp), v, seq);
       const int q = l & 31;
-      double got = 0.0;
-      if (q < G && !ll_load(sum_slot(par, l >> 5, q), seq, &got)) lds_fail[par] = 1;
-      slab_sums[par * 64 + l] = got;
+      const evomg_u64* const slot[1] = {sum_slot(par, l >> 5, q < G ? q : grp)};
+      const bool need[1] = {q < G};
+      double got[1];
+      if (!ll_poll16<1>(slot, need, seq, got)) lds_fail[par] = 1;
+      slab_sums[par * 64 + l] = q < G ? got[0] : 0.0;
     }
     __syncthreads();
     double a = slab_sums[par * 64], d = slab_sums[par * 64 + 32];
@@ -550,8 +498,14 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     const int par = (int)(seq & 1u);
     w_lo = 0.0;
     w_hi = 0.0;
-    if (col && grp > 0) faces_ok &= ll_load(face_slot(par, grp - 1, 1), seq, &w_lo);
-    if (col && grp < G - 1) faces_ok &= ll_load(face_slot(par, grp + 1, 0), seq, &w_hi);
+    const evomg_u64* const slot[2] = {face_slot(par, grp > 0 ? grp - 1 : grp, 1), face_slot(par, grp < G - 1 ? grp + 1 : grp, 0)};
+    const bool need[2] = {col && grp > 0, col && grp < G - 1};
+    double got[2];
+    if (need[0] || need[1]) {
+      faces_ok &= ll_poll16<2>(slot, need, seq, got);
+      if (need[0]) w_lo = got[0];
+      if (need[1]) w_hi = got[1];
+    }
   };
 
   unsigned seq = seq_base;
