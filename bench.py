@@ -31,7 +31,7 @@ import time
 
 # hardware queues for the candidates-in-flight modes: must be in the environment before the HIP runtime initialises
 # (evostencils_amd/__init__.py explains; ranks started by the launcher inherit it)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 # A/B of the coarse-grid CG's two forms (ProgramGenerator(coarse_cg=...)); the default is the product's default
 COARSE_CG = os.environ.get("EVOMG_BENCH_COARSE_CG", "single-reduction")
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--concurrency", type=int, default=1,
                     help="candidates in flight per GPU inside the HEADLINE timed region (1 = isolated timing, the "
                          "reference's sequential semantics)")
-    ap.add_argument("--throughput-workers", type=int, default=12,
+    ap.add_argument("--throughput-workers", type=int, default=16,
                     help="after the headline region, also time a throughput-mode region with this many candidates in "
                          "flight per GPU and report it as `throughput_mode` (0/1 = skip)")
     ap.add_argument("--population", type=int, default=256,
@@ -664,12 +664,30 @@ def main():
     coarse_op = next(o for o in ops if o.opcode == abi.OP_COARSE_SOLVE)
     coarse_solve = {"kernel": handle.kernel_name(coarse_op), "grid": f"{(1 << lo) + 1}^2", "ms_per_call": cs.ms,
                     "calls_per_solve": cs.launches / 3.0, "share_of_solve": cs.ms * cs.launches / 3.0 / float(extra[0][1]),
-                    "bound": "VALU issue of ONE compute unit",
-                    "note": "CG to 1e-12 on the coarsest grid (the reference's solver settings): two dependent reductions per iteration; "
-                            "a grid-wide rendezvous costs more than the arithmetic it would spread (profiles/r03_rendezvous.md), so it "
-                            "runs as one 512-thread workgroup out of registers, 2.1 us per iteration, VALU active 72 % of its busy "
-                            "cycles (profiles/r03_pmc_tables.txt). What the other 255 compute units do meanwhile is the next "
-                            "candidate: throughput_mode"}
+                    "iterations_per_call": (handle.coarse_iterations() / (cs.launches / 3.0)) if cs.launches else None,
+                    "bound": "one grid-wide exchange per CG iteration (its trip to the fabric and back) + one unit's issue rate"
+                             if COARSE_CG == "single-reduction" else "VALU issue of ONE compute unit",
+                    "note": "CG to 1e-12 on the coarsest grid (the reference's solver settings, Poisson/2D_FD_Poisson_fromL2.exa3:12-14). "
+                            "Round 5: the single-reduction form of the recurrence (Chronopoulos-Gear: both inner products of an "
+                            "iteration in ONE reduction; csrc/evomg_cg1.h) on eight co-resident workgroups of four waves — the five "
+                            "vectors of 129^2 in registers, ghost rows instead of a second exchange, exchanged doubles as self-validating "
+                            "16-byte words: about 1.5 us per iteration where the classical two-reduction form on ONE compute unit "
+                            "(EVOMG_BENCH_COARSE_CG=classical: cgs_kind CGS_CG_CLASSICAL, evomg_cg_reg2d) takes 2.05; of an iteration "
+                            "roughly 1.1 us are the exchange, 0.25 the arithmetic, the rest wave reductions and the scalar chain "
+                            "(profiles/r05_cg1.md)"}
+    # the whole solve against the roofline of the metric BASELINE names (candidate solves/s): algorithmic bytes of one solve as
+    # launched — per iteration the cross launch on the finest level (24 B/node + 2 x 8 B per coarse node), on every level between
+    # a pre-smoothing launch from an elided zero field with residual + restriction (16 + 2 B/node) and a prolongation + sweep
+    # (24 + 2 B/node); the first iteration's head and the last one's tail as two plain fused launches more
+    _rho_h, t_ms, its = (float(v) for v in last[0])
+    nodes = lambda L: float(((1 << L) + 1) ** 2)
+    bytes_per_iteration = 28.0 * nodes(hi) + sum(44.0 * nodes(L) for L in range(lo + 1, hi))
+    bytes_per_solve = bytes_per_iteration * its + 2.0 * 26.0 * nodes(hi)
+    solve_roofline = {"bound": "hbm", "algorithmic_bytes_per_solve": bytes_per_solve, "algorithmic_bytes_per_iteration": bytes_per_iteration,
+                      "achieved": bytes_per_solve / (t_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                      "frac": bytes_per_solve / (t_ms * 1e-3) / 8e12,
+                      "note": "ONE candidate alone on the GPU: its coarse-grid solves (latency-bound, 8 of 256 compute units) are most "
+                              "of its time; the bandwidth-bound rate of the metric is throughput_mode.roofline"}
 
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:
@@ -685,11 +703,20 @@ def main():
             tt = torch.tensor([el2], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
+        rate = n / el2                            # per GPU
         throughput = {"candidates_in_flight_per_gpu": k, "steps": n, "value": world * n / el2, "unit": "solves/s",
                       "ms_per_step": 1e3 * el2 / n,
-                      "note": "same workload, several candidates in flight per GPU (own stream + fields each): the "
-                              "single-workgroup coarse-grid solve of one candidate overlaps the bandwidth-bound sweeps "
-                              "of the others; rho/iterations unchanged, per-candidate time includes contention"}
+                      "roofline": {"bound": "hbm", "algorithmic_bytes_per_solve": bytes_per_solve, "achieved": bytes_per_solve * rate / 1e9,
+                                   "peak": 8000.0, "unit": "GB/s", "frac": bytes_per_solve * rate / 8e12,
+                                   "traffic_per_solve": measured_traffic("c2_solve")[0],
+                                   "note": "per GPU: algorithmic bytes of one solve x solves per second. With a dozen working sets of "
+                                           "1.1 GB each nothing stays in the 256 MB Infinity Cache: the streaming rate these kernels "
+                                           "reach from HBM alone is 0.55-0.57 of peak (8193^2, profiles/r04_8193_raw.txt), which puts the "
+                                           "ceiling of this mode near 500 solves/s; profiles/r05_throughput.md has the kernel trace "
+                                           "(what is in flight when) and the counter passes"},
+                      "note": "same workload, several candidates in flight per GPU (own stream + fields each): the latency-bound "
+                              "coarse-grid solve of one candidate overlaps the bandwidth-bound sweeps of the others; rho/iterations "
+                              "unchanged, per-candidate time includes contention"}
     if workers is not None:
         workers.close()
 
@@ -717,6 +744,7 @@ def main():
                                                          "in the population section"},
                        "candidates_in_flight_per_gpu": args.concurrency},
             "roofline": roofline,
+            "solve_roofline": solve_roofline,
             "coarse_solve": coarse_solve,
         }
         if throughput is not None:

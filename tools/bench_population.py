@@ -5,7 +5,7 @@ GPU, fitness all-gathered over RCCL. usage:
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_population.py"""
 import argparse, json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
+sys.path[:0] = [REPO]
 
 
 def main():
@@ -26,7 +26,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from evostencils_amd import candidates, native, population, problems
     from evostencils_amd.code_generation.hip import ProgramGenerator
-    from helpers import context_for
+    context_for = candidates.production_context
     hi = args.level; lo = hi - args.levels + 1
 
     def make():
