@@ -129,6 +129,7 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   __shared__ double sums_lds[2][64];
   __shared__ double seam_lds[2][2][E][WAVES * 64];  // [parity][edge: first / last row][element][band slot = thread]
   __shared__ int lds_fail[2];                        // sticky; [parity of the exchange whose barrier publishes it]
+  __shared__ int lds_same_xcd;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int gw = group * WAVES + w;
   const int m = g.n - 2;
@@ -190,6 +191,7 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   __syncthreads();                                   // the zeroed LDS slots
 
   double gam, del, gn = 0.0, dl = 0.0;
+  bool same_xcd = false;                             // established below (MULTI): the exchanges may stay inside one XCD's L2
 #ifdef EVOMG_CG1_PROFILE
   long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = clock64();
 #endif
@@ -247,14 +249,14 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     if constexpr (!MULTI) {
       if ((l & 31) == 0) sums_lds[par][(l & 32) + w] = ws;
     } else {
-      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, gw), ws, seq);
+      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, gw), ws, seq, same_xcd);
       if (w == 0 && group > 0) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) ll_store16(seam_slot(par, group, 0, e), wv[0][e], seq);
+        for (int e = 0; e < E; ++e) ll_store16(seam_slot(par, group, 0, e), wv[0][e], seq, same_xcd);
       }
       if (w == WAVES - 1 && group < groups - 1) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) ll_store16(seam_slot(par, group, 1, e), wv[R - 1][e], seq);
+        for (int e = 0; e < E; ++e) ll_store16(seam_slot(par, group, 1, e), wv[R - 1][e], seq, same_xcd);
       }
       // wave 0 collects the sums of all waves (lane = (quantity, wave)); the edge waves fetch the neighbouring workgroups'
       // edge rows. Everything a lane waits for is asked for in one go and polled together: one round trip, not one per word.
@@ -276,7 +278,7 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
         for (int k = 0; k < K; ++k)
           if (!need[k]) slot[k] = sum_slot(par, 0, gw);
         double got[K];
-        __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);       // the words cannot have landed yet: do not load the fabric with a poll that must fail
+        if (!same_xcd) __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);      // across XCDs the words cannot have landed yet: no poll that must fail
         const bool all = ll_poll16<K>(slot, need, seq, got);
         // a missing sum is seen by everybody behind THIS barrier, a missing edge row behind the next one
         if (!all) lds_fail[need[0] ? par : par ^ 1] = 1;
@@ -315,6 +317,28 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   };
 
   unsigned seq = seq_base;
+  if constexpr (MULTI) {
+    // Do all workgroups sit on ONE XCD (the host asked for that with stride 8; workgroups are dealt round-robin)? Every wave
+    // publishes its XCD's number the safe way, wave 0 of every workgroup compares all of them: if so, the exchanges of the
+    // solve stay inside that XCD's L2 (ll_store16). Every workgroup reaches the same verdict from the same words.
+    ++seq;
+    const int par = (int)(seq & 1u);
+    const unsigned xcc = ll_xcc_id();
+    if (l == 0) ll_store16(sum_slot(par, 0, gw), (double)xcc, seq, false);
+    if (w == 0) {
+      const int total = groups * WAVES;
+      const evomg_u64* const slot[1] = {sum_slot(par, 0, (l & 31) < total ? (l & 31) : gw)};
+      const bool need[1] = {true};
+      double got[1] = {0.0};
+      const bool arrived = ll_poll16<1>(slot, need, seq, got);
+      if (!arrived) lds_fail[par] = 1;
+      const bool same = arrived && got[0] == (double)xcc;
+      const bool all_same = __builtin_amdgcn_ballot_w64(same) == ~0ull;
+      if (l == 0) lds_same_xcd = (stride > 1 && all_same) ? 1 : 0;
+    }
+    __syncthreads();
+    same_xcd = lds_same_xcd != 0;
+  }
   apply();
   bool alive = exchange(++seq);
   const double res0 = sc_norm_from_dot(gn);
@@ -393,7 +417,7 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double* wave_sums = reinterpret_cast<double*>(lds_raw);       // [parity][64]: (r, r) of wave q at q, (w, r) at 32 + q
   double* slab_sums = wave_sums + 128;                           // [parity][64]: (r, r) of slab q at q, (w, r) at 32 + q
-  int* lds_fail = reinterpret_cast<int*>(slab_sums + 128);       // [2], sticky
+  int* lds_fail = reinterpret_cast<int*>(slab_sums + 128);       // [0], [1]: sticky failure flags; [2]: all workgroups on one XCD
   double* img = slab_sums + 128 + 2;                             // S planes x (m+2) x (m+2), zero halo
   const KrylovOwn own = krylov_own<3>(g.n);
   const int m = own.m, W = m + 2, PS = W * W;
@@ -439,6 +463,7 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     return v;
   };
   double gam, del, gn = 0.0, dl = 0.0;
+  bool same_xcd = false;                             // established below: the exchanges may stay inside one XCD's L2
   auto apply = [&]() {
     gam = 0.0;
     del = 0.0;
@@ -468,13 +493,13 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     const int par = (int)(seq & 1u);
     const double ws = cg1_wave_sums(gam, del);
     if ((l & 31) == 0) wave_sums[par * 64 + (l & 32) + wv_id] = ws;
-    if (col && grp > 0) ll_store16(face_slot(par, grp, 0), wv[0], seq);
-    if (col && grp < G - 1) ll_store16(face_slot(par, grp, 1), last_of(wv), seq);
+    if (col && grp > 0) ll_store16(face_slot(par, grp, 0), wv[0], seq, same_xcd);
+    if (col && grp < G - 1) ll_store16(face_slot(par, grp, 1), last_of(wv), seq, same_xcd);
     __syncthreads();
     if (wv_id == 0) {
       double v = wave_sums[par * 64 + l];            // lanes 0..15: (r, r) of the 16 waves, lanes 32..47: (w, r)
       v = cg1_cross_tree<16>(v);
-      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, grp), v, seq);
+      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, grp), v, seq, same_xcd);
       const int q = l & 31;
       const evomg_u64* const slot[1] = {sum_slot(par, l >> 5, q < G ? q : grp)};
       const bool need[1] = {q < G};
@@ -509,7 +534,24 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   };
 
   unsigned seq = seq_base;
-  __syncthreads();                                   // the image of r
+  {
+    // all eight workgroups on ONE XCD (stride 8)? then the exchanges stay inside its L2 (evomg_cg1_band2d explains)
+    ++seq;
+    const int par = (int)(seq & 1u);
+    const unsigned xcc = ll_xcc_id();
+    if (t == 0) ll_store16(sum_slot(par, 0, grp), (double)xcc, seq, false);
+    if (wv_id == 0) {
+      const evomg_u64* const slot[1] = {sum_slot(par, 0, (l & 31) < G ? (l & 31) : grp)};
+      const bool need[1] = {true};
+      double got[1] = {0.0};
+      const bool arrived = ll_poll16<1>(slot, need, seq, got);
+      if (!arrived) lds_fail[par] = 1;
+      const bool all_same = __builtin_amdgcn_ballot_w64(arrived && got[0] == (double)xcc) == ~0ull;
+      if (l == 0) lds_fail[2] = (stride > 1 && all_same) ? 1 : 0;
+    }
+    __syncthreads();                                 // (also: the image of r)
+    same_xcd = lds_fail[2] != 0;
+  }
   apply();
   bool alive = exchange(++seq);
   const double res0 = sc_norm_from_dot(gn);

@@ -97,7 +97,7 @@
       }
       cg_multi_used_ = true;
       unsigned seq_base = 0;
-      const int rc_seq = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u, &seq_base);
+      const int rc_seq = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 3u, &seq_base);
       if (rc_seq != EVOMG_OK) return rc_seq;
       const int blocks = EVOMG_CG_GROUPS * cg_stride_;
       if constexpr (!scalar_traits<T>::is_complex) {       // complex problems are 2D only
@@ -157,7 +157,7 @@
       unsigned base = 0;
       int stride = 1;
       if (MULTI) {
-        const int rc = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 2u, &base);
+        const int rc = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 3u, &base);
         if (rc != EVOMG_OK) return rc;
         // alone on the device: all workgroups on one XCD (92 against 86 solves/s isolated); while other evaluations of this
         // process are under way — candidates in flight — one workgroup per XCD (throughput_mode 335 against 290 solves/s,

@@ -131,7 +131,7 @@ static void run(const char* name, int level, int groups, int stride, bool check)
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());
-    seq += 1002;
+    seq += 1003;
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
