@@ -43,6 +43,15 @@ if REPO not in sys.path:
 TRAFFIC_TABLE = os.path.join(REPO, "profiles", "pmc_traffic.json")
 
 
+_T0 = time.time()
+
+
+def progress(stage):
+    """One line per stage on stderr (the JSON line owns stdout): where a long run is, and that it is alive."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:7.1f} s] {stage}", file=sys.stderr, flush=True)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,8 +132,8 @@ def cpu_baseline(ops, lo, hi, threads):
         pd = problems.poisson_2d(lo, hi)
         u0, rhs = pd.initial_solution(hi), pd.right_hand_side(hi)
         runs = {}
-        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or threads)
-        for nt in (usable, 4):                       # all cores first; the reference's 4 threads too if that leaves the sample bounded
+        usable = cpu_share(threads)
+        for nt in (usable, 4):                       # this process's share of the host first; the reference's 4 threads too if that leaves the sample bounded
             if str(nt) in runs or (runs and sum(v["seconds"] for v in runs.values()) > 12.0):
                 continue
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(nt))
@@ -149,6 +158,31 @@ def cpu_baseline(ops, lo, hi, threads):
             "tuned": tuned}
 
 
+def cpu_share(fallback):
+    """CPUs this process may actually use: its affinity mask, cut down to the cgroup's quota where there is one (a GPU box
+    shows all 256 hardware threads to a container that is throttled to 16 of them: an OpenMP team of 256 then spends its time
+    being descheduled), and to 32 (the sweeps are memory-bound well before that)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or fallback
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if text[0] != "max":
+                    n = min(n, max(1, int(int(text[0]) / int(text[1]))))
+            else:
+                quota = int(text[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 32))
+
+
 def host_cpu():
     """CPU model, logical CPUs of the host and the share this process may run on (BASELINE.md asks for them beside every
     CPU number)."""
@@ -165,7 +199,7 @@ def host_cpu():
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         usable = os.cpu_count()
-    return {"cpu_model": model, "nproc": os.cpu_count(), "nproc_usable": usable}
+    return {"cpu_model": model, "nproc": os.cpu_count(), "nproc_usable": usable, "cpu_share": cpu_share(usable or 1)}
 
 
 def measured_traffic(kernel_key):
@@ -227,6 +261,7 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
     rows = None
     rows_first = None
     for mode in (("static", "dynamic") if world > 1 else ("static", "static_repeat")) + (("static_in_flight", "static_in_flight_isolated_time") if in_flight else ()):
+        progress(f"population: {mode}")
         busy[0] = 0.0
         fence()
         t0 = time.perf_counter()
@@ -602,7 +637,9 @@ def main():
     smooth = next(o for o in ops if o.opcode == abi.OP_SMOOTH and o.level == hi)
     handle = gen._handle
 
+    progress("warm-up")
     run_steps(args.warmup)
+    progress("headline: timed steps")
     fence()
     # live HIP-event timing of the dominant kernel (finest-level RB-GS sweep) on the backend's own stream,
     # over exactly the timed region
@@ -657,6 +694,7 @@ def main():
                         f"profile), null when no profile matches the launched kernel and level"}
 
     # ---- where the rest of an isolated solve goes: the coarse-grid solve, timed the same way over three more solves ----
+    progress("coarse solve timing")
     handle.profile_begin(abi.OP_COARSE_SOLVE, lo)
     extra = run_steps(3)
     fence()
@@ -689,6 +727,7 @@ def main():
                       "note": "ONE candidate alone on the GPU: its coarse-grid solves (latency-bound, 8 of 256 compute units) are most "
                               "of its time; the bandwidth-bound rate of the metric is throughput_mode.roofline"}
 
+    progress("throughput mode")
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:
         k = args.throughput_workers
@@ -722,6 +761,7 @@ def main():
 
     pop_section = None
     if args.population > 0:
+        progress("population")
         pop_section = population_section(args, dist, torch, rank, world, local_rank, reduce_device)
 
     if rank == 0:
@@ -753,18 +793,22 @@ def main():
             line["population"] = pop_section
         if world == 1 and not args.no_reference_size:
             try:                                             # auxiliary, rank-local: must not cost the headline line
+                progress("reference size")
                 line["reference_size"] = reference_size_section(local_rank, rank, in_flight=args.throughput_workers)
             except Exception as exc:                         # noqa: BLE001
                 line["reference_size"] = {"error": repr(exc)}
         if world == 1 and not args.no_configs:
             try:                                             # auxiliary, rank-local: must not cost the headline line
+                progress("configs C3, C4")
                 line["configs"] = other_configs_section(local_rank)
             except Exception as exc:                         # noqa: BLE001
                 line["configs"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N = 1 only
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            threads = args.cpu_threads or min(16, cpu_share(os.cpu_count() or 1))
             try:
+                progress("cpu baseline")
                 line["cpu_baseline"] = cpu_baseline(ops, lo, hi, threads)
+                progress("done")
             except Exception as exc:                         # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port", "sample": "", "error": repr(exc)}
         print(json.dumps(line), file=real_stdout, flush=True)

@@ -648,7 +648,19 @@ template <typename T>
 __global__ void __launch_bounds__(256) evomg_dot_final(const T* __restrict__ partial, int count, T* __restrict__ out) {
   __shared__ T red[17];
   T s = scalar_traits<T>::zero();
-  for (int i = threadIdx.x; i < count; i += blockDim.x) s = sc_add(s, partial[i]);
+  // eight loads in flight per thread, added in the order they would have been added one by one: with candidates in flight a
+  // load takes microseconds, and 36 of them in a dependent chain made this 12 us kernel an 75 us one (profiles/r05_throughput.md)
+  for (int i0 = threadIdx.x; i0 < count; i0 += 8 * blockDim.x) {
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * blockDim.x;
+      v[j] = partial[i < count ? i : i0];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + j * (int)blockDim.x < count) s = sc_add(s, v[j]);
+  }
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[0] = s;
 }

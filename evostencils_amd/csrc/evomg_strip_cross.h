@@ -219,7 +219,8 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
 
   // The row loop exists twice: EDGE — the wave touches the domain's boundary (first / last strip, first / last chunk), every
   // relaxation is masked to the inner nodes; interior waves (nine in ten at 4097^2) run the same steps without any of the
-  // masks: no selects, no compares (the kernel is bound by VALU issue, not by memory: profiles/r04_cross_kernel.md).
+  // masks: no selects, no compares (a sixth fewer instructions; what bounds the launch is the bytes it moves — it streams at the
+  // fabric's rate, VALU active a fifth of the wave cycles: profiles/r04_cross_kernel.md, profiles/r05_cross_kernel.md).
   auto march = [&](auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
     const bool in_a = !EDGE || inner_a, in_b = !EDGE || inner_b;

@@ -34,7 +34,7 @@ static void sweep_colour(level_t* L, int colour, double w) {
   const double o = L->inv_h2, c0 = 4.0 * o, wi = w / c0, wm = 1.0 - w;
   double* u = L->u;
   const double* f = L->f;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= 257)
   for (int j = 1; j < n - 1; ++j) {
     double* row = u + (size_t)n * j;
     const double *south = row - n, *north = row + n, *fr = f + (size_t)n * j;
@@ -109,7 +109,7 @@ static int coarse_cg(level_t* L, double* p, double* ap, int maxit, double tol) {
   memset(x, 0, sizeof(double) * N);
   memset(p, 0, sizeof(double) * N);
   double rr = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : rr)
+#pragma omp parallel for schedule(static) reduction(+ : rr) if (n >= 257)
   for (int j = 1; j < n - 1; ++j)
     for (int i = 1; i < n - 1; ++i) {
       const size_t q = at(n, i, j);
@@ -122,7 +122,7 @@ static int coarse_cg(level_t* L, double* p, double* ap, int maxit, double tol) {
   int it = 0;
   while (it < maxit) {
     double pap = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : pap)
+#pragma omp parallel for schedule(static) reduction(+ : pap) if (n >= 257)
     for (int j = 1; j < n - 1; ++j)
       for (int i = 1; i < n - 1; ++i) {
         const size_t q = at(n, i, j);
@@ -132,7 +132,7 @@ static int coarse_cg(level_t* L, double* p, double* ap, int maxit, double tol) {
       }
     const double alpha = rr / pap;
     double rrn = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : rrn)
+#pragma omp parallel for schedule(static) reduction(+ : rrn) if (n >= 257)
     for (int j = 1; j < n - 1; ++j)
       for (int i = 1; i < n - 1; ++i) {
         const size_t q = at(n, i, j);
@@ -143,7 +143,7 @@ static int coarse_cg(level_t* L, double* p, double* ap, int maxit, double tol) {
     ++it;
     if (!(sqrt(rrn) > tol * res0)) break;
     const double beta = rrn / rr;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= 257)
     for (int j = 1; j < n - 1; ++j)
       for (int i = 1; i < n - 1; ++i) {
         const size_t q = at(n, i, j);

@@ -1,9 +1,9 @@
-# Round-4 profile refresh (run on the GPU box: bash tools/profile_round4.sh). Writes under gpurun_out/r4/; copy what is to
-# be judged into profiles/ afterwards (tools/collect_round4.py).
+# Round-5 profile refresh (run on the GPU box: bash tools/profile_round4.sh). Writes under gpurun_out/r5/; copy what is to
+# be judged into profiles/ afterwards (tools/collect_round5.py).
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4
+O=$R/gpurun_out/r5
 mkdir -p $O
 # kernel-trace statistics of the bench command and of each named configuration
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -- python3 $R/bench.py --steps 10 --warmup 2 --population 0 --no-cpu-baseline --throughput-workers 0 --no-reference-size --no-configs > $O/bench_under_rocprof.json 2> $O/bench_prof.err

@@ -3,8 +3,9 @@ usage: python tools/run_config.py c4|c2|c3|c5|t9|t8|fas|ela|p3d|h7"""
 import os, sys, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
-from evostencils_amd import abi, native, problems
-from test_full_size_gpu import vcycle
+from evostencils_amd import abi, candidates, native, problems
+vcycle = candidates.v_cycle_ops
+reference_vcycle_ops = lambda lo, hi: candidates.v_cycle_ops(lo, hi, 2, 1, omega=0.6)
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
 if cfg == "c4":
@@ -45,7 +46,6 @@ elif cfg == "p3d":
     ops = vcycle(lo, hi, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.25))
 elif cfg == "h7":
     # the reference's Helmholtz example at its own level range (3..7, 129^2, k = 80): its hand-written V(2,1) cycle
-    from test_helmholtz_oracle import reference_vcycle_ops
     lo, hi = 3, 7
     pd = problems.helmholtz_2d(lo, hi, k=80.0)
     ops = reference_vcycle_ops(lo, hi)
@@ -55,7 +55,6 @@ elif cfg in ("t9", "t8"):
     pd = problems.poisson_2d(lo, hi)
     ops = vcycle(lo, hi, 1, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK, (1, 1, 1), 1.0))
 else:
-    from test_helmholtz_oracle import reference_vcycle_ops
     lo, hi = 7, 11
     pd = dataclasses.replace(problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi)), max_iterations=50)
     ops = reference_vcycle_ops(lo, hi)
