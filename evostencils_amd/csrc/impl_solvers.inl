@@ -89,6 +89,7 @@
     Level<T>& lv = lv_[L];
     int nh = 0;
     const double t0 = wall_ms();
+    double t_end = -1.0;
     T d;
     if (!norm_event_) HIP_TRY(hipEventCreateWithFlags(&norm_event_, hipEventDisableTiming));
     int ahead = 0;                // ops of the coming iteration that have already been launched (speculatively)
@@ -253,11 +254,18 @@
             head_done = true;
           }
         }
-        if (stop) break;
+        if (stop) {
+          // the clock stops where the solve is over: the norm that ended the loop has been waited for, so every launch of the
+          // last cycle has finished; what is still queued is the speculative sweep of a cycle that will not happen (drained
+          // below, outside the timer — as the BiCGStab loop does). With the cross launch the final iterate is still to
+          // be formed (cross_finalize, queued above): then the clock runs until the stream is empty.
+          if (!cross) t_end = wall_ms();
+          break;
+        }
       }
     if (ahead) undo_speculation();                 // the sweep queued for an iteration that is not going to happen
     HIP_TRY(hipStreamSynchronize(stream_));
-    const double t_end = wall_ms();
+    if (t_end < 0.0) t_end = wall_ms();
     if (res_stale) {
       // leave RES@max as the reference's loop would (the residual of the returned iterate); outside the solve timer
       residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
