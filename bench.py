@@ -559,11 +559,13 @@ def main():
     from evostencils_amd.code_generation.hip import ProgramGenerator
     from evostencils_amd import population
 
-    # what tools/preflight_8gpu.py checks, on every rank of THIS launch: queue / IPC environment, device count,
-    # LOCAL_RANK -> device, librccl; at N > 1 also one all-gather through the library's own communicator (C-ABI, RCCL)
+    # what tools/preflight_8gpu.py checks without its --collective part, on every rank of THIS launch: queue / IPC environment,
+    # device count, LOCAL_RANK -> device, librccl (the collective that matters here is the process group above; the C-ABI
+    # communicator's own all-gather across ranks stays with the preflight tool: a first contact with a multi-GPU node
+    # belongs in a tool that may hang, not in the start-up of the benchmark)
     try:
         from evostencils_amd import preflight
-        rccl["preflight"] = preflight.report(collective=(world > 1 and backend == "nccl"))
+        rccl["preflight"] = preflight.report(collective=False)
     except Exception as exc:                                  # noqa: BLE001 — reported on the line, must not cost it
         rccl["preflight"] = {"ok": False, "failures": [repr(exc)]}
 

@@ -112,7 +112,7 @@ template <int R, int E, int H, int WAVES, bool MULTI, bool XZERO, int MASK_FROM>
 __global__ void __launch_bounds__(64 * WAVES)
 evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
                  double* __restrict__ b_copy, int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll,
-                 unsigned seq_base, int groups, int stride) {
+                 unsigned seq_base, int groups, int stride, int try_local) {
   static_assert(E >= 1 && E <= EVOMG_CG1_MAX_E && (E == 1 || H == 1), "columns per lane");
   static_assert(!MULTI || H == 1, "several workgroups: full-width bands only");
   constexpr int C = 64 / H;                          // lanes per band
@@ -334,7 +334,7 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
       if (!arrived) lds_fail[par] = 1;
       const bool same = arrived && got[0] == (double)xcc;
       const bool all_same = __builtin_amdgcn_ballot_w64(same) == ~0ull;
-      if (l == 0) lds_same_xcd = (stride > 1 && all_same) ? 1 : 0;
+      if (l == 0) lds_same_xcd = (try_local && stride > 1 && all_same) ? 1 : 0;
     }
     __syncthreads();
     same_xcd = lds_same_xcd != 0;
@@ -410,7 +410,7 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
 // (static: the header is part of several translation units)
 static __global__ void __launch_bounds__(1024)
 evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
-                 int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll, unsigned seq_base, int stride) {
+                 int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll, unsigned seq_base, int stride, int try_local) {
   constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
   if ((int)blockIdx.x % stride != 0) return;
   const int grp = (int)blockIdx.x / stride;
@@ -547,7 +547,7 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
       const bool arrived = ll_poll16<1>(slot, need, seq, got);
       if (!arrived) lds_fail[par] = 1;
       const bool all_same = __builtin_amdgcn_ballot_w64(arrived && got[0] == (double)xcc) == ~0ull;
-      if (l == 0) lds_fail[2] = (stride > 1 && all_same) ? 1 : 0;
+      if (l == 0) lds_fail[2] = (try_local && stride > 1 && all_same) ? 1 : 0;
     }
     __syncthreads();                                 // (also: the image of r)
     same_xcd = lds_fail[2] != 0;

@@ -157,6 +157,7 @@
     HIP_TRY(hipMemcpy(info, dinfo_, sizeof info, hipMemcpyDeviceToHost));
     if (info[1] != 0) {
       snprintf(err, sizeof err, "coarse-grid CG: its workgroups did not rendezvous (GPU oversubscribed?)");
+      cg_local_exchange_ = false;       // whatever the cause: the retry (and everything after it) exchanges over the fabric
       return EVOMG_ERR_DEVICE;
     }
     return EVOMG_OK;

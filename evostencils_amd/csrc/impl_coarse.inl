@@ -103,7 +103,7 @@
       if constexpr (!scalar_traits<T>::is_complex) {       // complex problems are 2D only
         if (single_reduction)
           hipLaunchKernelGGL(evomg_cg1_slab3d, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
-                             prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
+                             prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_, cg_local_exchange_ ? 1 : 0);
         else
           hipLaunchKernelGGL(evomg_cg_multi_wg3d<double>, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
                              prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
@@ -168,10 +168,10 @@
       const dim3 grid(MULTI ? groups * stride : 1), block(64 * WAVES);
       if (b_copy)
         hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, true, MASK>), grid, block, 0, stream_, lv.g, lv.st, x, b, r, b_copy,
-                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, cg_ll_, base, groups, stride);
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, cg_ll_, base, groups, stride, cg_local_exchange_ ? 1 : 0);
       else
         hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, false, MASK>), grid, block, 0, stream_, lv.g, lv.st, x, b, r, (T*)nullptr,
-                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, cg_ll_, base, groups, stride);
+                           prob_.cgs_max_iterations, prob_.cgs_target_res_reduction, dinfo_, cg_ll_, base, groups, stride, cg_local_exchange_ ? 1 : 0);
       return EVOMG_OK;
     }
   }

@@ -61,6 +61,9 @@
   bool cg_multi_used_ = false;
   // the 129^2 single-reduction CG (evomg_cg1.h): its 32 waves as eight workgroups of four or four of eight — a tuning
   // choice, the summation order does not depend on it
+  // exchanges of a multi-workgroup solve inside one XCD's L2 (evomg_krylov.h: ll_store16): asked for when all workgroups are
+  // placed on one XCD; a solve that misses its rendezvous in that mode turns it off for the handle before the retry
+  bool cg_local_exchange_ = getenv("EVOMG_NO_LOCAL_EXCHANGE") == nullptr;
   int cg1_groups_ = getenv("EVOMG_CG1_GROUPS") ? atoi(getenv("EVOMG_CG1_GROUPS")) : 8;
   bool cg_lds_attr_set_[24] = {};
   int prof_opcode_ = -1, prof_level_ = -1;

@@ -127,7 +127,7 @@ static void run(const char* name, int level, int groups, int stride, bool check)
     CHECK(hipMemset(dx, 0, N * 8));
     CHECK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, false, MASK>), dim3(blocks), dim3(64 * WAVES), 0, 0, g, st, dx, (const double*)db, dr,
-                       (double*)nullptr, 1000, 1e-12, dinfo, ll, seq, groups, stride);
+                       (double*)nullptr, 1000, 1e-12, dinfo, ll, seq, groups, stride, 1);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());
