@@ -22,6 +22,7 @@ REAL_F64, COMPLEX_F64 = 0, 1
 BC_DIRICHLET, BC_HELMHOLTZ_ROBIN = 0, 1
 OUTER_MG_ITERATION, OUTER_PBICGSTAB = 0, 1
 CGS_CG, CGS_BICGSTAB, CGS_FAS_SMOOTHER, CGS_CG_CLASSICAL = 0, 1, 2, 3
+STENCIL_STAR, STENCIL_COMPACT = 0, 1
 NONLINEAR_NONE, NONLINEAR_GAM_U_EXP_U = 0, 1
 # `with jacobi` slot handling (include/evomg.h EVOMG_JACOBI_*): TEXTBOOK = the sweep's result becomes the field;
 # EXASTENCILS_V11 = the next slot is never advanced, as in the reference's pipeline (notebooks/tutorial.ipynb:3373)
@@ -58,7 +59,7 @@ class Problem(C.Structure):
         ("wavenumber", C.c_double),
         ("jacobi_semantics", C.c_int32), ("n_unknowns", C.c_int32),
         ("sys_stencil", (((C.c_double * 9) * MAX_UNKNOWNS) * MAX_UNKNOWNS) * MAX_LEVELS),
-        ("nonlinear_kind", C.c_int32), ("reserved0", C.c_int32), ("nonlinear_gamma", C.c_double),
+        ("nonlinear_kind", C.c_int32), ("stencil_kind", C.c_int32), ("nonlinear_gamma", C.c_double),
         ("fas_cgs_omega", C.c_double),
     ]
 

@@ -376,11 +376,19 @@ class ProgramGenerator:
                 stencil = st.operator_entry.generate_stencil()
             if stencil is None or hasattr(stencil, "constant_stencils"):
                 raise lowering.UnsupportedExpression("system operator must be a constant stencil")
-            expected = self._problem.mg_stencil(st.level, self._problem.parameters)
-            offsets = problems._star_offsets(self.dimension)
             got = {tuple(o): complex(v) for o, v in stencil.entries}
+            if self._problem.system is not None:
+                # a scalar problem with a compact nine-point stencil (include/evomg.h: EVOMG_STENCIL_COMPACT): it runs on the
+                # systems' path as a system of one unknown
+                if len(self._problem.system.field_names) != 1:
+                    raise lowering.UnsupportedExpression("the candidate treats a system of PDEs as a scalar problem")
+                offsets = list(problems.NINE_POINT_OFFSETS)
+                expected = self._problem.system.assembled(st.level)[0, 0]
+            else:
+                expected = self._problem.mg_stencil(st.level, self._problem.parameters)
+                offsets = problems._star_offsets(self.dimension)
             if set(got) - set(offsets):
-                raise lowering.UnsupportedExpression("only 5-/7-point star stencils are supported")
+                raise lowering.UnsupportedExpression("only 5-/7-point star stencils (in 2D: stencils of the 3 x 3 neighbourhood) are supported")
             for o, v in zip(offsets, expected):
                 if got.get(o, 0j) != complex(v):
                     raise lowering.UnsupportedExpression(

@@ -38,10 +38,11 @@ int check_problem(const evomg_problem_t* p, char* err, size_t len) {
       return EVOMG_ERR_UNSUPPORTED;
     }
   } else if (p->cgs_kind == EVOMG_CGS_FAS_SMOOTHER) { snprintf(err, len, "EVOMG_CGS_FAS_SMOOTHER needs a non-linear problem"); return EVOMG_ERR_INVALID; }
-  if (p->n_unknowns > 1) {
+  if (p->stencil_kind != EVOMG_STENCIL_STAR && p->stencil_kind != EVOMG_STENCIL_COMPACT) { snprintf(err, len, "bad stencil kind"); return EVOMG_ERR_INVALID; }
+  if (p->n_unknowns > 1 || p->stencil_kind == EVOMG_STENCIL_COMPACT) {
     if (p->n_unknowns > EVOMG_MAX_UNKNOWNS) { snprintf(err, len, "at most %d unknowns per node", EVOMG_MAX_UNKNOWNS); return EVOMG_ERR_UNSUPPORTED; }
     if (p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 || p->bc_kind != EVOMG_BC_DIRICHLET ||
-        p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_CG) {
+        p->outer_kind != EVOMG_OUTER_MG_ITERATION || (p->cgs_kind != EVOMG_CGS_CG && p->cgs_kind != EVOMG_CGS_CG_CLASSICAL)) {
       snprintf(err, len, "systems of PDEs: 2D real Dirichlet problems with the generated solver loop and CG only");
       return EVOMG_ERR_UNSUPPORTED;
     }
@@ -74,7 +75,7 @@ int evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t**
   if (rc != EVOMG_OK) return rc;
   ImplBase* impl = nullptr;
   if (problem->nonlinear_kind != EVOMG_NONLINEAR_NONE) impl = make_impl_fas(*problem, device_id);
-  else if (problem->n_unknowns > 1) impl = make_impl_system(*problem, device_id);
+  else if (problem->n_unknowns > 1 || problem->stencil_kind == EVOMG_STENCIL_COMPACT) impl = make_impl_system(*problem, device_id);
   else if (problem->scalar_kind == EVOMG_COMPLEX_F64) impl = make_impl_complex(*problem, device_id);
   else impl = make_impl_real(*problem, device_id);
   rc = impl->init();

@@ -204,6 +204,10 @@ class SystemImpl : public ImplBase {
   static dim3 blk() { return dim3(64, 4, 1); }
   static dim3 grd(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1); }
 
+  // the unknowns a SMOOTH lists; a scalar op program (mask 0) on a system of ONE unknown — a scalar problem with a compact
+  // nine-point stencil, EVOMG_STENCIL_COMPACT — means that unknown
+  int mask_of(const evomg_op_t& op) const { return op.unknowns ? op.unknowns : (nf_ == 1 ? 1 : 0); }
+
   // mirrors the oracle's sys_check_op
   int validate(const evomg_op_t* ops, int n_ops) {
     for (int i = 0; i < n_ops; ++i) {
@@ -213,7 +217,7 @@ class SystemImpl : public ImplBase {
       bool ok = op.level >= lo && op.level <= hi && fieldptr(op.level, op.dst) != nullptr;
       if (ok) switch (op.opcode) {
         case EVOMG_OP_SMOOTH: {
-          const int mask = op.unknowns;
+          const int mask = mask_of(op);
           ok = fieldptr(op.level, op.src1) != nullptr && mask > 0 && mask < (1 << nf_) && op.block[0] >= 1 && op.block[1] >= 1;
           if (!ok) break;
           int k = 0, first = 0;
@@ -259,7 +263,7 @@ class SystemImpl : public ImplBase {
     const Geo& g = lv.g;
     switch (op.opcode) {
       case EVOMG_OP_SMOOTH: {
-        const int mask = op.unknowns, inner = g.n - 2;
+        const int mask = mask_of(op), inner = g.n - 2;
         // per-unknown block shapes: the first unknown of the mask has `block`, the second `block_other` where that is set
         SysShapes sh{};
         int bx = 1, by = 1, seen = 0;

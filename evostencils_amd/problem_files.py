@@ -399,6 +399,12 @@ def describe(l2: Layer2, name: str, dimension: int, min_level: int, max_level: i
             raise UnsupportedProblem(f"field {f!r}: only `Real on Node` is supported, got `{kind} on {where}`")
     if op_name not in l2.operators:
         raise UnsupportedProblem(f"operator {op_name!r} is not declared")
+    # A stencil that is not a star (code_generation/parser.py:8-22 takes any offsets): in 2D, inside the 3 x 3 neighbourhood, the
+    # problem runs as a "system" of ONE unknown — the path of the coupled problems carries compact nine-point stencils
+    # (csrc/impl_system.hip); the tuned strip kernels of the scalar path are written for stars.
+    if dimension == 2 and any(len(off) == dimension and _star_slot(off) is None and all(abs(c) <= 1 for c in off)
+                              for off, _ in l2.operators[op_name]):
+        return describe_system(l2, name, dimension, min_level, max_level, hints)
     entries = {}
     for offset, expr in l2.operators[op_name]:
         slot = _star_slot(offset) if len(offset) == dimension else None

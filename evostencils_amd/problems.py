@@ -174,6 +174,7 @@ class ProblemDescription:
         p.target_res_reduction = self.target_res_reduction
         p.cgs_target_res_reduction = self.cgs_target_res_reduction
         p.n_unknowns = 1 if self.system is None else len(self.system.field_names)
+        p.stencil_kind = abi.STENCIL_STAR if self.system is None else abi.STENCIL_COMPACT
         for level in range(self.min_level, self.max_level + 1):
             if self.system is not None:
                 a = self.system.assembled(level)

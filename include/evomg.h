@@ -105,6 +105,14 @@ enum {
                                        (oracle/APPB_MATRIX.md). */
 };
 
+/* Shape of a scalar problem's operator (ABI 5). The reference's parser takes stencils with arbitrary offsets
+ * (code_generation/parser.py:8-22); none of its example problems uses a scalar one outside the star. */
+enum {
+  EVOMG_STENCIL_STAR = 0,     /* centre and +-1 per axis: mg_stencil (the tuned scalar path) */
+  EVOMG_STENCIL_COMPACT = 1   /* 2D, any entry of the 3 x 3 neighbourhood: sys_stencil[level][0][0] with n_unknowns = 1 — the
+                                 problem runs on the path of the systems of PDEs as a system of one unknown */
+};
+
 typedef struct { double re, im; } evomg_c64;
 
 /*
@@ -137,14 +145,15 @@ typedef struct {
   int32_t jacobi_semantics;     /* EVOMG_JACOBI_*; 0 is rejected: the caller has to choose */
   /* Systems of PDEs (example_problems/LinearElasticity/2D_FD_LinearElasticity_fromL2.exa2:11-50; ir/system.py:32-135):
    * n_unknowns > 1 fields per node, coupled by the block operator sys_stencil[level][equation][unknown][entry]
-   * (2D, real, Dirichlet; mg_stencil is ignored). n_unknowns <= 1: a scalar problem. */
+   * (2D, real, Dirichlet; mg_stencil is ignored). n_unknowns <= 1: a scalar problem (with stencil_kind = EVOMG_STENCIL_COMPACT:
+   * one whose nine-point stencil sits in sys_stencil[level][0][0], same restrictions as a system). */
   int32_t n_unknowns;
   double  sys_stencil[EVOMG_MAX_LEVELS][EVOMG_MAX_UNKNOWNS][EVOMG_MAX_UNKNOWNS][EVOMG_SYS_STENCIL_ENTRIES];
   /* Non-linear FAS problems (ABI 3; 2D, real, homogeneous Dirichlet; linear part = mg_stencil): nonlinear_kind != 0 selects
    * the FAS op vocabulary (EVOMG_OP_FAS_*) and the template's solver loop (repeat the cycle until the residual norm has
    * dropped by target_res_reduction or max_iterations, FAS_2D_Basic_template.exa4:130-160). */
   int32_t nonlinear_kind;       /* EVOMG_NONLINEAR_* */
-  int32_t reserved0;
+  int32_t stencil_kind;         /* EVOMG_STENCIL_* (ABI 5; 0 in older descriptors = EVOMG_STENCIL_STAR) */
   double  nonlinear_gamma;      /* `Val gam : Real` */
   double  fas_cgs_omega;        /* weight of the coarse-grid solver's Newton-Jacobi sweeps (template:66: 0.8) */
 } evomg_problem_t;

@@ -156,10 +156,11 @@ static int check_problem(const evomg_problem_t* p) {
       return EVOMG_ERR_UNSUPPORTED;
     }
   } else if (p->cgs_kind == EVOMG_CGS_FAS_SMOOTHER) return EVOMG_ERR_INVALID;
-  if (p->n_unknowns > 1) {
+  if (p->stencil_kind != EVOMG_STENCIL_STAR && p->stencil_kind != EVOMG_STENCIL_COMPACT) return EVOMG_ERR_INVALID;
+  if (p->n_unknowns > 1 || p->stencil_kind == EVOMG_STENCIL_COMPACT) {
     if (p->n_unknowns > EVOMG_MAX_UNKNOWNS) { snprintf(g_err, sizeof g_err, "too many unknowns"); return EVOMG_ERR_UNSUPPORTED; }
     if (p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 || p->bc_kind != EVOMG_BC_DIRICHLET ||
-        p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_CG) {
+        p->outer_kind != EVOMG_OUTER_MG_ITERATION || (p->cgs_kind != EVOMG_CGS_CG && p->cgs_kind != EVOMG_CGS_CG_CLASSICAL)) {
       snprintf(g_err, sizeof g_err, "systems of PDEs: 2D real Dirichlet problems with the generated solver loop and CG only");
       return EVOMG_ERR_UNSUPPORTED;
     }
@@ -173,7 +174,7 @@ int oracle_create(const evomg_problem_t* p, int device_id, oracle_handle_t** out
   if (rc != EVOMG_OK) return rc;
   oracle_handle_t* h = (oracle_handle_t*)calloc(1, sizeof *h);
   h->is_fas = p->nonlinear_kind != EVOMG_NONLINEAR_NONE;
-  h->is_system = !h->is_fas && p->n_unknowns > 1;
+  h->is_system = !h->is_fas && (p->n_unknowns > 1 || p->stencil_kind == EVOMG_STENCIL_COMPACT);
   h->is_complex = (p->scalar_kind == EVOMG_COMPLEX_F64);
   rc = h->is_fas ? fas_create(p, &h->fas) : h->is_system ? sys_create(p, &h->s) : h->is_complex ? create_c(p, &h->c) : create_r(p, &h->r);
   if (rc != EVOMG_OK) { free(h); return rc; }

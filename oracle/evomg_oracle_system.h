@@ -157,11 +157,13 @@ static void sys_local_solve(const sys_level_t* lv, int nf, int mask, double* con
   for (int p = 0; p < m; ++p) out[p] = omm * x[eu[p]][IDX2(n, ea[p], eb[p])] + om * r[p];
 }
 
+/* the unknowns a SMOOTH lists; a scalar op program (mask 0) on a system of ONE unknown (EVOMG_STENCIL_COMPACT) means that one */
+#define SYS_MASK_OF(c, op) ((op)->unknowns ? (op)->unknowns : ((c)->nf == 1 ? 1 : 0))
 /* SMOOTH on a system. Single partitioning (`with jacobi`): non-overlapping tiles, all from the old state, next slot;
  * red-black: point blocks, one pass per colour, each from the state before the pass (header). */
 static int sys_smooth(sys_ctx_t* c, const evomg_op_t* op) {
   sys_level_t* lv = &c->lv[op->level];
-  const int n = lv->n, nf = c->nf, mask = op->unknowns, inner = n - 2;
+  const int n = lv->n, nf = c->nf, mask = SYS_MASK_OF(c, op), inner = n - 2;
   /* block shape per unknown of the mask: `block` for the first, `block_other` (where set) for the second; tiles repeat with
    * the bounding box of the statement's unknowns [EXTERNAL: the loop ExaStencils generates around a `solve locally`
    * is not visible from the reference; with equal shapes this is the IR's non-overlapping tiling, stencils/multiple.py:204-217] */
@@ -326,7 +328,7 @@ static int sys_check_op(sys_ctx_t* c, const evomg_op_t* op) {
   switch (op->opcode) {
     case EVOMG_OP_SMOOTH: {
       if (!sys_field(c, op->level, op->src1)) return EVOMG_ERR_INVALID;
-      const int mask = op->unknowns;
+      const int mask = SYS_MASK_OF(c, op);
       if (mask <= 0 || mask >= (1 << c->nf)) return EVOMG_ERR_INVALID;
       if (op->block[0] < 1 || op->block[1] < 1) return EVOMG_ERR_INVALID;
       int k = 0;

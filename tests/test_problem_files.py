@@ -137,7 +137,7 @@ def test_3d_fixture_is_solved_exactly():
 
 
 @pytest.mark.parametrize("edit, message", [
-    (lambda s: s.replace("[ 1,  0] => -0.1", "[ 1,  1] => -0.1"), "outside the star stencil"),
+    (lambda s: s.replace("[ 1,  0] => -0.1", "[ 2,  0] => -0.1"), "outside the star stencil"),      # (a corner entry is fine: nine-point stencils run as a system of one unknown)
     (lambda s: s.replace("with Real on Node", "with Real on Cell", 1), "only `Real on Node`"),
     (lambda s: s.replace("Diffusion * v == load", "Diffusion * v + v == load"), "not a scaled stencil"),
     (lambda s: s.replace("-0.1 / ( vf_gridWidth_x ** 2 )", "-0.1 * vf_nodePos_x / ( vf_gridWidth_x ** 2 )", 1), "constant coefficients"),
@@ -294,3 +294,45 @@ def test_reference_helmholtz_files_reproduce_the_builtin_descriptor():
     for level in (3, 7):
         assert np.array_equal(p.right_hand_side(level), b.right_hand_side(level))
         assert np.array_equal(p.initial_solution(level), b.initial_solution(level))
+
+
+def test_scalar_problem_with_a_nine_point_stencil_becomes_a_system_of_one_unknown():
+    """code_generation/parser.py:8-22 reads stencils with any offsets; a 2D scalar operator with corner entries (the compact
+    "Mehrstellen" Laplacian of tests/golden/problems/Mehrstellen) is described as a system of ONE unknown — descriptor
+    stencil_kind = STENCIL_COMPACT, nine coefficients per level — and solved by the oracle to the discretisation error of its
+    manufactured solution; a stencil that reaches beyond the 3 x 3 neighbourhood is still rejected."""
+    from evostencils_amd import abi, candidates
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    from oracle import oracle
+    p = _load("Mehrstellen", "2D_FD_Mehrstellen")
+    assert p.system is not None and p.system.field_names == ["w"] and p.system.equation_names == ["compactEq"]
+    c = p.to_c()
+    assert (c.n_unknowns, c.stencil_kind) == (1, abi.STENCIL_COMPACT)
+    h2 = (1.0 / (1 << 4)) ** 2
+    want = np.array([20.0, -4.0, -4.0, -4.0, -4.0, -1.0, -1.0, -1.0, -1.0]) / (6.0 * h2)
+    assert np.allclose([c.sys_stencil[4][0][0][e] for e in range(9)], want, rtol=1e-15)
+    gen = ProgramGenerator(None, FIXTURES, "Mehrstellen/2D_FD_Mehrstellen.settings", "Mehrstellen/2D_FD_Mehrstellen.knowledge",
+                           library=object(), jacobi_semantics="textbook")
+    lo, hi = gen.min_level, gen.max_level
+    rb = [("rbgs", 18)]
+    expression = candidates.v_cycle(candidates.production_context(gen, lo, hi), hi - lo, [rb * 2] * (hi - lo), [rb] * (hi - lo))[0]
+    ops = gen.generate_op_program(expression, lo, hi)
+    assert all(o.unknowns == 0 for o in ops)                  # a scalar op program: the backend supplies the mask of the one unknown
+    handle = oracle.create(gen.problem)
+    out = handle.evaluate(ops, 1, 0, 64)
+    assert out.status == abi.SOLVE_CONVERGED and out.n_iterations <= 12
+    n = (1 << hi) + 1
+    x = np.arange(n) / (n - 1)
+    exact = np.sin(np.pi * x)[None, :] * np.sin(np.pi * x)[:, None] + x[None, :]
+    assert np.abs(handle.get_field(hi, abi.F_SOL) - exact).max() < 1e-3
+    # a candidate whose operator is NOT the problem's is refused at lowering (the op program carries no coefficients)
+    other = ProgramGenerator(None, FIXTURES, "Diffusion/2D_FD_AnisotropicDiffusion.settings", "Diffusion/2D_FD_AnisotropicDiffusion.knowledge",
+                             library=object(), jacobi_semantics="textbook")
+    other.reinitialize(lo, hi, {})
+    foreign = candidates.v_cycle(candidates.production_context(other, lo, hi), hi - lo, [rb] * (hi - lo), [rb] * (hi - lo))[0]
+    from evostencils_amd.code_generation import lowering
+    with pytest.raises(lowering.UnsupportedExpression):
+        gen.generate_op_program(foreign, lo, hi)
+    wide = pf.parse_layer2(open(os.path.join(FIXTURES, "Mehrstellen", "2D_FD_Mehrstellen.exa2")).read().replace("[-1, -1]", "[-2, 0]"))
+    with pytest.raises(pf.UnsupportedProblem):
+        pf.describe(wide, "wide", 2, 2, 5)

@@ -25,6 +25,10 @@ CASES = {
     # a system of two PDEs read from files (`Globals`, equations as sums of scaled stencils, four-corner cross derivative)
     "elasticity2d": ("Elasticity/2D_FD_Elasticity", [("rbgs", 18)], 3, 6),
     "elasticity2d_decoupled": ("Elasticity/2D_FD_Elasticity", [("decoupled", 14), ("blocks", 14, ((2, 1), (2, 1)))], 3, 5),
+    # a SCALAR problem whose stencil is not a star (compact nine-point Laplacian: code_generation/parser.py:8-22 admits any
+    # offsets): it runs as a system of one unknown (EVOMG_STENCIL_COMPACT)
+    "mehrstellen2d": ("Mehrstellen/2D_FD_Mehrstellen", [("rbgs", 18)], 2, 6),
+    "mehrstellen2d_jacobi_block": ("Mehrstellen/2D_FD_Mehrstellen", [("jacobi", 14), ("block", 14, (2, 2))], 3, 7),
 }
 
 
