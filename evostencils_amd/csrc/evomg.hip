@@ -209,6 +209,7 @@ int evomg_time_model_known_coarse(evomg_handle_t* h, const evomg_op_t* ops, int 
 }
 int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {
   if (!h || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
+  const InFlight in_flight;
   return h->impl->run_ops(ops, n_ops);
 }
 int evomg_norm(evomg_handle_t* h, int level, int field, double* out) {
