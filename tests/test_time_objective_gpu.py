@@ -141,3 +141,37 @@ def test_pool_with_the_isolated_time_objective_matches_sequential_times():
         if rel <= 0.05:
             break
     assert rel <= 0.05
+
+
+@pytest.mark.parametrize("kind", ["elasticity", "fas"])
+def test_time_model_of_problems_whose_coarse_iterations_are_not_counted(kind):
+    """Systems of PDEs and FAS problems do not report coarse-solver iterations (evomg_coarse_iterations is 0), so the time
+    model must not cap their coarse solver in its probes — nothing would add the cost back. fixed + per_iteration x
+    iterations has to land on the time of a sequential solve."""
+    import cycles
+    from evostencils_amd import native
+    if kind == "elasticity":
+        from helpers import generator_for
+        lo, hi = 4, 8
+        gen = generator_for("2D_FD_LinearElasticity_fromL2", lo, hi, library=native.library())
+        rb = [("rbgs", 23)]
+        expression, _ = cycles.v_cycle(context_for(gen, lo, hi), hi - lo, [rb * 2] * (hi - lo), [rb] * (hi - lo))
+        ops = gen.generate_op_program(expression, lo, hi)
+        handle = native.create(gen.problem)
+    else:
+        from test_fas_lowering import fas_context, fas_generator
+        gen = fas_generator(library=native.library(), levels=(5, 9))
+        sm = [[cycles._nw(14)] for _ in range(4)]
+        ops = gen.generate_op_program(cycles.fas_v_cycle(fas_context(gen, 4), 4, sm, sm)[0])
+        handle = native.create(gen.problem_description())
+    handle.evaluate(ops, 1, 0, 0)
+    solves = sorted((handle.evaluate(ops, 1, 0, 0) for _ in range(3)), key=lambda o: o.time_ms)
+    ref = solves[0]
+    assert ref.n_iterations >= 6 and handle.coarse_iterations() == 0
+    fixed, per_iteration, per_coarse = handle.time_model(ops, 2, 6)
+    modelled = max(fixed, 0.0) + per_iteration * ref.n_iterations
+    print(f"{kind}: sequential {ref.time_ms:.3f} ms over {ref.n_iterations:.0f} iterations, modelled {modelled:.3f} ms "
+          f"(fixed {fixed:.3f}, per iteration {per_iteration:.4f}, per coarse iteration {per_coarse})")
+    assert per_coarse == 0.0
+    assert abs(modelled - ref.time_ms) <= 0.12 * ref.time_ms
+    handle.close()
