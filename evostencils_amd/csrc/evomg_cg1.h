@@ -55,7 +55,10 @@
 #define EVOMG_CG1_MAX_E 2
 // exchange words across workgroups: [parity][quantity][wave][2 words] sums, then [parity][group][edge][element][lane][2 words]
 #define EVOMG_CG1_LL_SUM_WORDS (2 * 2 * EVOMG_CG1_MAX_WAVES * 2)
-#define EVOMG_CG1_LL_WORDS (EVOMG_CG1_LL_SUM_WORDS + 2 * EVOMG_CG1_MAX_GROUPS * 2 * EVOMG_CG1_MAX_E * 64 * 2)
+#define EVOMG_CG1_LL_GROUP_SEAM_WORDS (2 * EVOMG_CG1_MAX_GROUPS * 2 * EVOMG_CG1_MAX_E * 64 * 2)
+// AUTO (every wave exchanges for itself): [parity][wave][edge][element][lane][2 words] edge rows of every wave
+#define EVOMG_CG1_LL_WAVE_SEAM_WORDS (2 * EVOMG_CG1_MAX_WAVES * 2 * EVOMG_CG1_MAX_E * 64 * 2)
+#define EVOMG_CG1_LL_WORDS (EVOMG_CG1_LL_SUM_WORDS + EVOMG_CG1_LL_GROUP_SEAM_WORDS + EVOMG_CG1_LL_WAVE_SEAM_WORDS)
 
 // the band layout of a grid: rows per band, columns per lane, bands per wave, waves in total; waves == 0: no banded form
 struct Cg1Plan {
@@ -108,13 +111,16 @@ __host__ __device__ constexpr int cg1_pow2_ceil(int v) { return v <= 1 ? 1 : v <
 // MASK_FROM: first unrolled row that may lie outside the grid (cg1_plan().mask_from, or 0 when padding waves exist).
 // XZERO / b_copy: the SET_ZERO of the solution and the COPY `gen_rhs = RHS` in front of the solve folded in, as in
 // evomg_cg_reg2d: b is the copy's source, the copy (whole array) is written to b_copy, x is not read.
-template <int R, int E, int H, int WAVES, bool MULTI, bool XZERO, int MASK_FROM>
+// AUTO (MULTI only): every wave publishes its sums AND both its edge rows as words and polls for what it needs itself — no
+// collector, no LDS, no barrier in the loop; meant for the placement in which the words stay in one XCD's L2.
+template <int R, int E, int H, int WAVES, bool MULTI, bool XZERO, int MASK_FROM, bool AUTO = false>
 __global__ void __launch_bounds__(64 * WAVES)
 evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
                  double* __restrict__ b_copy, int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll,
                  unsigned seq_base, int groups, int stride, int try_local) {
   static_assert(E >= 1 && E <= EVOMG_CG1_MAX_E && (E == 1 || H == 1), "columns per lane");
   static_assert(!MULTI || H == 1, "several workgroups: full-width bands only");
+  static_assert(!AUTO || MULTI, "wave-autonomous exchange: the multi-workgroup form");
   constexpr int C = 64 / H;                          // lanes per band
   int group = 0;
   if constexpr (MULTI) {
@@ -233,10 +239,54 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   };
   // the one synchronisation of an iteration: sums of both inner products over all waves (gn, dl) and the neighbouring
   // bands' edge rows of w (w_gs, w_gn). false: a workgroup never arrived (not co-resident) — reported, not waited for again.
+  auto wseam_slot = [&](int par, int wave, int edge, int e) {
+    return ll + EVOMG_CG1_LL_SUM_WORDS + EVOMG_CG1_LL_GROUP_SEAM_WORDS +
+           (((((size_t)par * EVOMG_CG1_MAX_WAVES + wave) * 2 + edge) * EVOMG_CG1_MAX_E + e) * 64 + l) * 2;
+  };
+  bool wave_alive = true;
   auto exchange = [&](unsigned seq) -> bool {
     const int par = (int)(seq & 1u);
     PROF(0);
     const double ws = cg1_wave_sums(gam, del);       // lane 0: the wave's (r, r), lane 32: its (w, r)
+    if constexpr (AUTO) {
+      const int total = groups * WAVES;
+      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, gw), ws, seq, same_xcd);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (gw > 0) ll_store16(wseam_slot(par, gw, 0, e), wv[0][e], seq, same_xcd);
+        if (gw + 1 < total) ll_store16(wseam_slot(par, gw, 1, e), wv[R - 1][e], seq, same_xcd);
+      }
+      PROF(1);
+      constexpr int K = 1 + 2 * E;
+      const evomg_u64* slot[K];
+      bool need[K];
+      slot[0] = sum_slot(par, l >> 5, (l & 31) < total ? (l & 31) : gw);
+      need[0] = (l & 31) < total;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        slot[1 + e] = gw > 0 ? wseam_slot(par, gw - 1, 1, e) : sum_slot(par, 0, gw);
+        need[1 + e] = gw > 0;
+        slot[1 + E + e] = gw + 1 < total ? wseam_slot(par, gw + 1, 0, e) : sum_slot(par, 0, gw);
+        need[1 + E + e] = gw + 1 < total;
+      }
+      double got[K];
+      if (!same_xcd) __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);
+      const bool all = ll_poll16<K>(slot, need, seq, got);
+      if (__builtin_amdgcn_ballot_w64(!all) != 0ull) wave_alive = false;
+      PROF(2);
+      PROF(3);
+      double t = need[0] ? got[0] : 0.0;
+      t = cg1_cross_tree<32>(t);
+      gn = cg1_lane(t, 0);
+      dl = cg1_lane(t, 32);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        w_gs[e] = has_south ? got[1 + e] : 0.0;
+        w_gn[e] = has_north ? got[1 + E + e] : 0.0;
+      }
+      PROF(4);
+      return wave_alive;
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       seam_lds[par][0][e][tid] = wv[0][e];

@@ -89,7 +89,7 @@ struct HostCg1 {
   }
 };
 
-template <int R, int E, int H, int WAVES, bool MULTI, int MASK>
+template <int R, int E, int H, int WAVES, bool MULTI, int MASK, bool AUTO = false>
 static void run(const char* name, int level, int groups, int stride, bool check) {
   const int n = (1 << level) + 1, m = n - 2;
   const int pitch = (n + 15) / 16 * 16;
@@ -126,7 +126,7 @@ static void run(const char* name, int level, int groups, int stride, bool check)
   for (int rep = 0; rep < 6; ++rep) {
     CHECK(hipMemset(dx, 0, N * 8));
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, false, MASK>), dim3(blocks), dim3(64 * WAVES), 0, 0, g, st, dx, (const double*)db, dr,
+    hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, false, MASK, AUTO>), dim3(blocks), dim3(64 * WAVES), 0, 0, g, st, dx, (const double*)db, dr,
                        (double*)nullptr, 1000, 1e-12, dinfo, ll, seq, groups, stride, 1);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
@@ -169,6 +169,9 @@ int main(int argc, char** argv) {
   if (level == 7) {
     run<4, 2, 1, 4, true, 3>("cg1 R4 E2, 8 groups x 4 waves, one XCD", 7, 8, 8, true);
     run<4, 2, 1, 4, true, 3>("cg1 R4 E2, 8 groups x 4 waves, 8 XCDs", 7, 8, 1, false);
+    run<4, 2, 1, 4, true, 3, true>("cg1 R4 E2, 8 x 4, one XCD, every wave for itself", 7, 8, 8, true);
+    run<4, 2, 1, 2, true, 3, true>("cg1 R4 E2, 16 x 2, one XCD, every wave for itself", 7, 16, 8, true);
+    run<4, 2, 1, 4, true, 3, true>("cg1 R4 E2, 8 x 4, 8 XCDs, every wave for itself", 7, 8, 1, false);
     run<4, 2, 1, 8, true, 3>("cg1 R4 E2, 4 groups x 8 waves, one XCD", 7, 4, 8, true);
     run<4, 2, 1, 2, true, 3>("cg1 R4 E2, 16 groups x 2 waves, one XCD", 7, 16, 8, false);
     run<8, 2, 1, 4, true, 7>("cg1 R8 E2, 4 groups x 4 waves, one XCD", 7, 4, 8, true);
