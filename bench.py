@@ -733,7 +733,7 @@ def main():
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:
         k = args.throughput_workers
-        n = max(args.steps, 4 * k)
+        n = max(args.steps, 12 * k)               # long enough for the ramp at both ends not to show (16 in flight: 192 solves, half a second)
         run_steps(k, in_flight=k)
         fence()
         t1 = time.perf_counter()
