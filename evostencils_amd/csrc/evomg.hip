@@ -13,6 +13,10 @@ thread_local char g_create_error[512] = "";
 
 std::atomic<int> g_evaluations_in_flight{0};
 int evaluations_in_flight() { return g_evaluations_in_flight.load(std::memory_order_relaxed); }
+int next_cg_phase() {
+  static std::atomic<int> counter{0};
+  return counter.fetch_add(1, std::memory_order_relaxed) & 0x7fff;
+}
 struct InFlight {
   InFlight() { g_evaluations_in_flight.fetch_add(1, std::memory_order_relaxed); }
   ~InFlight() { g_evaluations_in_flight.fetch_sub(1, std::memory_order_relaxed); }

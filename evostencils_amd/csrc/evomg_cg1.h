@@ -117,17 +117,17 @@ template <int R, int E, int H, int WAVES, bool MULTI, bool XZERO, int MASK_FROM,
 __global__ void __launch_bounds__(64 * WAVES)
 evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
                  double* __restrict__ b_copy, int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll,
-                 unsigned seq_base, int groups, int stride, int try_local) {
+                 unsigned seq_base, int groups, int stride, int try_local, int phase = 0) {
   static_assert(E >= 1 && E <= EVOMG_CG1_MAX_E && (E == 1 || H == 1), "columns per lane");
   static_assert(!MULTI || H == 1, "several workgroups: full-width bands only");
   static_assert(!AUTO || MULTI, "wave-autonomous exchange: the multi-workgroup form");
   constexpr int C = 64 / H;                          // lanes per band
   int group = 0;
   if constexpr (MULTI) {
-    // only every stride-th block takes part: workgroups are dealt to the XCDs round-robin, so stride 8 puts the solve on ONE
-    // XCD (a rendezvous is cheaper there: isolated solves), stride 1 one workgroup on each (candidates in flight: their
-    // solves then do not pile onto one XCD's 32 compute units — the host chooses, impl_coarse.inl)
-    if ((int)blockIdx.x % stride != 0) return;
+    // only the blocks `phase` modulo `stride` take part: workgroups are dealt to the XCDs round-robin, so stride 8 puts the
+    // solve on ONE XCD — XCD `phase`; the host deals the solves of candidates in flight round-robin (impl_coarse.inl) —,
+    // stride 1 one workgroup on each
+    if ((int)blockIdx.x % stride != phase) return;        // `phase`: which XCD (the host deals solves in flight round-robin)
     group = (int)blockIdx.x / stride;
   } else {
     groups = 1;
@@ -460,9 +460,9 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
 // (static: the header is part of several translation units)
 static __global__ void __launch_bounds__(1024)
 evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r_out,
-                 int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll, unsigned seq_base, int stride, int try_local) {
+                 int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll, unsigned seq_base, int stride, int try_local, int phase = 0) {
   constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
-  if ((int)blockIdx.x % stride != 0) return;
+  if ((int)blockIdx.x % stride != phase) return;         // `phase`: which XCD (evomg_cg1_band2d)
   const int grp = (int)blockIdx.x / stride;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double* wave_sums = reinterpret_cast<double*>(lds_raw);       // [parity][64]: (r, r) of wave q at q, (w, r) at 32 + q

@@ -24,6 +24,7 @@ extern thread_local char g_create_error[512];
 // evomg_evaluate calls of this process under way right now (defined in evomg.hip): more than one means candidates in
 // flight on the device
 int evaluations_in_flight();
+int next_cg_phase();       // a process-wide round-robin counter (which XCD the next multi-workgroup solve in flight sits on)
 
 inline double wall_ms() {
   using namespace std::chrono;

@@ -103,7 +103,8 @@
       if constexpr (!scalar_traits<T>::is_complex) {       // complex problems are 2D only
         if (single_reduction)
           hipLaunchKernelGGL(evomg_cg1_slab3d, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
-                             prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_, cg_local_exchange_ ? 1 : 0);
+                             prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_, cg_local_exchange_ ? 1 : 0,
+                             (cg_stride_ > 1 && evaluations_in_flight() > 1) ? next_cg_phase() % cg_stride_ : 0);
         else
           hipLaunchKernelGGL(evomg_cg_multi_wg3d<double>, dim3(blocks), dim3(1024), lds_bytes, stream_, lv.g, lv.st, x, b, r, prob_.cgs_max_iterations,
                              prob_.cgs_target_res_reduction, dinfo_, cg_ll_, seq_base, cg_stride_);
@@ -155,15 +156,19 @@
     if constexpr (scalar_traits<T>::is_complex) return invalid("launch_cg1: real problems only");
     else {
       unsigned base = 0;
-      int stride = 1;
+      int stride = 1, phase = 0;
       bool wave_autonomous = false;
       if (MULTI) {
         const int rc = take_ll_sequence((unsigned)(prob_.cgs_max_iterations > 0 ? prob_.cgs_max_iterations : 0) + 3u, &base);
         if (rc != EVOMG_OK) return rc;
-        // alone on the device: all workgroups on one XCD (92 against 86 solves/s isolated); while other evaluations of this
-        // process are under way — candidates in flight — one workgroup per XCD (throughput_mode 335 against 290 solves/s,
+        // All workgroups of a solve on ONE XCD (every eighth block of the grid takes part): its exchanges then stay in that
+        // XCD's L2. Alone on the device that is XCD 0; while other evaluations of this process are under way — candidates in
+        // flight — the solves are dealt to the XCDs round-robin, so that they neither pile onto one XCD's 32 units (290
+        // solves/s with twelve in flight) nor pay the fabric's latency with one workgroup per XCD (EVOMG_CG_SPREAD_XCDS=1: the
+        // population of BASELINE config C5 52 against 55 solves/s, sixteen identical candidates 387 against 381:
         // profiles/r05_cg1_placement_raw.txt)
-        stride = (cg_stride_ > 1 && evaluations_in_flight() > 1) ? 1 : cg_stride_;
+        stride = cg_stride_;
+        if (stride > 1 && evaluations_in_flight() > 1) phase = next_cg_phase() % stride;
         // on one XCD the words of an exchange stay in its L2: every wave then exchanges for itself (no collector, no barrier:
         // 1.58 -> 1.49 us per iteration); over the fabric the collector form moves fewer words (2.06 against 2.15 us)
         wave_autonomous = stride > 1 && cg_local_exchange_ && cg1_wave_autonomous_;
@@ -173,7 +178,7 @@
       const int maxit = prob_.cgs_max_iterations, local = cg_local_exchange_ ? 1 : 0;
       const double tol = prob_.cgs_target_res_reduction;
 #define EVOMG_CG1_LAUNCH(XZ, AUTO, COPY) hipLaunchKernelGGL((evomg_cg1_band2d<R, E, H, WAVES, MULTI, XZ, MASK, AUTO>), grid, block, 0, stream_, lv.g, lv.st, x, b, r, \
-                                                            COPY, maxit, tol, dinfo_, cg_ll_, base, groups, stride, local)
+                                                            COPY, maxit, tol, dinfo_, cg_ll_, base, groups, stride, local, phase)
       if constexpr (MULTI) {
         if (wave_autonomous) {
           if (b_copy) EVOMG_CG1_LAUNCH(true, true, b_copy);
