@@ -671,13 +671,18 @@ __global__ void __launch_bounds__(256) evomg_dot_final(const T* __restrict__ par
 // partial sums — and with evomg_dot_final the dot products — carry the same bits as the separate passes they replace.
 // 2D. partial: [NDOT][gridDim.x].
 // v = A x (stored); dot 0 = w0 . v; dot 1 (NDOT == 2) = v . v
+// The hardware deals consecutive workgroups to the eight XCDs in turn; the rows b - 1, b, b + 1 a stencil reads would then be
+// fetched by three XCDs, each through its own L2 (measured at 2049^2 complex: 264 MB read for 134 MB of operands,
+// profiles/r05_pmc_c3_tables.txt). `row_block` renumbers the workgroups so that one XCD walks one contiguous band of rows: the
+// neighbouring rows come out of its L2. Which workgroup sums which rows — partial[row_block] — is evomg_dot_partial's order.
 template <typename T, int NDOT>
 __global__ void __launch_bounds__(256) evomg_apply_dots(Geo g, Stencil<T> st, const T* __restrict__ x, T* __restrict__ v,
                                                         const T* __restrict__ w0, T* __restrict__ partial) {
   __shared__ T red[17];
   const int m = g.n - 2;
+  const int row_block = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   T s0 = scalar_traits<T>::zero(), s1 = scalar_traits<T>::zero();
-  for (long r = blockIdx.x; r < m; r += gridDim.x) {
+  for (long r = row_block; r < m; r += gridDim.x) {
     const long base = gidx<2>(g, 0, 1 + (int)r, 0);
     for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
       const long c = base + i;
@@ -688,10 +693,10 @@ __global__ void __launch_bounds__(256) evomg_apply_dots(Geo g, Stencil<T> st, co
     }
   }
   s0 = block_sum(s0, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s0;
+  if (threadIdx.x == 0) partial[row_block] = s0;
   if (NDOT == 2) {
     s1 = block_sum(s1, red);
-    if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = s1;
+    if (threadIdx.x == 0) partial[gridDim.x + row_block] = s1;
   }
 }
 // z = x + a y (stored); dot 0 = z . z; dot 1 = w . z

@@ -1197,6 +1197,141 @@ __global__ void __launch_bounds__(256) kb_check(const T* __restrict__ partial_rr
   if (threadIdx.x == 0) state[cur ^ 1] = KbState<T>{scal[2], st0.res0, st0.it + 1, (res < tol * st0.res0 || !(res == res)) ? 1 : 0};
 }
 
+// ---- the same BiCGStab in THREE launches per iteration (round 5) ---------------------------------------------------------------
+// A launch of these kernels is 3.5-4.5 us however little it does (127 workgroups at 129^2), six of them per iteration were a
+// sixth of a C3 outer iteration. Two of the six only prepared a vector for the stencil application behind them, and the vector is
+// an elementwise formula: kb2_ps applies the stencil to p_new = r + beta (p - omega nu) EVALUATED at the five nodes it reads
+// (same fused multiply-adds as kb_p: same bits; the Robin column next to an inner column by the same division) — p and nu are
+// double-buffered so that no workgroup reads what another one is overwriting —, kb2_hst does the same with s = r - alpha nu
+// (kb_hs + kb_spmv<2>). kb_check's test moves to the head of the NEXT iteration's first launch (every workgroup forms it from
+// the same partial sums), kb_start's into the first one: state[k & 1] is WRITTEN by kb2_ps of iteration k (rho' of this
+// iteration, the count of completed iterations, done) and read by the other launches of that iteration; kb2_finish closes a
+// batch (the test for its last iteration) in the slot the host reads. Dot products, node order, scalars: those of kb_*.
+template <typename T, bool ROBIN, bool FIRST>
+__global__ void __launch_bounds__(256) kb2_ps(Geo g, Stencil<T> st, const T* __restrict__ r, const T* __restrict__ rhat, const T* __restrict__ nu_in,
+                                              T* __restrict__ nu_out, const T* __restrict__ p_in, T* __restrict__ p_out,
+                                              const T* __restrict__ partial_r, int count, T* __restrict__ partial_nu, KbState<T>* state, int cur,
+                                              const T* __restrict__ scal, double kh, double tol) {
+  __shared__ T red[17];
+  const T one = scalar_traits<T>::from_real(1.0), zero = scalar_traits<T>::zero();
+  KbState<T> prev;
+  T alpha = one, omega = one;
+  if constexpr (FIRST) {
+    const double res0 = sc_norm_from_dot(kcg_reduce(partial_r, count, red));
+    prev = KbState<T>{one, res0, 0, res0 == 0.0 ? 1 : 0};
+    if (prev.done) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) state[cur] = prev;
+      return;
+    }
+  } else {
+    prev = state[cur ^ 1];
+    if (prev.done) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) state[cur] = prev;
+      return;
+    }
+    const double res = sc_norm_from_dot(kcg_reduce(partial_r, count, red));        // kb_check of the iteration before
+    if (res < tol * prev.res0 || !(res == res)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) state[cur] = KbState<T>{prev.rho, prev.res0, prev.it + 1, 1};
+      return;
+    }
+    prev.it += 1;
+    alpha = scal[0];
+    omega = scal[1];
+  }
+  const T rho_new = kcg_reduce(partial_r + count, count, red);
+  const T beta = sc_mul(sc_div(rho_new, prev.rho), sc_div(alpha, omega));
+  const T nomega = sc_neg(omega);
+  const int n = g.n;
+  auto p_inner = [&](long q) -> T { return sc_fma(beta, sc_fma(nomega, nu_in[q], p_in[q]), r[q]); };
+  auto p_at = [&](long q, int i, int j) -> T {            // p_new at a node the stencil reads: (i, j) with i or j possibly on the boundary
+    if (j < 1 || j > n - 2) return p_in[q];                // boundary rows are never written: both buffers hold the same values
+    if (i >= 1 && i <= n - 2) return p_inner(q);
+    if constexpr (ROBIN && scalar_traits<T>::is_complex) return sc_div(p_inner(i == 0 ? q + 1 : q - 1), cplx{1.0, -kh});
+    else return p_in[q];
+  };
+  T s0 = zero;
+  const int m = n - 2;
+  for (long row = blockIdx.x; row < m; row += gridDim.x) {
+    const int j = 1 + (int)row;
+    const long base = gidx<2>(g, 0, j, 0);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
+      const long c = base + i;
+      const T pc = p_inner(c);
+      p_out[c] = pc;
+      kb_robin<T, ROBIN>(g, p_out, c, i, pc, kh);
+      T a = sc_mul(st.c[0], pc);                           // apply_stencil_fma's order
+      a = sc_fma(st.c[1], p_at(c - 1, i - 1, j), a);
+      a = sc_fma(st.c[2], p_at(c + 1, i + 1, j), a);
+      a = sc_fma(st.c[3], p_at(c - g.pitch, i, j - 1), a);
+      a = sc_fma(st.c[4], p_at(c + g.pitch, i, j + 1), a);
+      nu_out[c] = a;
+      s0 = sc_fma(rhat[c], a, s0);
+    }
+  }
+  s0 = block_sum(s0, red);
+  if (threadIdx.x == 0) partial_nu[blockIdx.x] = s0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) state[cur] = KbState<T>{rho_new, prev.res0, prev.it, 0};
+}
+// alpha ; h = x + alpha p ; s = r - alpha nu (stored) ; t = A s with s evaluated at the five nodes ; t . s, t . t
+template <typename T, bool ROBIN>
+__global__ void __launch_bounds__(256) kb2_hst(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ p,
+                                               const T* __restrict__ nu, T* __restrict__ hh, T* __restrict__ s, T* __restrict__ t,
+                                               const T* __restrict__ partial_nu, int count, T* __restrict__ partial_t, const KbState<T>* state, int cur,
+                                               T* scal, double kh) {
+  __shared__ T red[17];
+  if (state[cur].done) return;
+  const T alpha = sc_div(state[cur].rho, kcg_reduce(partial_nu, count, red));
+  const T nalpha = sc_neg(alpha);
+  const T zero = scalar_traits<T>::zero();
+  const int n = g.n;
+  auto s_inner = [&](long q) -> T { return sc_fma(nalpha, nu[q], r[q]); };
+  auto s_at = [&](long q, int i, int j) -> T {
+    if (j < 1 || j > n - 2) return s[q];                   // boundary rows: never written
+    if (i >= 1 && i <= n - 2) return s_inner(q);
+    if constexpr (ROBIN && scalar_traits<T>::is_complex) return sc_div(s_inner(i == 0 ? q + 1 : q - 1), cplx{1.0, -kh});
+    else return s[q];                                      // Dirichlet columns: never written
+  };
+  T s0 = zero, s1 = zero;
+  const int m = n - 2;
+  for (long row = blockIdx.x; row < m; row += gridDim.x) {
+    const int j = 1 + (int)row;
+    const long base = gidx<2>(g, 0, j, 0);
+    for (int i = 1 + threadIdx.x; i <= m; i += blockDim.x) {
+      const long c = base + i;
+      hh[c] = sc_fma(alpha, p[c], x[c]);
+      const T sc = s_inner(c);
+      s[c] = sc;                                           // no launch-mate reads a stored inner or Robin value of s: they form it
+      kb_robin<T, ROBIN>(g, s, c, i, sc, kh);
+      T a = sc_mul(st.c[0], sc);
+      a = sc_fma(st.c[1], s_at(c - 1, i - 1, j), a);
+      a = sc_fma(st.c[2], s_at(c + 1, i + 1, j), a);
+      a = sc_fma(st.c[3], s_at(c - g.pitch, i, j - 1), a);
+      a = sc_fma(st.c[4], s_at(c + g.pitch, i, j + 1), a);
+      t[c] = a;
+      s0 = sc_fma(a, sc, s0);
+      s1 = sc_fma(a, a, s1);
+    }
+  }
+  s0 = block_sum(s0, red);
+  if (threadIdx.x == 0) partial_t[blockIdx.x] = s0;
+  s1 = block_sum(s1, red);
+  if (threadIdx.x == 0) partial_t[gridDim.x + blockIdx.x] = s1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = alpha;
+}
+// closes a batch: the convergence test for its last iteration (state[cur], written by that iteration's kb2_ps) into state[cur ^ 1],
+// which the host reads and the next batch's first kb2_ps overwrites
+template <typename T>
+__global__ void __launch_bounds__(256) kb2_finish(const T* __restrict__ partial_r, int count, KbState<T>* state, int cur, double tol) {
+  __shared__ T red[17];
+  const KbState<T> st0 = state[cur];
+  if (st0.done) {
+    if (threadIdx.x == 0) state[cur ^ 1] = st0;
+    return;
+  }
+  const double res = sc_norm_from_dot(kcg_reduce(partial_r, count, red));
+  if (threadIdx.x == 0) state[cur ^ 1] = KbState<T>{st0.rho, st0.res0, st0.it + 1, (res < tol * st0.res0 || !(res == res)) ? 1 : 0};
+}
+
 // ---- CG on 33^3 across EVOMG_CG_GROUPS compute units (3D column ownership, m >= 16) ------------------------------------
 // One CU moves 64 B/clk: with 29 791 unknowns and 17 vector accesses per unknown and iteration the single-workgroup
 // kernel above needs ~60 us per iteration, and the 3D configuration spends half its time there. Here the grid is cut

@@ -64,7 +64,7 @@ struct ImplBase {
   } while (0)
 
 constexpr int kDotBlocks = 1024;
-constexpr int kTmpVectors = 6;
+constexpr int kTmpVectors = 8;      // BiCGStab: six work vectors + the second buffers of p and nu (kb2_ps)
 
 // factories of the four implementations (impl_real.hip, impl_complex.hip, impl_system.hip, impl_fas.hip)
 ImplBase* make_impl_real(const evomg_problem_t& p, int device);

@@ -33,6 +33,9 @@
 
 #include "evomg_strip.h"
 
+#ifndef EVOMG_CROSS_TIMING
+#define EVOMG_CROSS_TIMING 0     // developer builds only (tools/ab_cross_timing.sh): 1 halo rows from the chunk's own rows, 2 no loads of x / f, 4 no stores, 8 no loads of the coarse correction — WRONG results
+#endif
 #define EVOMG_CROSS_STRIP_COLS 116
 #define EVOMG_CROSS_UNROLL 6
 #ifndef EVOMG_CROSS_PF
@@ -145,15 +148,27 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
   const Pair<double> zpair{0.0, 0.0};
   const bool inner_a = c0 >= 1 && c0 <= n - 2;
   const bool inner_b = c0 + 1 >= 1 && c0 + 1 <= n - 2;
+#if EVOMG_CROSS_TIMING & 4
+  const bool store_lane = lane >= HALO && lane <= 63 - HALO && col_ok && n < 0;
+#else
   const bool store_lane = lane >= HALO && lane <= 63 - HALO && col_ok;
+#endif
   const int c_clamped = min(max(c0, 0), n - 1);
   auto load_row = [&](const double* __restrict__ base, int row) -> Pair<double> {
+#if EVOMG_CROSS_TIMING & 1                                    // developer builds: WRONG results — what the halo rows cost (profiles/r05_cross_kernel.md)
+    const int r = min(max(row, y0), y1 - 1);
+#else
     const int r = min(max(row, 0), n - 1);
+#endif
     if constexpr (NT_XY) return load_pair_nt<double>(base + pitch * r + c_clamped);
     else return load_pair<double>(base + pitch * r + c_clamped);
   };
   auto load_row_f = [&](const double* __restrict__ base, int row) -> Pair<double> {
+#if EVOMG_CROSS_TIMING & 1
+    const int r = min(max(row, y0), y1 - 1);
+#else
     const int r = min(max(row, 0), n - 1);
+#endif
     return load_pair<double>(base + pitch * r + c_clamped);
   };
   const int nc = a.gc.n;
@@ -219,8 +234,9 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
 
   // The row loop exists twice: EDGE — the wave touches the domain's boundary (first / last strip, first / last chunk), every
   // relaxation is masked to the inner nodes; interior waves (nine in ten at 4097^2) run the same steps without any of the
-  // masks: no selects, no compares (a sixth fewer instructions; what bounds the launch is the bytes it moves — it streams at the
-  // fabric's rate, VALU active a fifth of the wave cycles: profiles/r04_cross_kernel.md, profiles/r05_cross_kernel.md).
+  // masks: no selects, no compares (a sixth fewer instructions — and instructions are what two thirds of this launch are: with
+  // every load and store taken out it still takes 60 of its 92 us, a wave issuing one FP64 instruction per 8 cycles:
+  // profiles/r05_cross_kernel.md, "What bounds it").
   auto march = [&](auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
     const bool in_a = !EDGE || inner_a, in_b = !EDGE || inner_b;
@@ -232,14 +248,18 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           const int parity = (1 + d) & 1;                      // js is odd
           Pair<double> xp = xq[d % PF];
           const Pair<double> fc = fq[d % PF];
+#if !(EVOMG_CROSS_TIMING & 2)                                  // 2: no loads of x / f in the loop (the prologue's rows go round)
           xq[d % PF] = load_row(x, j + 1 + PF);
           fq[d % PF] = load_row_f(f, j + PF);
+#endif
           if constexpr (PRO) {
             const bool odd_next = ((parity + 1) & 1) != 0;     // row j + 1
             xp = corrected(xp, j + 1, odd_next, c_lo, c_hi, EDGE);
             if (odd_next) {
               c_lo = c_hi;
+#if !(EVOMG_CROSS_TIMING & 8)                                  // 8: no loads of the coarse correction in the loop
               c_hi = load_coarse(((j + 1) >> 1) + 2);
+#endif
             }
           }
           xw[(d + 1) % 3] = xp;

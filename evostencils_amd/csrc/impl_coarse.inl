@@ -47,7 +47,8 @@
       return invalid("coarse_solve: folded copy on a complex problem");
     }
     T* w[kTmpVectors];
-    const int need = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? 6 : 2;
+    const bool kb_route = prob_.cgs_kind == EVOMG_CGS_BICGSTAB && dim_ == 2 && kcg_enabled_ && lv.g.n >= kb_min_n_;
+    const int need = prob_.cgs_kind == EVOMG_CGS_BICGSTAB ? (kb_route && kb_fused_ ? 8 : 6) : 2;
     for (int i = 0; i < need; ++i) {
       int rc = tmpvec(L, i, &w[i]);
       if (rc != EVOMG_OK) return rc;
@@ -252,7 +253,8 @@
   }
 
   // BiCGStab as a sequence of launches (2D, 129^2 and up). The batches between two reads of the done flag start small
-  // (C3 converges in two iterations) and double up to 16.
+  // (C3 converges in two iterations) and double up to 16. Three launches per iteration (kb2_ps, kb2_hst, kb_xr; w[6], w[7]: the
+  // second buffers of p and nu) or, with EVOMG_NO_KB_FUSE, the six of round 4 — the same bits either way.
   template <bool ROBIN> int coarse_bicgstab_per_launch(int L, const Level<T>& lv, T* x, const T* b, T* r, T* const* w) {
     if constexpr (ROBIN && !scalar_traits<T>::is_complex) return invalid("Robin columns on a real problem");
     else {
@@ -272,31 +274,61 @@
       const double khv = ROBIN ? kh(L) : 0.0;
       const double tol = prob_.cgs_target_res_reduction;
       hipLaunchKernelGGL((kb_init<T, ROBIN>), grid, block, 0, stream_, g, lv.st, (const T*)x, b, r, rhat, nu, p, part_r, khv);
-      hipLaunchKernelGGL((kb_start<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, kb_scal_);
-      const int maxit = prob_.cgs_max_iterations;
-      int k = 0, batch = 2;
+      const int maxit = prob_.cgs_max_iterations;           // >= 1 (evomg_create)
+      int k = 0, batch = 2, slot = 0;            // slot: where the state the host reads (and the iteration count) ends up
       kb_host_->done = 0;
-      while (k < maxit) {
-        const int todo = maxit - k < batch ? maxit - k : batch;
-        for (int j = 0; j < todo; ++j, ++k) {
-          const int cur = k & 1;
-          const KbState<T>* st = kb_state_;
-          hipLaunchKernelGGL((kb_p<T, ROBIN>), grid, block, 0, stream_, g, (const T*)r, (const T*)nu, p, (const T*)(part_r + blocks), blocks, st, cur,
-                             kb_scal_, khv);
-          hipLaunchKernelGGL((kb_spmv<T, 1>), grid, block, 0, stream_, g, lv.st, (const T*)p, nu, (const T*)rhat, part_nu, st, cur);
-          hipLaunchKernelGGL((kb_hs<T, ROBIN>), grid, block, 0, stream_, g, (const T*)x, (const T*)r, (const T*)p, (const T*)nu, hh, s,
-                             (const T*)part_nu, blocks, st, cur, kb_scal_, khv);
-          hipLaunchKernelGGL((kb_spmv<T, 2>), grid, block, 0, stream_, g, lv.st, (const T*)s, t, (const T*)s, part_t, st, cur);
-          hipLaunchKernelGGL((kb_xr<T, ROBIN>), grid, block, 0, stream_, g, x, r, (const T*)s, (const T*)hh, (const T*)t, (const T*)rhat,
-                             (const T*)part_t, blocks, part_r, st, cur, kb_scal_, khv);
-          hipLaunchKernelGGL((kb_check<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, (const T*)kb_scal_, tol);
+      if (kb_fused_) {
+        T *p2 = w[6], *nu2 = w[7];
+        while (k < maxit) {
+          const int todo = maxit - k < batch ? maxit - k : batch;
+          int cur = 0;
+          for (int j = 0; j < todo; ++j, ++k) {
+            cur = k & 1;
+            const T *p_in = cur ? p2 : p, *nu_in = cur ? nu2 : nu;
+            T *p_out = cur ? p : p2, *nu_out = cur ? nu : nu2;
+            if (k == 0)
+              hipLaunchKernelGGL((kb2_ps<T, ROBIN, true>), grid, block, 0, stream_, g, lv.st, (const T*)r, (const T*)rhat, nu_in, nu_out, p_in, p_out,
+                                 (const T*)part_r, blocks, part_nu, kb_state_, cur, (const T*)kb_scal_, khv, tol);
+            else
+              hipLaunchKernelGGL((kb2_ps<T, ROBIN, false>), grid, block, 0, stream_, g, lv.st, (const T*)r, (const T*)rhat, nu_in, nu_out, p_in, p_out,
+                                 (const T*)part_r, blocks, part_nu, kb_state_, cur, (const T*)kb_scal_, khv, tol);
+            hipLaunchKernelGGL((kb2_hst<T, ROBIN>), grid, block, 0, stream_, g, lv.st, (const T*)x, (const T*)r, (const T*)p_out, (const T*)nu_out, hh, s, t,
+                               (const T*)part_nu, blocks, part_t, (const KbState<T>*)kb_state_, cur, kb_scal_, khv);
+            hipLaunchKernelGGL((kb_xr<T, ROBIN>), grid, block, 0, stream_, g, x, r, (const T*)s, (const T*)hh, (const T*)t, (const T*)rhat,
+                               (const T*)part_t, blocks, part_r, (const KbState<T>*)kb_state_, cur, kb_scal_, khv);
+          }
+          hipLaunchKernelGGL((kb2_finish<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, tol);
+          slot = cur ^ 1;
+          HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
+          HIP_TRY(hipStreamSynchronize(stream_));
+          if (kb_host_->done) break;
+          if (batch < 16) batch *= 2;
         }
-        HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + (k & 1), sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
-        if (kb_host_->done) break;
-        if (batch < 16) batch *= 2;
+      } else {
+        hipLaunchKernelGGL((kb_start<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, kb_scal_);
+        while (k < maxit) {
+          const int todo = maxit - k < batch ? maxit - k : batch;
+          for (int j = 0; j < todo; ++j, ++k) {
+            const int cur = k & 1;
+            const KbState<T>* st = kb_state_;
+            hipLaunchKernelGGL((kb_p<T, ROBIN>), grid, block, 0, stream_, g, (const T*)r, (const T*)nu, p, (const T*)(part_r + blocks), blocks, st, cur,
+                               kb_scal_, khv);
+            hipLaunchKernelGGL((kb_spmv<T, 1>), grid, block, 0, stream_, g, lv.st, (const T*)p, nu, (const T*)rhat, part_nu, st, cur);
+            hipLaunchKernelGGL((kb_hs<T, ROBIN>), grid, block, 0, stream_, g, (const T*)x, (const T*)r, (const T*)p, (const T*)nu, hh, s,
+                               (const T*)part_nu, blocks, st, cur, kb_scal_, khv);
+            hipLaunchKernelGGL((kb_spmv<T, 2>), grid, block, 0, stream_, g, lv.st, (const T*)s, t, (const T*)s, part_t, st, cur);
+            hipLaunchKernelGGL((kb_xr<T, ROBIN>), grid, block, 0, stream_, g, x, r, (const T*)s, (const T*)hh, (const T*)t, (const T*)rhat,
+                               (const T*)part_t, blocks, part_r, st, cur, kb_scal_, khv);
+            hipLaunchKernelGGL((kb_check<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, (const T*)kb_scal_, tol);
+          }
+          slot = k & 1;
+          HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
+          HIP_TRY(hipStreamSynchronize(stream_));
+          if (kb_host_->done) break;
+          if (batch < 16) batch *= 2;
+        }
       }
-      hipLaunchKernelGGL(evomg_accumulate_iterations, dim3(1), dim3(64), 0, stream_, dinfo_, (const int*)&kb_state_[k & 1].it);
+      hipLaunchKernelGGL(evomg_accumulate_iterations, dim3(1), dim3(64), 0, stream_, dinfo_, (const int*)&kb_state_[slot].it);
       HIP_TRY(hipGetLastError());
       return EVOMG_OK;
     }

@@ -719,11 +719,13 @@ def test_one_wave_bicgstab_is_bit_identical(native, oracle, kind, lo, monkeypatc
 
 
 @pytest.mark.parametrize("kind,lo", [("helmholtz", 7), ("helmholtz", 8), ("poisson", 7)])
-def test_large_coarsest_grids_run_bicgstab_as_launches(native, oracle, kind, lo):
-    """129^2 and up (C3's coarsest grid): BiCGStab as six many-unit launches per iteration with the scalars in a device-side
-    state (kb_*), Robin columns written beside their inner neighbours, dot products in the blocked order with fused
-    accumulation that the oracle restates: solution and residual incl. the Robin columns bit for bit, same iteration count
-    (a cap of 7 iterations exercises the batches 2 + 4 + 1 and kernels launched past the last iteration)."""
+def test_large_coarsest_grids_run_bicgstab_as_launches(native, oracle, kind, lo, monkeypatch):
+    """129^2 and up (C3's coarsest grid): BiCGStab as many-unit launches with the scalars in a device-side state — three per
+    iteration (kb2_ps / kb2_hst / kb_xr: p and s evaluated at the nodes the stencil reads, the convergence test at the head of
+    the next iteration) or round 4's six (EVOMG_NO_KB_FUSE) —, Robin columns written beside their inner neighbours, dot products
+    in the blocked order with fused accumulation that the oracle restates: solution and residual incl. the Robin columns bit
+    for bit in both forms (caps of 7, 3, 2 and 1 iterations exercise the batches 2 + 4 + 1, a batch cut short and kernels
+    launched past the last iteration; a zero right-hand side the solve that is done before it iterates)."""
     import dataclasses
     if kind == "helmholtz":
         pd = problems.helmholtz_2d(lo, lo + 1, k=0.625 * (1 << (lo + 1)))
@@ -731,23 +733,38 @@ def test_large_coarsest_grids_run_bicgstab_as_launches(native, oracle, kind, lo)
         pd = dataclasses.replace(problems.poisson_2d(lo, lo + 1), cgs_kind=abi.CGS_BICGSTAB, cgs_target_res_reduction=1e-9)
     n = (1 << lo) + 1
     cplx = kind == "helmholtz"
-    for cap in (None, 7):
-        pdc = pd if cap is None else dataclasses.replace(pd, cgs_max_iterations=cap)
+    for cap in (None, 7, 3, 2, 1, "zero"):
+        pdc = pd if cap in (None, "zero") else dataclasses.replace(pd, cgs_max_iterations=cap)
         rng = np.random.default_rng(29 + lo)
         rhs = random_field(rng, (n, n), cplx)
         x0 = zero_boundary(random_field(rng, (n, n), cplx)) * 1e-2
+        if cap == "zero":
+            rhs, x0 = rhs * 0, x0 * 0
         ops = [abi.make_op(abi.OP_COARSE_SOLVE, lo)]
-        got = []
-        for lib in (native, oracle):
-            h = lib.create(pdc)
+        ho = oracle.create(pdc)
+        ho.set_field(lo, abi.F_CGS_RHS, rhs)
+        ho.set_field(lo, abi.F_CORR, x0)
+        ho.run_ops(ops)
+        want = ho.get_field(lo, abi.F_CORR), ho.get_field(lo, abi.F_RES)
+        ho.close()
+        for knob in (None, "EVOMG_NO_KB_FUSE"):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            h = native.create(pdc)
             h.set_field(lo, abi.F_CGS_RHS, rhs)
             h.set_field(lo, abi.F_CORR, x0)
             h.run_ops(ops)
-            got.append((h.get_field(lo, abi.F_CORR), h.get_field(lo, abi.F_RES)))
+            got = h.get_field(lo, abi.F_CORR), h.get_field(lo, abi.F_RES)
+            h.run_ops(ops)                                   # a second solve on the same handle: the buffers of p and nu start over
+            again = h.get_field(lo, abi.F_CORR)
             h.close()
-        assert np.array_equal(got[0][0], got[1][0]), (kind, lo, cap)
-        assert np.array_equal(got[0][1][1:-1, :], got[1][1][1:-1, :]), (kind, lo, cap)
-        assert not np.array_equal(got[0][0], x0)
+            if knob:
+                monkeypatch.delenv(knob)
+            assert np.array_equal(got[0], want[0]), (kind, lo, cap, knob)
+            assert np.array_equal(got[1][1:-1, :], want[1][1:-1, :]), (kind, lo, cap, knob)
+            assert np.all(np.isfinite(again)), (kind, lo, cap, knob)
+        if cap != "zero":
+            assert not np.array_equal(want[0], x0)
 
 
 @pytest.mark.parametrize("kind,smoother,pre,post", [("poisson", "rbgs", 1, 1), ("poisson", "jacobi", 2, 1), ("helmholtz", "rbgs", 2, 1),

@@ -1,7 +1,7 @@
 """Developer tool: soak of the multi-workgroup coarse-grid CG kernels (csrc/evomg_cg1.h) — their rendezvous is the one place of
 the backend where workgroups wait for each other. (1) `solves` solves of 129^2 and of 33^3 one after the other on one handle,
 every solution compared bit for bit with the first (sequence numbers, parity buffers, the XCD-local exchange); (2) `workers`
-threads, own handle each, running such solves at the same time (one workgroup per XCD then, the fabric path; co-residency under
+threads, own handle each, running such solves at the same time (each solve on one XCD, dealt round-robin; co-residency under
 load) — again every solution bit-identical to the thread's first. Prints failures (mismatches, device errors).
 usage: python tools/soak_cg1.py [solves=2000] [workers=16] [rounds=60]"""
 import os, sys, threading, time
