@@ -302,7 +302,7 @@
           HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
           HIP_TRY(hipStreamSynchronize(stream_));
           if (kb_host_->done) break;
-          if (batch < 16) batch *= 2;
+          if (k >= 4 && batch < 16) batch *= 2;            // 2, 2, 4, 8, 16: C3's solves end after two to four iterations
         }
       } else {
         hipLaunchKernelGGL((kb_start<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, kb_scal_);
