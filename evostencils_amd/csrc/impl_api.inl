@@ -192,7 +192,10 @@
       if (rc != EVOMG_OK) return rc;
       rc = coarse_solver_health();
       if (rc == EVOMG_OK) return rc;
-      if (attempt == 0) HIP_TRY(hipDeviceSynchronize());
+      if (attempt == 0) {
+        if (getenv("EVOMG_LOG_RETRIES")) fprintf(stderr, "evomg: coarse-grid rendezvous missed with %d evaluations in flight; evaluating once more, alone\n", evaluations_in_flight());
+        HIP_TRY(hipDeviceSynchronize());
+      }
     }
     return rc;
   }
