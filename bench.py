@@ -487,7 +487,7 @@ def other_configs_section(local_rank):
                                                                      "double sweep, launched speculatively (evomg_tile3d_twice<NORM0>: x, f read "
                                                                      "once for the norm and both sweeps, the swept field written) + two "
                                                                      "reduction launches; this launch is also one of double_sweep's"),
-                              ("coarse_solve", abi.OP_COARSE_SOLVE, "CG on 33^3, eight rendezvousing workgroups (evomg_cg_multi_wg3d)")):
+                              ("coarse_solve", abi.OP_COARSE_SOLVE, "CG on 33^3, single-reduction form on eight rendezvousing workgroups of one XCD (evomg_cg1_slab3d)")):
         h.profile_begin(opcode, lo if opcode == abi.OP_COARSE_SOLVE else hi)
         solve = h.evaluate(ops, 1, 0, 0)
         b = h.profile_end()
@@ -693,7 +693,10 @@ def main():
                         f"(24 B/node + 2 x 8 B per coarse node) for the work of TWO sweeps; mean over the timed launches: "
                         f"{live.bytes / 1e6:.1f} MB. 'back_to_back' = median of 5 batches of 100 consecutive plain ping-pong sweeps. "
                         f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC passes (profiles/pmc_traffic.json names the "
-                        f"profile), null when no profile matches the launched kernel and level"}
+                        f"profile), null when no profile matches the launched kernel and level. What holds the cross launch at "
+                        f"0.60-0.66 of the HBM peak is not its bytes: with every load and store taken out it still takes 60 of its "
+                        f"90-95 us (98 vector instructions per row step, 64 of them FP64, and ONE wave issues an FP64 instruction every "
+                        f"8 cycles: two waves per SIMD leave the vector unit half idle) - profiles/r05_cross_kernel.md"}
 
     # ---- where the rest of an isolated solve goes: the coarse-grid solve, timed the same way over three more solves ----
     progress("coarse solve timing")
@@ -705,15 +708,17 @@ def main():
     coarse_solve = {"kernel": handle.kernel_name(coarse_op), "grid": f"{(1 << lo) + 1}^2", "ms_per_call": cs.ms,
                     "calls_per_solve": cs.launches / 3.0, "share_of_solve": cs.ms * cs.launches / 3.0 / float(extra[0][1]),
                     "iterations_per_call": (handle.coarse_iterations() / (cs.launches / 3.0)) if cs.launches else None,
-                    "bound": "one grid-wide exchange per CG iteration (its trip to the fabric and back) + one unit's issue rate"
+                    "bound": "one grid-wide exchange per CG iteration (a round trip through one XCD's L2) + three dependent reduction / scalar chains"
                              if COARSE_CG == "single-reduction" else "VALU issue of ONE compute unit",
                     "note": "CG to 1e-12 on the coarsest grid (the reference's solver settings, Poisson/2D_FD_Poisson_fromL2.exa3:12-14). "
                             "Round 5: the single-reduction form of the recurrence (Chronopoulos-Gear: both inner products of an "
                             "iteration in ONE reduction; csrc/evomg_cg1.h) on eight co-resident workgroups of four waves — the five "
                             "vectors of 129^2 in registers, ghost rows instead of a second exchange, exchanged doubles as self-validating "
-                            "16-byte words: about 1.5 us per iteration where the classical two-reduction form on ONE compute unit "
+                            "16-byte words that stay in ONE XCD's L2, every wave exchanging for itself: about 1.5 us per iteration where the "
+                            "classical two-reduction form on ONE compute unit "
                             "(EVOMG_BENCH_COARSE_CG=classical: cgs_kind CGS_CG_CLASSICAL, evomg_cg_reg2d) takes 2.05; of an iteration "
-                            "roughly 1.1 us are the exchange, 0.25 the arithmetic, the rest wave reductions and the scalar chain "
+                            "roughly 0.55 us are the exchange, 0.25 the arithmetic (one wave issues an FP64 instruction every 8 cycles), the rest "
+                            "publishing, wave reductions and the scalar chain "
                             "(profiles/r05_cg1.md)"}
     # the whole solve against the roofline of the metric BASELINE names (candidate solves/s): algorithmic bytes of one solve as
     # launched — per iteration the cross launch on the finest level (24 B/node + 2 x 8 B per coarse node), on every level between

@@ -314,7 +314,8 @@
         const bool real_cg = prob_.cgs_kind != EVOMG_CGS_BICGSTAB && !scalar_traits<T>::is_complex;
         if (prob_.cgs_kind == EVOMG_CGS_BICGSTAB) {
           base = (dim_ == 2 && n <= 9 && use_reg_krylov_) ? "evomg_bicgstab_wave2d"
-                 : (dim_ == 2 && kcg_enabled_ && n >= kb_min_n_) ? "kb_init / kb_p / kb_spmv / kb_hs / kb_xr / kb_check" : "evomg_bicgstab_single_wg";
+                 : (dim_ == 2 && kcg_enabled_ && n >= kb_min_n_) ? (kb_fused_ ? "kb_init / kb2_ps / kb2_hst / kb_xr / kb2_finish" : "kb_init / kb_p / kb_spmv / kb_hs / kb_xr / kb_check")
+                                                                  : "evomg_bicgstab_single_wg";
         } else if (cg1_serves(lv_[prob_.min_level].g)) base = "evomg_cg1_band2d";
         else if (real_cg && dim_ == 3 && krylov_cg_groups<3>(n) > 1) base = prob_.cgs_kind == EVOMG_CGS_CG ? "evomg_cg1_slab3d" : "evomg_cg_multi_wg3d";
         else if (real_cg && kcg_enabled_ && (dim_ == 2 ? krylov_cg_per_launch<2>(n) : krylov_cg_per_launch<3>(n))) base = "kcg_init / kcg_apply / kcg_update / kcg_direct";
@@ -322,7 +323,8 @@
         else if (real_cg && use_reg_krylov_ && dim_ == 2 && krylov_own<2>(n, true).tile && krylov_own<2>(n, true).lanes == 512) base = "evomg_cg_reg2d";
         else if (real_cg && use_reg_krylov_ && dim_ == 3 && krylov_own<3>(n, true).column && krylov_own<3>(n, true).m <= EVOMG_CG_WAVE3D_MAX_M) base = "evomg_cg_wave3d";
         else base = "evomg_cg_single_wg";
-        break;
+        snprintf(buf, len, "%s", base);          // the solvers' template arguments are tile shapes, not <type, dimension>
+        return EVOMG_OK;
       }
     }
     snprintf(buf, len, "%s<%s, %d", base, type_name<T>::get(), dim_);

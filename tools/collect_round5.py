@@ -1,4 +1,4 @@
-"""Copy what tools/profile_round5.sh left under gpurun_out/r4/ into profiles/ under round-5 names."""
+"""Copy what tools/profile_round5.sh left under gpurun_out/r5/ into profiles/ under round-5 names."""
 import glob, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(R, "gpurun_out", "r5"), os.path.join(R, "profiles")
@@ -7,7 +7,7 @@ names = {"bench_prof": "r05_bench_kernel_stats.csv", "c4_prof": "r05_c4_poisson3
 for d, out in names.items():
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
-        shutil.copy(hits[0], os.path.join(dst, out))
+        shutil.copy(max(hits, key=os.path.getmtime), os.path.join(dst, out))      # the newest run (gpurun_out keeps earlier ones)
         print(out)
 for f, out in (("bench.json", "r05_bench.json"), ("bench_under_rocprof.json", "r05_bench_under_rocprof.json"), ("configs_plain.txt", "r05_configs_plain.txt")):
     p = os.path.join(src, f)
