@@ -1,4 +1,6 @@
 #include <atomic>
+#include <sys/prctl.h>
+#include <time.h>
 // evomg.hip — the C-ABI of include/evomg.h: descriptor checks, the handle, dispatch to one of four implementation classes
 // (impl_real.hip / impl_complex.hip: evomg_impl.h, the tuned scalar path; impl_system.hip; impl_fas.hip).
 //
@@ -16,6 +18,30 @@ int evaluations_in_flight() { return g_evaluations_in_flight.load(std::memory_or
 int next_cg_phase() {
   static std::atomic<int> counter{0};
   return counter.fetch_add(1, std::memory_order_relaxed) & 0x7fff;
+}
+namespace {
+const bool g_spin_waits = getenv("EVOMG_SPIN_WAITS") != nullptr;
+const long g_wait_sleep_ns = getenv("EVOMG_WAIT_SLEEP_US") ? 1000L * atol(getenv("EVOMG_WAIT_SLEEP_US")) : 20000L;
+template <typename Q> hipError_t sleepy_wait(Q&& query) {
+  // a sleeping thread wakes `timer slack` late (50 us by default, two to three times the sleep asked for): 1 us for this thread
+  static thread_local const bool slack_set = (prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0), true);
+  (void)slack_set;
+  for (int polls = 0;; ++polls) {
+    const hipError_t q = query();
+    if (q != hipErrorNotReady) return q;
+    if (polls < 4) continue;                                   // what is nearly there: no sleep
+    const timespec ts{0, g_wait_sleep_ns};
+    nanosleep(&ts, nullptr);
+  }
+}
+}  // namespace
+hipError_t wait_event(hipEvent_t e) {
+  if (g_spin_waits || evaluations_in_flight() <= 1) return hipEventSynchronize(e);
+  return sleepy_wait([&] { return hipEventQuery(e); });
+}
+hipError_t wait_stream(hipStream_t s) {
+  if (g_spin_waits || evaluations_in_flight() <= 1) return hipStreamSynchronize(s);
+  return sleepy_wait([&] { return hipStreamQuery(s); });
 }
 struct InFlight {
   InFlight() { g_evaluations_in_flight.fetch_add(1, std::memory_order_relaxed); }

@@ -242,7 +242,7 @@
                              prob_.cgs_target_res_reduction);
         }
         HIP_TRY(hipMemcpyAsync(kcg_host_, kcg_state_ + (k & 1), sizeof(KcgState), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(wait_stream(stream_));
         if (kcg_host_->done) break;
       }
       hipLaunchKernelGGL(evomg_accumulate_iterations, dim3(1), dim3(64), 0, stream_, dinfo_, (const int*)&kcg_state_[k & 1].it);
@@ -300,7 +300,7 @@
           hipLaunchKernelGGL((kb2_finish<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, tol);
           slot = cur ^ 1;
           HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
-          HIP_TRY(hipStreamSynchronize(stream_));
+          HIP_TRY(wait_stream(stream_));
           if (kb_host_->done) break;
           if (k >= 4 && batch < 16) batch *= 2;            // 2, 2, 4, 8, 16: C3's solves end after two to four iterations
         }
@@ -323,7 +323,7 @@
           }
           slot = k & 1;
           HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
-          HIP_TRY(hipStreamSynchronize(stream_));
+          HIP_TRY(wait_stream(stream_));
           if (kb_host_->done) break;
           if (batch < 16) batch *= 2;
         }

@@ -14,7 +14,7 @@
   int dot_to_host(int L, const T* a, const T* b, T* out) {
     dot_async(L, a, b, dscalar_);
     HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     *out = hscalar_[0];
     return EVOMG_OK;
   }
@@ -58,7 +58,7 @@
     }
     flush();
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
 
@@ -192,7 +192,7 @@
       set_fieldptr(l0, ops[0].dst, saved_x);
     };
     auto wait_norm = [&]() -> int {
-      HIP_TRY(hipEventSynchronize(norm_event_));
+      HIP_TRY(wait_event(norm_event_));
       d = host_norm_ ? hnorm_[0] : hscalar_[0];
       return EVOMG_OK;
     };
@@ -264,12 +264,12 @@
         }
       }
     if (ahead) undo_speculation();                 // the sweep queued for an iteration that is not going to happen
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     if (t_end < 0.0) t_end = wall_ms();
     if (res_stale) {
       // leave RES@max as the reference's loop would (the residual of the returned iterate); outside the solve timer
       residual(L, lv.st, fieldptr(L, EVOMG_F_SOL), fieldptr(L, EVOMG_F_RHS), fieldptr(L, EVOMG_F_RES));
-      HIP_TRY(hipStreamSynchronize(stream_));
+      HIP_TRY(wait_stream(stream_));
     }
     if (it > prob_.max_iterations) it = prob_.max_iterations;
     out->time_ms = t_end - t0;
@@ -296,7 +296,7 @@
     const T* RHS = lv.init[EVOMG_F_RHS];
     if (!RHS) return invalid("no right-hand side set");
     int nh = 0;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     const double t0 = wall_ms();
     if (lv.init[EVOMG_F_SOL]) HIP_TRY(hipMemcpyAsync(Sol, lv.init[EVOMG_F_SOL], bytes, hipMemcpyDeviceToDevice, stream_));
     apply_bc(L, Sol);
@@ -354,7 +354,7 @@
     auto fetch_dots = [&](int ndot, T* out0, T* out1) -> int {
       hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, ndot, dscalar_);
       HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T) * ndot, hipMemcpyDeviceToHost, stream_));
-      HIP_TRY(hipStreamSynchronize(stream_));
+      HIP_TRY(wait_stream(stream_));
       *out0 = hscalar_[0];
       if (ndot > 1) *out1 = hscalar_[1];
       return EVOMG_OK;
@@ -373,7 +373,7 @@
       const T zero_t = scalar_traits<T>::zero();
       T init[5] = {zero_t, rho_new, one, one, one};
       HIP_TRY(hipMemcpyAsync(dscalar_, init, sizeof init, hipMemcpyHostToDevice, stream_));
-      HIP_TRY(hipStreamSynchronize(stream_));         // `init` is a stack array
+      HIP_TRY(wait_stream(stream_));         // `init` is a stack array
       if (!outer_event_) HIP_TRY(hipEventCreateWithFlags(&outer_event_, hipEventDisableTiming));
       auto front = [&]() -> int {                     // beta ; p = Res + beta (p - omega ap) ; u = M^-1 p
         hipLaunchKernelGGL((evomg_bicg_beta<T>), dim3(1), dim3(64), 0, stream_, dscalar_);
@@ -398,7 +398,7 @@
         HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipEventRecord(outer_event_, stream_));
         if (it < prob_.max_iterations && (rc = front()) != EVOMG_OK) return rc;      // the next iteration's first half
-        HIP_TRY(hipEventSynchronize(outer_event_));
+        HIP_TRY(wait_event(outer_event_));
         d = hscalar_[0];
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
@@ -466,11 +466,11 @@
         if (wall_limit_ms > 0 && wall_ms() - t0 > wall_limit_ms) { status = EVOMG_SOLVE_WALL_LIMIT; break; }
       }
     if (it > prob_.max_iterations) it = prob_.max_iterations;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     out->time_ms = (t_end >= 0.0 ? t_end : wall_ms()) - t0;
     HIP_TRY(hipMemcpyAsync(lv.f[EVOMG_F_CORR], Sol, bytes, hipMemcpyDeviceToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(lv.f[EVOMG_F_RES], Res, bytes, hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     out->n_iterations = (double)it;
     out->init_res_norm = res0;
     out->final_res_norm = res;

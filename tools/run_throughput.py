@@ -38,7 +38,19 @@ def work(g, e):
         g.generate_and_evaluate(e, None, lo, hi, "", evaluation_samples=1)
 
 
+def cgroup_cpu():                                       # (usage_usec, nr_throttled, throttled_usec) of this cgroup, zeros where there is none
+    out = {}
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            out[k] = int(v)
+    except OSError:
+        pass
+    return out.get("usage_usec", 0), out.get("nr_throttled", 0), out.get("throttled_usec", 0)
+
+
 threads = [threading.Thread(target=work, args=(g, e)) for g, e in zip(workers.generators, expr)]
+cpu0, cg0 = os.times(), cgroup_cpu()
 t0n = time.clock_gettime_ns(time.CLOCK_MONOTONIC)   # (rocprofv3 timestamps: CLOCK_BOOTTIME-like; the window is printed in both)
 t0 = time.perf_counter()
 for t in threads:
@@ -46,5 +58,9 @@ for t in threads:
 for t in threads:
     t.join()
 wall = time.perf_counter() - t0
+cpu1, cg1 = os.times(), cgroup_cpu()
+print("host: %.2f CPU-seconds (user %.2f, system %.2f) in %.3f s of wall = %.1f cores busy; cgroup throttled %d times, %.3f s"
+      % (cpu1.user - cpu0.user + cpu1.system - cpu0.system, cpu1.user - cpu0.user, cpu1.system - cpu0.system, wall,
+         (cpu1.user - cpu0.user + cpu1.system - cpu0.system) / wall, cg1[1] - cg0[1], (cg1[2] - cg0[2]) / 1e6))
 print("throughput: %d workers, %d solves in %.3f s = %.1f solves/s; window_start_ns %d window_ns %d" % (W, S, wall, S / wall, t0n, int(wall * 1e9)))
 workers.close()
