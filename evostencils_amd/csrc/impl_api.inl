@@ -81,7 +81,7 @@
       HIP_TRY(alloc_zero(&lv.alt, lv.elems));
     }
     load_stencils(prob_);
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
 
@@ -97,7 +97,7 @@
     lv.alt_mirror = nullptr;
     HIP_TRY(upload(lv, lv.init[field], host));
     HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
 
@@ -110,7 +110,7 @@
     dirty_[level][canon(level, field)] = true;
     lv_[level].alt_mirror = nullptr;
     HIP_TRY(upload(lv_[level], d, host));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
 
@@ -121,7 +121,7 @@
     if (!d) return invalid("get_field: no such field on this level");
     const Level<T>& lv = lv_[level];
     const size_t rows = (size_t)lv.g.n * (dim_ == 3 ? lv.g.n : 1);
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(T), d, lv.g.pitch * sizeof(T), lv.g.n * sizeof(T), rows,
                         hipMemcpyDeviceToHost));
     return EVOMG_OK;
@@ -146,7 +146,7 @@
     mark_written(ops, n_ops, /*loop=*/false);
     rc = exec_program(ops, n_ops, /*cyclic=*/false);
     if (rc != EVOMG_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return coarse_solver_health();
   }
 
@@ -344,7 +344,7 @@
   int profile_end(evomg_bench_t* out) override {
     if (!out) return invalid("profile_end: null result");
     HIP_TRY(hipSetDevice(device_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     double total = 0.0;
     for (size_t i = 0; i + 1 < prof_used_; i += 2) {
       float ms = 0.f;

@@ -74,7 +74,7 @@ class FASImpl : public ImplBase {
     }
     ++g_fas_handles;
     counted_ = true;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
   int set_initial_field(int level, int field, const double* host) override {
@@ -84,7 +84,7 @@ class FASImpl : public ImplBase {
     if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
     HIP_TRY(upload(lv, lv.init[field], host));
     HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
   int set_field(int level, int field, const double* host) override {
@@ -97,7 +97,7 @@ class FASImpl : public ImplBase {
     if (!level_ok(level) || !host || !fieldptr(level, field)) return invalid("get_field: bad level/field/pointer");
     HIP_TRY(hipSetDevice(device_));
     const FLevel& lv = lv_[level];
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(double), fieldptr(level, field), lv.g.pitch * sizeof(double), lv.g.n * sizeof(double), lv.g.n, hipMemcpyDeviceToHost));
     return EVOMG_OK;
   }
@@ -106,11 +106,11 @@ class FASImpl : public ImplBase {
     HIP_TRY(hipSetDevice(device_));
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     *fas_info_host_ = 0;                  // a miss of an earlier call must not fail this one
     fas_missed_ = false;
     for (int i = 0; i < n_ops; ++i) if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return fas_health();
   }
   int norm(int level, int field, double* out) override {
@@ -132,7 +132,7 @@ class FASImpl : public ImplBase {
     // the device and evaluate once more, alone, before reporting a device error.
     int rc = EVOMG_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
-      HIP_TRY(hipStreamSynchronize(stream_));
+      HIP_TRY(wait_stream(stream_));
       *fas_info_host_ = 0;
       fas_missed_ = false;
       fas_tiles_off_ = attempt > 0;        // the second attempt: single-workgroup / launch-per-sweep coarse sweeps (same bits)
@@ -160,7 +160,7 @@ class FASImpl : public ImplBase {
         }
         HIP_TRY(hipMemsetAsync(lv.next, 0, lv.elems * sizeof(double), stream_));
       }
-      HIP_TRY(hipStreamSynchronize(stream_));
+      HIP_TRY(wait_stream(stream_));
       int nh = 0;
       const double t0 = wall_ms();
       double res0 = 0.0;
@@ -342,7 +342,7 @@ class FASImpl : public ImplBase {
     hipLaunchKernelGGL((evomg_dot_partial<double, 2>), dim3(blocks), dim3(256), 0, stream_, g, a, a, partials_);
     hipLaunchKernelGGL((evomg_dot_final<double>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dscalar_);
     HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     *out = hscalar_[0];
     return EVOMG_OK;
   }

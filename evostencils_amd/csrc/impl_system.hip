@@ -52,7 +52,7 @@ class SystemImpl : public ImplBase {
         HIP_TRY(alloc_zero(&lv.alt[u], lv.elems));
       }
     }
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
   int set_initial_field(int level, int field, const double* host) override {
@@ -64,7 +64,7 @@ class SystemImpl : public ImplBase {
     if (!lv.init[k]) HIP_TRY(alloc_zero(&lv.init[k], lv.elems));
     HIP_TRY(upload(lv, lv.init[k], host));
     HIP_TRY(hipMemcpyAsync(lv.f[k], lv.init[k], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
   int set_field(int level, int field, const double* host) override {
@@ -81,7 +81,7 @@ class SystemImpl : public ImplBase {
     const double* d = fieldptr(level, field);
     if (!d) return invalid("get_field: no such field on this level");
     const SLevel& lv = lv_[level];
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(double), d, lv.g.pitch * sizeof(double), lv.g.n * sizeof(double), lv.g.n, hipMemcpyDeviceToHost));
     return EVOMG_OK;
   }
@@ -91,7 +91,7 @@ class SystemImpl : public ImplBase {
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
     if ((rc = exec_all(ops, n_ops)) != EVOMG_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
   }
   int norm(int level, int field, double* out) override {
@@ -123,7 +123,7 @@ class SystemImpl : public ImplBase {
           if (lv.init[k]) HIP_TRY(hipMemcpyAsync(lv.f[k], lv.init[k], lv.elems * sizeof(double), hipMemcpyDeviceToDevice, stream_));
           else HIP_TRY(hipMemsetAsync(lv.f[k], 0, lv.elems * sizeof(double), stream_));
         }
-      HIP_TRY(hipStreamSynchronize(stream_));
+      HIP_TRY(wait_stream(stream_));
       int nh = 0;
       const double t0 = wall_ms();
       double res0 = 0.0;
@@ -416,7 +416,7 @@ class SystemImpl : public ImplBase {
     hipLaunchKernelGGL((evomg_dot_partial<double, 2>), dim3(blocks), dim3(256), 0, stream_, g, a, a, partials_);
     hipLaunchKernelGGL((evomg_dot_final<double>), dim3(1), dim3(256), 0, stream_, partials_, blocks, dscalar_);
     HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(wait_stream(stream_));
     *out = hscalar_[0];
     return EVOMG_OK;
   }
