@@ -28,7 +28,12 @@ template <typename Q> hipError_t sleepy_wait(Q&& query) {
   (void)slack_set;
   for (int polls = 0;; ++polls) {
     const hipError_t q = query();
-    if (q != hipErrorNotReady) return q;
+    if (q != hipErrorNotReady) {
+      // "not ready" is an answer, not an error: should the runtime have recorded it as this thread's last error, take it back
+      // (the launch checks of the solver loops read that slot); any other recorded error stays where it is
+      if (polls > 0 && hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+      return q;
+    }
     if (polls < 4) continue;                                   // what is nearly there: no sleep
     const timespec ts{0, g_wait_sleep_ns};
     nanosleep(&ts, nullptr);
