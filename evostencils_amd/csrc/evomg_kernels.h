@@ -826,15 +826,20 @@ __global__ void __launch_bounds__(256) evomg_axpy2(Geo g, T* __restrict__ z, con
   const T t = sc_add(x1[c], sc_mul(a, y1[c]));
   z[c] = sc_add(x2[c], sc_mul(b, t));
 }
-// up to two final reductions in one launch: out[d] = sum of partial[d][0 .. count)
+// up to two final reductions in one launch: out[d] = sum of partial[d][0 .. count); host_out: the first sum once more, in pinned
+// host memory (the host reads it behind an event without a copy launch)
 template <typename T>
-__global__ void __launch_bounds__(256) evomg_dot_final2(const T* __restrict__ partial, int count, int ndot, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) evomg_dot_final2(const T* __restrict__ partial, int count, int ndot, T* __restrict__ out,
+                                                        T* __restrict__ host_out = nullptr) {
   __shared__ T red[17];
   for (int d = 0; d < ndot; ++d) {
     T s = scalar_traits<T>::zero();
     for (int i = threadIdx.x; i < count; i += blockDim.x) s = sc_add(s, partial[(long)d * count + i]);
     s = block_sum(s, red);
-    if (threadIdx.x == 0) out[d] = s;
+    if (threadIdx.x == 0) {
+      out[d] = s;
+      if (d == 0 && host_out) host_out[0] = s;
+    }
   }
 }
 

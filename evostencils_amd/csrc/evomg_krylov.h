@@ -1320,16 +1320,22 @@ __global__ void __launch_bounds__(256) kb2_hst(Geo g, Stencil<T> st, const T* __
 }
 // closes a batch: the convergence test for its last iteration (state[cur], written by that iteration's kb2_ps) into state[cur ^ 1],
 // which the host reads and the next batch's first kb2_ps overwrites
+// host_out: the same state once more, in pinned host memory — the host reads it behind the stream without a copy launch
 template <typename T>
-__global__ void __launch_bounds__(256) kb2_finish(const T* __restrict__ partial_r, int count, KbState<T>* state, int cur, double tol) {
+__global__ void __launch_bounds__(256) kb2_finish(const T* __restrict__ partial_r, int count, KbState<T>* state, int cur, double tol,
+                                                  KbState<T>* __restrict__ host_out) {
   __shared__ T red[17];
   const KbState<T> st0 = state[cur];
   if (st0.done) {
-    if (threadIdx.x == 0) state[cur ^ 1] = st0;
+    if (threadIdx.x == 0) { state[cur ^ 1] = st0; *host_out = st0; }
     return;
   }
   const double res = sc_norm_from_dot(kcg_reduce(partial_r, count, red));
-  if (threadIdx.x == 0) state[cur ^ 1] = KbState<T>{st0.rho, st0.res0, st0.it + 1, (res < tol * st0.res0 || !(res == res)) ? 1 : 0};
+  if (threadIdx.x == 0) {
+    const KbState<T> next{st0.rho, st0.res0, st0.it + 1, (res < tol * st0.res0 || !(res == res)) ? 1 : 0};
+    state[cur ^ 1] = next;
+    *host_out = next;
+  }
 }
 
 // ---- CG on 33^3 across EVOMG_CG_GROUPS compute units (3D column ownership, m >= 16) ------------------------------------

@@ -259,9 +259,10 @@
     if constexpr (ROBIN && !scalar_traits<T>::is_complex) return invalid("Robin columns on a real problem");
     else {
       if (!kb_state_) {
-        HIP_TRY(hipMalloc(&kb_state_, 2 * sizeof(KbState<T>)));
+        HIP_TRY(hipMalloc(&kb_state_, 3 * sizeof(KbState<T>)));          // [2]: where kb2_finish's second copy goes when the host memory is not mapped
         HIP_TRY(hipMalloc(&kb_scal_, 4 * sizeof(T)));
-        HIP_TRY(hipHostMalloc(&kb_host_, sizeof(KbState<T>)));
+        HIP_TRY(hipHostMalloc(&kb_host_, sizeof(KbState<T>), hipHostMallocMapped));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&kb_host_dev_), kb_host_, 0) != hipSuccess) kb_host_dev_ = nullptr;
       }
       T *p = w[0], *nu = w[1], *hh = w[2], *s = w[3], *t = w[4], *rhat = w[5];
       const Geo& g = lv.g;
@@ -297,9 +298,11 @@
             hipLaunchKernelGGL((kb_xr<T, ROBIN>), grid, block, 0, stream_, g, x, r, (const T*)s, (const T*)hh, (const T*)t, (const T*)rhat,
                                (const T*)part_t, blocks, part_r, (const KbState<T>*)kb_state_, cur, kb_scal_, khv);
           }
-          hipLaunchKernelGGL((kb2_finish<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, tol);
+          // the state the host reads: written by the kernel itself into pinned host memory (no copy launch), else copied
+          hipLaunchKernelGGL((kb2_finish<T>), dim3(1), block, 0, stream_, (const T*)part_r, blocks, kb_state_, cur, tol,
+                             kb_host_dev_ ? kb_host_dev_ : kb_state_ + 2);
           slot = cur ^ 1;
-          HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
+          if (!kb_host_dev_) HIP_TRY(hipMemcpyAsync(kb_host_, kb_state_ + slot, sizeof(KbState<T>), hipMemcpyDeviceToHost, stream_));
           HIP_TRY(wait_stream(stream_));
           if (kb_host_->done) break;
           if (k >= 4 && batch < 16) batch *= 2;            // 2, 2, 4, 8, 16: C3's solves end after two to four iterations

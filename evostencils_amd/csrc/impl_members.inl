@@ -49,6 +49,7 @@
   KcgState* kcg_host_ = nullptr;
   KbState<T>* kb_state_ = nullptr;
   KbState<T>* kb_host_ = nullptr;
+  KbState<T>* kb_host_dev_ = nullptr;     // its device address (kb2_finish writes the state there itself)
   T* kb_scal_ = nullptr;
   bool outer_fuse_ = getenv("EVOMG_NO_OUTER_FUSE") == nullptr;      // fused passes of the preconditioned BiCGStab loop
   bool outer_dev_steps_ = getenv("EVOMG_NO_OUTER_DEV_STEPS") == nullptr;   // ... with alpha and omega formed on the device

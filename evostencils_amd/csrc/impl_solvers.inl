@@ -394,12 +394,12 @@
         hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u);
         apply_bc(L, Sol);
         hipLaunchKernelGGL((evomg_axpy_dots_dev<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, (const T*)(dscalar_ + 3), (const T*)t, (const T*)rhat, partials_);
-        hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_);
-        HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
+        hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_, host_norm_ ? hnorm_dev_ : (T*)nullptr);
+        if (!host_norm_) HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipEventRecord(outer_event_, stream_));
         if (it < prob_.max_iterations && (rc = front()) != EVOMG_OK) return rc;      // the next iteration's first half
         HIP_TRY(wait_event(outer_event_));
-        d = hscalar_[0];
+        d = host_norm_ ? hnorm_[0] : hscalar_[0];
         res = sc_norm_from_dot(d);
         if (hist && nh < cap) hist[nh] = res;
         ++nh;
