@@ -783,14 +783,22 @@ __global__ void __launch_bounds__(256) evomg_axpy_pair_dev(Geo g, T* __restrict_
   z2[c] = sc_add(x2[c], sc_mul(sc_neg(a), y2[c]));
 }
 // z = x + a y on inner nodes, a = *ap
-template <typename T>
+// ROBIN (Helmholtz columns x_b = x_in / (1 - i k h), evomg_robin_bc's division): the thread of an inner node beside a Robin column
+// writes that column's node as well — the boundary pass behind the update is gone
+template <typename T, bool ROBIN = false>
 __global__ void __launch_bounds__(256) evomg_axpy_dev(Geo g, T* __restrict__ z, const T* __restrict__ x, const T* __restrict__ ap,
-                                                      const T* __restrict__ y) {
+                                                      const T* __restrict__ y, double kh = 0.0) {
   int i, j, k;
   if (!node_of_thread<2>(g, i, j, k)) return;
   if (!is_inner<2>(g, i, j, k)) return;
   const long c = gidx<2>(g, i, j, k);
-  z[c] = sc_add(x[c], sc_mul(*ap, y[c]));
+  const T v = sc_add(x[c], sc_mul(*ap, y[c]));
+  z[c] = v;
+  if constexpr (ROBIN && scalar_traits<T>::is_complex) {
+    const cplx den{1.0, -kh};
+    if (i == 1) z[c - 1] = sc_div(v, den);
+    if (i == g.n - 2) z[c + 1] = sc_div(v, den);
+  }
 }
 // evomg_axpy_dots with a = -(*ap)
 template <typename T>
@@ -828,9 +836,11 @@ __global__ void __launch_bounds__(256) evomg_axpy2(Geo g, T* __restrict__ z, con
 }
 // up to two final reductions in one launch: out[d] = sum of partial[d][0 .. count); host_out: the first sum once more, in pinned
 // host memory (the host reads it behind an event without a copy launch)
+// beta_step (the outer BiCGStab's device-side scalars, out = scal): evomg_bicg_beta's two lines behind the sums, by the thread
+// that has just written scal[1] — the launch of its own between two iterations is gone
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_dot_final2(const T* __restrict__ partial, int count, int ndot, T* __restrict__ out,
-                                                        T* __restrict__ host_out = nullptr) {
+                                                        T* __restrict__ host_out = nullptr, int beta_step = 0) {
   __shared__ T red[17];
   for (int d = 0; d < ndot; ++d) {
     T s = scalar_traits<T>::zero();
@@ -839,6 +849,11 @@ __global__ void __launch_bounds__(256) evomg_dot_final2(const T* __restrict__ pa
     if (threadIdx.x == 0) {
       out[d] = s;
       if (d == 0 && host_out) host_out[0] = s;
+      if (beta_step && d == 1) {
+        const T rho = out[4];
+        out[5] = sc_mul(sc_div(s, rho), sc_div(out[2], out[3]));
+        out[4] = s;
+      }
     }
   }
 }

@@ -43,6 +43,7 @@
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
   // experiments only: the oracle restates the default (krylov_bicgstab_per_launch)
   int kb_min_n_ = getenv("EVOMG_KB_MIN_N") ? atoi(getenv("EVOMG_KB_MIN_N")) : 129;
+  bool outer_folds_ = getenv("EVOMG_NO_OUTER_FOLDS") == nullptr;      // outer BiCGStab: beta formed by the reduction before it, Robin columns by the update before them
   bool kb_fused_ = getenv("EVOMG_NO_KB_FUSE") == nullptr;            // the launch-per-step BiCGStab in three launches per iteration (kb2_*), else six
   bool kcg_enabled_ = getenv("EVOMG_NO_LAUNCH_CG") == nullptr;       // large coarsest grids: CG as a sequence of launches
   KcgState* kcg_state_ = nullptr;

@@ -375,12 +375,13 @@
       HIP_TRY(hipMemcpyAsync(dscalar_, init, sizeof init, hipMemcpyHostToDevice, stream_));
       HIP_TRY(wait_stream(stream_));         // `init` is a stack array
       if (!outer_event_) HIP_TRY(hipEventCreateWithFlags(&outer_event_, hipEventDisableTiming));
-      auto front = [&]() -> int {                     // beta ; p = Res + beta (p - omega ap) ; u = M^-1 p
-        hipLaunchKernelGGL((evomg_bicg_beta<T>), dim3(1), dim3(64), 0, stream_, dscalar_);
+      auto front = [&](bool beta_done) -> int {       // beta (unless the reduction before formed it) ; p = Res + beta (p - omega ap) ; u = M^-1 p
+        if (!beta_done) hipLaunchKernelGGL((evomg_bicg_beta<T>), dim3(1), dim3(64), 0, stream_, dscalar_);
         hipLaunchKernelGGL((evomg_axpy2_dev<T>), node_grid(g), node_block(), 0, stream_, g, p, (const T*)p, (const T*)ap, (const T*)Res, (const T*)dscalar_);
         return precondition(p);
       };
-      if ((rc = front()) != EVOMG_OK) return rc;
+      if ((rc = front(false)) != EVOMG_OK) return rc;
+      const bool robin_cols = outer_folds_ && prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && scalar_traits<T>::is_complex;
       for (it = 1; it <= prob_.max_iterations; ++it) {
         T* u = fieldptr(L, EVOMG_F_SOL);
         hipLaunchKernelGGL((evomg_apply_dots<T, 1>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, ap, (const T*)rhat, partials_);
@@ -391,13 +392,17 @@
         u = fieldptr(L, EVOMG_F_SOL);
         hipLaunchKernelGGL((evomg_apply_dots<T, 2>), dim3(dot_blocks), dim3(256), 0, stream_, g, outer_st_, (const T*)u, t, (const T*)s, partials_);
         hipLaunchKernelGGL((evomg_dot_final_quot<T>), dim3(1), dim3(256), 0, stream_, (const T*)partials_, dot_blocks, 2, one, dscalar_, 3, -1);
-        hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u);
-        apply_bc(L, Sol);
+        // Sol = hh + omega u, its Robin columns by the same launch (apply_bc's division)
+        if (robin_cols) hipLaunchKernelGGL((evomg_axpy_dev<T, true>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u, kh(L));
+        else {
+          hipLaunchKernelGGL((evomg_axpy_dev<T>), node_grid(g), node_block(), 0, stream_, g, Sol, (const T*)hh, (const T*)(dscalar_ + 3), (const T*)u, 0.0);
+          apply_bc(L, Sol);
+        }
         hipLaunchKernelGGL((evomg_axpy_dots_dev<T>), dim3(dot_blocks), dim3(256), 0, stream_, g, Res, (const T*)s, (const T*)(dscalar_ + 3), (const T*)t, (const T*)rhat, partials_);
-        hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_, host_norm_ ? hnorm_dev_ : (T*)nullptr);
+        hipLaunchKernelGGL((evomg_dot_final2<T>), dim3(1), dim3(256), 0, stream_, partials_, dot_blocks, 2, dscalar_, host_norm_ ? hnorm_dev_ : (T*)nullptr, outer_folds_ ? 1 : 0);
         if (!host_norm_) HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipEventRecord(outer_event_, stream_));
-        if (it < prob_.max_iterations && (rc = front()) != EVOMG_OK) return rc;      // the next iteration's first half
+        if (it < prob_.max_iterations && (rc = front(outer_folds_)) != EVOMG_OK) return rc;  // the next iteration's first half (beta: formed by the reduction above)
         HIP_TRY(wait_event(outer_event_));
         d = host_norm_ ? hnorm_[0] : hscalar_[0];
         res = sc_norm_from_dot(d);
