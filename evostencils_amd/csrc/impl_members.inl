@@ -91,7 +91,7 @@
   bool small2d_enabled_ = getenv("EVOMG_NO_SMALL2D") == nullptr;
   // largest grid that runs as LDS tiles: Helmholtz levels 3..7 149 (33) -> 137-146 (65) -> 131 ms (129), nothing beyond; real
   // sweeps at 129^2 are no faster than the strips (4.2 vs 3.7 us back to back), at 65^2 they are (3.7 vs 5.8 us)
-  int small2d_max_n_ = getenv("EVOMG_SMALL2D_MAX_N") ? atoi(getenv("EVOMG_SMALL2D_MAX_N")) : (scalar_traits<T>::is_complex ? 129 : 65);
+  int small2d_max_n_ = getenv("EVOMG_SMALL2D_MAX_N") ? atoi(getenv("EVOMG_SMALL2D_MAX_N")) : (scalar_traits<T>::is_complex ? 257 : 65);   // complex 257^2 as 8 x 8 tiles: C3 48.9 -> 47.8 ms (round 5); real levels: no difference between 65 and 257
   std::set<const void*> small2d_attr_set_;
   bool batch_enabled_ = (getenv("EVOMG_BATCH") != nullptr) && (getenv("EVOMG_NO_STRIP") == nullptr);
   int batch_max_n_ = getenv("EVOMG_BATCH_MAX_N") ? atoi(getenv("EVOMG_BATCH_MAX_N")) : 129;

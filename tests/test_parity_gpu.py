@@ -776,13 +776,13 @@ def test_small_grid_lds_sweeps_do_not_change_a_bit(native, kind, smoother, pre, 
     """Point smoothers with the field, or independent tiles of it with a recomputed halo, in LDS (evomg_small2d: plain,
     zero-input, prolongation + sweep, sweep + residual + restriction, the Robin columns of Helmholtz problems at every
     stage) against the marching-strip kernels they replace (EVOMG_NO_SMALL2D): identical residual histories, solutions,
-    residuals and coarse right-hand sides on every level of a 9^2 .. 129^2 hierarchy."""
+    residuals and coarse right-hand sides on every level of a 9^2 .. 129^2 (Helmholtz: 257^2) hierarchy."""
     from test_full_size_gpu import vcycle
-    lo, hi = 3, 7
+    lo, hi = (3, 7) if kind == "poisson" else (3, 8)       # Helmholtz: 257^2 as 8 x 8 tiles as well (its default since round 5)
     pd = problems.poisson_2d(lo, hi) if kind == "poisson" else problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
     part, om = (abi.PART_RED_BLACK, 1.1 if kind == "poisson" else 0.6) if smoother == "rbgs" else (abi.PART_SINGLE, 0.8 if kind == "poisson" else 0.6)
     ops = vcycle(lo, hi, pre, post, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, (1, 1, 1), om))
-    monkeypatch.setenv("EVOMG_SMALL2D_MAX_N", "129")      # 65^2 and 129^2 as 2 x 2 and 4 x 4 independent tiles with halos
+    monkeypatch.setenv("EVOMG_SMALL2D_MAX_N", "129" if kind == "poisson" else "257")      # 65^2, 129^2 (257^2) as 2 x 2, 4 x 4 (8 x 8) independent tiles with halos
     results = []
     for knob in (None, "EVOMG_NO_SMALL2D"):
         if knob:
