@@ -417,6 +417,7 @@ def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):
     return {"workload": f"2D Poisson 5-pt, {1 << hi}^2 grid (level {hi}), {hi - lo + 1}-level V(1,1) RB-Gauss-Seidel cycle, "
                         "CG coarse solve on 33^2 to 1e-12",
             "in_flight": flight,
+            "other_examples": reference_examples(local_rank),
             "steps": steps, "value": steps / wall, "unit": "solves/s", "ms_per_step": 1e3 * wall / steps,
             "solve_time_ms": t_ms, "iterations_per_solve": its, "convergence_factor": rho,
             "ms_per_vcycle": t_ms / its if its else None,
@@ -426,6 +427,31 @@ def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):
                                            "size; context, not a like-for-like baseline"},
             "note": "solve_time_ms = device time of the solver loop (what generate_and_evaluate returns); ms_per_step = wall "
                     "clock per generate_and_evaluate call incl. lowering and the host side of the launches"}
+
+
+def reference_examples(local_rank):
+    """The reference's other example problems at the level ranges its own files set (example_problems/*/*.knowledge), each
+    with the problem's own solver settings as the candidate: one solve alone on the device, best of three."""
+    from evostencils_amd import abi, candidates, native, problems
+    out = {}
+    cases = (("helmholtz_2d_129", "2D Helmholtz 128^2 (levels 3..7, k = 80), BiCGStab preconditioned with the hand-written V(2,1) "
+              "(Helmholtz/2D_FD_Helmholtz_fromL3.exa3:202-272)", problems.helmholtz_2d(3, 7, k=80.0),
+              candidates.v_cycle_ops(3, 7, 2, 1, omega=0.6)),
+             ("poisson_3d_65", "3D Poisson 64^3 (levels 2..6), V(2,1) red-black w = 1.25, CG on 5^3 "
+              "(Poisson/3D_FD_Poisson_fromL2.exa3)", problems.poisson_3d(2, 6),
+              candidates.v_cycle_ops(2, 6, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, abi.PART_RED_BLACK,
+                                                                       (1, 1, 1), 1.25))))
+    for key, what, pd, ops in cases:
+        h = native.create(pd, device_id=local_rank)
+        try:
+            h.evaluate(ops, 1, 0, 0)
+            runs = [h.evaluate(ops, 1, 0, 0) for _ in range(3)]
+            best = min(runs, key=lambda r: r.time_ms)
+            out[key] = {"workload": what, "solve_time_ms": best.time_ms, "iterations": best.n_iterations, "status": best.status,
+                        "ms_per_iteration": best.time_ms / best.n_iterations if best.n_iterations else None}
+        finally:
+            h.close()
+    return out
 
 
 def _frac(b):
