@@ -46,6 +46,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int ew = ex1 - ex0, eh = ey1 - ey0, en = ew * eh;
   T* A = reinterpret_cast<T*>(small_lds);
   T* B = A + en;
+  const double inv_c0k = relax_div_const(st, pro.inv_c0);    // relax5's divisor-side constant
   const T zero = scalar_traits<T>::zero();
   const int tid = (int)threadIdx.x;
   constexpr bool CPLX = scalar_traits<T>::is_complex;
@@ -123,7 +124,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     for (int k = 0; k < MAXK; ++k) {
       const int i = qi[k], j = qj[k], q = ql[k];
       if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && !((i + j) & 1) && depth(i, j) >= 1)
-        A[q] = relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, pro.inv_c0);
+        A[q] = relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, inv_c0k);
     }
     __syncthreads();
     // ---- black; Helmholtz: the two-pass form re-applies the Robin condition between the colours, so a black node next
@@ -139,7 +140,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
             if (i == n - 2) e = robin_div(A[q], robin_kh);
           }
         }
-        A[q] = relax5(st, A[q], w, e, A[q - ew], A[q + ew], fv[k], om, omm, pro.inv_c0);
+        A[q] = relax5(st, A[q], w, e, A[q - ew], A[q + ew], fv[k], om, omm, inv_c0k);
       }
     }
     __syncthreads();
@@ -150,7 +151,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
       const int i = qi[k], j = qj[k], q = ql[k];
       if (i >= 0) {
         const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && depth(i, j) >= 1;
-        B[q] = inner ? relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, pro.inv_c0) : A[q];
+        B[q] = inner ? relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, inv_c0k) : A[q];
       }
     }
     __syncthreads();

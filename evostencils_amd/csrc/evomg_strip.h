@@ -84,7 +84,23 @@ template <bool NT = false> __device__ __forceinline__ void store_pair(cplx* __re
 __device__ __forceinline__ double div_c0(double r, double c0, double inv_c0) {
   return inv_c0 != 0.0 ? r * inv_c0 : r / c0;
 }
-__device__ __forceinline__ cplx div_c0(cplx r, cplx c0, double) { return sc_div(r, c0); }
+// complex: inv_c0 != 0 is the refined reciprocal y of d = |c0|^2 (relax_div_const below, formed once per kernel): sc_div's two
+// quotients by d — the divisor is the same for every node of the launch — as three operations each (evomg_scalar.h: const_div,
+// the compiler's own division sequence with its divisor-only part hoisted: the same bits) instead of eleven, a rcp among them;
+// a complex relaxation is 50 instead of 69 FP64 instructions
+__device__ __forceinline__ cplx div_c0(cplx r, cplx c0, double inv_c0) {
+  if (inv_c0 == 0.0) return sc_div(r, c0);
+  const double d = c0.re * c0.re + c0.im * c0.im;            // sc_div's own numerators and denominator
+  const ConstDiv<double> cd{d, inv_c0};
+  return cplx{const_div(r.re * c0.re + r.im * c0.im, cd), const_div(r.im * c0.re - r.re * c0.im, cd)};
+}
+// what a kernel hands relax5 as inv_c0: real problems the host's exact reciprocal of a power-of-two centre (or 0); complex
+// problems the device-formed reciprocal of |c0|^2 when the host asks for it (host_inv_c0 != 0: impl_launch2d.inl inv_c0)
+__device__ __forceinline__ double relax_div_const(const Stencil<double>&, double host_inv_c0) { return host_inv_c0; }
+__device__ __forceinline__ double relax_div_const(const Stencil<cplx>& st, double host_inv_c0) {
+  if (host_inv_c0 == 0.0) return 0.0;
+  return const_div_make(st.c[0].re * st.c[0].re + st.c[0].im * st.c[0].im).y;
+}
 template <typename T>
 __device__ __forceinline__ T relax5(const Stencil<T>& st, T c, T w, T e, T s, T n, T f, double om, double omm, double inv_c0 = 0.0) {
   T r = f;
@@ -154,6 +170,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const bool col_ok = c0 >= 0 && c0 < n;                    // c0+1 <= n < pitch: the pair load stays inside the row
   const int y0 = chunk * rows_per_chunk;
   const int y1 = min(y0 + rows_per_chunk, n);               // stored rows [y0, y1)
+  const double inv_c0k = relax_div_const(st, pro.inv_c0);    // relax5's divisor-side constant
   const T zero = scalar_traits<T>::zero();
   const Pair<T> zpair{zero, zero};
   const bool inner_a = c0 >= 1 && c0 <= n - 2;
@@ -361,8 +378,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           const T wa = from_left(xc.b), eb = from_right(xc.a);
           Pair<T> out;
           if constexpr (MODE == STRIP_JACOBI) {
-            out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm, pro.inv_c0) : xc.a;
-            out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm, pro.inv_c0) : xc.b;
+            out.a = (row_inner && inner_a) ? relax5(st, xc.a, wa, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0k) : xc.a;
+            out.b = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, eb, xm.b, xp.b, fc.b, om, omm, inv_c0k) : xc.b;
             if (row_inner) robin_fix(out);
             if (store_lane && j >= y0 && j < y1) store_pair<NT_XY>(y + pitch * j + c0, out);
             if constexpr (TAIL) {
@@ -394,10 +411,10 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
           T rc;
           if (parity == 0) {
             const T w = from_left(xc.b);
-            rc = (row_inner && inner_a) ? relax5(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, pro.inv_c0) : xc.a;
+            rc = (row_inner && inner_a) ? relax5(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0k) : xc.a;
           } else {
             const T e = from_right(xc.a);
-            rc = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, pro.inv_c0) : xc.b;
+            rc = (row_inner && inner_b) ? relax5(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0k) : xc.b;
           }
           // ---- black nodes of row j-1 from the new reds of rows j-2 (rm2), j-1 (rm1), j (rc) ----
           const int jb = j - 1;
@@ -416,12 +433,12 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
                 if (c0 + 1 == n - 2) e = sc_div(xm.b, den);
               }
             }
-            const T bl = (brow_inner && inner_b) ? relax5(st, xm.b, w, e, rm2, rc, fm.b, om, omm, pro.inv_c0) : xm.b;
+            const T bl = (brow_inner && inner_b) ? relax5(st, xm.b, w, e, rm2, rc, fm.b, om, omm, inv_c0k) : xm.b;
             out.a = rm1;
             out.b = bl;
           } else {                      // red = b, black = a
             const T w = from_left(rm1);
-            const T bl = (brow_inner && inner_a) ? relax5(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, pro.inv_c0) : xm.a;
+            const T bl = (brow_inner && inner_a) ? relax5(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0k) : xm.a;
             out.a = bl;
             out.b = rm1;
           }

@@ -113,7 +113,8 @@
     if (!(m == 0.5 || m == -0.5) || e < -900 || e > 900 || !pow2_reciprocal_) return 0.0;
     return 1.0 / st.c[0];
   }
-  static double inv_c0(const Stencil<cplx>&) { return 0.0; }
+  // complex: a flag — non-zero asks the kernels to divide by |c0|^2 with its reciprocal formed once per launch (evomg_strip.h: div_c0)
+  static double inv_c0(const Stencil<cplx>&) { return cplx_const_div_ ? 1.0 : 0.0; }
 
   bool use_strip(const Geo& g) const { return dim_ == 2 && strip_enabled_ && g.n >= strip_min_n_; }
   // Non-temporal placement of the 2D strip kernels (template flag NT_XY): on a level whose three arrays (x, y, f) exceed

@@ -26,6 +26,7 @@
   bool dirty_[24][EVOMG_F_COUNT];
   const T* clean_ptr_[24][EVOMG_F_COUNT];
   static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
+  static inline const bool cplx_const_div_ = getenv("EVOMG_NO_CPLX_CONST_DIV") == nullptr;   // complex relaxations: the division by the centre with its divisor-only part hoisted
   bool pow2_fma_ = getenv("EVOMG_NO_POW2_FMA") == nullptr;       // 3D tiles: fused neighbour terms where the coefficients are powers of two
   // cross-iteration fusion on the finest 2D level (evomg_strip_cross.h): EVOMG_NO_XFUSE switches it off (same bits either way)
   bool xfuse_enabled_ = getenv("EVOMG_NO_XFUSE") == nullptr;

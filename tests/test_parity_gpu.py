@@ -800,6 +800,38 @@ def test_small_grid_lds_sweeps_do_not_change_a_bit(native, kind, smoother, pre, 
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("smoother,hi", [("rbgs", 7), ("jacobi", 7), ("rbgs", 9)])
+def test_complex_relaxations_divide_by_the_centre_with_a_hoisted_reciprocal(native, oracle, smoother, hi, monkeypatch):
+    """A complex relaxation divides by the stencil's centre: two real quotients by |c0|^2, the same divisor at every node of a
+    launch. The kernels (strips and LDS tiles) run the compiler's own division sequence with its divisor-only part formed once
+    per launch (evomg_strip.h: div_c0, evomg_scalar.h: const_div) — against the plain divisions (EVOMG_NO_CPLX_CONST_DIV):
+    identical histories and fields on every level; and the oracle's history to 1e-10 on the small hierarchy."""
+    from test_full_size_gpu import vcycle
+    lo = 3
+    pd = problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi))
+    part, om = (abi.PART_RED_BLACK, 0.6) if smoother == "rbgs" else (abi.PART_SINGLE, 0.6)
+    ops = vcycle(lo, hi, 2, 1, lambda L: abi.make_op(abi.OP_SMOOTH, L, abi.F_SOL, 0, abi.F_RHS, part, (1, 1, 1), om))
+    results = []
+    for knob in (None, "EVOMG_NO_CPLX_CONST_DIV"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        h = native.create(pd)
+        out = h.evaluate(ops, 1, 0, 64)
+        results.append((out, [h.get_field(L, f) for L in range(lo + 1, hi + 1) for f in (abi.F_SOL, abi.F_RHS)] + [h.get_field(hi, abi.F_RES)]))
+        h.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    (a, fa), (b, fb) = results
+    assert a.n_iterations == b.n_iterations and a.n_iterations >= 1
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+    if hi <= 7:
+        oo = oracle.create(pd).evaluate(ops, 1, 0, 64)
+        assert oo.n_iterations == a.n_iterations
+        assert (np.abs(a.history - oo.history) / oo.history).max() <= REL_TOL
+
+
 @pytest.mark.parametrize("kind,lo", [("helmholtz", 3), ("helmholtz", 2), ("poisson", 3)])
 def test_one_wave_bicgstab_folds_its_copy_and_zero(native, oracle, kind, lo, monkeypatch):
     """`gen_rhs = RHS; gen_error = 0; gen_mgCycle@min()` on grids up to 9^2 with BiCGStab as ONE launch (the kernel copies the
