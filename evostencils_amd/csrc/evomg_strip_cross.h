@@ -127,7 +127,7 @@ __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st,
 // grid: ceil(strips * chunks / 4) blocks (multiple of 8) of 256 threads = 4 independent waves; rows_per_chunk: multiple of 16
 // RECIP: every coefficient of the stencil is a power of two (see cross_relax5)
 template <bool NT_XY, bool PRO, bool TAILR, bool RECIP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // two waves per SIMD is what the chunks give it: scheduled for that, 1.5-2.5 % (same box, profiles/r05_cross_timing_raw.txt)
 evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ y,
                     int rows_per_chunk, int n_strips, int n_waves, CrossArgs a) {
   const int per_xcd = gridDim.x >> 3;
