@@ -161,7 +161,7 @@ def test_register_budgets_the_documentation_states_hold_in_the_built_code_object
         if name.split("EEv3Geo")[0].endswith("Lb1"):
             assert r["vgpr"] + r["agpr"] <= 168 and r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
     headline = next(v for k, v in cross.items() if "ILb1ELb1ELb1ELb1E" in k)
-    assert headline["vgpr"] == 158
+    assert headline["vgpr"] == 156                    # DESIGN.md 0 / 11 (158 before the kernel was scheduled for two waves per SIMD)
     # the single-reduction CG kernels: nothing spills (a spill inside a latency chain is a round trip to memory per iteration)
     cg1 = {k: v for k, v in res.items() if "evomg_cg1_" in k}
     assert len(cg1) >= 14
