@@ -21,7 +21,7 @@ int next_cg_phase() {
 }
 namespace {
 const bool g_spin_waits = getenv("EVOMG_SPIN_WAITS") != nullptr;
-const long g_wait_sleep_ns = getenv("EVOMG_WAIT_SLEEP_US") ? 1000L * atol(getenv("EVOMG_WAIT_SLEEP_US")) : 20000L;
+constexpr long g_wait_sleep_ns = 20000L;             // 5, 20 and 50 us measured alike (profiles/r05_throughput.md)
 template <typename Q> hipError_t sleepy_wait(Q&& query) {
   // a sleeping thread wakes `timer slack` late (50 us by default, two to three times the sleep asked for): 1 us for this thread
   static thread_local const bool slack_set = (prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0), true);

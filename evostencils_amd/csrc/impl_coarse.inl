@@ -197,8 +197,7 @@
   // into workgroups is free
   int launch_cg1(const Level<T>& lv, T* x, const T* b, T* r, T* b_copy) {
     switch (lv.g.n - 2) {
-      case 127:                                    // 32 waves: on eight compute units, or on four (same bits)
-        if (cg1_groups_ == 4) return launch_cg1_as<4, 2, 1, 8, true, 3>(lv, x, b, r, b_copy, 4);
+      case 127:                                    // 32 waves: eight workgroups of four (four of eight: same bits, measured slower)
         return launch_cg1_as<4, 2, 1, 4, true, 3>(lv, x, b, r, b_copy, 8);
       case 63: return launch_cg1_as<16, 1, 1, 4, false, 15>(lv, x, b, r, b_copy, 1);
       case 31: return launch_cg1_as<4, 1, 2, 4, false, 3>(lv, x, b, r, b_copy, 1);

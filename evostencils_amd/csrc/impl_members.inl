@@ -69,7 +69,6 @@
   // placed on one XCD; a solve that misses its rendezvous in that mode turns it off for the handle before the retry
   bool cg_local_exchange_ = getenv("EVOMG_NO_LOCAL_EXCHANGE") == nullptr;
   bool cg1_wave_autonomous_ = getenv("EVOMG_CG1_COLLECTOR") == nullptr;      // one-XCD placement: every wave exchanges for itself
-  int cg1_groups_ = getenv("EVOMG_CG1_GROUPS") ? atoi(getenv("EVOMG_CG1_GROUPS")) : 8;
   bool cg_lds_attr_set_[24] = {};
   int prof_opcode_ = -1, prof_level_ = -1;
   size_t prof_used_ = 0;
