@@ -659,6 +659,8 @@ class ProgramGeneratorPool:
             raise ValueError("n_workers must be at least 1")
         if time_objective not in ("contended", "isolated"):
             raise ValueError("time_objective must be 'contended' or 'isolated'")
+        from .. import population
+        population.warn_if_too_many_workers(n_workers)
         self._time_objective, self._probe_iterations = time_objective, probe_iterations
         self._cond = threading.Condition()
         self._active = 0                # solves in flight

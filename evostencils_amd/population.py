@@ -224,6 +224,20 @@ def evaluate_population_dynamic(evaluate: Callable[[int], Tuple[float, float, fl
     return [(i, r[1], r[2], r[3]) for i, r in enumerate(rows)], mine
 
 
+MAX_WORKERS_PER_GPU = 16
+
+
+def warn_if_too_many_workers(n_workers: int) -> None:
+    """Sixteen handles per process is the measured optimum AND a limit (profiles/r05_throughput.md): every handle owns a HIP
+    stream, `import evostencils_amd` asks the runtime for 24 hardware queues, and with more live streams than those carry every
+    launch of the process slows down — the isolated ones as well (18 workers: sequential solves -10 %, the isolated time objective
+    off by up to 19 %)."""
+    if n_workers > MAX_WORKERS_PER_GPU:
+        import warnings
+        warnings.warn(f"{n_workers} candidates in flight per GPU: more than {MAX_WORKERS_PER_GPU} live streams slow every launch "
+                      f"of the process, isolated solves and time-objective probes included (profiles/r05_throughput.md)", RuntimeWarning, stacklevel=3)
+
+
 class ConcurrentEvaluator:
     """Throughput mode for ONE GPU: `n_workers` independent ProgramGenerator instances (own HIP stream, own set of
     level fields) driven by as many host threads, so that several candidates are in flight on the device at once.
@@ -237,6 +251,7 @@ class ConcurrentEvaluator:
     def __init__(self, make_generator: Callable[[], object], n_workers: int):
         from concurrent.futures import ThreadPoolExecutor
         import threading
+        warn_if_too_many_workers(n_workers)
         self.generators = [make_generator() for _ in range(n_workers)]
         self._pool = ThreadPoolExecutor(max_workers=n_workers)
         self._local = threading.local()

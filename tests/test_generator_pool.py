@@ -182,3 +182,17 @@ def test_a_solve_that_raises_last_still_hands_the_probes_over():
     assert isinstance(results["raises"], RuntimeError)
     assert results["parks"] == (7.0, 0.5, 9.0)
     pool.close()
+
+
+def test_more_workers_than_the_hardware_queues_carry_is_said_aloud():
+    """More than sixteen handles per process slow every launch of it (profiles/r05_throughput.md): the pool and the evaluator
+    warn instead of silently handing the optimizer a distorted time objective."""
+    import warnings
+    from evostencils_amd import population
+    with pytest.warns(RuntimeWarning, match="in flight per GPU"):
+        ProgramGeneratorPool(_FakeGenerator, population.MAX_WORKERS_PER_GPU + 1)
+    with pytest.warns(RuntimeWarning, match="in flight per GPU"):
+        population.ConcurrentEvaluator(_FakeGenerator, population.MAX_WORKERS_PER_GPU + 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ProgramGeneratorPool(_FakeGenerator, population.MAX_WORKERS_PER_GPU)
