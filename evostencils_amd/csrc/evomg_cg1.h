@@ -122,6 +122,7 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   static_assert(!MULTI || H == 1, "several workgroups: full-width bands only");
   static_assert(!AUTO || MULTI, "wave-autonomous exchange: the multi-workgroup form");
   constexpr int C = 64 / H;                          // lanes per band
+  prio_latency();                                    // with candidates in flight: ahead of the streaming waves on its SIMDs
   int group = 0;
   if constexpr (MULTI) {
     // only the blocks `phase` modulo `stride` take part: workgroups are dealt to the XCDs round-robin, so stride 8 puts the
@@ -463,6 +464,7 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
                  int maxit, double tol, int* __restrict__ info, evomg_u64* __restrict__ ll, unsigned seq_base, int stride, int try_local, int phase = 0) {
   constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
   if ((int)blockIdx.x % stride != phase) return;         // `phase`: which XCD (evomg_cg1_band2d)
+  prio_latency();
   const int grp = (int)blockIdx.x / stride;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double* wave_sums = reinterpret_cast<double*>(lds_raw);       // [parity][64]: (r, r) of wave q at q, (w, r) at 32 + q

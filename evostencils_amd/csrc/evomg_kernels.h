@@ -11,7 +11,30 @@ struct Geo {
   int n;          // nodes per dimension
   int pitch;      // elements per row
   long plane;     // elements per z-plane (pitch * n), 0 for 2D
+  int prio;       // != 0: launches on this level sit on a candidate's critical path without filling the device (prio_level)
 };
+
+// ---- issue priority (round 6) --------------------------------------------------------------------------------------------
+// With candidates in flight the waves of one candidate's latency-bound launches (coarse-grid solves on eight units, final
+// reductions, one-workgroup levels, the levels below the finest) share SIMDs with the streaming waves of other candidates'
+// finest-level sweeps: at equal priority the arbiter alternates and a 0.5 ms coarse solve takes 1.3 ms, a 3 us reduction 86
+// (profiles/r05_throughput.md). s_setprio raises the issuing wave's priority for the rest of its life: the latency-bound
+// waves win the issue slot whenever they are ready, the streaming waves take the gaps (there are plenty: a coarse-solve
+// wave waits for its exchange most of an iteration). Alone on the device nothing changes. 0 = off (developer builds).
+#ifndef EVOMG_PRIO_LATENCY
+#define EVOMG_PRIO_LATENCY 3     // coarse solves, reductions, one-workgroup launches
+#endif
+#ifndef EVOMG_PRIO_LEVEL
+#define EVOMG_PRIO_LEVEL 2       // streaming kernels on levels below the handle's finest (Geo::prio)
+#endif
+__device__ __forceinline__ void prio_latency() {
+  if constexpr (EVOMG_PRIO_LATENCY > 0) __builtin_amdgcn_s_setprio(EVOMG_PRIO_LATENCY);
+}
+__device__ __forceinline__ void prio_level(const Geo& g) {
+  if constexpr (EVOMG_PRIO_LEVEL > 0) {
+    if (g.prio) __builtin_amdgcn_s_setprio(EVOMG_PRIO_LEVEL);       // kernel argument: a scalar branch
+  }
+}
 
 template <int DIM> __device__ __forceinline__ long gidx(const Geo& g, int i, int j, int k) {
   if (DIM == 2) return (long)i + (long)g.pitch * j;
@@ -646,6 +669,7 @@ __global__ void __launch_bounds__(256) evomg_residual_dot_partial(Geo g, Stencil
 // pass 2: one block sums the partials in a fixed order
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_dot_final(const T* __restrict__ partial, int count, T* __restrict__ out) {
+  prio_latency();
   __shared__ T red[17];
   T s = scalar_traits<T>::zero();
   // eight loads in flight per thread, added in the order they would have been added one by one: with candidates in flight a
@@ -731,6 +755,7 @@ __global__ void __launch_bounds__(256) evomg_axpy_dots(Geo g, T* __restrict__ z,
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_dot_final_quot(const T* __restrict__ partial, int count, int ndot, T num, T* __restrict__ scal, int slot,
                                                             int num_slot = -1) {
+  prio_latency();
   __shared__ T red[17];
   T d[2] = {scalar_traits<T>::zero(), scalar_traits<T>::zero()};
   for (int k = 0; k < ndot; ++k) {
@@ -841,6 +866,7 @@ __global__ void __launch_bounds__(256) evomg_axpy2(Geo g, T* __restrict__ z, con
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_dot_final2(const T* __restrict__ partial, int count, int ndot, T* __restrict__ out,
                                                         T* __restrict__ host_out = nullptr, int beta_step = 0) {
+  prio_latency();
   __shared__ T red[17];
   for (int d = 0; d < ndot; ++d) {
     T s = scalar_traits<T>::zero();

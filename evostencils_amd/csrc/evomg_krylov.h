@@ -194,6 +194,7 @@ template <typename T, int DIM>
 __global__ void __launch_bounds__(EVOMG_KRYLOV_THREADS)
 evomg_cg_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r,
                    T* __restrict__ p, T* __restrict__ ap, int maxit, double tol, int* __restrict__ info) {
+  prio_latency();
   __shared__ T red[17];
   const KrylovOwn own = krylov_own<DIM>(g.n, !scalar_traits<T>::is_complex);
   const T zero = scalar_traits<T>::zero();
@@ -260,6 +261,7 @@ evomg_bicgstab_single_wg(Geo g, Stencil<T> st, T* __restrict__ x, const T* __res
                          T* __restrict__ p, T* __restrict__ nu, T* __restrict__ hh, T* __restrict__ s,
                          T* __restrict__ t, T* __restrict__ rhat, int maxit, double tol, double kh,
                          int* __restrict__ info) {
+  prio_latency();
   __shared__ T red[17];
   const KrylovOwn own = krylov_own<DIM>(g.n);
   const T zero = scalar_traits<T>::zero();
@@ -441,6 +443,7 @@ template <typename T, bool ROBIN, bool XZERO = false>
 __global__ void __launch_bounds__(64)
 evomg_bicgstab_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ f, T* __restrict__ r_out, int maxit, double tol,
                       double kh, int* __restrict__ info, T* __restrict__ copy_dst = nullptr) {
+  prio_latency();
   evomg_bicgstab_wave2d_body<T, ROBIN, XZERO>(g, st, x, f, r_out, maxit, tol, kh, info, copy_dst);
 }
 
@@ -488,6 +491,7 @@ template <typename T, int R, int E, int MASK_FROM, bool POW2 = false, bool XZERO
 __global__ void __launch_bounds__(512)
 evomg_cg_reg2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit,
                double tol, int* __restrict__ info, T* __restrict__ b_copy = nullptr) {
+  prio_latency();
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* red = reinterpret_cast<T*>(lds_raw);          // 2 x 16 wave sums (double-buffered)
   T* row_seam = red + 32;                          // [wave][0: first row, 1: row R-1][element][lane]
@@ -825,6 +829,7 @@ template <typename T, bool XZERO, int MASK_FROM, bool POW2 = false>
 __global__ void __launch_bounds__(64)
 evomg_cg_wave2d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, T* __restrict__ b_copy,
                 int maxit, double tol, int* __restrict__ info) {
+  prio_latency();
   evomg_cg_wave2d_body<T, XZERO, MASK_FROM, POW2>(g, st, x, b, r_out, b_copy, maxit, tol, info);
 }
 
@@ -840,6 +845,7 @@ template <typename T>
 __global__ void __launch_bounds__(64)
 evomg_cg_wave3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict__ b, T* __restrict__ r_out, int maxit, double tol,
                 int* __restrict__ info) {
+  prio_latency();
   constexpr int S = EVOMG_CG_WAVE3D_MAX_M;
   __shared__ T img[S * (S + 2) * (S + 2)];
   const int m = g.n - 2, W = m + 2, PS = W * W;
@@ -1521,6 +1527,7 @@ evomg_cg_multi_wg3d(Geo g, Stencil<T> st, T* __restrict__ x, const T* __restrict
   static_assert(!scalar_traits<T>::is_complex, "the LL words carry one double");
   constexpr int G = EVOMG_CG_GROUPS, S = EVOMG_CG_SLAB;
   if ((int)blockIdx.x % stride != 0) return;
+  prio_latency();
   const int w = (int)blockIdx.x / stride;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* red = reinterpret_cast<T*>(lds_raw);              // 2 x 16 wave sums

@@ -34,6 +34,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   // nsweeps > 1 (red-black, ONE tile only — host-checked): that many identical sweeps in place before the tail, each followed
   // by the Robin columns as the separate ops would leave them
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "smoother modes only");
+  prio_latency();
   extern __shared__ __align__(16) unsigned char small_lds[];
   constexpr int MAXK = 2;                                   // (33 + 8)^2 nodes / 1024 threads
   constexpr int H = EVOMG_SMALL2D_HALO, BIG = 1 << 20;

@@ -157,6 +157,7 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
   if (wave >= n_waves) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const int strip = wave % n_strips;
   const int chunk = wave / n_strips;
@@ -492,6 +493,7 @@ evomg_strip_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict_
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
   if (wave >= n_waves) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const int strip = wave % n_strips;
   const int chunk = wave / n_strips;
@@ -609,6 +611,7 @@ evomg_strip_prolong(Geo g, Geo gc, const T* __restrict__ coarse, T* __restrict__
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
   if (wave >= n_waves) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const int strip = wave % n_strips;
   const int chunk = wave / n_strips;
@@ -761,6 +764,7 @@ evomg_strip3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -860,6 +864,7 @@ evomg_strip3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const int ytile = (logical_block % n_ygroups) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -37,6 +37,7 @@ evomg_strip2d_block(Geo g, Stencil<T> st, BlockPlan<T> pl, const T* __restrict__
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
   const int lane = threadIdx.x & 63;
+  prio_level(g);
   if (wave >= n_waves) {
     // two-cell shapes: what a cut tile leaves is a single node, i.e. a point relaxation (as evomg_block_jacobi_fast does).
     // The waves behind the strip waves walk that line — the last inner column (BX = 2) or row (BY = 2) — 64 nodes each,

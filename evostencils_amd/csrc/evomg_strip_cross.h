@@ -60,7 +60,12 @@ struct CrossArgs {
 // (4 fused instead of 4 + 4 in a relaxation, 4 instead of 8 in a residual; out-of-range intermediates — |values| beyond 1e300
 // or below 1e-300 — are the only place the two forms could part). Likewise om * (r * 2^-k) = (om * 2^-k) * r. The general form
 // is relax5 / residual5 of evomg_strip.h with the division (or the exact reciprocal) chosen by `inv_c0` at run time.
-template <bool POW2>
+// UNIT (with POW2 only): the relaxation factor is 1 — BASELINE's C2 cycle, and ExaStencils' own default smoothers are close to
+// it. omm = 1 - 1 = 0, so `omm * c + om_inv * r` is (+-0) + om_inv * r = om_inv * r: the same value from ONE instruction instead
+// of three (8 of a row step's 64 FP64 instructions, and FP64 issue is what two thirds of this launch are). The only bits that
+// can differ are the SIGN of an exact zero ((+0) + (-0) = +0, the product alone gives -0): no comparison, norm or later value
+// can tell them apart (a zero of either sign times a finite coefficient adds nothing to an fma).
+template <bool POW2, bool UNIT = false>
 __device__ __forceinline__ double cross_relax5(const Stencil<double>& st, double c, double w, double e, double s, double n, double f,
                                                double om, double omm, double inv_c0, double om_inv) {
   if constexpr (POW2) {
@@ -69,7 +74,8 @@ __device__ __forceinline__ double cross_relax5(const Stencil<double>& st, double
     r = __builtin_fma(-st.c[2], e, r);
     r = __builtin_fma(-st.c[3], s, r);
     r = __builtin_fma(-st.c[4], n, r);
-    return omm * c + om_inv * r;
+    if constexpr (UNIT) return om_inv * r;
+    else return omm * c + om_inv * r;
   } else {
     return relax5(st, c, w, e, s, n, f, om, omm, inv_c0);
   }
@@ -90,7 +96,7 @@ __device__ __forceinline__ double cross_residual5(const Stencil<double>& st, dou
 
 // one fused two-colour step: reds of row j from (xm, xc, xp) = rows j-1, j, j+1, then blacks of row j-1 from the new reds of
 // rows j-2 (red_slot on entry), j-1 (rm1), j; returns the finished row j-1 and leaves row j's reds in red_slot
-template <bool RECIP>
+template <bool RECIP, bool UNIT = false>
 __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st, int parity, const Pair<double>& xm, const Pair<double>& xc,
                                                        const Pair<double>& xp, const Pair<double>& fc, const Pair<double>& fm, double& red_slot,
                                                        double rm1, bool row_inner, bool brow_inner, bool inner_a, bool inner_b, double om,
@@ -101,22 +107,22 @@ __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st,
   double rc;
   if (parity == 0) {
     const double w = from_left(xc.b);
-    const double t = cross_relax5<RECIP>(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0, om_inv);
+    const double t = cross_relax5<RECIP, UNIT>(st, xc.a, w, xc.b, xm.a, xp.a, fc.a, om, omm, inv_c0, om_inv);
     rc = (row_inner && inner_a) ? t : xc.a;
   } else {
     const double e = from_right(xc.a);
-    const double t = cross_relax5<RECIP>(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0, om_inv);
+    const double t = cross_relax5<RECIP, UNIT>(st, xc.b, xc.a, e, xm.b, xp.b, fc.b, om, omm, inv_c0, om_inv);
     rc = (row_inner && inner_b) ? t : xc.b;
   }
   Pair<double> out;
   if (parity == 1) {            // row j-1 even: red = a, black = b
     const double e = from_right(rm1);
-    const double t = cross_relax5<RECIP>(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0, om_inv);
+    const double t = cross_relax5<RECIP, UNIT>(st, xm.b, rm1, e, rm2, rc, fm.b, om, omm, inv_c0, om_inv);
     out.a = rm1;
     out.b = (brow_inner && inner_b) ? t : xm.b;
   } else {                      // red = b, black = a
     const double w = from_left(rm1);
-    const double t = cross_relax5<RECIP>(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0, om_inv);
+    const double t = cross_relax5<RECIP, UNIT>(st, xm.a, w, rm1, rm2, rc, fm.a, om, omm, inv_c0, om_inv);
     out.a = (brow_inner && inner_a) ? t : xm.a;
     out.b = rm1;
   }
@@ -126,10 +132,12 @@ __device__ __forceinline__ Pair<double> cross_rb_step(const Stencil<double>& st,
 
 // grid: ceil(strips * chunks / 4) blocks (multiple of 8) of 256 threads = 4 independent waves; rows_per_chunk: multiple of 16
 // RECIP: every coefficient of the stencil is a power of two (see cross_relax5)
-template <bool NT_XY, bool PRO, bool TAILR, bool RECIP>
+// UNIT: both relaxation factors and the weight of the folded prolongation are 1 (host-checked), RECIP only
+template <bool NT_XY, bool PRO, bool TAILR, bool RECIP, bool UNIT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // two waves per SIMD is what the chunks give it: scheduled for that, 1.5-2.5 % (same box, profiles/r05_cross_timing_raw.txt)
 evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ y,
                     int rows_per_chunk, int n_strips, int n_waves, CrossArgs a) {
+  static_assert(!UNIT || RECIP, "the unit-weight form is a form of the power-of-two one");
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(logical_block * 4 + (threadIdx.x >> 6)));
@@ -181,16 +189,31 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
   auto corrected = [&](const Pair<double>& raw, int row, bool odd, const Pair<double>& cJp, const Pair<double>& cJ1p, bool edge = true) -> Pair<double> {
     const bool row_in = !edge || (row >= 1 && row <= n - 2);
     const double cJ = cJp.a, cJr = cJp.b;
-    double va, vb;
-    if (!odd) {
-      va = cJ;
-      vb = 0.5 * (cJ + cJr);
+    double ca, cb;
+    if constexpr (UNIT) {
+      // om_p = 1: 1 * v = v, and the products with 1/2 and 1/4 are exact, so fma(0.5, s, x) rounds x + 0.5 s once, as the
+      // product followed by the sum does: the same bits from 3 / 6 instructions per row instead of 6 / 10
+      if (!odd) {
+        ca = raw.a + cJ;
+        cb = __builtin_fma(0.5, cJ + cJr, raw.b);
+      } else {
+        const double cJ1 = cJ1p.a, cJ1r = cJ1p.b;
+        ca = __builtin_fma(0.5, cJ + cJ1, raw.a);
+        cb = __builtin_fma(0.25, (cJ + cJr) + (cJ1 + cJ1r), raw.b);
+      }
     } else {
-      const double cJ1 = cJ1p.a, cJ1r = cJ1p.b;
-      va = 0.5 * (cJ + cJ1);
-      vb = 0.25 * ((cJ + cJr) + (cJ1 + cJ1r));
+      double va, vb;
+      if (!odd) {
+        va = cJ;
+        vb = 0.5 * (cJ + cJr);
+      } else {
+        const double cJ1 = cJ1p.a, cJ1r = cJ1p.b;
+        va = 0.5 * (cJ + cJ1);
+        vb = 0.25 * ((cJ + cJr) + (cJ1 + cJ1r));
+      }
+      ca = raw.a + a.om_p * va;
+      cb = raw.b + a.om_p * vb;
     }
-    const double ca = raw.a + a.om_p * va, cb = raw.b + a.om_p * vb;
     Pair<double> out;
     out.a = (row_in && (!edge || inner_a)) ? ca : raw.a;
     out.b = (row_in && (!edge || inner_b)) ? cb : raw.b;
@@ -221,11 +244,16 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
     xq[k] = load_row(x, js + 1 + k);
     fq[k] = load_row_f(f, js + k);
   }
-  Pair<double> c_lo = zpair, c_hi = zpair;
+  // coarse rows of the folded prolongation: a ring of three (static indices: three coarse rows per six fine ones) — the rows
+  // (r >> 1), (r >> 1) + 1 the fine row r = j + 1 of this step lies between, and the next one, so that a coarse row is asked for
+  // four steps before it is first read (the vector-memory counter is in order: the SHORTEST prefetch distance of the loop is
+  // the one every wait observes)
+  Pair<double> cr[3] = {zpair, zpair, zpair};
   if constexpr (PRO) {
     const int r0 = js + 1;                                   // may be negative: >> floors, load_coarse clamps
-    c_lo = load_coarse(r0 >> 1);
-    c_hi = load_coarse((r0 >> 1) + 1);
+    cr[0] = load_coarse(r0 >> 1);
+    cr[1] = load_coarse((r0 >> 1) + 1);
+    cr[2] = load_coarse((r0 >> 1) + 2);
   }
   double nrm = 0.0;
   const double om_inv_a = a.om_a * a.inv_c0, om_inv_b = a.om_b * a.inv_c0;     // POW2: exact (om times a power of two)
@@ -248,26 +276,31 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           const int parity = (1 + d) & 1;                      // js is odd
           Pair<double> xp = xq[d % PF];
           const Pair<double> fc = fq[d % PF];
+          if constexpr (UNIT) {
+            // With unit weights the old value of a RED node is never read (x_new = (f - sum of the black neighbours) / c0), so
+            // half of every 16-byte load of x is dead. The register allocator then hands that half out again right behind the
+            // load's issue and the wave stalls at an `s_waitcnt vmcnt(0)` for the load it has just issued — a full memory round
+            // trip every second row step (seen in the ISA: profiles/r06_cross_kernel.md). Naming both halves here, where the row
+            // is consumed PF steps later, keeps the destination reserved until then; no instruction is emitted.
+            asm volatile("" : : "v"(xp.a), "v"(xp.b));
+          }
 #if !(EVOMG_CROSS_TIMING & 2)                                  // 2: no loads of x / f in the loop (the prologue's rows go round)
           xq[d % PF] = load_row(x, j + 1 + PF);
           fq[d % PF] = load_row_f(f, j + PF);
 #endif
           if constexpr (PRO) {
             const bool odd_next = ((parity + 1) & 1) != 0;     // row j + 1
-            xp = corrected(xp, j + 1, odd_next, c_lo, c_hi, EDGE);
-            if (odd_next) {
-              c_lo = c_hi;
+            xp = corrected(xp, j + 1, odd_next, cr[(d >> 1) % 3], cr[((d >> 1) + 1) % 3], EDGE);
 #if !(EVOMG_CROSS_TIMING & 8)                                  // 8: no loads of the coarse correction in the loop
-              c_hi = load_coarse(((j + 1) >> 1) + 2);
+            if (odd_next) cr[(d >> 1) % 3] = load_coarse(((j + 1) >> 1) + 3);      // the slot of the row just left behind
 #endif
-            }
           }
           xw[(d + 1) % 3] = xp;
           fw[d % 6] = fc;
           // ---- sweep A: reds of row j, blacks of row j-1 -> z row j-1 ----
           {
             const bool row_inner = !EDGE || (j >= 1 && j <= n - 2), brow_inner = !EDGE || (j - 1 >= 1 && j - 1 <= n - 2);
-            zw[(d + 2) % 3] = cross_rb_step<RECIP>(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
+            zw[(d + 2) % 3] = cross_rb_step<RECIP, UNIT>(st, parity, xw[(d + 2) % 3], xw[d % 3], xw[(d + 1) % 3], fc, fw[(d + 5) % 6], ra[d & 1], ra[(d + 1) & 1],
                                             row_inner, brow_inner, in_a, in_b, a.om_a, a.omm_a, a.inv_c0, om_inv_a);
           }
           const Pair<double>& z3 = zw[d % 3];                  // z rows j-3, j-2, j-1
@@ -295,7 +328,7 @@ evomg_strip2d_cross(Geo g, Stencil<double> st, const double* __restrict__ x, con
           {
             const int jb = j - 2;
             const bool row_inner = !EDGE || (jb >= 1 && jb <= n - 2), brow_inner = !EDGE || (jb - 1 >= 1 && jb - 1 <= n - 2);
-            const Pair<double> wrow = cross_rb_step<RECIP>(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, in_a,
+            const Pair<double> wrow = cross_rb_step<RECIP, UNIT>(st, parity, z3, z2, z1, f2, f3, rb[d & 1], rb[(d + 1) & 1], row_inner, brow_inner, in_a,
                                                     in_b, a.om_b, a.omm_b, a.inv_c0, om_inv_b);
             ww[d % 3] = wrow;
             const int jw = j - 3;
@@ -347,6 +380,7 @@ static evomg_norm_from_lane_sums(const double* __restrict__ lane_sums, int sums_
                                  double* __restrict__ partials) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (wave >= n_waves) return;
+  prio_latency();
   const int lane = threadIdx.x & 63;
   const int strip = wave % n_strips, c16 = wave / n_strips;
   const int c0 = strip * EVOMG_NORM_STRIP_COLS - 4 + 2 * lane;
@@ -354,4 +388,55 @@ static evomg_norm_from_lane_sums(const double* __restrict__ lane_sums, int sums_
   const double v = store_lane ? lane_sums[(long)c16 * sums_pitch + (c0 >> 1)] : 0.0;
   const double tot = wave_sum(v);
   if (lane == 0) partials[c16 * n_strips + strip] = tot;
+}
+
+// The same, and the loop's norm itself, in ONE launch (round 6): the workgroup whose arrival ticket is the last one adds up
+// all partial sums in evomg_dot_final's order (thread t: partials t, t + 256, ... one after the other; then block_sum) and
+// writes the squared norm where the solver loop waits for it — the reduction launch behind this one (3 us alone, 75-86 us with
+// candidates in flight: a single workgroup launched into saturated units, profiles/r05_throughput.md) is gone.
+// Hand-off between workgroups without fences (MI355X_MICROARCH.md, "Valid forms"): every partial is stored with an sc1
+// (agent-scope) store, the storing waves drain their stores (s_waitcnt vmcnt(0)) before the workgroup's barrier, ONE lane
+// then takes a ticket with an agent-scope atomic add; the workgroup that drew the last ticket reads the partials with sc1
+// loads behind a barrier of its own. The ticket counter is left at zero for the next launch (same stream: ordered).
+__global__ void __launch_bounds__(256)
+static evomg_norm_from_lane_sums_final(const double* __restrict__ lane_sums, int sums_pitch, int n, int n_strips, int n_waves,
+                                       double* __restrict__ partials, unsigned* __restrict__ ticket, double* __restrict__ out) {
+  prio_latency();
+  __shared__ double red[17];
+  __shared__ int is_last;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int lane = threadIdx.x & 63;
+  if (wave < n_waves) {
+    const int strip = wave % n_strips, c16 = wave / n_strips;
+    const int c0 = strip * EVOMG_NORM_STRIP_COLS - 4 + 2 * lane;
+    const bool store_lane = lane >= 2 && lane <= 61 && c0 >= 0 && c0 < n;
+    const double v = store_lane ? lane_sums[(long)c16 * sums_pitch + (c0 >> 1)] : 0.0;
+    const double tot = wave_sum(v);
+    if (lane == 0) __hip_atomic_store(partials + (c16 * n_strips + strip), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double s = 0.0;
+  for (int i0 = threadIdx.x; i0 < n_waves; i0 += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * 256;
+      v[j] = __hip_atomic_load(partials + (i < n_waves ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + j * 256 < n_waves) s = s + v[j];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }

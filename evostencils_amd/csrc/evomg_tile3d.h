@@ -62,6 +62,7 @@ evomg_tile3d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict_
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;                   // whole workgroup: no barrier is skipped by a part of it
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const ConstDiv<T> cdp0 = const_div_make(pl.pivot0), cdp1 = const_div_make(pl.pivot1);
@@ -296,6 +297,7 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -439,6 +441,7 @@ evomg_tile3d_rbgs(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __rest
 // elements b*256 + t, + gridDim.x*256, ...; then the block_sum trees; evomg_dot_final adds the block sums
 template <typename T>
 __global__ void __launch_bounds__(256) evomg_sum_stage1(const T* __restrict__ p, long count, T* __restrict__ out) {
+  prio_latency();
   __shared__ T red[17];
   T s = scalar_traits<T>::zero();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) s = sc_add(s, p[i]);
@@ -491,6 +494,7 @@ evomg_tile3d_twice(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __res
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const ConstDiv<T> cd0 = const_div_make(st.c[0]);     // quotients by the stencil centre (evomg_scalar.h)
   const ConstDiv<T> cdp0 = const_div_make(pl.pivot0), cdp1 = const_div_make(pl.pivot1);
@@ -754,6 +758,7 @@ evomg_tile3d_residual_restrict(Geo g, Geo gc, Stencil<T> st, const T* __restrict
   const int per_xcd = gridDim.x >> 3;
   const int logical_block = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (logical_block >= n_blocks) return;
+  prio_level(g);
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = logical_block % n_strips;                 // strip fastest: concurrent workgroups cover whole rows

@@ -24,6 +24,7 @@
     if (norm_partials_) (void)hipFree(norm_partials_);
     if (xf_rhs_spare_) (void)hipFree(xf_rhs_spare_);
     if (xf_lane_sums_) (void)hipFree(xf_lane_sums_);
+    if (norm_ticket_) (void)hipFree(norm_ticket_);
     if (cg_ll_) (void)hipFree(cg_ll_);
     if (kcg_state_) (void)hipFree(kcg_state_);
     if (kb_state_) (void)hipFree(kb_state_);
@@ -73,6 +74,7 @@
       lv.g.n = n;
       lv.g.pitch = ((n + align - 1) / align) * align;
       lv.g.plane = (dim_ == 3) ? (long)lv.g.pitch * n : 0;
+      lv.g.prio = (L < prob_.max_level) ? 1 : 0;       // evomg_kernels.h: prio_level
       lv.elems = (size_t)lv.g.pitch * n * (dim_ == 3 ? n : 1);
       for (int f = 0; f < EVOMG_F_COUNT; ++f) { bnd_zero_[L][f] = true; dirty_[L][f] = true; clean_ptr_[L][f] = nullptr; }
       for (int f : {EVOMG_F_SOL, EVOMG_F_RHS, EVOMG_F_RES}) HIP_TRY(alloc_zero(&lv.f[f], lv.elems));

@@ -377,7 +377,8 @@
   // Reads SOL@max (x), RHS@max, the coarse correction; writes w into the level's spare array, the next iteration's coarse
   // right-hand side into xf_rhs_spare_, the per-pair norm sums; then reduces those to the canonical partial sums in
   // norm_partials_. Nothing it writes is current until cross_commit().
-  int launch_cross(const evomg_op_t* ops, int n_ops, const CrossPlan& plan) {
+  // *norm_done: the launch has also summed the norm's partial sums (the solver loop queues no reduction of its own)
+  int launch_cross(const evomg_op_t* ops, int n_ops, const CrossPlan& plan, bool* norm_done = nullptr) {
     if constexpr (scalar_traits<T>::is_complex) return invalid("cross-iteration fusion: real problems only");
     else {
       const int L = prob_.max_level;
@@ -429,9 +430,12 @@
         const double m = frexp(lv.st.c[e], &ex);
         recip = recip && (m == 0.5 || m == -0.5) && ex > -900 && ex < 900;
       }
-#define EVOMG_CROSS_LAUNCH(NT, PRO, TR, RC) hipLaunchKernelGGL((evomg_strip2d_cross<NT, PRO, TR, RC>), grid, block, 0, stream_, g, lv.st, x, f, y, rows, strips, waves, a)
-#define EVOMG_CROSS_NT(PRO, TR) do { if (nt && recip) EVOMG_CROSS_LAUNCH(true, PRO, TR, true); else if (nt) EVOMG_CROSS_LAUNCH(true, PRO, TR, false); \
-                                     else if (recip) EVOMG_CROSS_LAUNCH(false, PRO, TR, true); else EVOMG_CROSS_LAUNCH(false, PRO, TR, false); } while (0)
+      // unit weights on both sweeps and on the folded prolongation (the C2 cycle): the kernel's shortest form
+      const bool unit = recip && cross_unit_ && a.om_a == 1.0 && a.om_b == 1.0 && (!plan.pro || a.om_p == 1.0);
+#define EVOMG_CROSS_LAUNCH(NT, PRO, TR, RC, UN) hipLaunchKernelGGL((evomg_strip2d_cross<NT, PRO, TR, RC, UN>), grid, block, 0, stream_, g, lv.st, x, f, y, rows, strips, waves, a)
+#define EVOMG_CROSS_NT(PRO, TR) do { if (nt && unit) EVOMG_CROSS_LAUNCH(true, PRO, TR, true, true); else if (unit) EVOMG_CROSS_LAUNCH(false, PRO, TR, true, true); \
+                                     else if (nt && recip) EVOMG_CROSS_LAUNCH(true, PRO, TR, true, false); else if (nt) EVOMG_CROSS_LAUNCH(true, PRO, TR, false, false); \
+                                     else if (recip) EVOMG_CROSS_LAUNCH(false, PRO, TR, true, false); else EVOMG_CROSS_LAUNCH(false, PRO, TR, false, false); } while (0)
       if (plan.pro && plan.tailr) EVOMG_CROSS_NT(true, true);
       else if (plan.pro) EVOMG_CROSS_NT(true, false);
       else if (plan.tailr) EVOMG_CROSS_NT(false, true);
@@ -445,8 +449,19 @@
         if (rc != EVOMG_OK) return rc;
       }
       const int nwaves_norm = nstrips_norm * chunks16;
-      hipLaunchKernelGGL(evomg_norm_from_lane_sums, dim3((nwaves_norm + 3) / 4), dim3(256), 0, stream_, (const double*)xf_lane_sums_, sums_pitch,
-                         g.n, nstrips_norm, nwaves_norm, norm_partials_);
+      if (norm_fold_) {
+        // canonical partial sums AND their sum — the loop's squared norm — in one launch (the last workgroup to arrive adds up)
+        if (!norm_ticket_) {
+          HIP_TRY(hipMalloc(&norm_ticket_, 128));
+          HIP_TRY(hipMemsetAsync(norm_ticket_, 0, 128, stream_));
+        }
+        hipLaunchKernelGGL(evomg_norm_from_lane_sums_final, dim3((nwaves_norm + 3) / 4), dim3(256), 0, stream_, (const double*)xf_lane_sums_,
+                           sums_pitch, g.n, nstrips_norm, nwaves_norm, (double*)norm_partials_, norm_ticket_, (double*)norm_out());
+        if (norm_done) *norm_done = true;
+      } else {
+        hipLaunchKernelGGL(evomg_norm_from_lane_sums, dim3((nwaves_norm + 3) / 4), dim3(256), 0, stream_, (const double*)xf_lane_sums_, sums_pitch,
+                           g.n, nstrips_norm, nwaves_norm, norm_partials_);
+      }
       HIP_TRY(hipGetLastError());
       return EVOMG_OK;
     }

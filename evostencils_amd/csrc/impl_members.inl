@@ -33,6 +33,9 @@
   // from 2049^2: one long marching pass per wave is a latency chain on smaller levels (same-box A/B of whole V(1,1) solves,
   // fused vs EVOMG_NO_XFUSE: 513^2 1.808 vs 1.747 ms, 1025^2 3.85 vs 3.79, 2049^2 11.89 vs 11.99, 4097^2 13.68 vs 14.12)
   int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 2049;
+  bool norm_fold_ = getenv("EVOMG_NO_NORM_FOLD") == nullptr;        // the cross launch's norm: partial sums and their sum in ONE launch (same bits)
+  unsigned* norm_ticket_ = nullptr;
+  bool cross_unit_ = getenv("EVOMG_NO_CROSS_UNIT") == nullptr;     // the cross kernel's unit-weight form (same bits; tests switch it off)
   int xfuse_rows_ = getenv("EVOMG_XFUSE_ROWS") ? atoi(getenv("EVOMG_XFUSE_ROWS")) : 0;      // chunk height of the cross kernel (tuning)
   T* xf_rhs_spare_ = nullptr;        // spare coarse right-hand side of level max - 1 (speculative output, swapped in on commit)
   T* xf_lane_sums_ = nullptr;        // per (16-row chunk, column pair) sums of the squared residual

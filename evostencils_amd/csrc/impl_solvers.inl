@@ -211,14 +211,14 @@
     if (res0 == 0.0) status = EVOMG_SOLVE_CONVERGED;
     else
       for (it = 1; it <= prob_.max_iterations; ++it) {
-        bool norm_rode_along = false;
+        bool norm_rode_along = false, norm_summed = false;
         // not in the last iteration the loop may run: there is no next cycle to start
         const bool cross = xplan.ok && it < prob_.max_iterations;
         const int first = head_done ? xplan.head_len : ahead;
         head_done = false;
         if (cross) {
           if ((rc = exec_program(ops, n_ops, /*cyclic=*/true, first, nullptr, n_ops - xplan.tail_len)) != EVOMG_OK) return rc;
-          if ((rc = launch_cross(ops, n_ops, xplan)) != EVOMG_OK) return rc;
+          if ((rc = launch_cross(ops, n_ops, xplan, &norm_summed)) != EVOMG_OK) return rc;
           norm_rode_along = true;
         } else rc = exec_program(ops, n_ops, /*cyclic=*/true, first, &norm_rode_along);
         ahead = 0;
@@ -228,7 +228,7 @@
           res_stale = true;
           const Geo& g = lv.g;
           const int parts = ((g.n + EVOMG_NORM_STRIP_COLS - 1) / EVOMG_NORM_STRIP_COLS) * ((g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS);
-          hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, norm_out());
+          if (!norm_summed) hipLaunchKernelGGL((evomg_dot_final<T>), dim3(1), dim3(256), 0, stream_, norm_partials_, parts, norm_out());
           if (!host_norm_) HIP_TRY(hipMemcpyAsync(hscalar_, dscalar_, sizeof(T), hipMemcpyDeviceToHost, stream_));
           HIP_TRY(hipEventRecord(norm_event_, stream_));
         } else {

@@ -37,6 +37,7 @@ class SystemImpl : public ImplBase {
       SLevel& lv = lv_[L];
       const int n = (1 << L) + 1;
       lv.g.n = n;
+      lv.g.prio = 0;
       lv.g.pitch = ((n + 15) / 16) * 16;
       lv.g.plane = 0;
       lv.elems = (size_t)lv.g.pitch * n;

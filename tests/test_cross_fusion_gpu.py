@@ -57,11 +57,16 @@ PLANS = {
     "v12_tailr_only": ([[R(1.2)]], [[R(1.0), R(0.8)]]),
     "v21_pro_only": ([[R(1.0), R(1.0)]], [[R(1.1)]]),
     "jacobi_between": ([[R(1.0)], [J(0.8)]], [[R(1.0)], [J(0.8), R(1.0)]]),   # coarser levels differ; finest still fuses
+    # every weight the launch sees is 1 (BASELINE's C2 cycle): the kernel's unit-weight form (round 6)
+    "v11_unit": ([[R(1.0)]], [[R(1.0)]], 1.0),
+    "v22_unit_plain": ([[R(1.0), R(1.0)]], [[R(1.0), R(1.0)]], 1.0),
+    "v12_unit_tailr_only": ([[R(1.0)]], [[R(0.9), R(1.0)]], 1.0),
+    "v21_unit_pro_only": ([[R(1.0), R(1.1)]], [[R(1.0)]], 1.0),
 }
 
 
 def solve(native, pd, ops, fields, env, monkeypatch):
-    for k in ("EVOMG_NO_XFUSE", "EVOMG_XFUSE_MIN_N", "EVOMG_STRIP_ROWS"):
+    for k in ("EVOMG_NO_XFUSE", "EVOMG_XFUSE_MIN_N", "EVOMG_STRIP_ROWS", "EVOMG_NO_CROSS_UNIT", "EVOMG_NO_NORM_FOLD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -75,9 +80,9 @@ def solve(native, pd, ops, fields, env, monkeypatch):
 @pytest.mark.parametrize("plan", sorted(PLANS))
 @pytest.mark.parametrize("lo,hi,rows", [(5, 8, "0"), (4, 9, "0"), (6, 9, "32"), (6, 10, "0")])
 def test_cross_fusion_does_not_change_a_bit(native, monkeypatch, plan, lo, hi, rows):
-    pre, post = PLANS[plan]
+    pre, post, cgc = (PLANS[plan] + (0.95,))[:3]
     pd = problems.poisson_2d(lo, hi)
-    ops = cycle(lo, hi, pre, post, cgc=0.95)
+    ops = cycle(lo, hi, pre, post, cgc=cgc)
     fields = [(hi, abi.F_SOL), (hi, abi.F_RES), (hi - 1, abi.F_RHS), (hi - 1, abi.F_SOL)]
     env = {"EVOMG_XFUSE_MIN_N": "65"}
     if rows != "0":
@@ -88,6 +93,12 @@ def test_cross_fusion_does_not_change_a_bit(native, monkeypatch, plan, lo, hi, r
     assert np.array_equal(a.history, b.history)
     for x, y, (L, f) in zip(fa, fb, fields):
         assert np.array_equal(x, y), (L, f)
+    if "unit" in plan:
+        # the unit-weight form against the general power-of-two form of the same launch
+        c, fc = solve(native, pd, ops, fields, {**env, "EVOMG_NO_CROSS_UNIT": "1"}, monkeypatch)
+        assert np.array_equal(a.history, c.history)
+        for x, y, (L, f) in zip(fa, fc, fields):
+            assert np.array_equal(x, y), (L, f)
 
 
 @pytest.mark.parametrize("rows", ["16", "48", "80", "96"])
@@ -106,15 +117,15 @@ def test_cross_fusion_at_the_iteration_cap_and_odd_chunk_heights(native, monkeyp
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("plan", ["v11_pro_tailr", "v22_plain", "v12_tailr_only"])
+@pytest.mark.parametrize("plan", ["v11_pro_tailr", "v22_plain", "v12_tailr_only", "v22_unit_plain", "v21_unit_pro_only"])
 def test_cross_fusion_against_the_oracle(native, monkeypatch, plan):
     """1025^2, five levels (the fusion's default threshold is 2049^2, where the oracle takes a minute per solve; the C2 / C5
     tests at full size run through it by default): same iterations, histories to 1e-10, the returned iterate bit for bit."""
     from oracle import oracle
     lo, hi = 6, 10
-    pre, post = PLANS[plan]
+    pre, post = PLANS[plan][:2]
     pd = problems.poisson_2d(lo, hi)
-    ops = cycle(lo, hi, pre, post)
+    ops = cycle(lo, hi, pre, post)                      # (correction weight 1: "v11_pro_tailr" is the all-unit C2 cycle here)
     a, (ua,) = solve(native, pd, ops, [(hi, abi.F_SOL)], {"EVOMG_XFUSE_MIN_N": "1025"}, monkeypatch)
     ho = oracle.create(pd)
     b = ho.evaluate(ops, 1, 0, 128)
@@ -122,6 +133,31 @@ def test_cross_fusion_against_the_oracle(native, monkeypatch, plan):
     assert np.all(np.abs(a.history - b.history) <= 1e-10 * b.history)
     assert np.array_equal(ua, ho.get_field(hi, abi.F_SOL))
     ho.close()
+
+
+@pytest.mark.parametrize("lo,hi", [(5, 8), (5, 9), (6, 10), (7, 11)])
+def test_the_norm_in_one_launch_is_the_norm_in_two(native, monkeypatch, lo, hi):
+    """Round 6: the cross launch's partial sums and their sum in ONE launch (the last workgroup to arrive adds them up in
+    evomg_dot_final's order) against the two launches it replaces — and, sixty solves on one handle, the arrival ticket back at
+    zero every time."""
+    pd = problems.poisson_2d(lo, hi)
+    ops = cycle(lo, hi, [[R(1.0)]], [[R(1.1)]], cgc=0.9)
+    fields = [(hi, abi.F_SOL), (hi - 1, abi.F_RHS)]
+    env = {"EVOMG_XFUSE_MIN_N": "65"}
+    a, fa = solve(native, pd, ops, fields, env, monkeypatch)
+    b, fb = solve(native, pd, ops, fields, {**env, "EVOMG_NO_NORM_FOLD": "1"}, monkeypatch)
+    assert a.status == b.status and a.n_iterations == b.n_iterations >= 2
+    assert np.array_equal(a.history, b.history)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+    if hi <= 9:
+        monkeypatch.delenv("EVOMG_NO_NORM_FOLD", raising=False)
+        monkeypatch.setenv("EVOMG_XFUSE_MIN_N", "65")
+        h = native.create(pd)
+        for _ in range(20):
+            out = h.evaluate(ops, 3, 0, 128)
+            assert np.array_equal(out.history, a.history)
+        h.close()
 
 
 def test_the_plan_is_taken_only_for_red_black_ends(native, monkeypatch):
