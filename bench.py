@@ -140,7 +140,8 @@ def cpu_baseline(ops, lo, hi, threads):
             _u, hist, k, seconds = oracle.tuned_poisson2d(lo, hi, u0, rhs, maxit=pd.max_iterations)
             runs[str(nt)] = {"solves_per_s": 1.0 / seconds, "seconds": seconds}
         best = max(runs, key=lambda q: runs[q]["solves_per_s"])
-        tuned = {"value": runs[best]["solves_per_s"], "unit": "solves/s", "cores": int(best), "kind": "port (tuned OpenMP solver, same algorithm; not bit-comparable with the HIP backend)",
+        tuned = {"value": runs[best]["solves_per_s"], "unit": "solves/s", "cores": int(best), "kind": "port",
+                 "what": "tuned OpenMP C solver, the same algorithm as a CPU code generator writes it (oracle/evomg_cpu_tuned.c); not bit-comparable with the HIP backend",
                  "sample": f"1 full solve of the same workload ({len(hist) - 1} V-cycles, {k} coarse CG iterations)",
                  "build": "oracle/Makefile: gcc -O3 -march=native -fopenmp (contraction on), built on this host",
                  "iterations": len(hist) - 1, "final_over_initial_residual": float(hist[-1] / hist[0]),
@@ -163,28 +164,14 @@ def cpu_baseline(ops, lo, hi, threads):
 
 
 def cpu_share(fallback):
-    """CPUs this process may actually use: its affinity mask, cut down to the cgroup's quota where there is one (a GPU box
+    """CPUs this process may actually use (evostencils_amd.preflight.usable_cores: affinity mask and cgroup quota — a GPU box
     shows all 256 hardware threads to a container that is throttled to 16 of them: an OpenMP team of 256 then spends its time
-    being descheduled), and to 32 (the sweeps are memory-bound well before that)."""
+    being descheduled), cut to 32 (the sweeps are memory-bound well before that)."""
+    from evostencils_amd import preflight
     try:
-        n = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        n = os.cpu_count() or fallback
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            text = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if text[0] != "max":
-                    n = min(n, max(1, int(int(text[0]) / int(text[1]))))
-            else:
-                quota = int(text[0])
-                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if quota > 0:
-                    n = min(n, max(1, quota // period))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return max(1, min(n, 32))
+        return max(1, min(preflight.usable_cores(), 32))
+    except Exception:                                        # noqa: BLE001
+        return max(1, min(fallback, 32))
 
 
 def host_cpu():
@@ -321,6 +308,9 @@ def population_section(args, dist, torch, rank, world, local_rank, reduce_device
                                    "faster of the two)")
             per_candidate = [min(walls_first[i], walls[i]) for i in range(args.population)]
             summary["projected_8gpu"] = _project_ranks(per_candidate, 8)
+            # the times the projection is made from (ms per generate_and_evaluate call, candidate order): the fixture of the
+            # eight-rank rehearsal (tests/golden/c5_candidate_times.json) is one such list
+            summary["per_candidate_ms"] = [round(1e3 * t, 3) for t in per_candidate]
         if mode == "static":
             finite = [r for r in rows if r[3] < 1e99]
             costs = sorted(r[2] for r in rows)
@@ -357,23 +347,10 @@ def _compare_times(reference, other):
 
 
 def _project_ranks(seconds_per_candidate, ranks):
-    """PROJECTION, not a measurement: wall time of one generation on `ranks` GPUs from the per-candidate wall times measured
-    on ONE (candidates are independent, one handle per GPU, no data-path collective: SURVEY 8e). static = the reference's split
-    i % ranks == rank (optimization/program.py:534-536), dynamic = the shared-counter work queue of
-    population.evaluate_population_dynamic (the next free rank takes the next index). The one collective per generation
-    (:582) is a few KiB and is left out."""
-    total = float(sum(seconds_per_candidate))
-    static = max(sum(seconds_per_candidate[r::ranks]) for r in range(ranks))
-    free = [0.0] * ranks
-    for t in seconds_per_candidate:
-        r = min(range(ranks), key=free.__getitem__)
-        free[r] += t
-    dynamic = max(free)
-    return {"ranks": ranks, "what": "PROJECTION from the per-candidate wall times of the sequential passes on one GPU (no multi-GPU "
-                                    "node has been available to any round)",
-            "one_gpu_wall_s": total, "static_wall_s": static, "dynamic_wall_s": dynamic,
-            "static_speedup": total / static, "dynamic_speedup": total / dynamic,
-            "static_efficiency": total / static / ranks, "dynamic_efficiency": total / dynamic / ranks}
+    """PROJECTION, not a measurement (evostencils_amd.population.project_ranks; rehearsed with eight `gloo` ranks replaying a
+    recorded set of per-candidate times in tests/test_population_gloo8.py)."""
+    from evostencils_amd import population
+    return population.project_ranks(seconds_per_candidate, ranks)
 
 
 def reference_size_section(local_rank, rank, steps=20, warmup=3, in_flight=0):

@@ -13,44 +13,65 @@ namespace evomg_detail {
 
 thread_local char g_create_error[512] = "";
 
-std::atomic<int> g_evaluations_in_flight{0};
-int evaluations_in_flight() { return g_evaluations_in_flight.load(std::memory_order_relaxed); }
+// evaluations under way PER DEVICE (one process driving several GPUs with one candidate each is alone on every one
+// of them). The entry points of the C-ABI note the handle's device for the calling thread (InFlight); the waits and the
+// coarse-solve placement of that thread consult that device's count.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_evaluations_in_flight[kMaxDevices];
+thread_local int tl_device = -1;
+int evaluations_in_flight() {
+  return tl_device >= 0 ? g_evaluations_in_flight[tl_device].load(std::memory_order_relaxed) : 0;
+}
 int next_cg_phase() {
   static std::atomic<int> counter{0};
   return counter.fetch_add(1, std::memory_order_relaxed) & 0x7fff;
 }
 namespace {
-const bool g_spin_waits = getenv("EVOMG_SPIN_WAITS") != nullptr;
 constexpr long g_wait_sleep_ns = 20000L;             // 5, 20 and 50 us measured alike (profiles/r05_throughput.md)
 template <typename Q> hipError_t sleepy_wait(Q&& query) {
-  // a sleeping thread wakes `timer slack` late (50 us by default, two to three times the sleep asked for): 1 us for this thread
-  static thread_local const bool slack_set = (prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0), true);
-  (void)slack_set;
+  // a sleeping thread wakes `timer slack` late (50 us by default, two to three times the sleep asked for): 1 us while this
+  // wait sleeps, the caller's own value again afterwards (it is the caller's thread — Python's, under ctypes)
+  long saved_slack = -1;
+  hipError_t q;
   for (int polls = 0;; ++polls) {
-    const hipError_t q = query();
+    q = query();
     if (q != hipErrorNotReady) {
       // "not ready" is an answer, not an error: should the runtime have recorded it as this thread's last error, take it back
       // (the launch checks of the solver loops read that slot); any other recorded error stays where it is
       if (polls > 0 && hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
-      return q;
+      break;
     }
     if (polls < 4) continue;                                   // what is nearly there: no sleep
+    if (saved_slack < 0) {
+      saved_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+      if (saved_slack < 0) saved_slack = 0;                    // (0 = "the default" when set)
+      prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    }
     const timespec ts{0, g_wait_sleep_ns};
     nanosleep(&ts, nullptr);
   }
+  if (saved_slack >= 0) prctl(PR_SET_TIMERSLACK, (unsigned long)saved_slack, 0, 0, 0);
+  return q;
 }
 }  // namespace
 hipError_t wait_event(hipEvent_t e) {
-  if (g_spin_waits || evaluations_in_flight() <= 1) return hipEventSynchronize(e);
+  if (evaluations_in_flight() <= 1) return hipEventSynchronize(e);
   return sleepy_wait([&] { return hipEventQuery(e); });
 }
 hipError_t wait_stream(hipStream_t s) {
-  if (g_spin_waits || evaluations_in_flight() <= 1) return hipStreamSynchronize(s);
+  if (evaluations_in_flight() <= 1) return hipStreamSynchronize(s);
   return sleepy_wait([&] { return hipStreamQuery(s); });
 }
 struct InFlight {
-  InFlight() { g_evaluations_in_flight.fetch_add(1, std::memory_order_relaxed); }
-  ~InFlight() { g_evaluations_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+  int device, previous;
+  explicit InFlight(int d) : device(d >= 0 && d < kMaxDevices ? d : 0), previous(tl_device) {
+    tl_device = device;
+    g_evaluations_in_flight[device].fetch_add(1, std::memory_order_relaxed);
+  }
+  ~InFlight() {
+    g_evaluations_in_flight[device].fetch_sub(1, std::memory_order_relaxed);
+    tl_device = previous;
+  }
 };
 
 int check_problem(const evomg_problem_t* p, char* err, size_t len) {
@@ -91,6 +112,7 @@ using namespace evomg_detail;
 
 struct evomg_handle {
   ImplBase* impl;
+  int device;
 };
 
 extern "C" {
@@ -119,7 +141,7 @@ int evomg_create(const evomg_problem_t* problem, int device_id, evomg_handle_t**
     delete impl;
     return rc;
   }
-  *out = new evomg_handle{impl};
+  *out = new evomg_handle{impl, device_id};
   return EVOMG_OK;
 }
 
@@ -145,9 +167,9 @@ int evomg_set_operators(evomg_handle_t* h, const evomg_problem_t* problem) {
 }
 int evomg_evaluate(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int evaluation_samples, double wall_limit_ms,
                    evomg_result_t* out, double* res_history, int history_capacity) {
-  const InFlight in_flight;
-  return h ? h->impl->evaluate(ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity)
-           : EVOMG_ERR_INVALID;
+  if (!h) return EVOMG_ERR_INVALID;
+  const InFlight in_flight(h->device);
+  return h->impl->evaluate(ops, n_ops, evaluation_samples, wall_limit_ms, out, res_history, history_capacity);
 }
 int evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, int n_iterations, double* ms_per_iteration, int* n_done) {
   if (!h || !ms_per_iteration || n_iterations < 1 || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
@@ -157,6 +179,7 @@ int evomg_time_iterations(evomg_handle_t* h, const evomg_op_t* ops, int n_ops, i
   p.max_iterations = n_iterations;
   p.target_res_reduction = -1.0;          // a norm is never below a negative bound: the loop runs all n_iterations
   evomg_result_t r;
+  const InFlight in_flight(h->device);    // the probes of the time model count as evaluations under way (they are meant to run alone: then they spin)
   const int rc = h->impl->evaluate(ops, n_ops, 1, 0.0, &r, nullptr, 0);
   p.max_iterations = saved_max;
   p.target_res_reduction = saved_target;
@@ -244,7 +267,7 @@ int evomg_time_model_known_coarse(evomg_handle_t* h, const evomg_op_t* ops, int 
 }
 int evomg_run_ops(evomg_handle_t* h, const evomg_op_t* ops, int n_ops) {
   if (!h || n_ops < 0 || (!ops && n_ops > 0)) return EVOMG_ERR_INVALID;
-  const InFlight in_flight;
+  const InFlight in_flight(h->device);
   return h->impl->run_ops(ops, n_ops);
 }
 int evomg_norm(evomg_handle_t* h, int level, int field, double* out) {

@@ -389,9 +389,13 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     }
     __syncthreads();
     same_xcd = lds_same_xcd != 0;
+    // a rendezvous missed HERE (a workgroup not co-resident) ends the solve at once, in every form of the exchange: the
+    // wave-autonomous one never looks at lds_fail again, and its verdict on the placement would differ between workgroups
+    // 
+    if (lds_fail[par] != 0) wave_alive = false;
   }
   apply();
-  bool alive = exchange(++seq);
+  bool alive = wave_alive && exchange(++seq);
   const double res0 = sc_norm_from_dot(gn);
   int it = 0;
   if (alive && res0 != 0.0 && maxit > 0) {

@@ -99,12 +99,39 @@ Rccl load_rccl() {
 
 thread_local char g_comm_error[512] = "";
 
-constexpr char kMagic[8] = {'E', 'V', 'O', 'M', 'G', 'I', 'D', '1'};
-// An id file that is older than this process (minus a grace period for ranks that start late) was left by another job —
-// a crashed one, or one whose rank 0 failed before evomg_comm_destroy: readers take it as absent and keep waiting for
-// rank 0's (a stale id would send them into ncclCommInitRank with nobody on the other side, which has no timeout).
-const time_t g_loaded_at = time(nullptr);
-constexpr time_t kStaleGraceSeconds = 60;
+constexpr char kMagic[8] = {'E', 'V', 'O', 'M', 'G', 'I', 'D', '2'};
+// Which launch an id file belongs to (the file's age says nothing — a rank that starts a minute late must still
+// accept rank 0's id, a relaunch seconds after a crash must not accept the dead job's): a nonce every rank of ONE launch
+// computes alike and no other launch can — the launcher process the ranks are children of (its pid AND its start time, from
+// /proc: pids are reused) together with the rendezvous the launcher handed down (TORCHELASTIC_RUN_ID, MASTER_PORT,
+// WORLD_SIZE). Rank 0 writes it behind the magic; a reader takes a file with another nonce as absent and keeps waiting (a
+// stale id would send it into ncclCommInitRank with nobody on the other side, which has no timeout).
+unsigned long long launch_nonce() {
+  unsigned long long h = 1469598103934665603ULL;                // FNV-1a
+  auto mix = [&](const char* s) {
+    for (; s && *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ULL; }
+    h ^= 0xff; h *= 1099511628211ULL;
+  };
+  const long ppid = (long)getppid();
+  char buf[1024];
+  snprintf(buf, sizeof buf, "%ld", ppid);
+  mix(buf);
+  snprintf(buf, sizeof buf, "/proc/%ld/stat", ppid);
+  if (FILE* f = fopen(buf, "r")) {
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    // field 22 (starttime) counted from behind the command name, which may itself contain blanks and parentheses
+    const char* q = strrchr(buf, ')');
+    int field = 2;
+    for (; q && *q; ++q)
+      if (*q == ' ' && ++field == 22) { mix(q + 1 < buf + n ? std::string(q + 1, strcspn(q + 1, " ")).c_str() : ""); break; }
+  }
+  mix(getenv("TORCHELASTIC_RUN_ID"));
+  mix(getenv("MASTER_PORT"));
+  mix(getenv("WORLD_SIZE"));
+  return h;
+}
 
 }  // namespace
 
@@ -178,7 +205,9 @@ int evomg_comm_create(int rank, int world, int device_id, const char* id_path, i
     // atomically: a reader sees either no file or the whole id
     const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
     FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(kMagic, 1, sizeof kMagic, f) != sizeof kMagic || fwrite(&id, 1, sizeof id, f) != sizeof id) {
+    const unsigned long long nonce = launch_nonce();
+    if (!f || fwrite(kMagic, 1, sizeof kMagic, f) != sizeof kMagic || fwrite(&nonce, 1, sizeof nonce, f) != sizeof nonce ||
+        fwrite(&id, 1, sizeof id, f) != sizeof id) {
       if (f) fclose(f);
       snprintf(g_comm_error, sizeof g_comm_error, "comm_create: cannot write %s", tmp.c_str());
       return EVOMG_ERR_INVALID;
@@ -190,21 +219,23 @@ int evomg_comm_create(int rank, int world, int device_id, const char* id_path, i
     }
   } else {
     const auto t0 = std::chrono::steady_clock::now();
-    bool have = false;
+    bool have = false, saw_foreign = false;
     while (!have) {
       FILE* f = fopen(path.c_str(), "rb");
       if (f) {
         char magic[sizeof kMagic];
-        struct stat st;
-        const bool fresh = fstat(fileno(f), &st) == 0 && st.st_mtime + kStaleGraceSeconds >= g_loaded_at;
-        have = fresh && fread(magic, 1, sizeof magic, f) == sizeof magic && memcmp(magic, kMagic, sizeof magic) == 0 &&
+        unsigned long long nonce = 0;
+        have = fread(magic, 1, sizeof magic, f) == sizeof magic && memcmp(magic, kMagic, sizeof magic) == 0 &&
+               fread(&nonce, 1, sizeof nonce, f) == sizeof nonce && nonce == launch_nonce() &&
                fread(&id, 1, sizeof id, f) == sizeof id;
+        if (!have) saw_foreign = true;
         fclose(f);
       }
       if (have) break;
       const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
       if (timeout_ms >= 0 && waited > timeout_ms) {
-        snprintf(g_comm_error, sizeof g_comm_error, "comm_create: rank %d waited %d ms for %s", rank, timeout_ms, path.c_str());
+        snprintf(g_comm_error, sizeof g_comm_error, "comm_create: rank %d waited %d ms for %s%s", rank, timeout_ms, path.c_str(),
+                 saw_foreign ? " (a file is there, but written by another launch: different launcher process or rendezvous)" : "");
         return EVOMG_ERR_DEVICE;
       }
       std::this_thread::sleep_for(std::chrono::milliseconds(5));

@@ -21,16 +21,16 @@
 namespace evomg_detail {
 
 extern thread_local char g_create_error[512];
-// evomg_evaluate calls of this process under way right now (defined in evomg.hip): more than one means candidates in
-// flight on the device
+// evaluations of this process under way right now ON THE DEVICE OF THE CALLING THREAD'S CURRENT C-ABI CALL (defined in
+// evomg.hip): more than one means candidates in flight on that device; 0 outside an evaluation
 int evaluations_in_flight();
 int next_cg_phase();       // a process-wide round-robin counter (which XCD the next multi-workgroup solve in flight sits on)
 
 // Host waits. HIP's own waits spin: a candidate alone on the device wants that (its solver loop ends every iteration with one,
 // a wake-up would cost more than the wait), but W candidates in flight kept W cores busy, and a GPU box's 16-core share throttles
 // the process beyond sixteen of them (tools/run_throughput.py: 20 in flight 3 s, 24 in flight 7 s of throttled time per 0.8 s of
-// wall — profiles/r05_throughput.md). With other evaluations under way a wait therefore polls and sleeps in between (the device
-// has the other candidates' work to do while this thread wakes up). EVOMG_SPIN_WAITS=1: always spin.
+// wall — profiles/r05_throughput.md). With other evaluations under way ON THE SAME DEVICE a wait therefore polls and sleeps in between
+// (the device has the other candidates' work to do while this thread wakes up).
 hipError_t wait_event(hipEvent_t e);
 hipError_t wait_stream(hipStream_t s);
 

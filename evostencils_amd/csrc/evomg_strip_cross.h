@@ -34,7 +34,7 @@
 #include "evomg_strip.h"
 
 #ifndef EVOMG_CROSS_TIMING
-#define EVOMG_CROSS_TIMING 0     // developer builds only (tools/ab_cross_timing.sh): 1 halo rows from the chunk's own rows, 2 no loads of x / f, 4 no stores, 8 no loads of the coarse correction — WRONG results
+#define EVOMG_CROSS_TIMING 0     // developer builds only (tools/build_variant.py t2 -DEVOMG_CROSS_TIMING=2, tools/ab_lib_cross.sh): 1 halo rows from the chunk's own rows, 2 no loads of x / f, 4 no stores, 8 no loads of the coarse correction — WRONG results
 #endif
 #define EVOMG_CROSS_STRIP_COLS 116
 #define EVOMG_CROSS_UNROLL 6

@@ -14,7 +14,7 @@
   T* hscalar_ = nullptr;
   T* hnorm_ = nullptr;             // pinned host scalar the solver loop's final reduction writes directly (host_norm_)
   T* hnorm_dev_ = nullptr;         // ... its device address
-  bool host_norm_ = getenv("EVOMG_NO_HOST_NORM") == nullptr;
+  bool host_norm_ = true;        // the final reduction writes the norm into pinned host memory (round 6: environment switch retired — measured, adopted); false where the mapping fails
   int* dinfo_ = nullptr;            // [0] iterations of the last coarse solve, [1] rendezvous miss, [2] iterations of all coarse solves
   long long coarse_iterations_ = 0;
   bool mirror_enabled_ = getenv("EVOMG_NO_BOUNDARY_MIRROR") == nullptr;
@@ -22,12 +22,12 @@
   bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
   bool bnd_zero_[24][EVOMG_F_COUNT];   // boundary of the field's current array is known to be all zero
   // lazy restore of the initial fields (reset_fields): written since the last restore / which array holds the pristine content
-  bool lazy_reset_ = getenv("EVOMG_NO_LAZY_RESET") == nullptr;
+  static constexpr bool lazy_reset_ = true;      // (round 6: environment switch retired — measured, adopted)
   bool dirty_[24][EVOMG_F_COUNT];
   const T* clean_ptr_[24][EVOMG_F_COUNT];
   static inline const bool pow2_reciprocal_ = getenv("EVOMG_NO_POW2_RECIPROCAL") == nullptr;
   static inline const bool cplx_const_div_ = getenv("EVOMG_NO_CPLX_CONST_DIV") == nullptr;   // complex relaxations: the division by the centre with its divisor-only part hoisted
-  bool pow2_fma_ = getenv("EVOMG_NO_POW2_FMA") == nullptr;       // 3D tiles: fused neighbour terms where the coefficients are powers of two
+  static constexpr bool pow2_fma_ = true;       // 3D tiles: fused neighbour terms where the coefficients are powers of two
   // cross-iteration fusion on the finest 2D level (evomg_strip_cross.h): EVOMG_NO_XFUSE switches it off (same bits either way)
   bool xfuse_enabled_ = getenv("EVOMG_NO_XFUSE") == nullptr;
   // from 2049^2: one long marching pass per wave is a latency chain on smaller levels (same-box A/B of whole V(1,1) solves,
@@ -36,7 +36,7 @@
   bool norm_fold_ = getenv("EVOMG_NO_NORM_FOLD") == nullptr;        // the cross launch's norm: partial sums and their sum in ONE launch (same bits)
   unsigned* norm_ticket_ = nullptr;
   bool cross_unit_ = getenv("EVOMG_NO_CROSS_UNIT") == nullptr;     // the cross kernel's unit-weight form (same bits; tests switch it off)
-  int xfuse_rows_ = getenv("EVOMG_XFUSE_ROWS") ? atoi(getenv("EVOMG_XFUSE_ROWS")) : 0;      // chunk height of the cross kernel (tuning)
+  static constexpr int xfuse_rows_ = 0;      // chunk height of the cross kernel: cross_rows() decides (EVOMG_STRIP_ROWS still forces one, tests)
   T* xf_rhs_spare_ = nullptr;        // spare coarse right-hand side of level max - 1 (speculative output, swapped in on commit)
   T* xf_lane_sums_ = nullptr;        // per (16-row chunk, column pair) sums of the squared residual
   size_t xf_lane_sums_cap_ = 0;
@@ -45,11 +45,11 @@
   hipEvent_t norm_event_ = nullptr;
   hipEvent_t outer_event_ = nullptr;
   bool speculate_ = getenv("EVOMG_NO_SPECULATION") == nullptr;
-  // experiments only: the oracle restates the default (krylov_bicgstab_per_launch)
-  int kb_min_n_ = getenv("EVOMG_KB_MIN_N") ? atoi(getenv("EVOMG_KB_MIN_N")) : 129;
+  // part of the arithmetic (the oracle restates it: krylov_bicgstab_per_launch): the launch-per-step BiCGStab from 129^2 up
+  static constexpr int kb_min_n_ = 129;
   bool outer_folds_ = getenv("EVOMG_NO_OUTER_FOLDS") == nullptr;      // outer BiCGStab: beta formed by the reduction before it, Robin columns by the update before them
   bool kb_fused_ = getenv("EVOMG_NO_KB_FUSE") == nullptr;            // the launch-per-step BiCGStab in three launches per iteration (kb2_*), else six
-  bool kcg_enabled_ = getenv("EVOMG_NO_LAUNCH_CG") == nullptr;       // large coarsest grids: CG as a sequence of launches
+  static constexpr bool kcg_enabled_ = true;       // large coarsest grids: CG as a sequence of launches (part of the arithmetic: the oracle restates its summation order)
   KcgState* kcg_state_ = nullptr;
   KcgState* kcg_host_ = nullptr;
   KbState<T>* kb_state_ = nullptr;
@@ -57,21 +57,19 @@
   KbState<T>* kb_host_dev_ = nullptr;     // its device address (kb2_finish writes the state there itself)
   T* kb_scal_ = nullptr;
   bool outer_fuse_ = getenv("EVOMG_NO_OUTER_FUSE") == nullptr;      // fused passes of the preconditioned BiCGStab loop
-  bool outer_dev_steps_ = getenv("EVOMG_NO_OUTER_DEV_STEPS") == nullptr;   // ... with alpha and omega formed on the device
-  bool strip_bc_ = getenv("EVOMG_NO_STRIP_BC") == nullptr;
+  static constexpr bool outer_dev_steps_ = true;   // ... with alpha and omega formed on the device
+  static constexpr bool strip_bc_ = true;          // the strip kernels write the Robin columns themselves
   T* norm_partials_ = nullptr;
   size_t norm_partials_cap_ = 0;
   unsigned long long* cg_ll_ = nullptr;   // exchange words of evomg_cg_multi_wg3d (EVOMG_CG_LL_WORDS, zeroed at creation)
   unsigned cg_seq_base_ = 0;              // sequence numbers handed out so far: they never repeat between launches
-  int cg_stride_ = getenv("EVOMG_CG_SPREAD_XCDS") ? 1 : 8;   // 8: the eight workgroups on ONE XCD (every eighth block of the grid)
+  static constexpr int cg_stride_ = 8;   // the eight workgroups of a multi-workgroup coarse solve on ONE XCD (every eighth block of the grid); one per XCD measured and dropped (profiles/r05_cg1_placement_raw.txt)
   bool cg_multi_attr_set_ = false;
   bool cg_multi_used_ = false;
-  // the 129^2 single-reduction CG (evomg_cg1.h): its 32 waves as eight workgroups of four or four of eight — a tuning
-  // choice, the summation order does not depend on it
   // exchanges of a multi-workgroup solve inside one XCD's L2 (evomg_krylov.h: ll_store16): asked for when all workgroups are
   // placed on one XCD; a solve that misses its rendezvous in that mode turns it off for the handle before the retry
-  bool cg_local_exchange_ = getenv("EVOMG_NO_LOCAL_EXCHANGE") == nullptr;
-  bool cg1_wave_autonomous_ = getenv("EVOMG_CG1_COLLECTOR") == nullptr;      // one-XCD placement: every wave exchanges for itself
+  bool cg_local_exchange_ = true;
+  static constexpr bool cg1_wave_autonomous_ = true;      // one-XCD placement: every wave exchanges for itself (the collector form stays the fallback when the workgroups do not share an XCD)
   bool cg_lds_attr_set_[24] = {};
   int prof_opcode_ = -1, prof_level_ = -1;
   size_t prof_used_ = 0;
@@ -81,12 +79,12 @@
   bool block_fast_ = (getenv("EVOMG_NO_BLOCK_FAST") == nullptr);
   bool fuse_enabled_ = (getenv("EVOMG_NO_FUSE") == nullptr);
   bool tile3d_rr_ = (getenv("EVOMG_NO_TILE3D_RR") == nullptr);
-  bool balance_rows_ = (getenv("EVOMG_NO_BALANCED_ROWS") == nullptr);
+  static constexpr bool balance_rows_ = true;
   bool strip_block_ = (getenv("EVOMG_NO_STRIP_BLOCK") == nullptr);
   // off by default: measured slower than the op-fused multi-CU launches it replaces (one compute unit
   // moves 64 B/clk, so a 129^2 op costs one workgroup what a launch costs; t9 2.90 vs 2.31 ms). EVOMG_BATCH=1: A/B, tests
-  bool reset_batch_ = getenv("EVOMG_NO_RESET_BATCH") == nullptr;     // restoring the initial fields: the small ones in one launch
-  bool residual_dot_fused_ = getenv("EVOMG_NO_RESIDUAL_DOT") == nullptr;   // generic loop norm: residual and r . r in one launch
+  static constexpr bool reset_batch_ = true;     // restoring the initial fields: the small ones in one launch
+  static constexpr bool residual_dot_fused_ = true;   // generic loop norm: residual and r . r in one launch
   bool rr3d_block_ = getenv("EVOMG_NO_RR3D_BLOCK") == nullptr;       // small 3D levels: residual + restriction in one launch
   bool rbgs3d_block_ = getenv("EVOMG_NO_RBGS3D_BLOCK") == nullptr;   // small 3D levels: both colours of a red-black sweep in one launch
   bool small3d_enabled_ = getenv("EVOMG_NO_SMALL3D") == nullptr;
@@ -101,18 +99,18 @@
   MicroBatch batch_ = {};
   int n_cu_ = 256;
   size_t max_lds_ = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock, read at init
-  int twice_planes_ = getenv("EVOMG_TWICE_PLANES") ? atoi(getenv("EVOMG_TWICE_PLANES")) : 16;
+  int twice_planes_ = 16;
   bool balance3d_ = getenv("EVOMG_NO_BALANCE3D") == nullptr;   // z-chunk depth of the 3D tiles by workgroup balance (launch3d: balanced_planes)
   bool cg_fold_reg_ = getenv("EVOMG_NO_CG_FOLD") == nullptr;     // COPY + SET_ZERO folded into the register CG too (65^2 .. 129^2)
   bool twice_xzero_ = getenv("EVOMG_NO_TWICE_XZERO") == nullptr;   // SET_ZERO + 3D double sweep: the zero field is not loaded
   bool head_norm_ = getenv("EVOMG_NO_HEAD_NORM") == nullptr;   // 3D: the loop norm rides on the coming cycle's first double sweep (solve_mg: norm_on_head)
-  bool twice_planes_forced_ = getenv("EVOMG_TWICE_PLANES") != nullptr, rr_cplanes_forced_ = getenv("EVOMG_RR_CPLANES") != nullptr;
+  static constexpr bool twice_planes_forced_ = false, rr_cplanes_forced_ = false;
   struct BalanceEntry { long tiles; int inner, halo, lo, align, planes; };
   mutable std::array<BalanceEntry, 16> balance_cache_{};      // balanced_planes: answers already worked out
   mutable unsigned balance_cache_next_ = 0;
-  bool xbalance3d_ = getenv("EVOMG_NO_XBALANCE3D") == nullptr;   // 3D tile strips of equal width (launch3d: tile3d_xpitch)
+  static constexpr bool xbalance3d_ = true;   // 3D tile strips of equal width (launch3d: tile3d_xpitch) — part of the 3D loop norm's canonical order
   int balance3d_cap_ = getenv("EVOMG_BALANCE3D") ? atoi(getenv("EVOMG_BALANCE3D")) : 0;   // > 1: deepest chunk it may pick
-  int rr_cplanes_ = getenv("EVOMG_RR_CPLANES") ? atoi(getenv("EVOMG_RR_CPLANES")) : 8;
+  int rr_cplanes_ = 8;
   bool strip_enabled_ = (getenv("EVOMG_NO_STRIP") == nullptr);
   // complex (Helmholtz) problems: from 17^2 — the strip kernels write the Robin columns themselves, where the generic ones
   // need a boundary launch behind every op (reference-range solve 212-224 -> 197-215 ms)
@@ -122,12 +120,12 @@
   int strip3d_min_n_ = getenv("EVOMG_STRIP3D_MIN_N") ? atoi(getenv("EVOMG_STRIP3D_MIN_N")) : 0;
   int strip_planes_ = getenv("EVOMG_STRIP_PLANES") ? atoi(getenv("EVOMG_STRIP_PLANES")) : 0;
   bool tile3d_enabled_ = getenv("EVOMG_NO_TILE3D") == nullptr;
-  bool tile3d_rbgs_ = getenv("EVOMG_NO_TILE3D_RBGS") == nullptr;
+  static constexpr bool tile3d_rbgs_ = true;
   bool tile3d_twice_ = getenv("EVOMG_NO_TILE3D_TWICE") == nullptr;
   bool tile3d_pro_ = getenv("EVOMG_NO_TILE3D_PRO") == nullptr;
-  int tile3d_nt_ = getenv("EVOMG_TILE3D_NT") ? atoi(getenv("EVOMG_TILE3D_NT")) : 0;   // bit 0: non-temporal f loads (measured slower at 513^3: profiles/r02_pmc_3d.md)
-  int tile3d_order_ = getenv("EVOMG_TILE3D_ORDER") ? atoi(getenv("EVOMG_TILE3D_ORDER")) : 1;
+  static constexpr int tile3d_nt_ = 0;   // non-temporal f loads measured slower at 513^3 (profiles/r02_pmc_3d.md)
+  static constexpr int tile3d_order_ = 1;
   int tile3d_waves_ = getenv("EVOMG_TILE3D_WAVES") ? atoi(getenv("EVOMG_TILE3D_WAVES")) : 0;
   bool strip_nt_ = getenv("EVOMG_STRIP_NT") ? atoi(getenv("EVOMG_STRIP_NT")) != 0 : true;
-  double nt_lo_mib_ = getenv("EVOMG_NT_LO_MIB") ? atof(getenv("EVOMG_NT_LO_MIB")) : 256.0;   // 3 fields above this: stream x, y
-  double nt_hi_mib_ = getenv("EVOMG_NT_HI_MIB") ? atof(getenv("EVOMG_NT_HI_MIB")) : 192.0;   // ... unless one field exceeds this
+  static constexpr double nt_lo_mib_ = 256.0;   // 3 fields above this: stream x, y
+  static constexpr double nt_hi_mib_ = 192.0;   // ... unless one field exceeds this

@@ -224,6 +224,27 @@ def evaluate_population_dynamic(evaluate: Callable[[int], Tuple[float, float, fl
     return [(i, r[1], r[2], r[3]) for i, r in enumerate(rows)], mine
 
 
+def project_ranks(seconds_per_candidate: Sequence[float], ranks: int) -> dict:
+    """PROJECTION, not a measurement: wall time of one generation on `ranks` GPUs from per-candidate wall times measured on
+    ONE (candidates are independent, one handle per GPU, no data-path collective: SURVEY 8e). static = the reference's split
+    i % ranks == rank (optimization/program.py:534-536), dynamic = the shared-counter work queue of
+    evaluate_population_dynamic (the next free rank takes the next index). The one collective per generation (:582) is a few
+    KiB and is left out; so is any interference between the ranks' host threads (preflight.host_budget).
+    tests/test_population_gloo8.py replays a recorded list with eight sleeping `gloo` ranks against these figures."""
+    total = float(sum(seconds_per_candidate))
+    static = max(sum(seconds_per_candidate[r::ranks]) for r in range(ranks))
+    free = [0.0] * ranks
+    for t in seconds_per_candidate:
+        r = min(range(ranks), key=free.__getitem__)
+        free[r] += t
+    dynamic = max(free)
+    return {"ranks": ranks, "what": "PROJECTION from the per-candidate wall times of the sequential passes on one GPU (no multi-GPU "
+                                    "node has been available to any round)",
+            "one_gpu_wall_s": total, "static_wall_s": static, "dynamic_wall_s": dynamic,
+            "static_speedup": total / static, "dynamic_speedup": total / dynamic,
+            "static_efficiency": total / static / ranks, "dynamic_efficiency": total / dynamic / ranks}
+
+
 MAX_WORKERS_PER_GPU = 16
 
 

@@ -6,7 +6,8 @@ Checks: GPU_MAX_HW_QUEUES in the environment before the runtime initialises (evo
 HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: RCCL across processes needs it on this pool); evomg_device_count() >= ranks on the
 node; LOCAL_RANK -> device as ProgramGenerator resolves it, one distinct device per local rank; librccl opens
 (evomg_rccl_version); with collective=True: the C-ABI communicator is built across all ranks and one evomg_allgather_fitness
-round trip returns every rank's row (optimization/program.py:582 is one such exchange per generation)."""
+round trip returns every rank's row (optimization/program.py:582 is one such exchange per generation); round 6: the host
+budget — usable cores (affinity and cgroup quota) against two per local rank (`host_budget`: a warning, not a failure)."""
 import os
 import sys
 
@@ -15,6 +16,46 @@ def id_path(tag="preflight"):
     """A rendezvous file name unique per launch: the ranks of one torchrun share MASTER_PORT and their parent (the launcher's
     agent); a rerun after a crash gets another name, so no rank can pick up a stale id."""
     return f"/dev/shm/evomg_{tag}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+
+
+def usable_cores():
+    """CPUs this process (and, under one launcher, its sibling ranks together) may actually use: the affinity mask, cut down
+    to the cgroup's quota where there is one — a GPU box shows all 256 hardware threads to a container throttled to 16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if text[0] != "max":
+                    n = min(n, max(1, int(int(text[0]) / int(text[1]))))
+            else:
+                quota = int(text[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def host_budget(local_world, workers_per_rank=16, cores=None):
+    """Host side of `local_world` ranks with `workers_per_rank` candidates in flight each: every worker is a host
+    thread that sleeps in its waits while other evaluations are under way (1-2 cores busy per rank, profiles/r05_throughput.md)
+    and spins only when its evaluation is alone on the device (one core). Budget: two cores per local rank; below that the
+    waits of one rank delay the launches of another and the projection of bench.py's `projected_8gpu` (zero host interference)
+    does not hold. Returns a dict with `ok` False and a warning then — a warning, not a failure: the run is still correct."""
+    cores = usable_cores() if cores is None else cores
+    need = 2 * max(1, local_world)
+    rep = {"usable_cores": cores, "local_ranks": local_world, "worker_threads": local_world * workers_per_rank,
+           "cores_per_rank": cores / max(1, local_world), "needed_cores": need, "ok": cores >= need}
+    if not rep["ok"]:
+        rep["warning"] = (f"{cores} usable cores for {local_world} ranks x {workers_per_rank} worker threads: fewer than two per "
+                          f"rank; expect host-side interference between ranks (set fewer candidates in flight, or widen the cgroup)")
+    return rep
 
 
 def report(collective=False, torch_imported_before=None):
@@ -54,6 +95,7 @@ def report(collective=False, torch_imported_before=None):
             failures.append("evomg_allgather_fitness returned the wrong rows")
         if len({int(r[1]) for r in table}) != min(rep["world"], count):
             failures.append("ranks share devices")
+    rep["host_budget"] = host_budget(rep["local_world"])          # a warning inside, never a failure
     rep["ok"] = not failures
     rep["failures"] = failures
     return rep

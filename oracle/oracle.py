@@ -9,7 +9,8 @@ import subprocess
 from evostencils_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevomg_oracle.so")
+# EVOMG_ORACLE_LIB: another build of the oracle (`make -C oracle sanitize` -> libevomg_oracle_asan.so, run under LD_PRELOAD=libasan)
+LIB_PATH = os.path.abspath(os.environ["EVOMG_ORACLE_LIB"]) if os.environ.get("EVOMG_ORACLE_LIB") else os.path.join(_HERE, "libevomg_oracle.so")
 
 
 def build(force=False):

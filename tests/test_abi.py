@@ -155,13 +155,16 @@ def test_register_budgets_the_documentation_states_hold_in_the_built_code_object
     off a build somebody remembers (the cross kernel was documented at 161 VGPRs and shipped with 176)."""
     res = build.kernel_resources("impl_real")
     cross = {k: v for k, v in res.items() if "evomg_strip2d_cross" in k}
-    assert len(cross) == 16
+    assert len(cross) >= 16                           # (24 since round 6: the unit-weight forms)
     # the variants a Poisson cycle launches (power-of-two stencil, <.., RECIP = true>): at most 168 VGPRs = three waves per SIMD
     for name, r in cross.items():
         if name.split("EEv3Geo")[0].endswith("Lb1"):
             assert r["vgpr"] + r["agpr"] <= 168 and r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
-    headline = next(v for k, v in cross.items() if "ILb1ELb1ELb1ELb1E" in k)
-    assert headline["vgpr"] == 156                    # DESIGN.md 0 / 11 (158 before the kernel was scheduled for two waves per SIMD)
+    # the headline launches — the general power-of-two form and (round 6) the unit-weight form C2 runs: a bound, not an equality
+    # (ADVICE r5: a compiler update must not fail the CPU suite); the figures as built are in DESIGN.md section 4: 166 / 164
+    for tag in ("ILb1ELb1ELb1ELb1ELb0E", "ILb1ELb1ELb1ELb1ELb1E"):
+        headline = next(v for k, v in cross.items() if tag in k)
+        assert headline["vgpr"] <= 168 and headline["sgpr_spill"] == 0, (tag, headline)
     # the single-reduction CG kernels: nothing spills (a spill inside a latency chain is a round trip to memory per iteration)
     cg1 = {k: v for k, v in res.items() if "evomg_cg1_" in k}
     assert len(cg1) >= 14

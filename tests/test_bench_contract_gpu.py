@@ -35,7 +35,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     cpu = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
-    assert cpu["kind"].startswith("port") and cpu.get("cpu_model") and cpu.get("nproc")
+    assert cpu["kind"] == "port" and cpu.get("cpu_model") and cpu.get("nproc")
     # the headline CPU figure is the tuned OpenMP solver, the bit-comparable parity oracle sits one level down (round 6)
     assert cpu["parity_oracle"]["kind"] == "port" and cpu["parity_oracle"]["value"] > 0 and cpu["value"] > 0
     # the metric with the GPU full is repeated at the head of the line

@@ -43,6 +43,12 @@ def test_one_rank_communicator_moves_the_fitness_table(tmp_path):
         native.communicator(1, 2, 0, str(tmp_path / "never_written"), timeout_ms=200)      # bounded wait for the id file
     with pytest.raises(abi.BackendError):
         native.communicator(0, 1, 99, str(tmp_path / "x"))                                 # no such device
+    # an id file of ANOTHER launch under the same name (a crashed job's, seconds old): right magic, foreign nonce — a joining
+    # rank takes it as absent and its bounded wait says why (round 6, ADVICE r5: validated by a launch nonce, not by its age)
+    foreign = tmp_path / "foreign"
+    foreign.write_bytes(b"EVOMGID2" + (0x1234567890ABCDEF).to_bytes(8, "little") + bytes(128))
+    with pytest.raises(abi.BackendError, match="another launch"):
+        native.communicator(1, 2, 0, str(foreign), timeout_ms=200)
 
 
 CHILD = r"""

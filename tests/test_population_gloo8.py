@@ -1,0 +1,144 @@
+"""The N > 1 path at the REAL rank count, on CPU: eight `gloo` ranks drive `evaluate_population` (the
+reference's split `i % nprocs == rank`, optimization/program.py:534-536) and `evaluate_population_dynamic` (shared counter +
+one all-reduce) over the 256-candidate C5 index set. The evaluators sleep for the per-candidate times MEASURED on one MI355X
+(tests/golden/c5_candidate_times.json: `population.per_candidate_ms` of a bench line, the list `projected_8gpu` is computed
+from), scaled down, so that what is rehearsed is exactly what the projection assumes: who evaluates what, that every candidate
+is evaluated once, the flag row, and that the measured wall time of a generation matches `population.project_ranks`."""
+import json
+import os
+import socket
+import sys
+import time
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from evostencils_amd import population
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(REPO, "tests", "golden", "c5_candidate_times.json")
+WORLD = 8
+SCALE = 0.4          # sleeping 40 % of the measured time: 256 candidates take about a second per mode on eight ranks
+
+
+def _times():
+    return [1e-3 * SCALE * t for t in json.load(open(FIXTURE))["per_candidate_ms"]]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fitness(i):
+    return (10.0 + i, 0.1 + 0.001 * i, float(5 + i % 3))      # (time_ms, rho, iterations)
+
+
+def _worker(rank, port, mode, queue):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        times = _times()
+        n = len(times)
+        evaluated = []
+
+        def evaluate(i):
+            evaluated.append(i)
+            if mode == "failure" and rank == 5 and len(evaluated) == 3:
+                raise ValueError("device lost")
+            time.sleep(times[i])
+            return _fitness(i)
+
+        dist.barrier()
+        t0 = time.perf_counter()
+        outcome = "ok"
+        rows = None
+        try:
+            if mode == "dynamic":
+                rows, _mine = population.evaluate_population_dynamic(evaluate, n)
+            else:
+                rows = population.evaluate_population(evaluate, n)
+        except population.RemoteEvaluationFailure:
+            outcome = "remote"
+        except ValueError:
+            outcome = "own"
+        wall = time.perf_counter() - t0
+        queue.put((rank, evaluated, rows, wall, outcome))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(mode):
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, mode, queue)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(WORLD):
+        rank, evaluated, rows, wall, outcome = queue.get(timeout=300)
+        results[rank] = (evaluated, rows, wall, outcome)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE), reason="fixture of measured per-candidate times missing")
+def test_static_split_on_eight_ranks_matches_the_projection():
+    times = _times()
+    n = len(times)
+    assert n == 256
+    results = _run("static")
+    proj = population.project_ranks(times, WORLD)
+    expected = [(i, 0.1 + 0.001 * i, 10.0 + i, float(5 + i % 3)) for i in range(n)]
+    for rank in range(WORLD):
+        evaluated, rows, _wall, outcome = results[rank]
+        assert outcome == "ok"
+        assert evaluated == [i for i in range(n) if i % WORLD == rank]            # program.py:534-535
+        assert [r[0] for r in rows] == list(range(n))
+        for got, want in zip(rows, expected):
+            assert got[0] == want[0] and all(abs(a - b) < 1e-15 for a, b in zip(got[1:], want[1:]))
+    wall = max(r[2] for r in results.values())
+    assert abs(wall / proj["static_wall_s"] - 1.0) < 0.05, (wall, proj["static_wall_s"])
+    # the speed-up the projection quotes, from measured walls: one rank's worth of sleeping against the generation's wall
+    assert proj["one_gpu_wall_s"] / wall > 0.95 * proj["static_speedup"]
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE), reason="fixture of measured per-candidate times missing")
+def test_dynamic_queue_on_eight_ranks_matches_the_projection():
+    times = _times()
+    n = len(times)
+    results = _run("dynamic")
+    proj = population.project_ranks(times, WORLD)
+    taken = sorted(i for r in results.values() for i in r[0])
+    assert taken == list(range(n))                                                 # every candidate exactly once
+    expected = [(i, 0.1 + 0.001 * i, 10.0 + i, float(5 + i % 3)) for i in range(n)]
+    for rank in range(WORLD):
+        assert results[rank][3] == "ok" and results[rank][1] == expected          # exact: the other ranks add zeros
+    wall = max(r[2] for r in results.values())
+    assert abs(wall / proj["dynamic_wall_s"] - 1.0) < 0.05, (wall, proj["dynamic_wall_s"])
+    assert proj["dynamic_wall_s"] <= proj["static_wall_s"] * 1.001
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE), reason="fixture of measured per-candidate times missing")
+def test_a_failing_rank_among_eight_reaches_the_collective_and_every_rank_raises():
+    results = _run("failure")
+    assert results[5][3] == "own" and len(results[5][0]) == 3                      # stopped evaluating at once
+    for rank in range(WORLD):
+        if rank != 5:
+            assert results[rank][3] == "remote"                                    # the flag row, seen by all seven others
+            assert len(results[rank][0]) == 32                                     # ... after finishing their own share
+
+
+def test_host_budget_warns_below_two_cores_per_rank():
+    from evostencils_amd import preflight
+    assert preflight.host_budget(8, cores=128)["ok"] and "warning" not in preflight.host_budget(8, cores=16)
+    tight = preflight.host_budget(8, cores=8)
+    assert not tight["ok"] and "fewer than two per rank" in tight["warning"] and tight["worker_threads"] == 128
+    assert preflight.usable_cores() >= 1

@@ -1,3 +1,4 @@
+#!/bin/bash
 # Developer tool: rocprofv3 kernel statistics of one named configuration (tools/run_config.py): bash tools/prof_config.sh c3
 # Writes gpurun_out/prof_<cfg>/ and prints the twenty kernels with the most time.
 cd /tmp && export TMPDIR=/tmp

@@ -1,9 +1,11 @@
-# Round-5 profile refresh (run on the GPU box: bash tools/profile_round4.sh). Writes under gpurun_out/r5/; copy what is to
-# be judged into profiles/ afterwards (tools/collect_round5.py).
+#!/bin/bash
+# Profile refresh of a round (run on the GPU box: bash tools/profile_round.sh r06). Writes under gpurun_out/<tag>/; copy what
+# is to be judged into profiles/ afterwards (python tools/collect_round.py r06).
 set -e
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 # kernel-trace statistics of the bench command and of each named configuration
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -- python3 $R/bench.py --steps 10 --warmup 2 --population 0 --no-cpu-baseline --throughput-workers 0 --no-reference-size --no-configs > $O/bench_under_rocprof.json 2> $O/bench_prof.err

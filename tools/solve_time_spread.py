@@ -1,7 +1,8 @@
 """Run-to-run spread of the solve time of one candidate (the time objective's noise floor): C2-like V(1,1) RB-GS cycle on
 levels lo..hi, `reps` evaluations one after the other. usage: python tools/solve_time_spread.py [lo hi reps] [classical]"""
+import os
 import sys
-sys.path[:0] = ['/root/repo']
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import dataclasses
 import numpy as np
 from evostencils_amd import abi, native, problems, candidates as cand
