@@ -674,7 +674,7 @@ def main():
         # since round 4 one launch per iteration does the cycle's last sweep (+ prolongation, + the loop's norm) AND the next
         # cycle's first sweep (+ residual + restriction); the first iteration's head and the last one's tail run as the
         # round-3 fused sweeps (they are in the mean below: 2 of 13 launches per solve)
-        kname = ("evomg_strip2d_cross<true, true, true, true> (csrc/evomg_strip_cross.h): prolongation + sweep + residual norm of "
+        kname = ("evomg_strip2d_cross<true, true, true, true, true> (csrc/evomg_strip_cross.h; the last flag: unit-weight form): prolongation + sweep + residual norm of "
                  "iteration k and sweep + residual + restriction of iteration k + 1 in ONE pass; replaces two launches of "
                  f"{(24.0 * n_nodes + 8.0 * ((1 << (hi - 1)) + 1) ** 2) / 1e6:.1f} MB each")
     elif fused:
@@ -701,9 +701,10 @@ def main():
                         f"{live.bytes / 1e6:.1f} MB. 'back_to_back' = median of 5 batches of 100 consecutive plain ping-pong sweeps. "
                         f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC passes (profiles/pmc_traffic.json names the "
                         f"profile), null when no profile matches the launched kernel and level. What holds the cross launch at "
-                        f"0.60-0.66 of the HBM peak is not its bytes: with every load and store taken out it still takes 60 of its "
-                        f"90-95 us (98 vector instructions per row step, 64 of them FP64, and ONE wave issues an FP64 instruction every "
-                        f"8 cycles: two waves per SIMD leave the vector unit half idle) - profiles/r05_cross_kernel.md"}
+                        f"0.60-0.66 of the HBM peak (round 6, profiles/r06_cross_kernel.md): it moves its 545 MB at the fabric at "
+                        f"6.0-6.2 TB/s - the copy rate the hardware guide measures (6.29) - so what is left is the over-fetch (1.17x: "
+                        f"eleven halo rows per 80-row chunk), not instructions: the unit-weight form C2 runs since round 6 "
+                        f"(19 % fewer FP64 instructions per row step) and prefetch rings of 3 and 6 rows take the same time"}
 
     # ---- where the rest of an isolated solve goes: the coarse-grid solve, timed the same way over three more solves ----
     progress("coarse solve timing")
