@@ -398,21 +398,33 @@ static evomg_norm_from_lane_sums(const double* __restrict__ lane_sums, int sums_
 // (agent-scope) store, the storing waves drain their stores (s_waitcnt vmcnt(0)) before the workgroup's barrier, ONE lane
 // then takes a ticket with an agent-scope atomic add; the workgroup that drew the last ticket reads the partials with sc1
 // loads behind a barrier of its own. The ticket counter is left at zero for the next launch (same stream: ordered).
+// EVOMG_NORM_FOLD_PER partial sums per wave: 2 249 workgroups taking tickets from ONE counter serialise on it (same-address
+// atomics: ~10 ns each — the launch took 33 us alone, twice the two launches it replaces); with eight partials per wave 282 do.
+#define EVOMG_NORM_FOLD_PER 8
 __global__ void __launch_bounds__(256)
 static evomg_norm_from_lane_sums_final(const double* __restrict__ lane_sums, int sums_pitch, int n, int n_strips, int n_waves,
                                        double* __restrict__ partials, unsigned* __restrict__ ticket, double* __restrict__ out) {
   prio_latency();
   __shared__ double red[17];
   __shared__ int is_last;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  constexpr int PER = EVOMG_NORM_FOLD_PER;
+  const int first = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * PER;
   const int lane = threadIdx.x & 63;
-  if (wave < n_waves) {
+  double v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {                            // all loads first, then the trees
+    const int wave = first + k;
     const int strip = wave % n_strips, c16 = wave / n_strips;
     const int c0 = strip * EVOMG_NORM_STRIP_COLS - 4 + 2 * lane;
-    const bool store_lane = lane >= 2 && lane <= 61 && c0 >= 0 && c0 < n;
-    const double v = store_lane ? lane_sums[(long)c16 * sums_pitch + (c0 >> 1)] : 0.0;
-    const double tot = wave_sum(v);
-    if (lane == 0) __hip_atomic_store(partials + (c16 * n_strips + strip), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool store_lane = wave < n_waves && lane >= 2 && lane <= 61 && c0 >= 0 && c0 < n;
+    v[k] = store_lane ? lane_sums[(long)c16 * sums_pitch + (c0 >> 1)] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int wave = first + k;
+    const double tot = wave_sum(v[k]);
+    if (lane == 0 && wave < n_waves)
+      __hip_atomic_store(partials + wave, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -424,15 +436,15 @@ static evomg_norm_from_lane_sums_final(const double* __restrict__ lane_sums, int
   if (!is_last) return;
   double s = 0.0;
   for (int i0 = threadIdx.x; i0 < n_waves; i0 += 8 * 256) {
-    double v[8];
+    double q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int i = i0 + j * 256;
-      v[j] = __hip_atomic_load(partials + (i < n_waves ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q[j] = __hip_atomic_load(partials + (i < n_waves ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (i0 + j * 256 < n_waves) s = s + v[j];
+      if (i0 + j * 256 < n_waves) s = s + q[j];
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) {

@@ -106,6 +106,7 @@
   int set_field(int level, int field, const double* host) override {
     if (!level_ok(level) || !host) return invalid("set_field: bad level/pointer");
     HIP_TRY(hipSetDevice(device_));
+    { const int rc = flush_pending_residual(); if (rc != EVOMG_OK) return rc; }
     T* d = fieldptr(level, field);
     if (!d) return invalid("set_field: no such field on this level");
     bnd_zero_[level][canon(level, field)] = false;
@@ -123,6 +124,8 @@
     if (!d) return invalid("get_field: no such field on this level");
     const Level<T>& lv = lv_[level];
     const size_t rows = (size_t)lv.g.n * (dim_ == 3 ? lv.g.n : 1);
+    { const int rc = flush_pending_residual(); if (rc != EVOMG_OK) return rc; }
+    d = fieldptr(level, field);
     HIP_TRY(wait_stream(stream_));
     HIP_TRY(hipMemcpy2D(host, lv.g.n * sizeof(T), d, lv.g.pitch * sizeof(T), lv.g.n * sizeof(T), rows,
                         hipMemcpyDeviceToHost));
@@ -144,6 +147,8 @@
     HIP_TRY(hipSetDevice(device_));
     int rc = validate(ops, n_ops);
     if (rc != EVOMG_OK) return rc;
+    if ((rc = flush_pending_residual()) != EVOMG_OK) return rc;
+    info_fresh_ = false;
     if (cg_multi_used_) HIP_TRY(hipMemsetAsync(dinfo_, 0, sizeof(int) * 4, stream_));
     mark_written(ops, n_ops, /*loop=*/false);
     rc = exec_program(ops, n_ops, /*cyclic=*/false);
@@ -156,7 +161,9 @@
   int coarse_solver_health() {
     if (!cg_multi_used_) return EVOMG_OK;
     int info[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(info, dinfo_, sizeof info, hipMemcpyDeviceToHost));
+    if (info_fresh_) memcpy(info, last_info_, sizeof info);      // read behind the evaluation a moment ago: no second copy
+    else HIP_TRY(hipMemcpy(info, dinfo_, sizeof info, hipMemcpyDeviceToHost));
+    info_fresh_ = false;
     if (info[1] != 0) {
       snprintf(err, sizeof err, "coarse-grid CG: its workgroups did not rendezvous (GPU oversubscribed?)");
       cg_local_exchange_ = false;       // whatever the cause: the retry (and everything after it) exchanges over the fabric
@@ -168,6 +175,7 @@
   int norm(int level, int field, double* out) override {
     if (!level_ok(level) || !out) return invalid("norm: bad level/pointer");
     HIP_TRY(hipSetDevice(device_));
+    { const int rc = flush_pending_residual(); if (rc != EVOMG_OK) return rc; }
     const T* d = fieldptr(level, field);
     if (!d) return invalid("norm: no such field on this level");
     T v;
@@ -221,11 +229,11 @@
     }
     *out = r;
     out->time_ms = tsum / (double)done;
-    {
-      int k = 0;                       // behind the solve's own synchronisation, outside its timer
-      HIP_TRY(hipMemcpy(&k, dinfo_ + 2, sizeof(int), hipMemcpyDeviceToHost));
-      coarse_iterations_ = k;
-    }
+    // behind the solve's own synchronisation, outside its timer: the coarse solver's words in ONE copy (iterations of all
+    // coarse solves of the last sample; the rendezvous flag coarse_solver_health looks at)
+    HIP_TRY(hipMemcpy(last_info_, dinfo_, sizeof last_info_, hipMemcpyDeviceToHost));
+    coarse_iterations_ = last_info_[2];
+    info_fresh_ = true;
     return EVOMG_OK;
   }
   long long coarse_iterations() override { return coarse_iterations_; }
@@ -236,6 +244,7 @@
     if (!op || !out || reps < 1 || warmup < 0) return invalid("bench_op: bad arguments");
     int rc = validate(op, 1);
     if (rc != EVOMG_OK) return rc;
+    if ((rc = flush_pending_residual()) != EVOMG_OK) return rc;
     for (int i = 0; i < warmup; ++i) {
       rc = exec(*op);
       if (rc != EVOMG_OK) return rc;

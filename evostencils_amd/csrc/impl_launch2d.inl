@@ -455,7 +455,7 @@
           HIP_TRY(hipMalloc(&norm_ticket_, 128));
           HIP_TRY(hipMemsetAsync(norm_ticket_, 0, 128, stream_));
         }
-        hipLaunchKernelGGL(evomg_norm_from_lane_sums_final, dim3((nwaves_norm + 3) / 4), dim3(256), 0, stream_, (const double*)xf_lane_sums_,
+        hipLaunchKernelGGL(evomg_norm_from_lane_sums_final, dim3((nwaves_norm + 4 * EVOMG_NORM_FOLD_PER - 1) / (4 * EVOMG_NORM_FOLD_PER)), dim3(256), 0, stream_, (const double*)xf_lane_sums_,
                            sums_pitch, g.n, nstrips_norm, nwaves_norm, (double*)norm_partials_, norm_ticket_, (double*)norm_out());
         if (norm_done) *norm_done = true;
       } else {

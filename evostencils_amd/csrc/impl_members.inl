@@ -17,6 +17,9 @@
   bool host_norm_ = true;        // the final reduction writes the norm into pinned host memory (round 6: environment switch retired — measured, adopted); false where the mapping fails
   int* dinfo_ = nullptr;            // [0] iterations of the last coarse solve, [1] rendezvous miss, [2] iterations of all coarse solves
   long long coarse_iterations_ = 0;
+  bool res_pending_ = false;         // RES@max still has to be formed from the iterate the last solve returned (flush_pending_residual)
+  int last_info_[4] = {0, 0, 0, 0};  // dinfo_ as read behind the last evaluation; info_fresh_: coarse_solver_health may use it
+  bool info_fresh_ = false;
   bool mirror_enabled_ = getenv("EVOMG_NO_BOUNDARY_MIRROR") == nullptr;
   bool x_zero_next_ = false;
   bool zero_elision_ = getenv("EVOMG_NO_ZERO_ELISION") == nullptr;
