@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
@@ -23,7 +23,12 @@ BC_DIRICHLET, BC_HELMHOLTZ_ROBIN = 0, 1
 OUTER_MG_ITERATION, OUTER_PBICGSTAB = 0, 1
 CGS_CG, CGS_BICGSTAB, CGS_FAS_SMOOTHER, CGS_CG_CLASSICAL = 0, 1, 2, 3
 STENCIL_STAR, STENCIL_COMPACT = 0, 1
-NONLINEAR_NONE, NONLINEAR_GAM_U_EXP_U = 0, 1
+NONLINEAR_NONE, NONLINEAR_GAM_U_EXP_U, NONLINEAR_PROGRAM = 0, 1, 2
+# reverse-Polish programs of a non-linear stencil entry (include/evomg.h: evomg_nl_program_t, ABI 6)
+NL_MAX_OPS, NL_MAX_CONSTS, NL_MAX_STACK = 48, 8, 8
+NL_END, NL_PUSH_U, NL_PUSH_CONST, NL_DUP = 0, 1, 2, 10
+NL_ADD, NL_SUB, NL_MUL, NL_DIV, NL_NEG, NL_EXP, NL_SIN, NL_COS, NL_SQRT, NL_LOG, NL_TANH = 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26
+NL_SINH, NL_COSH = 27, 28
 # `with jacobi` slot handling (include/evomg.h EVOMG_JACOBI_*): TEXTBOOK = the sweep's result becomes the field;
 # EXASTENCILS_V11 = the next slot is never advanced, as in the reference's pipeline (notebooks/tutorial.ipynb:3373)
 JACOBI_TEXTBOOK, JACOBI_EXASTENCILS_V11 = 1, 2
@@ -47,6 +52,11 @@ class C64(C.Structure):
     _fields_ = [("re", C.c_double), ("im", C.c_double)]
 
 
+class NlProgram(C.Structure):
+    _fields_ = [("n_sigma", C.c_int32), ("n_jacobian", C.c_int32), ("sigma", C.c_uint8 * NL_MAX_OPS),
+                ("jacobian", C.c_uint8 * NL_MAX_OPS), ("consts", C.c_double * NL_MAX_CONSTS)]
+
+
 class Problem(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("dimension", C.c_int32), ("min_level", C.c_int32),
@@ -60,7 +70,7 @@ class Problem(C.Structure):
         ("jacobi_semantics", C.c_int32), ("n_unknowns", C.c_int32),
         ("sys_stencil", (((C.c_double * 9) * MAX_UNKNOWNS) * MAX_UNKNOWNS) * MAX_LEVELS),
         ("nonlinear_kind", C.c_int32), ("stencil_kind", C.c_int32), ("nonlinear_gamma", C.c_double),
-        ("fas_cgs_omega", C.c_double),
+        ("fas_cgs_omega", C.c_double), ("nonlinear_program", NlProgram),
     ]
 
 

@@ -96,6 +96,124 @@ def _exaslang_function(text, name, constants, others=()):
     return sympy.lambdify((x, y), parsed, "numpy"), (lambda a, b, e=parsed: e.subs({x: a, y: b}))
 
 
+# ---- the non-linear stencil entry: sympy expression -> reverse-Polish program (include/evomg.h: evomg_nl_program_t) -------
+SOLUTION_SYMBOL = sympy.Symbol("Solution")
+_NL_FUNCTIONS = {sympy.exp: abi.NL_EXP, sympy.sin: abi.NL_SIN, sympy.cos: abi.NL_COS, sympy.log: abi.NL_LOG, sympy.tanh: abi.NL_TANH,
+                 sympy.sinh: abi.NL_SINH, sympy.cosh: abi.NL_COSH}
+
+
+def nonlinear_expression(nonlinear_text, solution="Solution"):
+    """The stencil entry as a sympy expression of `Solution`, slot and level modifiers removed exactly as the reference does
+    (parser.extract_nonlinear_term, parser.py:146-169)."""
+    expr = re.sub("<[^>]+>", "", nonlinear_text)
+    expr = re.sub("@[^)]+", "", expr)
+    try:
+        return parse_expr(expr.replace("^", "**"), local_dict={solution: SOLUTION_SYMBOL, "gam": sympy.Symbol("gam")})
+    except Exception as exc:        # noqa: BLE001 — whatever sympy makes of a malformed entry: the problem is not ours to solve
+        raise UnsupportedFASExpression(f"non-linear stencil entry `{nonlinear_text}`: {type(exc).__name__}: {exc}") from exc
+
+
+def _rpn(expr, consts, values):
+    """Opcodes of `expr` in evaluation order (post-order, arguments left to right in sympy's canonical order)."""
+    if expr == SOLUTION_SYMBOL:
+        return [abi.NL_PUSH_U]
+    if expr.is_Symbol or expr.is_Number or expr.is_NumberSymbol:
+        if expr.is_Symbol:
+            if str(expr) not in values:
+                raise UnsupportedFASExpression(f"non-linear stencil entry: unknown symbol {expr}")
+            v = float(values[str(expr)])
+        else:
+            v = float(expr)
+        if v not in consts:
+            if len(consts) >= abi.NL_MAX_CONSTS:
+                raise UnsupportedFASExpression("non-linear stencil entry: too many constants")
+            consts.append(v)
+        return [abi.NL_PUSH_CONST + consts.index(v)]
+    if expr.is_Add or expr.is_Mul:
+        args = list(expr.args)
+        if expr.is_Mul and args[0] == -1 and len(args) >= 2:          # -x, -x*y: negate the product of the rest
+            return _rpn(sympy.Mul(*args[1:]), consts, values) + [abi.NL_NEG]
+        code = _rpn(args[0], consts, values)
+        for a in args[1:]:
+            if expr.is_Add and a.is_Mul and a.args[0] == -1:          # a - b
+                code += _rpn(sympy.Mul(*a.args[1:]), consts, values) + [abi.NL_SUB]
+            else:
+                code += _rpn(a, consts, values) + [abi.NL_ADD if expr.is_Add else abi.NL_MUL]
+        return code
+    if expr.is_Pow:
+        base_, e = expr.args
+        if e == sympy.Rational(1, 2):
+            return _rpn(base_, consts, values) + [abi.NL_SQRT]
+        if e == sympy.Rational(-1, 2):
+            return _rpn(sympy.Integer(1), consts, values) + _rpn(base_, consts, values) + [abi.NL_SQRT, abi.NL_DIV]
+        if e.is_Integer and 2 <= int(e) <= 8:
+            return _rpn(base_, consts, values) + [abi.NL_DUP] * (int(e) - 1) + [abi.NL_MUL] * (int(e) - 1)
+        if e.is_Integer and -8 <= int(e) <= -1:
+            return _rpn(sympy.Integer(1), consts, values) + _rpn(sympy.Pow(base_, -e), consts, values) + [abi.NL_DIV]
+        raise UnsupportedFASExpression(f"non-linear stencil entry: power {e} is not supported")
+    op = _NL_FUNCTIONS.get(expr.func)
+    if op is not None and len(expr.args) == 1:
+        return _rpn(expr.args[0], consts, values) + [op]
+    raise UnsupportedFASExpression(f"non-linear stencil entry: {expr.func} is not supported")
+
+
+def _stack_depth(code):
+    depth = peak = 0
+    for op in code:
+        if op == abi.NL_PUSH_U or op == abi.NL_DUP or abi.NL_PUSH_CONST <= op < abi.NL_PUSH_CONST + abi.NL_MAX_CONSTS:
+            depth += 1
+        elif abi.NL_ADD <= op <= abi.NL_DIV:
+            depth -= 1
+        peak = max(peak, depth)
+    return peak
+
+
+def compile_nonlinear(sigma_expr, values):
+    """(sigma opcodes, Newton-term opcodes, constants) of a stencil entry sigma(Solution): the entry itself and
+    d/dSolution [sigma * Solution], simplified by sympy as the reference's generator forms it (exastencils_FAS.py: sympy_jacobian).
+    `values`: the template's `Val` constants (gam). Raises UnsupportedFASExpression for what the programs cannot express."""
+    jacobian_expr = sympy.simplify(sympy.diff(sigma_expr * SOLUTION_SYMBOL, SOLUTION_SYMBOL))
+    consts = []
+    sigma = _rpn(sigma_expr, consts, values)
+    jacobian = _rpn(jacobian_expr, consts, values)
+    for code in (sigma, jacobian):
+        if len(code) > abi.NL_MAX_OPS or _stack_depth(code) > abi.NL_MAX_STACK:
+            raise UnsupportedFASExpression("non-linear stencil entry: too long or too deep for a straight-line program")
+    return sigma, jacobian, consts
+
+
+def evaluate_program(code, consts, u):
+    """Host-side evaluation of a program (tests, and the cross-check of classify_nonlinear): the same stack machine."""
+    stack = []
+    for op in code:
+        if op == abi.NL_PUSH_U:
+            stack.append(float(u))
+        elif op == abi.NL_DUP:
+            stack.append(stack[-1])
+        elif abi.NL_PUSH_CONST <= op < abi.NL_PUSH_CONST + abi.NL_MAX_CONSTS:
+            stack.append(consts[op - abi.NL_PUSH_CONST])
+        elif abi.NL_ADD <= op <= abi.NL_DIV:
+            b, a = stack.pop(), stack.pop()
+            stack.append(a + b if op == abi.NL_ADD else a - b if op == abi.NL_SUB else a * b if op == abi.NL_MUL else a / b)
+        else:
+            f = {abi.NL_NEG: lambda v: -v, abi.NL_EXP: math.exp, abi.NL_SIN: math.sin, abi.NL_COS: math.cos,
+                 abi.NL_SQRT: math.sqrt, abi.NL_LOG: math.log, abi.NL_TANH: math.tanh, abi.NL_SINH: math.sinh,
+                 abi.NL_COSH: math.cosh}[op]
+            stack[-1] = f(stack[-1])
+    assert len(stack) == 1
+    return stack[0]
+
+
+def classify_nonlinear(nonlinear_text, gamma):
+    """(abi.NONLINEAR_* kind, program or None) of a template's stencil entry. The reference's example — gam * exp(Solution) —
+    keeps its dedicated kernels (kind GAM_U_EXP_U: one exponential serves the entry and the Newton term); every other entry
+    becomes a pair of programs."""
+    sigma = nonlinear_expression(nonlinear_text)
+    if sympy.simplify(sigma - sympy.Symbol("gam") * sympy.exp(SOLUTION_SYMBOL)) == 0:
+        return abi.NONLINEAR_GAM_U_EXP_U, None
+    return abi.NONLINEAR_PROGRAM, compile_nonlinear(sigma, {"gam": gamma})
+
+
 def read_template(build_path, knowledge_file, template_file, nonlinear_stencil):
     dimension = min_level = max_level = None
     with open(os.path.join(build_path, knowledge_file)) as fh:       # parser.extract_knowledge_information, parser.py:114-125

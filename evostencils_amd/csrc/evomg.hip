@@ -87,10 +87,31 @@ int check_problem(const evomg_problem_t* p, char* err, size_t len) {
   if (p->jacobi_semantics != EVOMG_JACOBI_TEXTBOOK && p->jacobi_semantics != EVOMG_JACOBI_EXASTENCILS_V11) { snprintf(err, len, "jacobi_semantics must be EVOMG_JACOBI_TEXTBOOK or EVOMG_JACOBI_EXASTENCILS_V11"); return EVOMG_ERR_INVALID; }
   if (p->cgs_kind != EVOMG_CGS_CG && p->cgs_kind != EVOMG_CGS_BICGSTAB && p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER && p->cgs_kind != EVOMG_CGS_CG_CLASSICAL) { snprintf(err, len, "bad coarse-grid solver kind"); return EVOMG_ERR_INVALID; }
   if (p->nonlinear_kind != EVOMG_NONLINEAR_NONE) {
-    if (p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
+    if (p->nonlinear_kind == EVOMG_NONLINEAR_PROGRAM) {
+      // both programs well-formed: known opcodes, operands there when an operator wants them, at most EVOMG_NL_MAX_STACK
+      // values at a time, exactly one left at the end
+      const evomg_nl_program_t& q = p->nonlinear_program;
+      for (int which = 0; which < 2; ++which) {
+        const int n = which ? q.n_jacobian : q.n_sigma;
+        const uint8_t* code = which ? q.jacobian : q.sigma;
+        int depth = 0;
+        bool ok = n >= 1 && n <= EVOMG_NL_MAX_OPS;
+        for (int k = 0; ok && k < n; ++k) {
+          const int op = code[k];
+          if (op == EVOMG_NL_PUSH_U || (op >= EVOMG_NL_PUSH_CONST && op < EVOMG_NL_PUSH_CONST + EVOMG_NL_MAX_CONSTS)) ++depth;
+          else if (op == EVOMG_NL_DUP) { ok = depth >= 1; ++depth; }
+          else if (op >= EVOMG_NL_ADD && op <= EVOMG_NL_DIV) { ok = depth >= 2; --depth; }
+          else if (op >= EVOMG_NL_NEG && op <= EVOMG_NL_COSH) ok = depth >= 1;
+          else ok = false;
+          ok = ok && depth <= EVOMG_NL_MAX_STACK;
+        }
+        if (!ok || depth != 1) { snprintf(err, len, "non-linear FAS: malformed %s program", which ? "Newton-term" : "stencil-entry"); return EVOMG_ERR_INVALID; }
+      }
+    }
+    if ((p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U && p->nonlinear_kind != EVOMG_NONLINEAR_PROGRAM) || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
         p->bc_kind != EVOMG_BC_DIRICHLET || p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER ||
         p->n_unknowns > 1) {
-      snprintf(err, len, "non-linear FAS: 2D real Dirichlet scalar problems, N(u) = gam u exp(u), smoother as coarse solver");
+      snprintf(err, len, "non-linear FAS: 2D real Dirichlet scalar problems, N(u) = sigma(u) u (gam exp(u), or a program), smoother as coarse solver");
       return EVOMG_ERR_UNSUPPORTED;
     }
   } else if (p->cgs_kind == EVOMG_CGS_FAS_SMOOTHER) { snprintf(err, len, "EVOMG_CGS_FAS_SMOOTHER needs a non-linear problem"); return EVOMG_ERR_INVALID; }

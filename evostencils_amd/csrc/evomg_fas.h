@@ -1,4 +1,5 @@
-// evomg_fas.h — non-linear FAS problems: -Lap u + gam u e^u = f, 2D, real, u = 0 on the boundary; the
+// evomg_fas.h — non-linear FAS problems: -Lap u + sigma(u) u = f (the reference's example: sigma = gam e^u),
+// 2D, real, u = 0 on the boundary; the
 // statement kinds the reference's second backend emits (evostencils/code_generation/exastencils_FAS.py:99-319) on its
 // example problem (example_problems/FAS_2D_Basic/FAS_2D_Basic_template.exa4).
 //
@@ -11,42 +12,106 @@
 #include "evomg_kernels.h"
 #include "evomg_krylov.h"   // the cross-workgroup exchange primitives (xchg_store / xchg_load / grid_publish)
 
+// ---- the non-linear stencil entry sigma(S) and the Newton term d/du [sigma(u) u] -----------------------------------------
+// kind EVOMG_NONLINEAR_GAM_U_EXP_U: the reference's example, sigma = gam exp(S), written out (one exponential serves both);
+// kind EVOMG_NONLINEAR_PROGRAM (ABI 6): whatever entry the problem's template holds, as two straight-line programs in
+// reverse Polish notation (include/evomg.h: evomg_nl_program_t; compiled from sympy by code_generation/fas.py, the derivative
+// formed as the reference forms it, exastencils_FAS.py: simplify(diff(sigma u, u))). The operand stack is EIGHT named registers
+// moved by static shifts — a stack indexed at run time would live in scratch memory —; the program is a kernel argument, so
+// the opcode dispatch is a scalar branch. One IEEE operation per opcode, in program order: the oracle executes the same list.
+struct FasNl {
+  int kind;
+  double gam;
+  evomg_nl_program_t prog;
+};
+__device__ __forceinline__ double fas_nl_run(const evomg_nl_program_t& p, const uint8_t (&code)[EVOMG_NL_MAX_OPS], int n, double u) {
+  static_assert(EVOMG_NL_MAX_STACK == 8, "the operand stack is eight named registers");
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;      // s0 = top of the stack
+  for (int k = 0; k < n; ++k) {
+    const int op = code[k];
+    if (op == EVOMG_NL_PUSH_U || op == EVOMG_NL_DUP || (op >= EVOMG_NL_PUSH_CONST && op < EVOMG_NL_PUSH_CONST + EVOMG_NL_MAX_CONSTS)) {
+      const double v = op == EVOMG_NL_PUSH_U ? u : op == EVOMG_NL_DUP ? s0 : p.consts[op - EVOMG_NL_PUSH_CONST];
+      s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+    } else if (op >= EVOMG_NL_ADD && op <= EVOMG_NL_DIV) {
+      const double a = s1, b = s0;
+      const double r = op == EVOMG_NL_ADD ? a + b : op == EVOMG_NL_SUB ? a - b : op == EVOMG_NL_MUL ? a * b : a / b;
+      s0 = r; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+    } else {
+      switch (op) {
+        case EVOMG_NL_NEG: s0 = -s0; break;
+        case EVOMG_NL_EXP: s0 = exp(s0); break;
+        case EVOMG_NL_SIN: s0 = sin(s0); break;
+        case EVOMG_NL_COS: s0 = cos(s0); break;
+        case EVOMG_NL_SQRT: s0 = sqrt(s0); break;
+        case EVOMG_NL_LOG: s0 = log(s0); break;
+        case EVOMG_NL_TANH: s0 = tanh(s0); break;
+        case EVOMG_NL_SINH: s0 = sinh(s0); break;
+        case EVOMG_NL_COSH: s0 = cosh(s0); break;
+        default: break;
+      }
+    }
+  }
+  return s0;
+}
+// the stencil entry at Solution = s
+__device__ __forceinline__ double fas_nl_sigma(const FasNl& nl, double s) {
+  if (nl.kind == EVOMG_NONLINEAR_PROGRAM) return fas_nl_run(nl.prog, nl.prog.sigma, nl.prog.n_sigma, s);
+  return nl.gam * exp(s);
+}
+// the entry at u and the Newton term at u (what the smoother's denominator adds to the centre coefficient)
+__device__ __forceinline__ void fas_nl_both(const FasNl& nl, double u, double* sigma, double* newton) {
+  if (nl.kind == EVOMG_NONLINEAR_PROGRAM) {
+    *sigma = fas_nl_run(nl.prog, nl.prog.sigma, nl.prog.n_sigma, u);
+    *newton = fas_nl_run(nl.prog, nl.prog.jacobian, nl.prog.n_jacobian, u);
+  } else {
+    const double ex = exp(u);
+    *sigma = nl.gam * ex;
+    *newton = (nl.gam * (u + 1.0)) * ex;
+  }
+}
 // `centre`: the value of X at the node (the smoother's local iterate); s: Solution at the node (what gamSten reads)
-__device__ __forceinline__ double fas_apply(const Stencil<double>& st, double gam, const double* x, const Geo& g, long c, double centre, double s) {
+__device__ __forceinline__ double fas_apply(const Stencil<double>& st, const FasNl& nl, const double* x, const Geo& g, long c, double centre, double s) {
   double a = st.c[0] * centre;
   a = a + st.c[1] * x[c - 1];
   a = a + st.c[2] * x[c + 1];
   a = a + st.c[3] * x[c - g.pitch];
   a = a + st.c[4] * x[c + g.pitch];
-  return a + (gam * exp(s)) * centre;
+  return a + fas_nl_sigma(nl, s) * centre;
 }
-// Solution += w * ( ( RHS - A(Solution) ) / ( Laplace:[0,0] [+ gam*(Solution + 1)*exp(Solution)] ) ), n local steps
-__device__ __forceinline__ double fas_relax(const Stencil<double>& st, double gam, const double* x, const double* f, const Geo& g, long c,
+// Solution += w * ( ( RHS - A(Solution) ) / ( Laplace:[0,0] [+ d/du (sigma(u) u): gam*(Solution + 1)*exp(Solution)] ) ), n local steps
+__device__ __forceinline__ double fas_relax(const Stencil<double>& st, const FasNl& nl, const double* x, const double* f, const Geo& g, long c,
                                             double om, int newton, int n_steps) {
   double u = x[c];
   for (int s = 0; s < (n_steps > 1 ? n_steps : 1); ++s) {
-    const double num = f[c] - fas_apply(st, gam, x, g, c, u, u);
-    const double den = newton ? st.c[0] + (gam * (u + 1.0)) * exp(u) : st.c[0];
+    double a = st.c[0] * u;
+    a = a + st.c[1] * x[c - 1];
+    a = a + st.c[2] * x[c + 1];
+    a = a + st.c[3] * x[c - g.pitch];
+    a = a + st.c[4] * x[c + g.pitch];
+    double sig, jac;
+    fas_nl_both(nl, u, &sig, &jac);
+    const double num = f[c] - (a + sig * u);
+    const double den = newton ? st.c[0] + jac : st.c[0];
     u = u + om * (num / den);
   }
   return u;
 }
 // colour < 0: Jacobi sweep x -> y (inner nodes; y keeps its zero boundary); colour 0 | 1: one colour in place (y == x)
-__global__ void __launch_bounds__(256) evomg_fas_smooth(Geo g, Stencil<double> st, double gam, const double* x, const double* f, double* y,
+__global__ void __launch_bounds__(256) evomg_fas_smooth(Geo g, Stencil<double> st, FasNl nl, const double* x, const double* f, double* y,
                                                         double om, int newton, int n_steps, int colour) {
   int i, j, k;
   if (!node_of_thread<2>(g, i, j, k) || !is_inner<2>(g, i, j, 0)) return;
   if (colour >= 0 && ((i + j) & 1) != colour) return;
   const long c = gidx<2>(g, i, j, 0);
-  y[c] = fas_relax(st, gam, x, f, g, c, om, newton, n_steps);
+  y[c] = fas_relax(st, nl, x, f, g, c, om, newton, n_steps);
 }
 // Residual = ( RHS - A(Solution) )
-__global__ void __launch_bounds__(256) evomg_fas_residual(Geo g, Stencil<double> st, double gam, const double* __restrict__ x,
+__global__ void __launch_bounds__(256) evomg_fas_residual(Geo g, Stencil<double> st, FasNl nl, const double* __restrict__ x,
                                                           const double* __restrict__ f, double* __restrict__ r) {
   int i, j, k;
   if (!node_of_thread<2>(g, i, j, k) || !is_inner<2>(g, i, j, 0)) return;
   const long c = gidx<2>(g, i, j, 0);
-  r[c] = f[c] - fas_apply(st, gam, x, g, c, x[c], x[c]);
+  r[c] = f[c] - fas_apply(st, nl, x, g, c, x[c], x[c]);
 }
 __device__ __forceinline__ double fas_fw(const Geo& gf, const double* __restrict__ fine, int I, int J) {   // = evomg_restrict<double, 2>
   const long c = gidx<2>(gf, 2 * I, 2 * J, 0);
@@ -69,13 +134,13 @@ __global__ void __launch_bounds__(256) evomg_fas_restrict_solution(Geo gc, Geo g
   sol[c] = v;
 }
 // RHS@c = ( ( R * Residual@f ) + A(Approximation@c; Solution@c) )
-__global__ void __launch_bounds__(256) evomg_fas_coarse_rhs(Geo gc, Geo gf, Stencil<double> st, double gam, const double* __restrict__ fine_res,
+__global__ void __launch_bounds__(256) evomg_fas_coarse_rhs(Geo gc, Geo gf, Stencil<double> st, FasNl nl, const double* __restrict__ fine_res,
                                                             const double* __restrict__ approx, const double* __restrict__ sol,
                                                             double* __restrict__ rhs) {
   int I, J, K;
   if (!node_of_thread<2>(gc, I, J, K) || !is_inner<2>(gc, I, J, 0)) return;
   const long c = gidx<2>(gc, I, J, 0);
-  rhs[c] = fas_fw(gf, fine_res, I, J) + fas_apply(st, gam, approx, gc, c, approx[c], sol[c]);
+  rhs[c] = fas_fw(gf, fine_res, I, J) + fas_apply(st, nl, approx, gc, c, approx[c], sol[c]);
 }
 // Solution -= Approximation
 __global__ void __launch_bounds__(256) evomg_fas_subtract(Geo g, double* __restrict__ sol, const double* __restrict__ approx) {
@@ -90,7 +155,7 @@ __global__ void __launch_bounds__(256) evomg_fas_subtract(Geo g, double* __restr
 // floor for 200 x ~1 us of work. Thread t owns the inner nodes t, t + 1024, ...; a barrier between sweeps; the two slots
 // alternate. Same per-node formula as evomg_fas_smooth (fas_relax): bit-identical to the launch-per-sweep form.
 // After an even number of sweeps the result is in `a`, after an odd number in `b` (the host swaps accordingly).
-__global__ void __launch_bounds__(1024) evomg_fas_cgs(Geo g, Stencil<double> st, double gam, double* a, double* b, const double* f,
+__global__ void __launch_bounds__(1024) evomg_fas_cgs(Geo g, Stencil<double> st, FasNl nl, double* a, double* b, const double* f,
                                                       double om, int sweeps) {
   const int m = g.n - 2;
   const int total = m * m;
@@ -100,7 +165,7 @@ __global__ void __launch_bounds__(1024) evomg_fas_cgs(Geo g, Stencil<double> st,
     for (int q = threadIdx.x; q < total; q += 1024) {
       const int i = 1 + q % m, j = 1 + q / m;
       const long c = gidx<2>(g, i, j, 0);
-      y[c] = fas_relax(st, gam, x, f, g, c, om, 1, 1);
+      y[c] = fas_relax(st, nl, x, f, g, c, om, 1, 1);
     }
     __syncthreads();
     double* t = x; x = y; y = t;
@@ -114,7 +179,7 @@ __global__ void __launch_bounds__(1024) evomg_fas_cgs(Geo g, Stencil<double> st,
 // bit-identical to evomg_fas_cgs and to the launch-per-sweep form. a / b: as evomg_fas_cgs (the result of the last sweep
 // and of the one before it are written back to the slots where the global-memory form would have left them).
 // dynamic LDS: 2 * n * n doubles.
-__global__ void __launch_bounds__(1024) evomg_fas_cgs_lds(Geo g, Stencil<double> st, double gam, double* a, double* b, const double* f,
+__global__ void __launch_bounds__(1024) evomg_fas_cgs_lds(Geo g, Stencil<double> st, FasNl nl, double* a, double* b, const double* f,
                                                           double om, int sweeps) {
   extern __shared__ __align__(16) double fas_lds[];
   const int n = g.n, m = n - 2, total = m * m, nn = n * n;
@@ -149,10 +214,11 @@ __global__ void __launch_bounds__(1024) evomg_fas_cgs_lds(Geo g, Stencil<double>
       ap = ap + st.c[2] * cur[c + 1];
       ap = ap + st.c[3] * cur[c - n];
       ap = ap + st.c[4] * cur[c + n];
-      const double ex = exp(u);
-      ap = ap + (gam * ex) * u;
+      double sig, jac;
+      fas_nl_both(nl, u, &sig, &jac);
+      ap = ap + sig * u;
       const double num = fv[e] - ap;
-      const double den = st.c[0] + (gam * (u + 1.0)) * ex;
+      const double den = st.c[0] + jac;
       nxt[c] = u + om * (num / den);
     }
     __syncthreads();
@@ -201,7 +267,7 @@ __device__ __forceinline__ bool grid_wait(const unsigned* flags, int groups, uns
   __syncthreads();
   return *lds_flag == 0;
 }
-__global__ void __launch_bounds__(1024) evomg_fas_cgs_tiles(Geo g, Stencil<double> st, double gam, double* a, double* b, const double* f,
+__global__ void __launch_bounds__(1024) evomg_fas_cgs_tiles(Geo g, Stencil<double> st, FasNl nl, double* a, double* b, const double* f,
                                                             double om, int sweeps, double* xchg, unsigned* flags, int* info) {
   constexpr int T = EVOMG_FAS_TILE, H = EVOMG_FAS_HALO, W = T + 2 * H, IW = W + 2;
   static_assert(W * W == 1024, "one node of the extended tile per thread");
@@ -252,10 +318,11 @@ __global__ void __launch_bounds__(1024) evomg_fas_cgs_tiles(Geo g, Stencil<doubl
         ap = ap + st.c[2] * im[me + 1];
         ap = ap + st.c[3] * im[me - IW];
         ap = ap + st.c[4] * im[me + IW];
-        const double ex = exp(u);
-        ap = ap + (gam * ex) * u;
+        double sig, jac;
+        fas_nl_both(nl, u, &sig, &jac);
+        ap = ap + sig * u;
         const double num = fv - ap;
-        const double den = st.c[0] + (gam * (u + 1.0)) * ex;
+        const double den = st.c[0] + jac;
         const double un = u + om * (num / den);
         img[cur ^ 1][me] = un;
         prev = u;

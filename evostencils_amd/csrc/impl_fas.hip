@@ -258,9 +258,16 @@ class FASImpl : public ImplBase {
     }
     return EVOMG_OK;
   }
+  FasNl nl() const {
+    FasNl v;
+    v.kind = prob_.nonlinear_kind;
+    v.gam = prob_.nonlinear_gamma;
+    v.prog = prob_.nonlinear_program;
+    return v;
+  }
   void smooth(int L, double om, bool red_black, int n_newton) {
     FLevel& lv = lv_[L];
-    const double gam = prob_.nonlinear_gamma;
+    const FasNl gam = nl();      // the non-linear stencil entry (evomg_fas.h)
     double* x = lv.f[EVOMG_F_SOL];
     const double* f = lv.f[EVOMG_F_RHS];
     if (red_black) {
@@ -274,7 +281,7 @@ class FASImpl : public ImplBase {
   int exec(const evomg_op_t& op) {
     const int L = op.level;
     FLevel& lv = lv_[L];
-    const double gam = prob_.nonlinear_gamma;
+    const FasNl gam = nl();      // the non-linear stencil entry (evomg_fas.h)
     switch (op.opcode) {
       case EVOMG_OP_FAS_SMOOTH: smooth(L, op.omega, op.partitioning == EVOMG_PART_RED_BLACK, op.block[0]); break;
       case EVOMG_OP_FAS_RESIDUAL:
@@ -349,7 +356,7 @@ class FASImpl : public ImplBase {
   }
   int residual_norm(int L, double* out) {      // UpResidual@finest ; NormResidual_0@finest
     FLevel& lv = lv_[L];
-    hipLaunchKernelGGL(evomg_fas_residual, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.st, prob_.nonlinear_gamma, (const double*)lv.f[EVOMG_F_SOL],
+    hipLaunchKernelGGL(evomg_fas_residual, grd(lv.g.n), blk(), 0, stream_, lv.g, lv.st, nl(), (const double*)lv.f[EVOMG_F_SOL],
                        (const double*)lv.f[EVOMG_F_RHS], lv.f[EVOMG_F_RES]);
     double d;
     const int rc = dot_to_host(L, lv.f[EVOMG_F_RES], &d);

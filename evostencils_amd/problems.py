@@ -139,6 +139,8 @@ class ProblemDescription:
     nonlinear_kind: int = abi.NONLINEAR_NONE
     nonlinear_gamma: float = 0.0
     fas_cgs_omega: float = 0.0
+    # abi.NONLINEAR_PROGRAM: (sigma opcodes, Newton-term opcodes, constants) — code_generation.fas.compile_nonlinear
+    nonlinear_program: Optional[tuple] = None
 
     def nodes(self, level):
         return (1 << level) + 1
@@ -195,6 +197,18 @@ class ProblemDescription:
             jacobi_semantics = self.jacobi_semantics
         p.jacobi_semantics = abi.JACOBI_SEMANTICS.get(jacobi_semantics, jacobi_semantics)
         p.nonlinear_kind, p.nonlinear_gamma, p.fas_cgs_omega = self.nonlinear_kind, self.nonlinear_gamma, self.fas_cgs_omega
+        if self.nonlinear_program is not None:
+            sigma, jacobian, consts = self.nonlinear_program
+            if max(len(sigma), len(jacobian)) > abi.NL_MAX_OPS or len(consts) > abi.NL_MAX_CONSTS:
+                raise ValueError("non-linear stencil entry: program too long for the C-ABI descriptor")
+            q = p.nonlinear_program
+            q.n_sigma, q.n_jacobian = len(sigma), len(jacobian)
+            for k, op in enumerate(sigma):
+                q.sigma[k] = op
+            for k, op in enumerate(jacobian):
+                q.jacobian[k] = op
+            for k, v in enumerate(consts):
+                q.consts[k] = float(v)
         return p
 
     # ---- what the reference's parser would extract (parser.py:25-111) -------------------------
@@ -405,7 +419,7 @@ def linear_elasticity_2d(min_level=4, max_level=8, lam=195.0, mu=130.0) -> Probl
 
 
 def fas_2d(template, name="FAS_2D_Basic") -> ProblemDescription:
-    """-Laplace u + gam u e^u = f on (0,1)^2, u = 0 on the boundary, u0 = 0: the reference's non-linear FAS example
+    """-Laplace u + sigma(u) u = f on (0,1)^2, u = 0 on the boundary, u0 = 0 — sigma = gam e^u is the reference's non-linear FAS example
     (example_problems/FAS_2D_Basic/FAS_2D_Basic_template.exa4). `template`: code_generation.fas.FASTemplate, i.e. what the
     problem's .knowledge / _template.exa4 files say (levels, gam, right-hand side function, coarse solver, stopping rule)."""
     def st(level, _params):
@@ -423,15 +437,17 @@ def fas_2d(template, name="FAS_2D_Basic") -> ProblemDescription:
         X, Y = x[None, :], x[:, None]
         return np.asarray(template.rhs_function(X + 0.0 * Y, Y + 0.0 * X), dtype=np.float64)
 
-    if "exp" not in template.nonlinear_text or "gam" not in template.nonlinear_text:
-        raise ValueError(f"unsupported non-linear stencil: {template.nonlinear_text}")
+    # the stencil entry: the reference's example gam * exp(Solution) has kernels of its own; any other entry travels as a
+    # pair of reverse-Polish programs (abi.NONLINEAR_PROGRAM, ABI 6)
+    from evostencils_amd.code_generation import fas as fas_front
+    kind, program = fas_front.classify_nonlinear(template.nonlinear_text, template.gamma)
     return ProblemDescription(name, 2, template.min_level, template.max_level, mg_stencil=st,
                               initial_solution=u0, right_hand_side=rhs, cgs_kind=abi.CGS_FAS_SMOOTHER,
                               max_iterations=template.max_iterations, cgs_max_iterations=template.cgs_sweeps,
                               target_res_reduction=template.target_res_reduction,
                               field_name="Solution", rhs_name="RHS", operator_name="Laplace",
                               restriction_name="RestrictionNode", prolongation_name="CorrectionNode",
-                              nonlinear_kind=abi.NONLINEAR_GAM_U_EXP_U, nonlinear_gamma=template.gamma,
+                              nonlinear_kind=kind, nonlinear_gamma=template.gamma, nonlinear_program=program,
                               fas_cgs_omega=template.cgs_omega)
 
 

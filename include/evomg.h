@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EVOMG_ABI_VERSION 5
+#define EVOMG_ABI_VERSION 6
 #define EVOMG_MAX_LEVELS 24       /* levels are absolute: grid level L has 2^L+1 nodes per dimension */
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
@@ -87,9 +87,34 @@ enum {
 /* Non-linear term N(u) of a FAS problem -Lap u + N(u) = f, SURVEY 8f N4 (exastencils_FAS.py; FAS_2D_Basic_template.exa4) */
 enum {
   EVOMG_NONLINEAR_NONE = 0,
-  EVOMG_NONLINEAR_GAM_U_EXP_U = 1  /* `Stencil gamSten { [0,0] => gam * exp(Solution) }` applied to Solution:
+  EVOMG_NONLINEAR_GAM_U_EXP_U = 1, /* `Stencil gamSten { [0,0] => gam * exp(Solution) }` applied to Solution:
                                       N(u) = gam u e^u, N'(u) = gam (1 + u) e^u (template:27-29,69) */
+  EVOMG_NONLINEAR_PROGRAM = 2      /* ABI 6: ANY stencil entry sigma(Solution) the reference's parser admits
+                                      (code_generation/parser.py:146-169 takes an arbitrary sympy term): sigma and the
+                                      Newton term d/du [ sigma(u) u ] — sympy's own derivative, as exastencils_FAS.py
+                                      forms it — travel as two small straight-line programs, evomg_nl_program_t */
 };
+/* A straight-line program in reverse Polish notation over ONE variable (the value of Solution at the node), evaluated
+ * with an operand stack of at most EVOMG_NL_MAX_STACK entries, left to right, one IEEE operation per opcode (no
+ * contraction): the HIP kernels and the CPU oracle execute the same operations in the same order. */
+#define EVOMG_NL_MAX_OPS 48
+#define EVOMG_NL_MAX_CONSTS 8
+#define EVOMG_NL_MAX_STACK 8
+enum {
+  EVOMG_NL_END = 0,
+  EVOMG_NL_PUSH_U = 1,       /* the variable */
+  EVOMG_NL_PUSH_CONST = 2,   /* 2 + k: consts[k], k < EVOMG_NL_MAX_CONSTS */
+  EVOMG_NL_DUP = 10,
+  EVOMG_NL_ADD = 16, EVOMG_NL_SUB = 17, EVOMG_NL_MUL = 18, EVOMG_NL_DIV = 19,   /* (a b op): a op b */
+  EVOMG_NL_NEG = 20, EVOMG_NL_EXP = 21, EVOMG_NL_SIN = 22, EVOMG_NL_COS = 23, EVOMG_NL_SQRT = 24, EVOMG_NL_LOG = 25,
+  EVOMG_NL_TANH = 26, EVOMG_NL_SINH = 27, EVOMG_NL_COSH = 28
+};
+typedef struct {
+  int32_t n_sigma, n_jacobian;             /* opcodes in use (a program leaves exactly one value on the stack) */
+  uint8_t sigma[EVOMG_NL_MAX_OPS];         /* the stencil entry, e.g. `gam * Solution * Solution` */
+  uint8_t jacobian[EVOMG_NL_MAX_OPS];      /* d/du [ sigma(u) u ], the term the Newton-Jacobi denominator adds to the centre */
+  double  consts[EVOMG_NL_MAX_CONSTS];     /* shared by both programs (`Val gam`, numbers) */
+} evomg_nl_program_t;
 
 /* What a `with jacobi` sweep — every smoother with Single partitioning, point or block
  * (exastencils.py:64-70,778-822) — does to the field it relaxes. The sweep itself is the same in both modes
@@ -156,6 +181,7 @@ typedef struct {
   int32_t stencil_kind;         /* EVOMG_STENCIL_* (ABI 5; 0 in older descriptors = EVOMG_STENCIL_STAR) */
   double  nonlinear_gamma;      /* `Val gam : Real` */
   double  fas_cgs_omega;        /* weight of the coarse-grid solver's Newton-Jacobi sweeps (template:66: 0.8) */
+  evomg_nl_program_t nonlinear_program;   /* ABI 6: nonlinear_kind == EVOMG_NONLINEAR_PROGRAM */
 } evomg_problem_t;
 
 /* field slots of one level (exastencils.py:14-26,295-316) */

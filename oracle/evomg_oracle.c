@@ -148,8 +148,26 @@ static int check_problem(const evomg_problem_t* p) {
   if (p->cgs_kind != EVOMG_CGS_CG && p->cgs_kind != EVOMG_CGS_BICGSTAB && p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER && p->cgs_kind != EVOMG_CGS_CG_CLASSICAL) {
     snprintf(g_err, sizeof g_err, "bad coarse-grid solver kind"); return EVOMG_ERR_INVALID;
   }
+  if (p->nonlinear_kind == EVOMG_NONLINEAR_PROGRAM) {
+    /* both programs well-formed (the same check as csrc/evomg.hip: check_problem) */
+    for (int which = 0; which < 2; ++which) {
+      const int n = which ? p->nonlinear_program.n_jacobian : p->nonlinear_program.n_sigma;
+      const uint8_t* code = which ? p->nonlinear_program.jacobian : p->nonlinear_program.sigma;
+      int depth = 0, ok = n >= 1 && n <= EVOMG_NL_MAX_OPS;
+      for (int k = 0; ok && k < n; ++k) {
+        const int op = code[k];
+        if (op == EVOMG_NL_PUSH_U || (op >= EVOMG_NL_PUSH_CONST && op < EVOMG_NL_PUSH_CONST + EVOMG_NL_MAX_CONSTS)) ++depth;
+        else if (op == EVOMG_NL_DUP) { ok = depth >= 1; ++depth; }
+        else if (op >= EVOMG_NL_ADD && op <= EVOMG_NL_DIV) { ok = depth >= 2; --depth; }
+        else if (op >= EVOMG_NL_NEG && op <= EVOMG_NL_COSH) ok = depth >= 1;
+        else ok = 0;
+        ok = ok && depth <= EVOMG_NL_MAX_STACK;
+      }
+      if (!ok || depth != 1) { snprintf(g_err, sizeof g_err, "non-linear FAS: malformed program"); return EVOMG_ERR_INVALID; }
+    }
+  }
   if (p->nonlinear_kind != EVOMG_NONLINEAR_NONE) {
-    if (p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
+    if ((p->nonlinear_kind != EVOMG_NONLINEAR_GAM_U_EXP_U && p->nonlinear_kind != EVOMG_NONLINEAR_PROGRAM) || p->dimension != 2 || p->scalar_kind != EVOMG_REAL_F64 ||
         p->bc_kind != EVOMG_BC_DIRICHLET || p->outer_kind != EVOMG_OUTER_MG_ITERATION || p->cgs_kind != EVOMG_CGS_FAS_SMOOTHER ||
         p->n_unknowns > 1) {
       snprintf(g_err, sizeof g_err, "non-linear FAS: 2D real Dirichlet scalar problems, N(u) = gam u exp(u), smoother as coarse solver");

@@ -15,8 +15,8 @@ import cycles
 from helpers import GOLDEN
 
 
-def fas_generator(library=None, levels=None):
-    return ProgramGeneratorFAS("FAS_2D_Exponential", "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
+def fas_generator(library=None, levels=None, problem="FAS_2D_Exponential"):
+    return ProgramGeneratorFAS(problem, "Solution", "RHS", "Residual", "Approximation", "RestrictionNode",
                                "CorrectionNode", "Laplace", "gamSten", "gen_mgCycle", "CGS",
                                build_path=os.path.join(GOLDEN, "problems"), library=library, levels=levels)
 

@@ -16,15 +16,15 @@ import cycles
 from test_fas_lowering import fas_context, fas_generator
 
 
-def fas_problem(min_level, max_level):
-    gen = fas_generator(levels=(min_level, max_level))
+def fas_problem(min_level, max_level, problem="FAS_2D_Exponential"):
+    gen = fas_generator(levels=(min_level, max_level), problem=problem)
     return gen, gen.problem_description(), gen.template
 
 
-def ops_for(min_level, max_level, smoother=None):
+def ops_for(min_level, max_level, smoother=None, problem="FAS_2D_Exponential"):
     """FAS op program of a V(1,1) cycle (Newton-Jacobi, one local step, w = 0.8 unless `smoother` says otherwise) on a
     level range of the test problem."""
-    gen = fas_generator(levels=(min_level, max_level))
+    gen = fas_generator(levels=(min_level, max_level), problem=problem)
     depth = max_level - min_level
     sm = [[smoother or cycles._nw(14)] for _ in range(depth)]
     expression, _ = cycles.fas_v_cycle(fas_context(gen, depth), depth, sm, sm)
