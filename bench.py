@@ -746,7 +746,7 @@ def main():
     throughput = None
     if args.throughput_workers > 1 and args.throughput_workers != args.concurrency:
         k = args.throughput_workers
-        n = max(args.steps, 12 * k)               # long enough for the ramp at both ends not to show (16 in flight: 192 solves, half a second)
+        n = max(args.steps, 24 * k)               # long enough for the ramp at both ends not to weigh (16 in flight: 384 solves, a second; with 192 the last, partly idle round was a twelfth of the region)
         run_steps(k, in_flight=k)
         fence()
         t1 = time.perf_counter()
