@@ -14,7 +14,7 @@ MAX_LEVELS = 24
 MAX_DIM = 3
 STENCIL_ENTRIES = 7
 MAX_BLOCK_CELLS = 8
-MAX_UNKNOWNS = 2
+MAX_UNKNOWNS = 3
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3
 SOLVE_CONVERGED, SOLVE_MAXITER, SOLVE_DIVERGED, SOLVE_WALL_LIMIT = 0, 1, 2, 3
@@ -78,12 +78,12 @@ class Op(C.Structure):
     _fields_ = [
         ("opcode", C.c_int32), ("level", C.c_int32), ("dst", C.c_int32), ("src0", C.c_int32),
         ("src1", C.c_int32), ("partitioning", C.c_int32), ("block", C.c_int32 * MAX_DIM),
-        ("unknowns", C.c_int32), ("block_other", C.c_int32 * MAX_DIM), ("reserved", C.c_int32), ("omega", C.c_double),
+        ("unknowns", C.c_int32), ("block_other", C.c_int32 * MAX_DIM), ("block_third", C.c_int32), ("omega", C.c_double),
     ]
 
     def key(self):
         return (self.opcode, self.level, self.dst, self.src0, self.src1, self.partitioning,
-                tuple(self.block), self.omega, self.unknowns, tuple(self.block_other))
+                tuple(self.block), self.omega, self.unknowns, tuple(self.block_other), self.block_third)
 
     def __repr__(self):
         return (f"Op({OP_NAMES.get(self.opcode, self.opcode)}, L={self.level}, dst={self.dst}, "
@@ -110,8 +110,11 @@ def field_of(slot: int, unknown: int = 0) -> int:
 
 
 def make_op(opcode, level, dst=0, src0=0, src1=0, partitioning=PART_SINGLE, block=(1, 1, 1), omega=1.0, unknowns=0,
-            block_other=None) -> Op:
+            block_other=None, block_third=None) -> Op:
     op = Op()
+    if block_third is not None:   # system smoother over three unknowns: the third listed unknown's block shape (packed, ABI 6)
+        third = tuple(block_third) + (1,) * (MAX_DIM - len(block_third))
+        op.block_third = int(third[0]) | (int(third[1]) << 8) | (int(third[2]) << 16)
     if block_other is not None:   # system smoother: the second unknown's block shape where it differs from `block`
         other = tuple(block_other) + (1,) * (MAX_DIM - len(block_other))
         for i in range(MAX_DIM):

@@ -113,8 +113,8 @@ class Lowering:
         return cycle.relaxation_factor
 
     def _single_field(self, grids):
-        if len(grids) > 2:
-            raise UnsupportedExpression("systems with more than two unknowns are not supported")
+        if len(grids) > 3:          # abi.MAX_UNKNOWNS (ABI 6: three)
+            raise UnsupportedExpression("systems with more than three unknowns are not supported")
 
     def _zero_if_needed(self, approximation, grids):
         if isa(approximation, "system", "ZeroApproximation"):

@@ -11,7 +11,7 @@ _ROLE = {low.SOLUTION: abi.F_SOL, low.RHS: abi.F_RHS, low.RESIDUAL: abi.F_RES,
 
 def _f(ref: low.FieldRef) -> int:
     if not 0 <= ref.index < abi.MAX_UNKNOWNS:
-        raise low.UnsupportedExpression("systems with more than two unknowns are not supported")
+        raise low.UnsupportedExpression(f"systems with more than {abi.MAX_UNKNOWNS} unknowns are not supported")
     return abi.field_of(_ROLE[ref.role], ref.index)
 
 
@@ -52,9 +52,15 @@ def encode(statements) -> List[abi.Op]:
             mask = 0
             for u in st.unknowns:
                 mask |= 1 << u
-            other = st.blocks[1] if st.blocks and len(st.blocks) > 1 and st.blocks[1] != st.blocks[0] else None
+            # one block shape per listed unknown where they differ: the first in `block`, the second in `block_other`, the
+            # third in `block_third` (include/evomg.h; `st.blocks` is None when all are equal)
+            other = third = None
+            if st.blocks and len(st.blocks) > 1 and any(b != st.blocks[0] for b in st.blocks):
+                other = st.blocks[1]
+                if len(st.blocks) > 2:
+                    third = st.blocks[2]
             ops.append(abi.make_op(abi.OP_SMOOTH, st.level, _f(st.dst), 0, _f(st.rhs), partitioning, st.block,
-                                   _w(st.weight), unknowns=mask, block_other=other))
+                                   _w(st.weight), unknowns=mask, block_other=other, block_third=third))
         elif k == "smooth":
             _require_plain_operator(st)
             partitioning = abi.PART_RED_BLACK if st.partitioning == "red_black" else abi.PART_SINGLE

@@ -125,16 +125,17 @@ __global__ void __launch_bounds__(256) evomg_sys_point_smooth(Geo g, SysStencil 
   const bool inner = a >= 1 && b >= 1 && a <= n - 2 && b <= n - 2;
   if (!inner || (colour >= 0 && ((a + b) & 1) != colour)) {
 #pragma unroll
-    for (int u = 0; u < EVOMG_MAX_UNKNOWNS; ++u)
+    for (int u = 0; u < 2; ++u)
       if ((MASK >> u) & 1) y.p[u][c] = x.p[u][c];
     return;
   }
   constexpr int M0 = (MASK & 1) ? 0 : 1;                  // first listed unknown
   constexpr bool TWO = MASK == 3;
-  double rhs[2], xv[EVOMG_MAX_UNKNOWNS][9];
+  constexpr int NF = 2;                                   // this straight-line form is the two-unknown one (host-checked: nf == 2)
+  double rhs[2], xv[NF][9];
   // the nine values of both unknowns around the node (loaded once; the generic kernel reads them entry by entry)
 #pragma unroll
-  for (int j = 0; j < EVOMG_MAX_UNKNOWNS; ++j)      // host-checked: nf == EVOMG_MAX_UNKNOWNS
+  for (int j = 0; j < NF; ++j)
 #pragma unroll
     for (int e = 0; e < 9; ++e) xv[j][e] = x.p[j][(long)g.pitch * (b + sys_oy(e)) + a + sys_ox(e)];
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) evomg_sys_point_smooth(Geo g, SysStencil 
     const int i = TWO ? p : M0;
     double s = f.p[i][c];
 #pragma unroll
-    for (int j = 0; j < EVOMG_MAX_UNKNOWNS; ++j)
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
         if (e == 0 && ((MASK >> j) & 1)) continue;        // a listed unknown: goes into the local matrix

@@ -224,9 +224,15 @@ class SystemImpl : public ImplBase {
           int k = 0, first = 0;
           for (int u = 0; u < nf_; ++u) k += (mask >> u) & 1;
           while (!((mask >> first) & 1)) ++first;
-          const bool other = op.block_other[0] != 0 || op.block_other[1] != 0;       // second unknown: its own block shape
-          if (other && (k != 2 || op.block_other[0] < 1 || op.block_other[1] < 1)) { ok = false; break; }
-          const int cells = op.block[0] * op.block[1] + (k == 2 ? (other ? op.block_other[0] * op.block_other[1] : op.block[0] * op.block[1]) : 0);
+          const bool other = op.block_other[0] != 0 || op.block_other[1] != 0;       // the listed unknowns after the first: their own block shapes
+          if (other && (k < 2 || op.block_other[0] < 1 || op.block_other[1] < 1)) { ok = false; break; }
+          if (op.block_third != 0 && (k < 3 || !other || (op.block_third & 0xff) < 1 || ((op.block_third >> 8) & 0xff) < 1)) { ok = false; break; }
+          int cells = 0;
+          for (int q = 0; q < k; ++q) {
+            int sx, sy;
+            listed_shape(op, q, &sx, &sy);
+            cells += sx * sy;
+          }
           ok = cells <= EVOMG_MAX_BLOCK_CELLS && op.dst / EVOMG_F_COUNT == first && op.src1 / EVOMG_F_COUNT == first &&
                (op.partitioning == EVOMG_PART_SINGLE || op.partitioning == EVOMG_PART_RED_BLACK);
           if (ok && op.partitioning == EVOMG_PART_RED_BLACK && cells != k) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
@@ -235,8 +241,15 @@ class SystemImpl : public ImplBase {
           // block_diagonal(A_ij, shape_i) repeats every unknown with its own period). Where the sweep's RESULT is used
           // (textbook semantics) the candidate is therefore rejected; under the reference pipeline's semantics the sweep is
           // launched for its time only and its output never becomes the field, so rho and the iteration count are exact.
-          if (ok && other && (op.block_other[0] != op.block[0] || op.block_other[1] != op.block[1]) &&
-              prob_.jacobi_semantics == EVOMG_JACOBI_TEXTBOOK) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
+          if (ok && other && prob_.jacobi_semantics == EVOMG_JACOBI_TEXTBOOK) {
+            bool differ = false;
+            for (int q = 1; q < k; ++q) {
+              int sx, sy;
+              listed_shape(op, q, &sx, &sy);
+              differ = differ || sx != op.block[0] || sy != op.block[1];
+            }
+            if (differ) { ok = false; rc = EVOMG_ERR_UNSUPPORTED; }
+          }
           break;
         }
         case EVOMG_OP_RESIDUAL: ok = fieldptr(op.level, op.src0) && fieldptr(op.level, op.src1) && op.src0 / EVOMG_F_COUNT == 0; break;
@@ -253,6 +266,13 @@ class SystemImpl : public ImplBase {
     return EVOMG_OK;
   }
 
+  // block shape of the q-th LISTED unknown of a SMOOTH (include/evomg.h: block, block_other, block_third)
+  static void listed_shape(const evomg_op_t& op, int q, int* sx, int* sy) {
+    *sx = op.block[0];
+    *sy = op.block[1];
+    if (q >= 1 && op.block_other[0] > 0) { *sx = op.block_other[0]; *sy = op.block_other[1]; }
+    if (q >= 2 && op.block_third != 0) { *sx = op.block_third & 0xff; *sy = (op.block_third >> 8) & 0xff; }
+  }
   SysConstFields slot_fields(int level, int slot) {
     SysConstFields x{};
     for (int u = 0; u < nf_; ++u) x.p[u] = fieldptr(level, EVOMG_FIELD(slot, u));
@@ -265,14 +285,13 @@ class SystemImpl : public ImplBase {
     switch (op.opcode) {
       case EVOMG_OP_SMOOTH: {
         const int mask = mask_of(op), inner = g.n - 2;
-        // per-unknown block shapes: the first unknown of the mask has `block`, the second `block_other` where that is set
+        // per-unknown block shapes: the first unknown of the mask has `block`, the second `block_other`, the third
+        // `block_third` where those are set (listed_shape)
         SysShapes sh{};
         int bx = 1, by = 1, seen = 0;
         for (int u = 0; u < nf_; ++u) {
           if (!((mask >> u) & 1)) { sh.bx[u] = sh.by[u] = 0; continue; }
-          const bool second = seen++ > 0 && op.block_other[0] > 0;
-          sh.bx[u] = second ? op.block_other[0] : op.block[0];
-          sh.by[u] = second ? op.block_other[1] : op.block[1];
+          listed_shape(op, seen++, &sh.bx[u], &sh.by[u]);
           bx = sh.bx[u] > bx ? sh.bx[u] : bx;
           by = sh.by[u] > by ? sh.by[u] : by;
         }
@@ -351,29 +370,35 @@ class SystemImpl : public ImplBase {
     HIP_TRY(hipGetLastError());
     return EVOMG_OK;
   }
-  // ops[i], ops[i + 1]: the same statement for unknown 0 and unknown 1 (what a cycle emits back to back), independent of
-  // each other -> one launch with blockIdx.z = unknown (evomg_system.h)
-  bool same_statement_for_both_unknowns(const evomg_op_t& a, const evomg_op_t& b) const {
-    if (!sys_pair_fuse_ || nf_ != 2 || a.opcode != b.opcode || a.level != b.level) return false;
-    if (a.dst / EVOMG_F_COUNT != 0 || b.dst != a.dst + EVOMG_F_COUNT) return false;
+  // ops[i .. i + nf): the same statement for unknown 0, 1, ... (what a cycle emits back to back), independent of each other
+  // -> one launch with blockIdx.z = unknown (evomg_system.h)
+  bool same_statement_for_both_unknowns(const evomg_op_t& a, const evomg_op_t& b, int u) const {
+    if (a.opcode != b.opcode || a.level != b.level) return false;
+    if (a.dst / EVOMG_F_COUNT != 0 || b.dst != a.dst + EVOMG_F_COUNT * u) return false;
     switch (a.opcode) {
       case EVOMG_OP_RESIDUAL:        // row i reads every unknown's solution slot (src0 names unknown 0's) and its own rhs
-        return b.src0 == a.src0 && a.src1 / EVOMG_F_COUNT == 0 && b.src1 == a.src1 + EVOMG_F_COUNT &&
+        return b.src0 == a.src0 && a.src1 / EVOMG_F_COUNT == 0 && b.src1 == a.src1 + EVOMG_F_COUNT * u &&
                canon(a.level, a.dst) % EVOMG_F_COUNT != canon(a.level, a.src0) % EVOMG_F_COUNT &&
                canon(a.level, a.dst) % EVOMG_F_COUNT != canon(a.level, a.src1) % EVOMG_F_COUNT;
-      case EVOMG_OP_RESTRICT: return a.src0 / EVOMG_F_COUNT == 0 && b.src0 == a.src0 + EVOMG_F_COUNT;
+      case EVOMG_OP_RESTRICT: return a.src0 / EVOMG_F_COUNT == 0 && b.src0 == a.src0 + EVOMG_F_COUNT * u;
       case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET:
-        return a.src0 / EVOMG_F_COUNT == 0 && b.src0 == a.src0 + EVOMG_F_COUNT && a.omega == b.omega;
+        return a.src0 / EVOMG_F_COUNT == 0 && b.src0 == a.src0 + EVOMG_F_COUNT * u && a.omega == b.omega;
       case EVOMG_OP_SET_ZERO: return true;
       default: return false;
     }
   }
+  bool same_statement_for_all_unknowns(const evomg_op_t* ops, int left) const {
+    if (!sys_pair_fuse_ || nf_ < 2 || left < nf_) return false;
+    for (int u = 1; u < nf_; ++u)
+      if (!same_statement_for_both_unknowns(ops[0], ops[u], u)) return false;
+    return true;
+  }
   int exec_pair(const evomg_op_t& op) {
     const int L = op.level;
     const Geo& g = lv_[L].g;
-    const dim3 grid2((g.n + 63) / 64, (g.n + 3) / 4, 2);
+    const dim3 grid2((g.n + 63) / 64, (g.n + 3) / 4, nf_);
     SysFields d{};
-    for (int u = 0; u < 2; ++u) d.p[u] = fieldptr(L, op.dst + EVOMG_F_COUNT * u);
+    for (int u = 0; u < nf_; ++u) d.p[u] = fieldptr(L, op.dst + EVOMG_F_COUNT * u);
     switch (op.opcode) {
       case EVOMG_OP_RESIDUAL: {
         const SysConstFields x = slot_fields(L, canon(L, op.src0) % EVOMG_F_COUNT);
@@ -383,13 +408,13 @@ class SystemImpl : public ImplBase {
       }
       case EVOMG_OP_RESTRICT: {
         SysConstFields s{};
-        for (int u = 0; u < 2; ++u) s.p[u] = fieldptr(L + 1, op.src0 + EVOMG_F_COUNT * u);
+        for (int u = 0; u < nf_; ++u) s.p[u] = fieldptr(L + 1, op.src0 + EVOMG_F_COUNT * u);
         hipLaunchKernelGGL(evomg_sys_restrict2, grid2, blk(), 0, stream_, g, lv_[L + 1].g, s, d);
         break;
       }
       case EVOMG_OP_PROLONG_ADD: case EVOMG_OP_PROLONG_SET: {
         SysConstFields s{};
-        for (int u = 0; u < 2; ++u) s.p[u] = fieldptr(L - 1, op.src0 + EVOMG_F_COUNT * u);
+        for (int u = 0; u < nf_; ++u) s.p[u] = fieldptr(L - 1, op.src0 + EVOMG_F_COUNT * u);
         if (op.opcode == EVOMG_OP_PROLONG_ADD) hipLaunchKernelGGL(evomg_sys_prolong2<true>, grid2, blk(), 0, stream_, g, lv_[L - 1].g, s, d, op.omega);
         else hipLaunchKernelGGL(evomg_sys_prolong2<false>, grid2, blk(), 0, stream_, g, lv_[L - 1].g, s, d, 1.0);
         break;
@@ -403,9 +428,9 @@ class SystemImpl : public ImplBase {
   int exec_all(const evomg_op_t* ops, int n_ops) {
     for (int i = 0; i < n_ops; ++i) {
       int rc;
-      if (i + 1 < n_ops && same_statement_for_both_unknowns(ops[i], ops[i + 1])) {
+      if (same_statement_for_all_unknowns(ops + i, n_ops - i)) {
         if ((rc = exec_pair(ops[i])) != EVOMG_OK) return rc;
-        ++i;
+        i += nf_ - 1;
       } else if ((rc = exec(ops[i])) != EVOMG_OK) return rc;
     }
     return EVOMG_OK;

@@ -418,6 +418,49 @@ def linear_elasticity_2d(min_level=4, max_level=8, lam=195.0, mu=130.0) -> Probl
                                             "solver_smoother_jacobiType": "false"})
 
 
+def three_species_2d(min_level=3, max_level=6) -> ProblemDescription:
+    """Three diffusing species coupled by a symmetric, diagonally dominant reaction matrix and one mixed-derivative term:
+    a system of THREE PDEs (round 6, ABI 6: EVOMG_MAX_UNKNOWNS 3 — the reference's IR is general in the number of unknowns,
+    ir/system.py:32-50; its only example of a system has two). The same problem as the files under
+    tests/golden/problems/ThreeSpecies (tests/test_three_unknowns.py checks that the front end reads them to this descriptor):
+        d_a Lap' ca + k_aa ca - k_ab cb + m dxy cb = fa,   d_b Lap' cb - k_ab ca + k_bb cb - k_bc cc + m dxy ca = fb,
+        d_c Lap' cc - k_bc cb + k_cc cc = fc            (Lap' = -Laplace), cb = 0.1 x y on the boundary, zero start."""
+    diff, k_aa, k_ab, k_bb, k_bc, k_cc, mix = (1.0, 0.5, 2.0), 30.0, 10.0, 40.0, 15.0, 50.0, 0.2
+
+    def stencils(level):
+        h = 1.0 / (1 << level)
+        return {
+            "lap": [((0, 0), 2.0 / h ** 2 + 2.0 / h ** 2), ((-1, 0), -1.0 / h ** 2), ((1, 0), -1.0 / h ** 2),
+                    ((0, -1), -1.0 / h ** 2), ((0, 1), -1.0 / h ** 2)],
+            "one": [((0, 0), 1.0)],
+            "dxdy": [((-1, -1), 0.25 / (h * h)), ((1, -1), -0.25 / (h * h)), ((-1, 1), -0.25 / (h * h)), ((1, 1), 0.25 / (h * h))],
+        }
+
+    def equations(level):
+        L = level
+        return [f"( {diff[0]} * lap@{L} * ca@{L} + {k_aa} * one@{L} * ca@{L} - {k_ab} * one@{L} * cb@{L} + {mix} * dxdy@{L} * cb@{L} ) == fa@{L}",
+                f"( {diff[1]} * lap@{L} * cb@{L} - {k_ab} * one@{L} * ca@{L} + {k_bb} * one@{L} * cb@{L} - {k_bc} * one@{L} * cc@{L} + {mix} * dxdy@{L} * ca@{L} ) == fb@{L}",
+                f"( {diff[2]} * lap@{L} * cc@{L} - {k_bc} * one@{L} * cb@{L} + {k_cc} * one@{L} * cc@{L} ) == fc@{L}"]
+
+    def u0(level):
+        n, x = _coords(level, 2)
+        X, Y = x[None, :], x[:, None]
+        return [np.zeros((n, n)), np.where(_boundary_mask(n, 2), 0.1 * X * Y, 0.0), np.zeros((n, n))]
+
+    def rhs(level):
+        n, x = _coords(level, 2)
+        X, Y = x[None, :], x[:, None]
+        return [40.0 * np.sin(np.pi * X) * np.sin(2.0 * np.pi * Y) + 0.0 * X, np.zeros((n, n)), 25.0 * X * (1.0 - Y)]
+
+    spec = SystemSpec(["ca", "cb", "cc"], ["fa", "fb", "fc"], ["speciesA", "speciesB", "speciesC"], equations, stencils,
+                      [f"gen_restrictionForRes_{f}" for f in ("ca", "cb", "cc")],
+                      [f"gen_prolongationForSol_{f}" for f in ("ca", "cb", "cc")], u0, rhs)
+    return ProblemDescription("2D_FD_ThreeSpecies", 2, min_level, max_level, system=spec, max_iterations=80,
+                              cgs_max_iterations=800, target_res_reduction=1e-11, cgs_target_res_reduction=1e-11,
+                              solver_hints={"solver_smoother_numPre": 2, "solver_smoother_numPost": 1,
+                                            "solver_smoother_damping": 1.1, "solver_smoother_coloring": "red-black"})
+
+
 def fas_2d(template, name="FAS_2D_Basic") -> ProblemDescription:
     """-Laplace u + sigma(u) u = f on (0,1)^2, u = 0 on the boundary, u0 = 0 — sigma = gam e^u is the reference's non-linear FAS example
     (example_problems/FAS_2D_Basic/FAS_2D_Basic_template.exa4). `template`: code_generation.fas.FASTemplate, i.e. what the
@@ -451,5 +494,5 @@ def fas_2d(template, name="FAS_2D_Basic") -> ProblemDescription:
                               fas_cgs_omega=template.cgs_omega)
 
 
-BY_NAME = {"2D_FD_LinearElasticity_fromL2": linear_elasticity_2d, "2D_FD_Poisson_fromL2": poisson_2d, "3D_FD_Poisson_fromL2": poisson_3d,
+BY_NAME = {"2D_FD_ThreeSpecies": three_species_2d, "2D_FD_LinearElasticity_fromL2": linear_elasticity_2d, "2D_FD_Poisson_fromL2": poisson_2d, "3D_FD_Poisson_fromL2": poisson_3d,
            "2D_FD_Helmholtz_fromL3": helmholtz_2d}

@@ -30,7 +30,7 @@ extern "C" {
 #define EVOMG_MAX_DIM 3
 #define EVOMG_STENCIL_ENTRIES 7   /* star stencil: centre, -x, +x, -y, +y, -z, +z */
 #define EVOMG_MAX_BLOCK_CELLS 8   /* maximum_local_system_size default, optimization/program.py:107 */
-#define EVOMG_MAX_UNKNOWNS 2      /* systems of PDEs: unknowns per node (LinearElasticity: u, v) */
+#define EVOMG_MAX_UNKNOWNS 3      /* systems of PDEs: unknowns per node (LinearElasticity: u, v; ABI 6: three — ir/system.py:32-50 is general) */
 #define EVOMG_SYS_STENCIL_ENTRIES 9 /* 2D compact stencil: centre, W, E, S, N, SW, SE, NW, NE */
 
 /* status codes (function return values) */
@@ -247,9 +247,12 @@ typedef struct {
                             only under EVOMG_JACOBI_EXASTENCILS_V11, where the sweep is launched for its time and its
                             result never becomes the field (rho / iterations exact); EVOMG_ERR_UNSUPPORTED under
                             EVOMG_JACOBI_TEXTBOOK, where the unverified tiling would decide the candidate's fitness */
-  int32_t reserved;
+  int32_t block_third;   /* ABI 6 (the field was reserved before), SMOOTH on a system whose mask names THREE unknowns with
+                            differing shapes: the third listed unknown's block shape, packed bx | by << 8 | bz << 16; 0 = the
+                            same as the second's. Same acceptance rule as block_other */
   double  omega;         /* relaxation factor */
 } evomg_op_t;
+#define EVOMG_PACK_BLOCK(bx, by, bz) ((int32_t)((bx) | ((by) << 8) | ((bz) << 16)))
 
 typedef struct {
   double  time_ms;         /* mean wall time of the solve loop over evaluation_samples runs */

@@ -157,6 +157,13 @@ static void sys_local_solve(const sys_level_t* lv, int nf, int mask, double* con
   for (int p = 0; p < m; ++p) out[p] = omm * x[eu[p]][IDX2(n, ea[p], eb[p])] + om * r[p];
 }
 
+/* block shape of the q-th LISTED unknown of a SMOOTH (include/evomg.h: block, block_other, block_third) */
+static inline void sys_listed_shape(const evomg_op_t* op, int q, int* sx, int* sy) {
+  *sx = op->block[0];
+  *sy = op->block[1];
+  if (q >= 1 && op->block_other[0] > 0) { *sx = op->block_other[0]; *sy = op->block_other[1]; }
+  if (q >= 2 && op->block_third != 0) { *sx = op->block_third & 0xff; *sy = (op->block_third >> 8) & 0xff; }
+}
 /* the unknowns a SMOOTH lists; a scalar op program (mask 0) on a system of ONE unknown (EVOMG_STENCIL_COMPACT) means that one */
 #define SYS_MASK_OF(c, op) ((op)->unknowns ? (op)->unknowns : ((c)->nf == 1 ? 1 : 0))
 /* SMOOTH on a system. Single partitioning (`with jacobi`): non-overlapping tiles, all from the old state, next slot;
@@ -172,9 +179,7 @@ static int sys_smooth(sys_ctx_t* c, const evomg_op_t* op) {
   for (int u = 0; u < nf; ++u) {
     shape[u][0] = shape[u][1] = 0;
     if (!((mask >> u) & 1)) continue;
-    const int second = seen++ > 0 && op->block_other[0] > 0;
-    shape[u][0] = second ? op->block_other[0] : op->block[0];
-    shape[u][1] = second ? op->block_other[1] : op->block[1];
+    sys_listed_shape(op, seen++, &shape[u][0], &shape[u][1]);
     if (shape[u][0] > bx) bx = shape[u][0];
     if (shape[u][1] > by) by = shape[u][1];
   }
@@ -334,14 +339,20 @@ static int sys_check_op(sys_ctx_t* c, const evomg_op_t* op) {
       int k = 0;
       for (int u = 0; u < c->nf; ++u) k += (mask >> u) & 1;
       const int other = op->block_other[0] != 0 || op->block_other[1] != 0;
-      if (other && (k != 2 || op->block_other[0] < 1 || op->block_other[1] < 1)) return EVOMG_ERR_INVALID;
-      const int cells = op->block[0] * op->block[1] + (k == 2 ? (other ? op->block_other[0] * op->block_other[1] : op->block[0] * op->block[1]) : 0);
+      if (other && (k < 2 || op->block_other[0] < 1 || op->block_other[1] < 1)) return EVOMG_ERR_INVALID;
+      if (op->block_third != 0 && (k < 3 || !other || (op->block_third & 0xff) < 1 || ((op->block_third >> 8) & 0xff) < 1)) return EVOMG_ERR_INVALID;
+      int cells = 0, differ = 0;
+      for (int q = 0; q < k; ++q) {
+        int sx, sy;
+        sys_listed_shape(op, q, &sx, &sy);
+        cells += sx * sy;
+        differ = differ || sx != op->block[0] || sy != op->block[1];
+      }
       if (cells > EVOMG_MAX_BLOCK_CELLS) return EVOMG_ERR_INVALID;
       if (op->partitioning == EVOMG_PART_RED_BLACK && cells != k) return EVOMG_ERR_UNSUPPORTED;
       /* differing per-unknown shapes: the tiling around such a `solve locally` is [EXTERNAL]; accepted only where the sweep's
        * result is never used (EVOMG_JACOBI_EXASTENCILS_V11), rejected where it would be (see csrc/impl_system.hip) */
-      if (other && (op->block_other[0] != op->block[0] || op->block_other[1] != op->block[1]) &&
-          c->prob.jacobi_semantics == EVOMG_JACOBI_TEXTBOOK) return EVOMG_ERR_UNSUPPORTED;
+      if (other && differ && c->prob.jacobi_semantics == EVOMG_JACOBI_TEXTBOOK) return EVOMG_ERR_UNSUPPORTED;
       if (op->partitioning != EVOMG_PART_SINGLE && op->partitioning != EVOMG_PART_RED_BLACK) return EVOMG_ERR_INVALID;
       /* dst / src1 name the slots of the first unknown of the mask */
       int first = 0;

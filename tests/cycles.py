@@ -83,6 +83,12 @@ CASES = {
     "elasticity2d_L5_mixed_shapes": ("2D_FD_LinearElasticity_fromL2", 3, 5,
                                      lambda P: v_cycle(P, 2, [[("blocks", 12, ((2, 1), (1, 1))), _rb(20)], [("blocks", 14, ((2, 2), (2, 1)))]],
                                                        [[("blocks", 10, ((1, 1), (1, 2))), _rb(20)], [("blocks", 9, ((3, 1), (1, 3))), _rb(18)]])),
+    # a system of THREE PDEs (round 6): collective / decoupled / block smoothers over three unknowns
+    "threespecies2d_L5_mixed": ("2D_FD_ThreeSpecies", 3, 5,
+                                lambda P: v_cycle(P, 2, [[("decoupled", 14), _rb(20)], [("blocks", 12, ((2, 1), (2, 1), (2, 1)))]],
+                                                  [[_jac(12), ("decoupled_rb", 18)], [_rb(22)]])),
+    "threespecies2d_L6_v21_rb": ("2D_FD_ThreeSpecies", 3, 6,
+                                 lambda P: v_cycle(P, 3, [[_rb(20)] * 2] * 3, [[_rb(20)]] * 3)),
     "poisson3d_L4_v22_block": ("3D_FD_Poisson_fromL2", 2, 4,
                                lambda P: v_cycle(P, 2, [[_blk(10, (2, 1, 1))] * 2] * 2, [[_blk(10, (2, 1, 1))] * 2] * 2)),
     "poisson3d_L4_mixed": ("3D_FD_Poisson_fromL2", 2, 4,
