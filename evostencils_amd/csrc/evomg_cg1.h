@@ -245,49 +245,84 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
            (((((size_t)par * EVOMG_CG1_MAX_WAVES + wave) * 2 + edge) * EVOMG_CG1_MAX_E + e) * 64 + l) * 2;
   };
   bool wave_alive = true;
+  // AUTO: where an exchange publishes and polls depends on its parity only, not on the iteration: both address sets are
+  // formed ONCE (round 6 — the ISA of the loop had 175 instructions between the end of the stencil pass and the first poll,
+  // most of them 64-bit address arithmetic and branches around the five stores: a third of an iteration). The row loop below
+  // is unrolled by two so that each exchange names its set statically. A wave publishes BOTH its edge rows always (the
+  // first and the last wave's outer rows go to slots nobody polls), under ONE branch on the placement.
+  constexpr int KA = 1 + 2 * E;
+  struct AutoSlots {
+    evomg_u64* sum;                 // lane 0: (r, r), lane 32: (w, r) of this wave
+    evomg_u64* seam[2][E];          // this wave's first / last row of w
+    const evomg_u64* poll[KA];      // all wave sums (lane = (quantity, wave)), the neighbours' edge rows
+  };
+  AutoSlots slots_a{}, slots_b{};
+  bool auto_need[KA];
+  if constexpr (AUTO) {
+    const int total = groups * WAVES;
+    auto fill = [&](AutoSlots& S, int par) {
+      S.sum = sum_slot(par, l >> 5, gw);
+      S.poll[0] = sum_slot(par, l >> 5, (l & 31) < total ? (l & 31) : gw);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        S.seam[0][e] = wseam_slot(par, gw, 0, e);
+        S.seam[1][e] = wseam_slot(par, gw, 1, e);
+        S.poll[1 + e] = gw > 0 ? wseam_slot(par, gw - 1, 1, e) : sum_slot(par, 0, gw);
+        S.poll[1 + E + e] = gw + 1 < total ? wseam_slot(par, gw + 1, 0, e) : sum_slot(par, 0, gw);
+      }
+    };
+    // exchange number n of this launch (n = 0: the one behind the first stencil pass) carries seq_base + 2 + n
+    const int par_a = (int)((seq_base + 2u) & 1u);
+    fill(slots_a, par_a);
+    fill(slots_b, par_a ^ 1);
+    auto_need[0] = (l & 31) < total;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      auto_need[1 + e] = gw > 0;
+      auto_need[1 + E + e] = gw + 1 < total;
+    }
+  }
+  auto exchange_auto = [&](unsigned seq, const AutoSlots& S) -> bool {
+    PROF(0);
+    const double ws = cg1_wave_sums(gam, del);       // lane 0: the wave's (r, r), lane 32: its (w, r)
+    if (same_xcd) {
+      if ((l & 31) == 0) ll_store16(S.sum, ws, seq, true);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        ll_store16(S.seam[0][e], wv[0][e], seq, true);
+        ll_store16(S.seam[1][e], wv[R - 1][e], seq, true);
+      }
+    } else {
+      if ((l & 31) == 0) ll_store16(S.sum, ws, seq, false);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        ll_store16(S.seam[0][e], wv[0][e], seq, false);
+        ll_store16(S.seam[1][e], wv[R - 1][e], seq, false);
+      }
+      __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);   // across XCDs the words cannot have landed yet: no poll that must fail
+    }
+    PROF(1);
+    double got[KA];
+    const bool all = ll_poll16<KA>(S.poll, auto_need, seq, got);
+    if (__builtin_amdgcn_ballot_w64(!all) != 0ull) wave_alive = false;
+    PROF(2);
+    PROF(3);
+    double t = auto_need[0] ? got[0] : 0.0;
+    t = cg1_cross_tree<32>(t);
+    gn = cg1_lane(t, 0);
+    dl = cg1_lane(t, 32);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      w_gs[e] = has_south ? got[1 + e] : 0.0;
+      w_gn[e] = has_north ? got[1 + E + e] : 0.0;
+    }
+    PROF(4);
+    return wave_alive;
+  };
   auto exchange = [&](unsigned seq) -> bool {
     const int par = (int)(seq & 1u);
     PROF(0);
     const double ws = cg1_wave_sums(gam, del);       // lane 0: the wave's (r, r), lane 32: its (w, r)
-    if constexpr (AUTO) {
-      const int total = groups * WAVES;
-      if ((l & 31) == 0) ll_store16(sum_slot(par, l >> 5, gw), ws, seq, same_xcd);
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        if (gw > 0) ll_store16(wseam_slot(par, gw, 0, e), wv[0][e], seq, same_xcd);
-        if (gw + 1 < total) ll_store16(wseam_slot(par, gw, 1, e), wv[R - 1][e], seq, same_xcd);
-      }
-      PROF(1);
-      constexpr int K = 1 + 2 * E;
-      const evomg_u64* slot[K];
-      bool need[K];
-      slot[0] = sum_slot(par, l >> 5, (l & 31) < total ? (l & 31) : gw);
-      need[0] = (l & 31) < total;
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        slot[1 + e] = gw > 0 ? wseam_slot(par, gw - 1, 1, e) : sum_slot(par, 0, gw);
-        need[1 + e] = gw > 0;
-        slot[1 + E + e] = gw + 1 < total ? wseam_slot(par, gw + 1, 0, e) : sum_slot(par, 0, gw);
-        need[1 + E + e] = gw + 1 < total;
-      }
-      double got[K];
-      if (!same_xcd) __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP0);
-      const bool all = ll_poll16<K>(slot, need, seq, got);
-      if (__builtin_amdgcn_ballot_w64(!all) != 0ull) wave_alive = false;
-      PROF(2);
-      PROF(3);
-      double t = need[0] ? got[0] : 0.0;
-      t = cg1_cross_tree<32>(t);
-      gn = cg1_lane(t, 0);
-      dl = cg1_lane(t, 32);
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        w_gs[e] = has_south ? got[1 + e] : 0.0;
-        w_gn[e] = has_north ? got[1 + E + e] : 0.0;
-      }
-      PROF(4);
-      return wave_alive;
-    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       seam_lds[par][0][e][tid] = wv[0][e];
@@ -395,12 +430,18 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     if (lds_fail[par] != 0) wave_alive = false;
   }
   apply();
-  bool alive = wave_alive && exchange(++seq);
+  bool alive = wave_alive;
+  if (alive) {
+    ++seq;
+    if constexpr (AUTO) alive = exchange_auto(seq, slots_a);
+    else alive = exchange(seq);
+  }
   const double res0 = sc_norm_from_dot(gn);
   int it = 0;
   if (alive && res0 != 0.0 && maxit > 0) {
     double den = dl, alpha = sc_div(gn, dl), beta = 0.0;
-    for (;;) {
+    // one iteration; `xchg`: its exchange. false: the loop is over (converged, capped, or a rendezvous was missed)
+    auto iterate = [&](auto&& xchg) -> bool {
       const double inv_g = sc_div(1.0, gn);          // for the next beta: formed while the exchange is under way
       const double nalpha = sc_neg(alpha);
 #pragma unroll
@@ -420,15 +461,34 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
         r_gn[e] = sc_fma(nalpha, s_gn[e], r_gn[e]);
       }
       apply();
-      alive = exchange(++seq);
+      alive = xchg(++seq);
       ++it;
-      if (!alive) break;
+      if (!alive) return false;
+      // the scalars of the NEXT iteration are formed before the stopping test is branched on (they are simply not used when
+      // the loop ends here): the square root of the test and the division of alpha are two dependent chains of ~200 cycles
+      // each — in one basic block the scheduler interleaves them, behind the branch they ran one after the other
       const double res = sc_norm_from_dot(gn);
-      if (!(res > tol * res0) || it >= maxit) break;
-      beta = sc_mul(gn, inv_g);
-      den = sc_fma(sc_neg(sc_mul(beta, beta)), den, dl);
-      alpha = sc_div(gn, den);
+      const double beta_next = sc_mul(gn, inv_g);
+      const double den_next = sc_fma(sc_neg(sc_mul(beta_next, beta_next)), den, dl);
+      const double alpha_next = sc_div(gn, den_next);
+      if (!(res > tol * res0) || it >= maxit) return false;
+      beta = beta_next;
+      den = den_next;
+      alpha = alpha_next;
       PROF(5);
+      return true;
+    };
+    if constexpr (AUTO) {
+      // unrolled by two: the exchanges alternate between the two address sets (the first one above took set a)
+      auto xb = [&](unsigned q) { return exchange_auto(q, slots_b); };
+      auto xa = [&](unsigned q) { return exchange_auto(q, slots_a); };
+      for (;;) {
+        if (!iterate(xb)) break;
+        if (!iterate(xa)) break;
+      }
+    } else {
+      auto xg = [&](unsigned q) { return exchange(q); };
+      while (iterate(xg)) {}
     }
   }
 #pragma unroll

@@ -1462,21 +1462,26 @@ template <int K> __device__ __forceinline__ LLWords<K> ll_fetch16(const evomg_u6
                  : "v"(slot[0]), "v"(slot[1]), "v"(slot[2]), "v"(slot[3]), "v"(slot[4]) : "memory");
   return r;
 }
-// polls K slots until every NEEDED one carries `seq`; bounded (false: a peer never arrived; v is then unspecified)
+// polls K slots until every NEEDED one carries `seq`; bounded (false: a peer never arrived; v is then unspecified).
+// The loop is WAVE-UNIFORM (round 6): every lane fetches again until every lane of the wave has its words — one ballot and a
+// scalar branch per round instead of a divergent loop's exec-mask bookkeeping (59 scalar instructions per round in the ISA of
+// the 129^2 CG: a failed look cost 400 cycles before the next one was issued). A lane that already had its words fetches
+// them once more: they stay valid until the slot is written again two exchanges later.
 template <int K> __device__ __forceinline__ bool ll_poll16(const evomg_u64* const (&slot)[K], const bool (&need)[K], unsigned seq, double (&v)[K]) {
   int budget = 1 << 21;
+  LLWords<K> r;
+  unsigned bad;
   for (;;) {
-    const LLWords<K> r = ll_fetch16<K>(slot);
-    bool all = true;
+    r = ll_fetch16<K>(slot);
+    bad = 0u;
 #pragma unroll
-    for (int k = 0; k < K; ++k) all = all && (!need[k] || (r.w[k].y == seq && r.w[k].w == seq));
-    if (all) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) v[k] = __longlong_as_double((long long)(((evomg_u64)r.w[k].z << 32) | (evomg_u64)r.w[k].x));
-      return true;
-    }
-    if (--budget == 0) return false;
+    for (int k = 0; k < K; ++k) bad |= need[k] ? ((r.w[k].y ^ seq) | (r.w[k].w ^ seq)) : 0u;
+    if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0ull) break;
+    if (--budget == 0) break;
   }
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = __longlong_as_double((long long)(((evomg_u64)r.w[k].z << 32) | (evomg_u64)r.w[k].x));
+  return bad == 0u;
 }
 
 // all threads call it: threads q < groups fetch group q's partial sum of this exchange into lds_part (one buffer per

@@ -197,8 +197,8 @@
   // into workgroups is free
   int launch_cg1(const Level<T>& lv, T* x, const T* b, T* r, T* b_copy) {
     switch (lv.g.n - 2) {
-      case 127:                                    // 32 waves: eight workgroups of four (four of eight: same bits, measured slower)
-        return launch_cg1_as<4, 2, 1, 4, true, 3>(lv, x, b, r, b_copy, 8);
+      case 127:                                    // 32 waves as sixteen workgroups of two (round 6: 1.03 against 1.10 us per iteration as eight of four — the grouping is not part of the arithmetic; four of eight: slower)
+        return launch_cg1_as<4, 2, 1, 2, true, 3>(lv, x, b, r, b_copy, 16);
       case 63: return launch_cg1_as<16, 1, 1, 4, false, 15>(lv, x, b, r, b_copy, 1);
       case 31: return launch_cg1_as<4, 1, 2, 4, false, 3>(lv, x, b, r, b_copy, 1);
       case 15: return launch_cg1_as<2, 1, 4, 2, false, 1>(lv, x, b, r, b_copy, 1);

@@ -170,7 +170,7 @@ def test_register_budgets_the_documentation_states_hold_in_the_built_code_object
     assert len(cg1) >= 14
     for name, r in cg1.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
-    band129 = [v for k, v in cg1.items() if "band2dILi4ELi2ELi1ELi4E" in k]
-    assert band129 and all(v["vgpr"] <= 224 for v in band129)     # one wave per SIMD and workgroup: far inside the 512-register file
+    band129 = [v for k, v in cg1.items() if "band2dILi4ELi2ELi1ELi2E" in k]      # 129^2: sixteen workgroups of two waves (round 6)
+    assert band129 and all(v["vgpr"] <= 256 for v in band129)     # at most one wave per SIMD: far inside the 512-register file
     slab = next(v for k, v in cg1.items() if "slab3d" in k)
     assert slab["vgpr"] <= 128                       # 1024 threads per workgroup
