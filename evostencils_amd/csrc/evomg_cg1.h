@@ -9,7 +9,7 @@
 //     r0 = b - A x0, w0 = A r0, g = (r0, r0), d = (w0, r0), den = d, alpha = g / den, beta = 0, p = s = 0
 //     repeat:  p = r + beta p;  s = w + beta s  (= A p);  x += alpha p;  r -= alpha s
 //              w = A r;  g' = (r, r);  d = (w, r)                 <- the one reduction
-//              stop when sqrt(g') <= tol * sqrt(g0) or at the iteration cap
+//              stop when sqrt(g') <= tol * sqrt(g0) or at the iteration cap   (decided on g' itself: cg1_stop_threshold)
 //              beta = g' / g;  den = d - beta^2 den;  alpha = g' / den;  g = g'
 // (den_k = d_k - beta_k g_k / alpha_{k-1} with alpha_{k-1} = g_{k-1} / den_{k-1}: the same real number as in the paper,
 // with two divisions on the scalar chain instead of three.) Same iterates as classical CG in exact arithmetic, same
@@ -35,8 +35,12 @@
 // every grouping of the waves into workgroups, so `groups` and WAVES are tuning parameters, not part of the arithmetic
 // (R, E and H are). Both inner products share ONE tree: after the first step (one v_permlane32_swap of the two registers)
 // lanes 0..31 carry (r, r), lanes 32..63 (w, r).
-// Scalars: 1 / g is formed while the exchange is under way, so the chain behind the sums is two products, one fused
-// multiply-add and ONE division: beta = g' (1 / g), den = d - beta^2 den, alpha = g' / den.
+// Scalars: 1 / g is formed between the stores of the exchange and its first look (time the wave otherwise sleeps through: the
+// words take ~400 cycles to land, and a look that comes back without them costs its instructions and a round trip), so the
+// chain behind the sums is two products, one fused multiply-add and ONE division: beta = g' (1 / g), den = d - beta^2 den,
+// alpha = g' / den — formed ahead of the stopping test, which compares g' with a threshold instead of taking its square root
+// (cg1_stop_threshold: the same decisions bit for bit). Round 6, from the ISA of the loop: the compiler had sunk 1 / g to
+// its use and put the square root of the test in front of everything — three dependent chains behind every exchange.
 #pragma once
 #include "evomg_krylov.h"
 
@@ -49,6 +53,9 @@
 
 #ifndef EVOMG_CG1_SLEEP0
 #define EVOMG_CG1_SLEEP0 8
+#endif
+#ifndef EVOMG_CG1_SLEEP_LOCAL
+#define EVOMG_CG1_SLEEP_LOCAL 4   // x 64 cycles, before the first look inside one XCD
 #endif
 #define EVOMG_CG1_MAX_WAVES 32    // all wave sums of both inner products fit one wave64: (r, r) in lanes 0..31, (w, r) in 32..63
 #define EVOMG_CG1_MAX_GROUPS 16
@@ -88,6 +95,50 @@ __device__ __forceinline__ double cg1_lane(double v, int lane) {
 // wave sums of two quantities in one tree: the first step (offset 32) is one v_permlane32_swap per 32-bit half — afterwards
 // lanes 0..31 hold a[l] + a[l + 32], lanes 32..63 hold b[l - 32] + b[l] — then offsets 16, 8, 4, 2, 1 inside each half.
 // Lane 0 ends up with the sum of a, lane 32 with the sum of b; summation order = wave_sum_fast's.
+// The stopping rule `sqrt(g) <= T` (T = tol * sqrt(g0)) decided on g ITSELF: sqrt is monotone and correctly rounded, so there is
+// a largest double g* with sqrt(g*) <= T, and `sqrt(g) <= T` holds exactly when g <= g*. g* lies within a few units in the
+// last place of T * T and is found once per solve by stepping; the square root (a dependent chain of ~200 cycles that every
+// iteration ended with) leaves the loop, the decisions are the same ones bit for bit. Where the search does not settle
+// within its few steps (T * T under- or overflows, T negative, infinite or not a number) the loop keeps the square root.
+struct Cg1Stop { double gstar; double t; bool exact; };
+__device__ __forceinline__ Cg1Stop cg1_stop_threshold(double t) {
+  Cg1Stop s{0.0, t, false};
+  if (t >= 0.0 && t < __builtin_inf()) {
+    double g = sc_mul(t, t);
+    if (g < __builtin_inf()) {
+      auto up = [](double v) { return __longlong_as_double(__double_as_longlong(v) + 1); };      // v >= 0 and finite
+      auto down = [](double v) { return __longlong_as_double(__double_as_longlong(v) - 1); };    // v > 0
+      for (int k = 0; k < 4; ++k)
+        if (g > 0.0 && sqrt(g) > t) g = down(g);
+      for (int k = 0; k < 4; ++k) {
+        const double u = up(g);
+        if (u < __builtin_inf() && sqrt(u) <= t) g = u;
+      }
+      const double u = up(g);
+      s.gstar = g;
+      s.exact = sqrt(g) <= t && (!(u < __builtin_inf()) || sqrt(u) > t);
+    }
+  }
+  return s;
+}
+// true: the iteration stops (also for a sum that is not a number, as `!(sqrt(g) > T)` did)
+__device__ __forceinline__ bool cg1_stops(const Cg1Stop& s, double g) {
+  if (s.exact) return !(g > s.gstar);
+  asm volatile("" : "+v"(g));                        // a real branch: without this the compiler forms the root on both paths and selects
+  return !(sc_norm_from_dot(g) > s.t);
+}
+// `v` is formed where this stands, not where it is first used (the compiler sinks a division to its use — onto the chain
+// behind the exchange — however early the source forms it)
+__device__ __forceinline__ double cg1_formed_here(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// ... and what is computed from the result is computed behind the stores that precede this in the source
+__device__ __forceinline__ double cg1_formed_after_stores(double v) {
+  asm volatile("" : "+v"(v) : : "memory");
+  return v;
+}
+
 __device__ __forceinline__ double cg1_wave_sums(double a, double b) {
   const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
   const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
@@ -282,9 +333,13 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
       auto_need[1 + E + e] = gw + 1 < total;
     }
   }
-  auto exchange_auto = [&](unsigned seq, const AutoSlots& S) -> bool {
+  // `recip`: in: the g of the iteration before; out: 1 / g, which the scalars behind the exchange start from. Its division is
+  // formed HERE, between the stores of the exchange and the first look — time the wave would otherwise sleep through, waiting
+  // for the words to land (left to the compiler the division sinks to its use, onto the chain behind the exchange)
+  auto exchange_auto = [&](unsigned seq, const AutoSlots& S, double& recip) -> bool {
     PROF(0);
     const double ws = cg1_wave_sums(gam, del);       // lane 0: the wave's (r, r), lane 32: its (w, r)
+    // (ONE branch on the placement around all five stores: the kind of store is then a constant of each arm)
     if (same_xcd) {
       if ((l & 31) == 0) ll_store16(S.sum, ws, seq, true);
 #pragma unroll
@@ -292,7 +347,12 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
         ll_store16(S.seam[0][e], wv[0][e], seq, true);
         ll_store16(S.seam[1][e], wv[R - 1][e], seq, true);
       }
+      // the first look is not taken before the words can have landed: a look that comes back without them costs its ~25
+      // instructions and a round trip (measured before this wait: 1.87 looks per poll)
+      recip = cg1_formed_here(sc_div(1.0, cg1_formed_after_stores(recip)));
+      __builtin_amdgcn_s_sleep(EVOMG_CG1_SLEEP_LOCAL);
     } else {
+      recip = sc_div(1.0, recip);
       if ((l & 31) == 0) ll_store16(S.sum, ws, seq, false);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -319,10 +379,11 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     PROF(4);
     return wave_alive;
   };
-  auto exchange = [&](unsigned seq) -> bool {
+  auto exchange = [&](unsigned seq, double& recip) -> bool {
     const int par = (int)(seq & 1u);
     PROF(0);
     const double ws = cg1_wave_sums(gam, del);       // lane 0: the wave's (r, r), lane 32: its (w, r)
+    recip = cg1_formed_here(sc_div(1.0, recip));
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       seam_lds[par][0][e][tid] = wv[0][e];
@@ -433,16 +494,18 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   bool alive = wave_alive;
   if (alive) {
     ++seq;
-    if constexpr (AUTO) alive = exchange_auto(seq, slots_a);
-    else alive = exchange(seq);
+    double none = 1.0;
+    if constexpr (AUTO) alive = exchange_auto(seq, slots_a, none);
+    else alive = exchange(seq, none);
   }
   const double res0 = sc_norm_from_dot(gn);
+  const Cg1Stop stop = cg1_stop_threshold(tol * res0);
   int it = 0;
   if (alive && res0 != 0.0 && maxit > 0) {
     double den = dl, alpha = sc_div(gn, dl), beta = 0.0;
     // one iteration; `xchg`: its exchange. false: the loop is over (converged, capped, or a rendezvous was missed)
     auto iterate = [&](auto&& xchg) -> bool {
-      const double inv_g = sc_div(1.0, gn);          // for the next beta: formed while the exchange is under way
+      double inv_g = gn;                             // for the next beta: the exchange turns it into 1 / g (see exchange_auto)
       const double nalpha = sc_neg(alpha);
 #pragma unroll
       for (int i = 0; i < R; ++i)
@@ -461,17 +524,17 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
         r_gn[e] = sc_fma(nalpha, s_gn[e], r_gn[e]);
       }
       apply();
-      alive = xchg(++seq);
+      alive = xchg(++seq, inv_g);
       ++it;
       if (!alive) return false;
-      // the scalars of the NEXT iteration are formed before the stopping test is branched on (they are simply not used when
-      // the loop ends here): the square root of the test and the division of alpha are two dependent chains of ~200 cycles
-      // each — in one basic block the scheduler interleaves them, behind the branch they ran one after the other
-      const double res = sc_norm_from_dot(gn);
+      // the scalars of the NEXT iteration are formed before the stopping test is branched on (simply not used when the loop
+      // ends here). What the ISA of the loop showed before round 6's second pass: square root of the test -> branch -> the
+      // division 1 / g (sunk here from the top of the iteration) -> two products, one fused multiply-add -> the division
+      // of alpha: three dependent chains one after the other, ~500 cycles of an iteration's ~2500. Now the one division.
       const double beta_next = sc_mul(gn, inv_g);
       const double den_next = sc_fma(sc_neg(sc_mul(beta_next, beta_next)), den, dl);
-      const double alpha_next = sc_div(gn, den_next);
-      if (!(res > tol * res0) || it >= maxit) return false;
+      const double alpha_next = cg1_formed_here(sc_div(gn, den_next));
+      if (cg1_stops(stop, gn) || it >= maxit) return false;
       beta = beta_next;
       den = den_next;
       alpha = alpha_next;
@@ -480,14 +543,14 @@ evomg_cg1_band2d(Geo g, Stencil<double> st, double* __restrict__ x, const double
     };
     if constexpr (AUTO) {
       // unrolled by two: the exchanges alternate between the two address sets (the first one above took set a)
-      auto xb = [&](unsigned q) { return exchange_auto(q, slots_b); };
-      auto xa = [&](unsigned q) { return exchange_auto(q, slots_a); };
+      auto xb = [&](unsigned q, double& recip) { return exchange_auto(q, slots_b, recip); };
+      auto xa = [&](unsigned q, double& recip) { return exchange_auto(q, slots_a, recip); };
       for (;;) {
         if (!iterate(xb)) break;
         if (!iterate(xa)) break;
       }
     } else {
-      auto xg = [&](unsigned q) { return exchange(q); };
+      auto xg = [&](unsigned q, double& recip) { return exchange(q, recip); };
       while (iterate(xg)) {}
     }
   }
@@ -671,11 +734,12 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
   apply();
   bool alive = exchange(++seq);
   const double res0 = sc_norm_from_dot(gn);
+  const Cg1Stop stop = cg1_stop_threshold(tol * res0);
   int it = 0;
   if (alive && res0 != 0.0 && maxit > 0) {
     double den = dl, alpha = sc_div(gn, dl), beta = 0.0;
     for (;;) {
-      const double inv_g = sc_div(1.0, gn);
+      const double inv_g = cg1_formed_here(sc_div(1.0, gn));
       const double nalpha = sc_neg(alpha);
 #pragma unroll
       for (int i = 0; i < S; ++i) {
@@ -695,11 +759,14 @@ evomg_cg1_slab3d(Geo g, Stencil<double> st, double* __restrict__ x, const double
       alive = exchange(++seq);
       ++it;
       if (!alive) break;
-      const double res = sc_norm_from_dot(gn);
-      if (!(res > tol * res0) || it >= maxit) break;
-      beta = sc_mul(gn, inv_g);
-      den = sc_fma(sc_neg(sc_mul(beta, beta)), den, dl);
-      alpha = sc_div(gn, den);
+      // (as in evomg_cg1_band2d: the next scalars ahead of the stopping branch)
+      const double beta_next = sc_mul(gn, inv_g);
+      const double den_next = sc_fma(sc_neg(sc_mul(beta_next, beta_next)), den, dl);
+      const double alpha_next = cg1_formed_here(sc_div(gn, den_next));
+      if (cg1_stops(stop, gn) || it >= maxit) break;
+      beta = beta_next;
+      den = den_next;
+      alpha = alpha_next;
     }
   }
 #pragma unroll

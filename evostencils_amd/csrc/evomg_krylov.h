@@ -1467,6 +1467,9 @@ template <int K> __device__ __forceinline__ LLWords<K> ll_fetch16(const evomg_u6
 // scalar branch per round instead of a divergent loop's exec-mask bookkeeping (59 scalar instructions per round in the ISA of
 // the 129^2 CG: a failed look cost 400 cycles before the next one was issued). A lane that already had its words fetches
 // them once more: they stay valid until the slot is written again two exchanges later.
+#ifdef EVOMG_CG1_PROFILE
+__device__ unsigned long long evomg_ll_poll_rounds[2];      // developer builds: [0] polls, [1] fetch rounds they took
+#endif
 template <int K> __device__ __forceinline__ bool ll_poll16(const evomg_u64* const (&slot)[K], const bool (&need)[K], unsigned seq, double (&v)[K]) {
   int budget = 1 << 21;
   LLWords<K> r;
@@ -1479,6 +1482,12 @@ template <int K> __device__ __forceinline__ bool ll_poll16(const evomg_u64* cons
     if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0ull) break;
     if (--budget == 0) break;
   }
+#ifdef EVOMG_CG1_PROFILE
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&evomg_ll_poll_rounds[0], 1ull);
+    atomicAdd(&evomg_ll_poll_rounds[1], (unsigned long long)((1 << 21) - budget + 1));
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = __longlong_as_double((long long)(((evomg_u64)r.w[k].z << 32) | (evomg_u64)r.w[k].x));
   return bad == 0u;

@@ -140,6 +140,10 @@ static void run(const char* name, int level, int groups, int stride, bool check)
   printf("%-34s %d^2: %4d iterations, %8.1f us per solve, %.3f us per iteration, status %d\n", name, n, info[0], best * 1e3, best * 1e3 / (info[0] ? info[0] : 1), info[1]);
 #ifdef EVOMG_CG1_PROFILE
   {
+    unsigned long long rounds[2], zero[2] = {0, 0};
+    CHECK(hipMemcpyFromSymbol(rounds, HIP_SYMBOL(evomg_ll_poll_rounds), sizeof rounds));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(evomg_ll_poll_rounds), zero, sizeof zero));
+    printf("    polls %llu, fetch rounds per poll %.3f\n", rounds[0], rounds[0] ? (double)rounds[1] / (double)rounds[0] : 0.0);
     const long long* pr = reinterpret_cast<const long long*>(info + 4);
     long long tot = 0;
     for (int k = 0; k < 6; ++k) tot += pr[k];
