@@ -701,10 +701,11 @@ def main():
                         f"{live.bytes / 1e6:.1f} MB. 'back_to_back' = median of 5 batches of 100 consecutive plain ping-pong sweeps. "
                         f"'traffic' = HBM-side bytes/launch from rocprofv3 PMC passes (profiles/pmc_traffic.json names the "
                         f"profile), null when no profile matches the launched kernel and level. What holds the cross launch at "
-                        f"0.60-0.66 of the HBM peak (round 6, profiles/r06_cross_kernel.md): it moves its 545 MB at the fabric at "
-                        f"6.0-6.2 TB/s - the copy rate the hardware guide measures (6.29) - so what is left is the over-fetch (1.17x: "
-                        f"eleven halo rows per 80-row chunk), not instructions: the unit-weight form C2 runs since round 6 "
-                        f"(19 % fewer FP64 instructions per row step) and prefetch rings of 3 and 6 rows take the same time"}
+                        f"0.60-0.66 of the HBM peak (round 6, profiles/r06_cross_kernel.md): two walls at the same place. It moves "
+                        f"its 534 MB at the fabric at 6.0-6.2 TB/s - the copy rate the hardware guide measures (6.29) - and a wave "
+                        f"marches its 91 row steps at 0.95 us each, a chain of dependent stages: the unit-weight form C2 runs since "
+                        f"round 6 (19 % fewer FP64 instructions per row step) and prefetch rings of 3 and 6 rows take the same "
+                        f"time, taller chunks (fewer halo rows, fewer bytes) take LONGER (96 .. 144 rows: 95 .. 128 us)"}
 
     # ---- where the rest of an isolated solve goes: the coarse-grid solve, timed the same way over three more solves ----
     progress("coarse solve timing")
@@ -719,15 +720,16 @@ def main():
                     "bound": "one grid-wide exchange per CG iteration (a round trip through one XCD's L2) + three dependent reduction / scalar chains"
                              if COARSE_CG == "single-reduction" else "VALU issue of ONE compute unit",
                     "note": "CG to 1e-12 on the coarsest grid (the reference's solver settings, Poisson/2D_FD_Poisson_fromL2.exa3:12-14). "
-                            "Round 5: the single-reduction form of the recurrence (Chronopoulos-Gear: both inner products of an "
-                            "iteration in ONE reduction; csrc/evomg_cg1.h) on eight co-resident workgroups of four waves — the five "
+                            "The single-reduction form of the recurrence (Chronopoulos-Gear: both inner products of an "
+                            "iteration in ONE reduction; csrc/evomg_cg1.h) on sixteen co-resident workgroups of two waves - the five "
                             "vectors of 129^2 in registers, ghost rows instead of a second exchange, exchanged doubles as self-validating "
-                            "16-byte words that stay in ONE XCD's L2, every wave exchanging for itself: about 1.5 us per iteration where the "
+                            "16-byte words that stay in ONE XCD's L2, every wave exchanging for itself: 0.96 us per iteration (1.47 before "
+                            "round 6 read the loop's ISA: exchange addresses formed once, wave-uniform polls, the first look timed behind "
+                            "the stores, one division on the scalar chain instead of square root + two: profiles/r06_cg1.md) where the "
                             "classical two-reduction form on ONE compute unit "
-                            "(EVOMG_BENCH_COARSE_CG=classical: cgs_kind CGS_CG_CLASSICAL, evomg_cg_reg2d) takes 2.05; of an iteration "
-                            "roughly 0.55 us are the exchange, 0.25 the arithmetic (one wave issues an FP64 instruction every 8 cycles), the rest "
-                            "publishing, wave reductions and the scalar chain "
-                            "(profiles/r05_cg1.md)"}
+                            "(EVOMG_BENCH_COARSE_CG=classical: cgs_kind CGS_CG_CLASSICAL, evomg_cg_reg2d) takes 2.05; of an iteration's "
+                            "~2 300 cycles about 600 are the L2 round trip of the exchange, the rest the ~375 instructions a wave issues "
+                            "(88 of them the stencil's arithmetic) and four dependent chains: two reduction trees, the scalars, stencil + update"}
     # the whole solve against the roofline of the metric BASELINE names (candidate solves/s): algorithmic bytes of one solve as
     # launched — per iteration the cross launch on the finest level (24 B/node + 2 x 8 B per coarse node), on every level between
     # a pre-smoothing launch from an elided zero field with residual + restriction (16 + 2 B/node) and a prolongation + sweep
