@@ -12,7 +12,8 @@ def threshold(t):
     t = np.float64(t)
     if not (t >= 0.0 and t < np.inf):
         return np.float64(0.0), False
-    g = t * t
+    with np.errstate(over="ignore", under="ignore"):
+        g = t * t
     if not g < np.inf:
         return np.float64(0.0), False
     up = lambda v: (v.view(np.int64) + 1).view(np.float64)
