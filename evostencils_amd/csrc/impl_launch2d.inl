@@ -361,7 +361,15 @@
   // with the most blocks: ceil(blocks / units) x (rows + 9 pipeline steps); heights that need more than three blocks on a unit
   // pay a whole extra round. At 4097^2 (36 strips): 64 rows -> 585 blocks, three on some units, two on most (measured 103 us);
   // 80 rows -> 468 blocks, two on nearly every unit.
-  int cross_rows(int n, int strips) const {
+  int cross_rows(const Geo& g, int strips) const {
+    const int n = g.n;
+    // With the device full of other evaluations (candidates in flight) a launch on a level that streams from HBM neither needs
+    // every unit for itself nor ends when its slowest unit does: what counts is the bytes it moves, so the chunks are tall —
+    // 256 rows: eleven halo rows are 4 % of x and f instead of 14 %. Same-box A/B with sixteen C2 solves (4097^2) in flight:
+    // 402-405 -> 412-417 and 368 -> 375 solves/s on two boxes (384 and 512 rows: less, 1024: a loss; the same rule for the
+    // other strips of the big levels: less; with eight in flight +1 %). NOT on levels the Infinity Cache holds: 2049^2 with
+    // sixteen in flight 849 -> 780 solves/s — there the march of a wave is what a launch costs. Placement only: the same bits.
+    if (strip_streams(g) && evaluations_in_flight() >= 8) return 16 * EVOMG_NORM_ROWS;
     long best_cost = -1;
     int best = 4 * EVOMG_NORM_ROWS;
     for (int r = 2 * EVOMG_NORM_ROWS; r <= 8 * EVOMG_NORM_ROWS; r += EVOMG_NORM_ROWS) {
@@ -388,7 +396,7 @@
       const evomg_op_t &sa = ops[n_ops - 1], &sb = ops[0];
       const int strips = (g.n + EVOMG_CROSS_STRIP_COLS - 1) / EVOMG_CROSS_STRIP_COLS;
       const int forced_rows = xfuse_rows_ > 0 ? xfuse_rows_ : strip_rows_;
-      int rows = forced_rows > 0 ? ((forced_rows + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : cross_rows(g.n, strips);
+      int rows = forced_rows > 0 ? ((forced_rows + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS) * EVOMG_NORM_ROWS : cross_rows(g, strips);
       const int chunks = (g.n + rows - 1) / rows;
       const int waves = strips * chunks;
       const int chunks16 = (g.n + EVOMG_NORM_ROWS - 1) / EVOMG_NORM_ROWS;

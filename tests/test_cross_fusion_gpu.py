@@ -3,7 +3,7 @@
 a bit: residual histories, the returned iterate, the residual field and the coarse right-hand side are compared with the same
 solve under EVOMG_NO_XFUSE, and with the oracle where it finishes in seconds — for every shape of the plan (with / without the
 folded prolongation, with / without the restriction tail), different relaxation factors on the two sweeps, chunk heights of
-16 .. 96 rows, solves that converge, solves that run into the iteration cap and a cap of one."""
+16 .. 256 rows, solves that converge, solves that run into the iteration cap and a cap of one."""
 import dataclasses
 
 import numpy as np
@@ -101,7 +101,7 @@ def test_cross_fusion_does_not_change_a_bit(native, monkeypatch, plan, lo, hi, r
             assert np.array_equal(x, y), (L, f)
 
 
-@pytest.mark.parametrize("rows", ["16", "48", "80", "96"])
+@pytest.mark.parametrize("rows", ["16", "48", "80", "96", "256"])     # 256: the height the launch takes when the device is full
 @pytest.mark.parametrize("cap", [1, 2, 5])
 def test_cross_fusion_at_the_iteration_cap_and_odd_chunk_heights(native, monkeypatch, rows, cap):
     lo, hi = 5, 9
