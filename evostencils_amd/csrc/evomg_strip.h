@@ -28,6 +28,7 @@ enum { STRIP_JACOBI = 0, STRIP_RBGS = 1, STRIP_RESIDUAL = 2, STRIP_RESNORM = 3 }
 // for the sweep itself — nobody reads them — but the residual of the first stored column would. With two halo lanes
 // every value the residual touches is exact. The width is part of the canonical summation order of the norm.
 #define EVOMG_NORM_STRIP_COLS 120
+#define EVOMG_XGEN_STRIP_COLS 116   // three halo lanes per side (XGEN below)
 
 template <typename T> struct Pair {
   T a, b;
@@ -143,8 +144,16 @@ template <typename T> struct ProlongIn {
 // TAIL_RESTRICT (smoother modes): the sweep is followed by RESIDUAL + RESTRICT of a residual nobody else reads. Same
 // finalised-row window, one more halo row per side; the residual rows feed a three-row residual window from which
 // every second step emits one row of the coarse right-hand side exactly as evomg_strip_residual_restrict does.
+// XGEN (round 6; red-black, with TAIL_RESTRICT and XZERO): the sweep is the SECOND of two identical sweeps that start from the
+// zero field (the pre-smoothing of a V(2,.) cycle on every level below the finest, and on the finest one inside a
+// preconditioner). What the first sweep leaves in memory is a function of f alone — its red nodes see nothing but zeros, its
+// black nodes the reds of three rows — so the rows of x are FORMED here from f rows r-1, r, r+1 (evaluating the first sweep's
+// own expressions on literal zeros, Robin columns included) instead of being written by one launch and read back by the
+// next: f read once, y and the coarse right-hand side written — 24 + 2 instead of 56 + 2 B/node for SMOOTH, SMOOTH,
+// RESIDUAL, RESTRICT. The black node a generated row holds in the outermost lane has no red neighbour inside the wave:
+// three halo lanes per side (116 stored columns), as in the cross-iteration kernel.
 template <typename T, int MODE, int PF, bool NT_XY, bool PRO = false, bool TAIL_NORM = false, bool TAIL_RESTRICT = false,
-          bool XZERO = false>
+          bool XZERO = false, bool XGEN = false>
 __global__ void __launch_bounds__(256)
 evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y,
               double om, double omm, int rows_per_chunk, int n_strips, int n_waves, double robin_kh,
@@ -164,9 +173,10 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   const int n = g.n;
   const long pitch = g.pitch;
   // halo lanes per side: 1 (124 stored columns), 2 for the kernels that carry the residual norm (120 columns)
-  constexpr int HALO = (TAIL_NORM || TAIL_RESTRICT || MODE == STRIP_RESNORM) ? 2 : 1;
+  static_assert(!XGEN || (MODE == STRIP_RBGS && TAIL_RESTRICT && XZERO && !PRO), "generated input: second of two red-black sweeps from zero");
+  constexpr int HALO = XGEN ? 3 : (TAIL_NORM || TAIL_RESTRICT || MODE == STRIP_RESNORM) ? 2 : 1;
   constexpr int COLS = 128 - 4 * HALO;
-  static_assert(HALO == 1 ? COLS == EVOMG_STRIP_COLS : COLS == EVOMG_NORM_STRIP_COLS, "strip widths");
+  static_assert(HALO == 1 ? COLS == EVOMG_STRIP_COLS : HALO == 2 ? COLS == EVOMG_NORM_STRIP_COLS : COLS == EVOMG_XGEN_STRIP_COLS, "strip widths");
   const int c0 = strip * COLS - 2 * HALO + 2 * lane;        // first column of this lane's pair (even)
   const bool col_ok = c0 >= 0 && c0 < n;                    // c0+1 <= n < pitch: the pair load stays inside the row
   const int y0 = chunk * rows_per_chunk;
@@ -218,6 +228,57 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
       }
     }
   };
+  // ---- XGEN: the rows of x as the first sweep from zero leaves them, formed from f (rows in ascending order) ----
+  // red of row q at this lane's red element of that row (a when q is even), zero where the first sweep relaxes nothing
+  auto gen_red = [&](const Pair<T>& fq_, int q) -> T {
+    const bool q_in = q >= 1 && q <= n - 2;
+    if ((q & 1) == 0) return (q_in && inner_a) ? relax5(st, zero, zero, zero, zero, zero, fq_.a, om, omm, inv_c0k) : zero;
+    return (q_in && inner_b) ? relax5(st, zero, zero, zero, zero, zero, fq_.b, om, omm, inv_c0k) : zero;
+  };
+  constexpr int GP = 2;                                      // f rows in flight ahead of the generator
+  Pair<T> gen_f = zpair, gen_fq[GP];                         // f of the row formed next; f of the rows behind it
+  T gen_rp = zero, gen_rc = zero;                            // reds of the row before the one formed next, and of that row
+  int gen_row = 0;                                           // the row formed next
+  auto gen_start = [&](int first) {
+    gen_row = first;
+    gen_rp = gen_red(load_row_f(f, first - 1), first - 1);
+    gen_f = load_row_f(f, first);
+    gen_rc = gen_red(gen_f, first);
+#pragma unroll
+    for (int k = 0; k < GP; ++k) gen_fq[k] = load_row_f(f, first + 1 + k);
+  };
+  // whole wave (DPP); k: which slot of the ring holds f of the next row (static at the call sites)
+  auto gen_next = [&](int k) -> Pair<T> {
+    const int r = gen_row;
+    const Pair<T> fn = gen_fq[k];
+    gen_fq[k] = load_row_f(f, r + 1 + GP);
+    const T rn = gen_red(fn, r + 1);
+    const bool r_in = r >= 1 && r <= n - 2;
+    Pair<T> out;
+    if ((r & 1) == 0) {                 // red = a, black = b
+      T e = from_right(gen_rc);
+      T w = gen_rc;
+      if constexpr (scalar_traits<T>::is_complex) {
+        if (robin_kh != 0.0) {          // (as below: the Robin condition between the colours, on the black node's old value — zero)
+          const cplx den{1.0, -robin_kh};
+          if (c0 == 0) w = sc_div(zero, den);
+          if (c0 + 1 == n - 2) e = sc_div(zero, den);
+        }
+      }
+      out.a = gen_rc;
+      out.b = (r_in && inner_b) ? relax5(st, zero, w, e, gen_rp, rn, gen_f.b, om, omm, inv_c0k) : zero;
+    } else {                            // red = b, black = a
+      const T w = from_left(gen_rc);
+      out.a = (r_in && inner_a) ? relax5(st, zero, w, gen_rc, gen_rp, rn, gen_f.a, om, omm, inv_c0k) : zero;
+      out.b = gen_rc;
+    }
+    if (r_in) robin_fix(out);
+    gen_rp = gen_rc;
+    gen_rc = rn;
+    gen_f = fn;
+    gen_row = r + 1;
+    return out;
+  };
   constexpr int LEAD = (MODE == STRIP_RBGS) ? 1 : 0;        // RB-GS relaxes red one row ahead of black
   constexpr int EXT = TAIL_RESTRICT ? 2 : (TAIL_NORM ? 1 : 0);   // extra finalised rows on each side for the residual
   constexpr bool TAIL = TAIL_NORM || TAIL_RESTRICT;
@@ -264,8 +325,15 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     }
     return out;
   };
-  Pair<T> xm = load_row(x, js - 1);
-  Pair<T> xc = load_row(x, js);
+  Pair<T> xm, xc;
+  if constexpr (XGEN) {
+    gen_start(js - 1);
+    xm = gen_next(0);
+    xc = gen_next(1);
+  } else {
+    xm = load_row(x, js - 1);
+    xc = load_row(x, js);
+  }
   if constexpr (PRO) {
     // y0 is even: row js has the parity of LEAD + EXT, row js - 1 the other one
     constexpr bool odd_c = ((LEAD + EXT) & 1) != 0, odd_m = !odd_c;
@@ -276,7 +344,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   Pair<T> xq[PF], fq[PF];
 #pragma unroll
   for (int d = 0; d < PF; ++d) {
-    xq[d] = load_row(x, js + 1 + d);
+    if constexpr (XGEN) xq[d] = gen_next(d % GP);            // (two rows formed above: the ring slot of row js + 1 + d is d mod GP)
+    else xq[d] = load_row(x, js + 1 + d);
     fq[d] = load_row_f(f, js + d);
   }
   // PRO: the coarse rows around the fine row that is corrected next (row j + 1 at step j) live in a two-row register
@@ -362,7 +431,8 @@ evomg_strip2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
       if (j < je) {                                          // wave-uniform
         Pair<T> xp = xq[d];
         const Pair<T> fc = fq[d];
-        xq[d] = load_row(x, j + 1 + PF);
+        if constexpr (XGEN) xq[d] = gen_next((PF + d) % GP);   // rows js - 1 .. : the slot of the next row advances by one per row formed
+        else xq[d] = load_row(x, j + 1 + PF);
         fq[d] = load_row_f(f, j + PF);
         const bool row_inner = j >= 1 && j <= n - 2;
         // chunk heights are even and js = y0 - LEAD, so with an even prefetch depth the row parity is static

@@ -261,6 +261,18 @@
       return;
     }
     if (take_x_zero()) {
+      if constexpr (MODE == STRIP_RBGS) {
+        if (nsweeps == 2) {
+          // two identical sweeps from zero + residual + restriction: the first sweep's result is formed from f inside the
+          // launch (evomg_strip2d<.., XGEN>; three halo lanes per side: its own strip count)
+          const int gstrips = (g.n + EVOMG_XGEN_STRIP_COLS - 1) / EVOMG_XGEN_STRIP_COLS;
+          int grows = strip_rows_ > 0 ? ((strip_rows_ + 1) & ~1) : balanced_rows(g.n, gstrips, 2, 8, 96);
+          const int gwaves = gstrips * ((g.n + grows - 1) / grows);
+          const dim3 ggrid((((gwaves + 3) / 4 + 7) / 8) * 8);
+          hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true, true, true>), ggrid, block, 0, stream_, g, st, x, f, y, om, omm, grows, gstrips, gwaves, rkh, (T*)nullptr, rout, pro);
+          return;
+        }
+      }
       hipLaunchKernelGGL((evomg_strip2d<T, MODE, EVOMG_FUSED_PF, false, false, false, true, true>), grid, block, 0, stream_, g, st, x, f, y, om, omm, rows, strips, waves, rkh, (T*)nullptr, rout, pro);
       return;
     }

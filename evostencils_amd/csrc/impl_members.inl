@@ -38,6 +38,7 @@
   int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 2049;
   bool norm_fold_ = getenv("EVOMG_NO_NORM_FOLD") == nullptr;        // the cross launch's norm: partial sums and their sum in ONE launch (same bits)
   unsigned* norm_ticket_ = nullptr;
+  bool xgen_enabled_ = getenv("EVOMG_NO_XGEN") == nullptr;            // two sweeps from zero + residual + restriction on strips: the first sweep formed from f (same bits; tests switch it off)
   bool cross_unit_ = getenv("EVOMG_NO_CROSS_UNIT") == nullptr;     // the cross kernel's unit-weight form (same bits; tests switch it off)
   static constexpr int xfuse_rows_ = 0;      // chunk height of the cross kernel: cross_rows() decides (EVOMG_STRIP_ROWS still forces one, tests)
   T* xf_rhs_spare_ = nullptr;        // spare coarse right-hand side of level max - 1 (speculative output, swapped in on commit)

@@ -116,7 +116,13 @@
     if (canon(a.level, a.dst) != canon(b.level, b.dst) || canon(a.level, a.src1) != canon(b.level, b.src1)) return false;
     if (prof_matches(a) || prof_matches(b) || prof_matches(ops[i + 2]) || prof_matches(ops[i + 3])) return false;
     const Geo& g = lv_[a.level].g;
-    return small2d_ok(g) && small2d_tiles(g.n) == 1 && use_strip(g);
+    if (small2d_ok(g) && small2d_tiles(g.n) == 1 && use_strip(g)) return true;
+    // strip levels: when the sweeps start from the zero field (the SET_ZERO in front of them elided, or the cycle's known-zero
+    // input), the first sweep's result is formed from f inside the second's launch (evomg_strip2d<.., XGEN>); with Helmholtz's
+    // Robin columns only when the kernels write them themselves
+    if (!xgen_enabled_ || !x_zero_next_ || !use_strip(g) || small2d_ok(g)) return false;
+    if (prob_.bc_kind == EVOMG_BC_HELMHOLTZ_ROBIN && !strip_bc_) return false;
+    return !jacobi_lost(a);
   }
   bool fusable_smooth_residual_restrict(const evomg_op_t* ops, int n_ops, int i, bool cyclic) const {
     if (!fuse_enabled_ || !tail_restrict_enabled_ || !cyclic || i + 2 >= n_ops || dim_ != 2) return false;

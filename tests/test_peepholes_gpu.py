@@ -103,6 +103,9 @@ def v_cycle(s, lo, hi, pre, post):
 CYCLIC = {
     "sweep_residual_restrict_2d": (2, 4, 7, "EVOMG_NO_TAIL_RESTRICT", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 1)),
     "two_sweeps_residual_restrict_2d": (2, 3, 6, "EVOMG_NO_SMALL2D", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
+    # round 6: on strip levels two red-black sweeps that start from zero + residual + restriction in ONE launch, the first sweep's
+    # result formed from f (evomg_strip2d<.., XGEN>): levels 8 and 7 of this cycle (257^2, 129^2; 65^2 is an LDS tile)
+    "two_sweeps_from_zero_on_strips_2d": (2, 5, 9, "EVOMG_NO_XGEN", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
     "tail_norm_2d": (2, 4, 7, "EVOMG_NO_TAIL_NORM", lambda s, lo, hi: v_cycle(s, lo, hi, 1, 2)),
     "dead_residual_2d": (2, 4, 7, "EVOMG_NO_FUSE", lambda s, lo, hi: v_cycle(s, lo, hi, 0, 1)),
     "speculation_2d": (2, 4, 7, "EVOMG_NO_SPECULATION", lambda s, lo, hi: v_cycle(s, lo, hi, 2, 1)),
