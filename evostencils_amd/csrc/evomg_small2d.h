@@ -20,10 +20,11 @@
 
 #define EVOMG_SMALL2D_TILE 33
 #define EVOMG_SMALL2D_HALO 4
+#define EVOMG_SMALL2D_HALO2 6       // two sweeps before the tail on a grid of several tiles (round 6): every sweep needs two more nodes
 __host__ __device__ inline int small2d_tiles(int n) { return (n - 1 + 31) / 32; }                    // per direction
 __host__ __device__ inline int small2d_tile_size(int n) { const int t = small2d_tiles(n); return (n + t - 1) / t; }
-__host__ __device__ inline int small2d_image_elems(int n) {
-  const int w = small2d_tiles(n) == 1 ? n : small2d_tile_size(n) + 2 * EVOMG_SMALL2D_HALO;
+__host__ __device__ inline int small2d_image_elems(int n, int halo = EVOMG_SMALL2D_HALO) {
+  const int w = small2d_tiles(n) == 1 ? n : small2d_tile_size(n) + 2 * halo;
   return w * w;
 }
 
@@ -31,15 +32,18 @@ template <typename T, int MODE, bool PRO, bool TAIL_RESTRICT, bool XZERO>
 __global__ void __launch_bounds__(1024)
 evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict__ f, T* __restrict__ y, double om, double omm,
               double robin_kh, int robin_out, ProlongIn<T> pro, int nsweeps) {
-  // nsweeps > 1 (red-black, ONE tile only — host-checked): that many identical sweeps in place before the tail, each followed
-  // by the Robin columns as the separate ops would leave them
+  // nsweeps > 1 (red-black; host-checked: 1 or 2): that many identical sweeps in place before the tail, each followed by the
+  // Robin columns as the separate ops would leave them. On a grid of several tiles the second sweep is valid two nodes further
+  // inside the extended tile than the first (red 3, black 4, residual 5 nodes from an edge that is not the domain's): the halo
+  // is six nodes then (round 6; 45 x 45 nodes, still two per thread)
   static_assert(MODE == STRIP_JACOBI || MODE == STRIP_RBGS, "smoother modes only");
   prio_latency();
   extern __shared__ __align__(16) unsigned char small_lds[];
   constexpr int MAXK = 2;                                   // (33 + 8)^2 nodes / 1024 threads
-  constexpr int H = EVOMG_SMALL2D_HALO, BIG = 1 << 20;
+  constexpr int BIG = 1 << 20;
   const int n = g.n;
   const int tiles = small2d_tiles(n), ts = small2d_tile_size(n);
+  const int H = (nsweeps > 1 && tiles > 1) ? EVOMG_SMALL2D_HALO2 : EVOMG_SMALL2D_HALO;
   const int tx = (int)blockIdx.x % tiles, ty = (int)blockIdx.x / tiles;
   // owned nodes [ox0, ox1) x [oy0, oy1); extended tile [ex0, ex1) x [ey0, ey1), clipped to the grid
   const int ox0 = tx * ts, ox1 = min(ox0 + ts, n), oy0 = ty * ts, oy1 = min(oy0 + ts, n);
@@ -115,7 +119,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     if (sweep > 0) {
       if constexpr (CPLX) {
         if (robin && robin_out) {
-          robin_columns(A, robin_kh, 2);
+          robin_columns(A, robin_kh, 2 * sweep);
           __syncthreads();
         }
       }
@@ -124,7 +128,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
       const int i = qi[k], j = qj[k], q = ql[k];
-      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && !((i + j) & 1) && depth(i, j) >= 1)
+      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && !((i + j) & 1) && depth(i, j) >= 2 * sweep + 1)
         A[q] = relax5(st, A[q], A[q - 1], A[q + 1], A[q - ew], A[q + ew], fv[k], om, omm, inv_c0k);
     }
     __syncthreads();
@@ -133,7 +137,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
       const int i = qi[k], j = qj[k], q = ql[k];
-      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && ((i + j) & 1) && depth(i, j) >= 2) {
+      if (i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && ((i + j) & 1) && depth(i, j) >= 2 * sweep + 2) {
         T w = A[q - 1], e = A[q + 1];
         if constexpr (CPLX) {
           if (robin) {
@@ -160,7 +164,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
   }
   if constexpr (CPLX) {
     if (robin && robin_out) {
-      robin_columns(cur, robin_kh, 2);
+      robin_columns(cur, robin_kh, MODE == STRIP_RBGS ? 2 * nsweeps : 2);
       __syncthreads();
     }
   }
@@ -177,7 +181,7 @@ evomg_small2d(Geo g, Stencil<T> st, const T* __restrict__ x, const T* __restrict
     for (int k = 0; k < MAXK; ++k) {
       const int i = qi[k], j = qj[k], q = ql[k];
       if (i >= 0) {
-        const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && depth(i, j) >= 3;
+        const bool inner = i >= 1 && i <= n - 2 && j >= 1 && j <= n - 2 && depth(i, j) >= (MODE == STRIP_RBGS ? 2 * nsweeps + 1 : 3);
         res[q] = inner ? residual5(st, cur[q], cur[q - 1], cur[q + 1], cur[q - ew], cur[q + ew], fv[k]) : zero;
       }
     }

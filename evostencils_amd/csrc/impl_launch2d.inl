@@ -156,8 +156,9 @@
   void launch_small2d(const Geo& g, const Stencil<T>& st, const T* x, const T* f, T* y, double om, double omm, double rkh, int rout,
                       const ProlongIn<T>& pro, int nsweeps = 1) {
     auto kern = evomg_small2d<T, MODE, PRO, TAILR, XZ>;
-    const size_t lds_bytes = (size_t)((MODE == STRIP_JACOBI || TAILR) ? 2 : 1) * small2d_image_elems(g.n) * sizeof(T);
     const int tiles = small2d_tiles(g.n);
+    const int halo = (nsweeps > 1 && tiles > 1) ? EVOMG_SMALL2D_HALO2 : EVOMG_SMALL2D_HALO;      // (as the kernel picks it)
+    const size_t lds_bytes = (size_t)((MODE == STRIP_JACOBI || TAILR) ? 2 : 1) * small2d_image_elems(g.n, halo) * sizeof(T);
     const void* key = reinterpret_cast<const void*>(kern);
     if (lds_bytes > 48 * 1024 && !small2d_attr_set_.count(key)) {
       if (hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_) != hipSuccess) (void)hipGetLastError();   // the launch reports it

@@ -117,6 +117,11 @@
     if (prof_matches(a) || prof_matches(b) || prof_matches(ops[i + 2]) || prof_matches(ops[i + 3])) return false;
     const Geo& g = lv_[a.level].g;
     if (small2d_ok(g) && small2d_tiles(g.n) == 1 && use_strip(g)) return true;
+    // a grid of several LDS tiles: both sweeps in each tile's launch, with a halo of six nodes (evomg_small2d.h; tiles read
+    // their halo from x while others store y: y is the level's spare array)
+    if (xgen_enabled_ && small2d_ok(g) && use_strip(g) && small2d_tile_size(g.n) + 2 * EVOMG_SMALL2D_HALO2 <= 45 &&
+        2 * small2d_image_elems(g.n, EVOMG_SMALL2D_HALO2) * sizeof(T) <= max_lds_)
+      return true;
     // strip levels: when the sweeps start from the zero field (the SET_ZERO in front of them elided, or the cycle's known-zero
     // input), the first sweep's result is formed from f inside the second's launch (evomg_strip2d<.., XGEN>); with Helmholtz's
     // Robin columns only when the kernels write them themselves

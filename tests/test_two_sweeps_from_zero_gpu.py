@@ -41,7 +41,9 @@ def _solve(native, pd, ops, hi, monkeypatch, env):
     return out, fields
 
 
-@pytest.mark.parametrize("lo,hi,cap", [(5, 9, 6), (6, 10, 3), (7, 10, 4)])
+# (3, 7) and (4, 8): no strip level at all — the levels of several LDS tiles (65^2 .. 257^2 complex) run both sweeps, the residual
+# and the restriction in each tile's launch with a halo of six nodes (csrc/evomg_small2d.h), same switch
+@pytest.mark.parametrize("lo,hi,cap", [(5, 9, 6), (6, 10, 3), (7, 10, 4), (3, 7, 40), (4, 8, 12)])
 def test_helmholtz_preconditioner_with_the_first_sweep_formed_from_f(native, oracle, monkeypatch, lo, hi, cap):
     pd = dataclasses.replace(problems.helmholtz_2d(lo, hi, k=0.625 * (1 << hi)), max_iterations=cap)
     ops = candidates.v_cycle_ops(lo, hi, 2, 1, omega=0.6)
