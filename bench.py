@@ -474,8 +474,10 @@ def other_configs_section(local_rank):
                  "solve_time_ms": res.time_ms,
                  "reference_vcycle": {"what": "the reference's hand-written V(2,1) cycle as preconditioner (exa3:202-272: 2 V-cycles "
                                               "per outer iteration), same cap", "ms_per_outer_iteration": res_hand.time_ms / res_hand.n_iterations},
-                 "dominant_kernel": {"name": h.kernel_name(smooth), "what": "finest-level RB-GS sweeps (12 per outer iteration: plain, "
-                                     "sweep + residual + restriction, prolongation + sweep)", **_frac(sweeps),
+                 "dominant_kernel": {"name": h.kernel_name(smooth), "what": "finest-level RB-GS sweeps as this timed pass launches them (12 per outer iteration: "
+                                     "plain, sweep + residual + restriction, prolongation + sweep; the pass times one launch per SMOOTH op, "
+                                     "so the round-6 fusion of a pre-smoothing pair that starts from zero into ONE launch - which the "
+                                     "untimed solves above run - is off here)", **_frac(sweeps),
                                      "share_of_solve": sweeps.ms * sweeps.launches / res.time_ms}}
     h.close()
     # ---- C4: 3D Poisson 512^3, V(2,2) block-Jacobi (2,1,1) w = 0.8, levels 9..5, textbook `with jacobi` semantics
