@@ -297,3 +297,34 @@ def test_c4_full_size_in_the_reference_pipelines_semantics(native):
     print(f"C4 [exastencils-v1.1]: 12 iterations, rho {a.conv_factor:.4f}, {a.time_ms:.0f} ms with the (lost) sweeps, "
           f"{bare.time_ms:.0f} ms without")
     h.close()
+
+
+# ---- C2 with the device full ------------------------------------------------------------------------------------------------
+def test_c2_in_flight_at_full_size_is_the_sequential_solve(native):
+    """configs[1] (the headline candidate: 2D Poisson 4097^2, levels 12..7, V(1,1) red-black, CG on 129^2) with EIGHT evaluations
+    in flight — the regime in which the cross-iteration launch takes 256-row chunks on levels that stream from HBM
+    (csrc/impl_launch2d.inl: cross_rows; round 6) and the coarse solves are dealt to the XCDs in turn — against the same candidate
+    evaluated alone: convergence factor and iteration count bit for bit, from every worker, twice."""
+    import bench
+    from evostencils_amd.code_generation.hip import ProgramGenerator
+    lo, hi = 7, 12
+
+    def make():
+        g = ProgramGenerator(problem=problems.poisson_2d(lo, hi), library=native.library())
+        g.initialize_code_generation(lo, hi)
+        return g
+
+    gen = make()
+    candidate = bench.build_candidate(gen, lo, hi)
+    alone = gen.generate_and_evaluate(candidate, None, lo, hi, "", evaluation_samples=1)
+    gen.close()
+    assert 0.0 < alone[1] < 0.2 and alone[2] == 12.0
+    workers = population.ConcurrentEvaluator(make, 8)
+    try:
+        rows = population.evaluate_population_in_flight(
+            workers, lambda g, i: g.generate_and_evaluate(candidate, None, lo, hi, "", evaluation_samples=1), 16)
+    finally:
+        workers.close()
+    assert len(rows) == 16
+    for r in rows:
+        assert r[1] == alone[1] and r[3] == alone[2], (r, alone)
