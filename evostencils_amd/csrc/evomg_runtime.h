@@ -34,6 +34,16 @@ int next_cg_phase();       // a process-wide round-robin counter (which XCD the 
 hipError_t wait_event(hipEvent_t e);
 hipError_t wait_stream(hipStream_t s);
 
+// Read-only device arrays shared between the handles of a process (round 6): the right-hand side of the finest level is the same
+// array for every candidate of a problem, and with candidates in flight sixteen private copies of it (134 MB each at 4097^2)
+// stream from HBM where ONE copy is read sixteen times and partly stays in the 256 MB Infinity Cache (sixteen C2 solves in
+// flight: 421 -> 439 solves/s). Keyed by device, size and a 64-bit hash of the host data it was uploaded from.
+// shared_array_acquire: `candidate` is the caller's freshly uploaded device copy; returns the array to use — `candidate`
+// itself (now registered: the registry owns it) or an equal one registered earlier (the caller frees its candidate).
+void* shared_array_acquire(int device, size_t device_bytes, uint64_t hash, void* candidate);
+void shared_array_release(void* array);       // the last release frees it
+uint64_t hash_words(const void* data, size_t bytes);
+
 inline double wall_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();

@@ -5,6 +5,7 @@
 
   ~Impl() override {
     (void)hipSetDevice(device_);
+    drop_shared_rhs();
     for (int L = prob_.min_level; L <= prob_.max_level; ++L) {
       Level<T>& lv = lv_[L];
       for (int f = 0; f < EVOMG_F_COUNT; ++f) {
@@ -93,20 +94,70 @@
     field = canon(level, field);
     Level<T>& lv = lv_[level];
     if (field < 0 || !lv.f[field]) return invalid("set_initial_field: no such field on this level");
+    const bool rhs_max = level == prob_.max_level && field == EVOMG_F_RHS;
+    if (rhs_max) drop_shared_rhs();           // (a second upload: the handle owns plain arrays again before anything else)
     if (!lv.init[field]) HIP_TRY(alloc_zero(&lv.init[field], lv.elems));
     bnd_zero_[level][field] = false;
     dirty_[level][field] = true;
     lv.alt_mirror = nullptr;
     HIP_TRY(upload(lv, lv.init[field], host));
+    // The finest level's right-hand side is read-only to a multigrid solve and the same for every candidate of a problem: the
+    // handles of a process read ONE device copy of it (evomg_runtime.h). Not under the preconditioned outer solver, whose
+    // cycles use RHS@max as a work array.
+    if (rhs_max && share_rhs_ && prob_.outer_kind == EVOMG_OUTER_MG_ITERATION) {
+      HIP_TRY(wait_stream(stream_));
+      const size_t host_bytes = (size_t)lv.g.n * lv.g.n * (dim_ == 3 ? lv.g.n : 1) * sizeof(T);
+      T* mine = lv.init[field];
+      T* shared = static_cast<T*>(shared_array_acquire(device_, lv.elems * sizeof(T), hash_words(host, host_bytes), mine));
+      if (shared != mine) (void)hipFree(mine);
+      lv.init[field] = shared;
+      rhs_shared_ = true;
+      rhs_private_ = lv.f[field];
+      lv.f[field] = shared;
+      rhs_aliased_ = true;
+      dirty_[level][field] = false;
+      clean_ptr_[level][field] = shared;
+      return EVOMG_OK;
+    }
     HIP_TRY(hipMemcpyAsync(lv.f[field], lv.init[field], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
     HIP_TRY(wait_stream(stream_));
     return EVOMG_OK;
+  }
+  // RHS@max is about to be written (set_field, an op program that names it as a destination): the handle's own array takes
+  // over, with the shared array's content
+  int privatize_rhs() {
+    if (!rhs_aliased_) return EVOMG_OK;
+    Level<T>& lv = lv_[prob_.max_level];
+    HIP_TRY(hipMemcpyAsync(rhs_private_, lv.init[EVOMG_F_RHS], lv.elems * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    lv.f[EVOMG_F_RHS] = rhs_private_;
+    rhs_private_ = nullptr;
+    rhs_aliased_ = false;
+    clean_ptr_[prob_.max_level][EVOMG_F_RHS] = lv.f[EVOMG_F_RHS];
+    lv.alt_mirror = nullptr;
+    return EVOMG_OK;
+  }
+  // plain ownership again (before a new upload, before the destructor's frees)
+  void drop_shared_rhs() {
+    Level<T>& lv = lv_[prob_.max_level];
+    if (rhs_aliased_) {
+      lv.f[EVOMG_F_RHS] = rhs_private_;
+      rhs_private_ = nullptr;
+      rhs_aliased_ = false;
+      dirty_[prob_.max_level][EVOMG_F_RHS] = true;
+      clean_ptr_[prob_.max_level][EVOMG_F_RHS] = nullptr;
+    }
+    if (rhs_shared_) {
+      shared_array_release(lv.init[EVOMG_F_RHS]);
+      lv.init[EVOMG_F_RHS] = nullptr;
+      rhs_shared_ = false;
+    }
   }
 
   int set_field(int level, int field, const double* host) override {
     if (!level_ok(level) || !host) return invalid("set_field: bad level/pointer");
     HIP_TRY(hipSetDevice(device_));
     { const int rc = flush_pending_residual(); if (rc != EVOMG_OK) return rc; }
+    if (level == prob_.max_level && canon(level, field) == EVOMG_F_RHS) { const int rc = privatize_rhs(); if (rc != EVOMG_OK) return rc; }
     T* d = fieldptr(level, field);
     if (!d) return invalid("set_field: no such field on this level");
     bnd_zero_[level][canon(level, field)] = false;
@@ -151,6 +202,7 @@
     info_fresh_ = false;
     if (cg_multi_used_) HIP_TRY(hipMemsetAsync(dinfo_, 0, sizeof(int) * 4, stream_));
     mark_written(ops, n_ops, /*loop=*/false);
+    if (dirty_[prob_.max_level][EVOMG_F_RHS] && (rc = privatize_rhs()) != EVOMG_OK) return rc;
     rc = exec_program(ops, n_ops, /*cyclic=*/false);
     if (rc != EVOMG_OK) return rc;
     HIP_TRY(wait_stream(stream_));
@@ -220,6 +272,7 @@
       if (rc != EVOMG_OK) return rc;
       HIP_TRY(hipMemsetAsync(dinfo_ + 2, 0, sizeof(int), stream_));      // coarse-solver iterations of this sample
       mark_written(ops, n_ops, /*loop=*/true);
+      if (dirty_[prob_.max_level][EVOMG_F_RHS] && (rc = privatize_rhs()) != EVOMG_OK) return rc;
       if (prob_.outer_kind == EVOMG_OUTER_PBICGSTAB) rc = solve_pbicgstab(ops, n_ops, wall_limit_ms, &r, hist, cap);
       else rc = solve_mg(ops, n_ops, wall_limit_ms, &r, hist, cap);
       if (rc != EVOMG_OK) return rc;
@@ -245,6 +298,7 @@
     int rc = validate(op, 1);
     if (rc != EVOMG_OK) return rc;
     if ((rc = flush_pending_residual()) != EVOMG_OK) return rc;
+    if (op->level == prob_.max_level && canon(op->level, op->dst) == EVOMG_F_RHS && (rc = privatize_rhs()) != EVOMG_OK) return rc;
     for (int i = 0; i < warmup; ++i) {
       rc = exec(*op);
       if (rc != EVOMG_OK) return rc;

@@ -37,6 +37,12 @@
   // fused vs EVOMG_NO_XFUSE: 513^2 1.808 vs 1.747 ms, 1025^2 3.85 vs 3.79, 2049^2 11.89 vs 11.99, 4097^2 13.68 vs 14.12)
   int xfuse_min_n_ = getenv("EVOMG_XFUSE_MIN_N") ? atoi(getenv("EVOMG_XFUSE_MIN_N")) : 2049;
   bool norm_fold_ = getenv("EVOMG_NO_NORM_FOLD") == nullptr;        // the cross launch's norm: partial sums and their sum in ONE launch (same bits)
+  // RHS@max shared between the handles of a process (evomg_runtime.h: shared_array_acquire): init[RHS]@max is the registry's
+  // array; as long as nothing writes RHS@max the working field f[RHS]@max IS that array (rhs_aliased_) and the handle's own
+  // array waits in rhs_private_ for the first writer (privatize_rhs)
+  bool share_rhs_ = getenv("EVOMG_NO_SHARED_RHS") == nullptr;
+  bool rhs_shared_ = false, rhs_aliased_ = false;
+  T* rhs_private_ = nullptr;
   unsigned* norm_ticket_ = nullptr;
   bool xgen_enabled_ = getenv("EVOMG_NO_XGEN") == nullptr;            // two sweeps from zero + residual + restriction on strips: the first sweep formed from f (same bits; tests switch it off)
   bool cross_unit_ = getenv("EVOMG_NO_CROSS_UNIT") == nullptr;     // the cross kernel's unit-weight form (same bits; tests switch it off)
