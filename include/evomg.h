@@ -286,7 +286,11 @@ int  evomg_device_count(void);
 
 /* -- problem data (K10): dense host arrays, x fastest, (2^L+1)^d scalars; complex = interleaved re,im -- */
 /* Sets the *initial* content of a field (restored at the start of every solve). Only SOL and RHS of the
- * finest level are meaningful inputs (u with its boundary values, RHS_u). */
+ * finest level are meaningful inputs (u with its boundary values, RHS_u).
+ * RHS of the finest level (EVOMG_OUTER_MG_ITERATION): handles of one process that upload the same data share ONE device copy
+ * of it — with several candidates in flight it is read from the Infinity Cache instead of once per handle from HBM. Invisible
+ * to the caller: a handle that writes the field (evomg_set_field, an op program with it as a destination, another upload) is
+ * given an array of its own first. EVOMG_NO_SHARED_RHS=1 switches it off. */
 int  evomg_set_initial_field(evomg_handle_t* h, int level, int field, const double* host);
 /* Reads back the current content of a field after an evaluate/run_ops call. */
 int  evomg_get_field(evomg_handle_t* h, int level, int field, double* host);
